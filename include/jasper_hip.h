@@ -1,0 +1,101 @@
+/*
+ * jasper_hip.h -- C-ABI of libjasper_hip.so, the MI355X-native replacement for the hot path of
+ * alguoo314/JASPER:   reads -> canonical k-mer counts (HBM table) -> histogram -> scan / lookup / fix -> (bad,total).
+ *
+ * Plain C, opaque handles, caller-owned outputs, no exceptions, no torch types.  Every entry point returns
+ * 0 on success and a negative code on failure; jasper_last_error() then returns a message (thread-local).
+ * A handle may be used from one host thread at a time; all work of a handle is issued on its own HIP stream
+ * of its own device.
+ *
+ * What each entry point replaces in the reference ("src/..." = /root/reference/src, "JF::..." = inside the
+ * vendored jellyfish-2.3.0.tar.gz):
+ *
+ *   jasper_table_create / _destroy     `jellyfish count -s SIZE -m K` table set-up          JF::sub_commands/count_main.cc:258-283
+ *                                      and jf.QueryMerFile(path) open / close               JF::swig/mer_file.i:18-36
+ *   jasper_count_reads_files           `zcat -f READS | jellyfish count -C -m K /dev/stdin` src/jasper.sh:177
+ *   jasper_count_reads_text            the same on an in-memory FASTA/FASTQ stream          JF::include/jellyfish/mer_overlap_sequence_parser.hpp:120-307
+ *   jasper_count_bases[_device]        mer_counter_base::start hot loop on parsed bases     JF::sub_commands/count_main.cc:152-184
+ *   jasper_histogram                   `jellyfish histo`                                    JF::sub_commands/histo_main.cc:34-44,64-84 (src/jasper.sh:177,189)
+ *   jasper_lookup                      qf[jf.MerDNA(s).get_canonical()]                     JF::swig/mer_file.i:41, JF::swig/mer_dna.i:12-19 (src/jasper.py:70-71 ...)
+ *   jasper_table_export/_import[_device]  `jellyfish merge` (sum by key)                    JF::jellyfish/merge_files.cc:44-176 -> multi-GPU table merge
+ *   jasper_polish_batch + jasper_result_*   one `jasper.py --db DB --query BATCH ...` process   src/jasper.py:12-137 (invoked at src/jasper.sh:207-212)
+ */
+#ifndef JASPER_HIP_H
+#define JASPER_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jasper_table jasper_table;
+typedef struct jasper_result jasper_result;
+
+/* one repair, as src/jasper.py:218-222 records it ([seqname, index, fixed_base, original]) */
+typedef struct jasper_fixrec {
+    int64_t index;     /* Base_coord: chunk- and pass-relative */
+    uint32_t chunk;    /* position of the chunk in the batch */
+    uint32_t seqno;    /* emission order inside (chunk, pass) */
+    uint8_t pass;
+    uint8_t kind;      /* 's' substitution  'i' inserted base(s) removed  'd' deleted base(s) restored  'x' path extension */
+    uint8_t newc;      /* 's': new base   'd': restored base, repeated rep times */
+    uint8_t oldc;      /* 's': old base   'i': removed base, repeated rep times */
+    uint32_t rep;      /* 'x': length of the replaced original segment */
+    uint32_t aux_off;  /* 'x': offset of  patch ++ original segment  in the chunk's aux bytes */
+    uint32_t aux_len;  /* 'x': length of the patch */
+} jasper_fixrec;
+
+#define JASPER_OK 0
+#define JASPER_ERR -1           /* HIP / IO / argument error */
+#define JASPER_ERR_CAPACITY -2  /* table or scratch too small (message says which) */
+#define JASPER_ERR_FORMAT -3    /* "Unsupported format" / "Invalid fastq sequence" (Jellyfish's wording) */
+#define JASPER_ERR_REFERENCE_EXIT -4 /* the reference itself would exit(1) on this input (src/jasper.py:221 IndexError) */
+
+const char *jasper_last_error(void);
+int jasper_device_count(int *n);
+
+/* k in [1,64]; min_slots is a size hint like `jellyfish count -s` (rounded up to a power of two; the table
+ * doubles by itself when half full).  k > 26 needs at least 2^(2k-53) slots (k=37: 2^21 = 32 MiB). */
+int jasper_table_create(int k, uint64_t min_slots, int device, jasper_table **out);
+void jasper_table_destroy(jasper_table *t);
+int jasper_table_info(jasper_table *t, int *k, uint64_t *slots, uint64_t *distinct, uint64_t *occurrences);
+int jasper_table_sync(jasper_table *t);
+
+/* bases: concatenated read sequences, records separated by any non-ACGTacgt byte; windows do not span calls */
+int jasper_count_bases(jasper_table *t, const char *bases, uint64_t n);
+/* the same with the bases already resident in this table's device memory (16-byte aligned for full speed) */
+int jasper_count_bases_device(jasper_table *t, const void *d_bases, uint64_t n);
+int jasper_count_reads_text(jasper_table *t, const char *text, uint64_t n);
+int jasper_count_reads_files(jasper_table *t, const char *const *paths, int n_paths);
+
+int jasper_histogram(jasper_table *t, uint64_t *out10002);
+/* string i is chars[offsets[i] .. offsets[i+1]); out[i] = count of canonical(pad(string i)) clamped to 2^32-1 */
+int jasper_lookup(jasper_table *t, const char *chars, const int64_t *offsets, uint64_t n, uint32_t *out);
+
+/* entries are 3 x uint64 each: mixed-hash high word, low word, exact count.  Any table with the same k accepts them. */
+int jasper_table_export(jasper_table *t, uint64_t *n_entries, uint64_t *host_entries /* NULL: size query */);
+int jasper_table_import(jasper_table *t, const uint64_t *host_entries, uint64_t n_entries);
+int jasper_table_export_device(jasper_table *t, uint64_t *n_entries, void **d_entries);
+int jasper_table_import_device(jasper_table *t, const void *d_entries, uint64_t n_entries);
+int jasper_device_free(jasper_table *t, void *d_ptr);
+
+/* one batch of chunk records through `passes` fixing passes + the final QV pass (src/jasper.py:25-26) */
+int jasper_polish_batch(jasper_table *t, int n_chunks, const char *const *seqs, const int64_t *lens,
+                        int solid_thre, int passes, int fix, jasper_result **out);
+int jasper_result_num_chunks(const jasper_result *r);
+int jasper_result_seq(const jasper_result *r, int chunk, const char **seq, int64_t *len);
+int jasper_result_records(const jasper_result *r, const jasper_fixrec **recs, uint64_t *n);
+int jasper_result_aux(const jasper_result *r, int chunk, const char **aux, uint64_t *n);
+int jasper_result_qv(const jasper_result *r, int64_t out4[4]); /* bad0,total0,badP,totalP  (src/jasper.py:107-111) */
+int jasper_result_lookups(const jasper_result *r, uint64_t *n);
+double jasper_result_seconds(const jasper_result *r);         /* device time of the passes (HIP events) */
+void jasper_result_free(jasper_result *r);
+
+/* kernel timing for bench.py: HIP-event time of the last counting call on this table, and its launch count */
+int jasper_last_count_timing(jasper_table *t, double *kernel_ms, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+"""ctypes binding of libjasper_hip.so (C-ABI declared in include/jasper_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjasper_hip.so")
+
+JASPER_OK = 0
+JASPER_ERR = -1
+JASPER_ERR_CAPACITY = -2
+JASPER_ERR_FORMAT = -3
+JASPER_ERR_REFERENCE_EXIT = -4
+
+
+class FixRec(C.Structure):
+    _fields_ = [("index", C.c_int64), ("chunk", C.c_uint32), ("seqno", C.c_uint32), ("pass_", C.c_uint8),
+                ("kind", C.c_uint8), ("newc", C.c_uint8), ("oldc", C.c_uint8), ("rep", C.c_uint32),
+                ("aux_off", C.c_uint32), ("aux_len", C.c_uint32)]
+
+
+assert C.sizeof(FixRec) == 32
+
+# every symbol include/jasper_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "jasper_last_error": (C.c_char_p, []),
+    "jasper_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "jasper_table_create": (C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(_P)]),
+    "jasper_table_destroy": (None, [_P]),
+    "jasper_table_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "jasper_table_sync": (C.c_int, [_P]),
+    "jasper_count_bases": (C.c_int, [_P, C.c_char_p, C.c_uint64]),
+    "jasper_count_bases_device": (C.c_int, [_P, _P, C.c_uint64]),
+    "jasper_count_reads_text": (C.c_int, [_P, C.c_char_p, C.c_uint64]),
+    "jasper_count_reads_files": (C.c_int, [_P, C.POINTER(C.c_char_p), C.c_int]),
+    "jasper_histogram": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "jasper_lookup": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64), C.c_uint64, C.POINTER(C.c_uint32)]),
+    "jasper_table_export": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "jasper_table_import": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_uint64]),
+    "jasper_table_export_device": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(_P)]),
+    "jasper_table_import_device": (C.c_int, [_P, _P, C.c_uint64]),
+    "jasper_device_free": (C.c_int, [_P, _P]),
+    "jasper_polish_batch": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "jasper_result_num_chunks": (C.c_int, [_P]),
+    "jasper_result_seq": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "jasper_result_records": (C.c_int, [_P, C.POINTER(C.POINTER(FixRec)), C.POINTER(C.c_uint64)]),
+    "jasper_result_aux": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "jasper_result_qv": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "jasper_result_lookups": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "jasper_result_seconds": (C.c_double, [_P]),
+    "jasper_result_free": (None, [_P]),
+    "jasper_last_count_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+}
+
+_lib = None
+
+
+class JasperHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libjasper_hip: %s (code %d)" % (msg, code))
+        self.code = code
+
+
+def lib():
+    """load libjasper_hip.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not built: run `make -C jasper_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise JasperHipError(rc, lib().jasper_last_error().decode(errors="replace"))

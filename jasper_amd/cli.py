@@ -1,0 +1,382 @@
+"""Drop-in driver for `jasper.sh` (src/jasper.sh): same flags, batch/pass semantics, working-directory artefacts,
+sentinel files and log lines; the Jellyfish + per-batch python processes are replaced by the HBM table and the GPU
+polisher.  Lines are cited as src/jasper.sh:N.
+
+    python -m jasper_amd.cli -r 'R1.fq R2.fq' -a asm.fa -k 37 -t 16 -p 2
+
+Differences that are deliberate and documented in DESIGN.md:
+  * contigs are written to <asm>.polished.fasta in input order (the reference's order is perl-hash random, :220)
+  * column sums for the QV are exact integers (gawk behaviour)
+  * `mer_counts$K.jf` is not written (the table lives in HBM); an existing one, or -j, is not read yet
+"""
+import datetime
+import glob
+import os
+import re
+import sys
+
+from . import polisher, qv
+from .table import KmerTable
+
+MAX_BATCH_SIZE = 25000000  # :9
+
+
+def _tty():
+    try:
+        return os.isatty(1)
+    except Exception:
+        return False
+
+
+def log(msg):  # :30-33
+    d = datetime.datetime.now().astimezone().strftime("%a %b %d %H:%M:%S %Z %Y")
+    if _tty():
+        print("\033[0;32m[%s]\033[0m %s" % (d, msg), flush=True)
+    else:
+        print("[%s] %s" % (d, msg), flush=True)
+
+
+def error_exit(msg, code=1):  # :35-39
+    d = datetime.datetime.now().astimezone().strftime("%a %b %d %H:%M:%S %Z %Y")
+    sys.stderr.write("[%s] %s\n" % (d, msg))
+    sys.exit(code)
+
+
+USAGE = """JASPER version 1.0.2
+Usage: jasper.sh [options]
+Options:
+Options (default value in (), *required):
+-b, --batch=uint64              Desired batch size for the query (default value based on number of threads and assembly size)
+-t, --threads=uint32            Number of threads (2)
+-a, --assembly=path             *Assembly file
+-j, --jf=path                   Jellyfish k-mer count database file. Required if --reads is not provided
+-r|--reads=path                 File(s) containing the polishing reads. If two or more files are provided, please enclose the list with single-quotes, e.g. -r '/path_to/file1.fa /path_to/file2.fa'. Required if -j (--jf) is not provided
+-k|--kmer=uint64                k-mer size (37)
+-p|--num_passes=uint16          Number of polishing iterations (3), not recommended to increase much past 4
+-h|--help                       This message
+-v|--verbose                    Verbose (False)
+-d|--debug                      Debug mode. If supplied, all intermediate output files are kept"""
+
+
+class Options:
+    def __init__(self):
+        self.num_threads = "2"       # :6
+        self.batch_size = "0"        # :8
+        self.passes = "2"            # :10
+        self.kmer = "37"             # :11
+        self.jf_size = 0
+        self.debug = False
+        self.query = "random.fa"
+        self.query_fn = "random.fa"
+        self.reads = "random.fastq"
+        self.jf_db = None
+        self.verbose = False
+        self.device = 0
+
+
+def parse_args(argv):
+    """the `case` parser of src/jasper.sh:58-110, including `-d` swallowing the following argument (:93-96)"""
+    o = Options()
+    i = 0
+    while i < len(argv):
+        key = argv[i]
+        nxt = argv[i + 1] if i + 1 < len(argv) else ""
+        if key in ("-b", "--batch"):
+            o.batch_size = nxt; i += 1
+        elif key in ("-t", "--threads"):
+            o.num_threads = nxt; i += 1
+        elif key in ("-a", "--assembly"):
+            o.query = nxt; o.query_fn = os.path.basename(nxt); i += 1
+        elif key in ("-j", "--jf"):
+            o.jf_db = nxt; i += 1
+        elif key in ("-r", "--reads"):
+            o.reads = nxt
+            tot = 0
+            for f in nxt.split():
+                try:
+                    tot += os.stat(f).st_size
+                except OSError:
+                    pass
+            o.jf_size = int(tot / 10)                                  # :82
+            i += 1
+        elif key in ("-p", "--num_passes"):
+            o.passes = nxt; i += 1
+        elif key in ("-k", "--kmer"):
+            o.kmer = nxt; i += 1
+        elif key in ("-d", "--debug"):
+            o.debug = True; i += 1                                     # the extra `shift`
+        elif key in ("-v", "--verbose"):
+            o.verbose = True
+        elif key in ("-h", "--help", "-u", "--usage"):
+            print(USAGE)
+            sys.exit(0)
+        elif key == "--device":                                        # extension: which GPU
+            o.device = int(nxt); i += 1
+        else:
+            print("Unknown option %s" % key)
+            sys.exit(1)
+        i += 1
+    return o
+
+
+def read_assembly(path):
+    """perl #1 of src/jasper.sh:155: header = first whitespace token of a '>' line, sequence = first tokens of other lines"""
+    contigs = []
+    name, parts = None, []
+    with open(path, "r", errors="replace") as f:
+        for line in f:
+            F = line.split()
+            if not F:
+                continue
+            if F[0].startswith(">"):
+                if name is not None and parts:
+                    contigs.append((name, "".join(parts)))
+                name, parts = F[0], []
+            else:
+                parts.append(F[0])
+    if name is not None and parts:
+        contigs.append((name, "".join(parts)))
+    return contigs
+
+
+def sequence_bytes(path):
+    """`grep -v '^>' $QUERY | tr -d '\\n' | wc` third column (src/jasper.sh:132)"""
+    n = 0
+    with open(path, "rb") as f:
+        for line in f:
+            if not line.startswith(b">"):
+                n += len(line) - (1 if line.endswith(b"\n") else 0)
+    return n
+
+
+def split_batches(contigs, batch_size, query_fn):
+    """src/jasper.sh:155-156: chunk records '>name:offset' of <= batch_size bases; a new batch file starts at a
+    header once more than batch_size bases have been written to the current one"""
+    bs = int(batch_size)
+    records = []
+    for name, seq in contigs:
+        if bs <= 0:
+            # perl's `for($ci=0;$ci<length;$ci+=0)` would never end; jasper.sh guarantees bs>0 for non-empty input
+            records.append(("%s:0" % name, seq))
+            continue
+        for ci in range(0, len(seq), bs):
+            records.append(("%s:%d" % (name, ci), seq[ci:ci + bs]))
+    files = []
+    batch_index, output = 0, 0
+    f = open("%s.batch.%d.fa" % (query_fn, batch_index), "w")
+    files.append(f.name)
+    for hdr, seq in records:
+        if output > bs:
+            f.close()
+            batch_index += 1
+            f = open("%s.batch.%d.fa" % (query_fn, batch_index), "w")
+            files.append(f.name)
+            output = 0
+        f.write(hdr + "\n")
+        f.write(seq + "\n")
+        output += len(seq)
+    f.close()
+    return files
+
+
+def join_polished(fixed_files, batch_size, contig_order):
+    """perl of src/jasper.sh:220: chunks keyed '>name:offset', emitted per contig by walking offsets 0, bs, 2bs ..."""
+    bs = int(batch_size)
+    if bs <= 0:
+        bs = 1
+    h = {}
+    ctg, seq = None, []
+    for path in fixed_files:
+        with open(path) as f:
+            for line in f:
+                F = line.split()
+                if not F:
+                    continue
+                if F[0].startswith(">"):
+                    if seq:
+                        h[ctg] = "".join(seq)
+                        seq = []
+                    ctg = F[0]
+                else:
+                    seq.append(F[0])
+    if ctg is not None:
+        h[ctg] = "".join(seq)
+    out = []
+    keys = [c for c in h if c.endswith(":0")]
+    rank = {n: i for i, n in enumerate(contig_order)}
+    keys.sort(key=lambda c: rank.get(c[:c.rfind(":")], len(rank)))
+    for c in keys:
+        base = c[:c.rfind(":")]
+        out.append(base + "\n")
+        b = 0
+        while (base + ":%d" % b) in h:
+            out.append(h[base + ":%d" % b])
+            b += bs
+        out.append("\n")
+    return "".join(out)
+
+
+def merge_fix_csvs(csv_files):
+    """src/jasper.sh:222-226 (awk | awk -F: | sort -k1,1 -k2,2n -k3,3n | awk); byte order for the name key"""
+    lines = []
+    for n, path in enumerate(csv_files):
+        with open(path, "r", newline="") as f:
+            content = f.read().split("\n")
+        if content and content[-1] == "":
+            content.pop()
+        for fnr, ln in enumerate(content, start=1):
+            if (n == 0 and fnr == 1) or fnr > 1:
+                lines.append(ln)
+    rows = []
+    for ln in lines:
+        parts = ln.split(":")
+        s = parts[0] + " " + (parts[1] if len(parts) > 1 else "")
+        rows.append(s)
+
+    def num(x):
+        m = re.match(r"\s*-?\d+", x)
+        return int(m.group(0)) if m else 0
+
+    def key(s):
+        F = s.split()
+        return (F[0].encode() if F else b"", num(F[1]) if len(F) > 1 else 0, num(F[2]) if len(F) > 2 else 0)
+
+    rows.sort(key=key)
+    out = []
+    for s in rows:
+        F = s.split()
+        F += [""] * (5 - len(F))
+        out.append("%s:%s %s %s %s\n" % (F[0], F[1], F[2], F[3], F[4]))
+    return "".join(out)
+
+
+def run(argv):
+    o = parse_args(argv)
+    if not (os.path.isfile(o.query) and os.path.getsize(o.query) > 0):
+        error_exit("The query file does not exist. Please supply a valid fasta file to be polished with -a option.")
+    batch_size = o.batch_size
+    if not re.match(r"^[0-9]+$", str(batch_size)):
+        log("BATCH SIZE supplied is not a positive integer. Calculating BATCH SIZE from QUERY SIZE")
+        batch_size = "0"
+    batch_size = int(batch_size)
+    try:
+        nthreads = float(o.num_threads)
+        bs = int(sequence_bytes(o.query) / nthreads * .9)               # :132
+    except (ValueError, ZeroDivisionError):
+        error_exit("The number of threads supplied by -t must be a positive integer")
+    if bs > batch_size:                                                 # :133-138
+        batch_size = bs
+        if batch_size > MAX_BATCH_SIZE:
+            batch_size = MAX_BATCH_SIZE
+    log("Using BATCH SIZE %d" % batch_size)
+    if not re.match(r"^-?[0-9]+$", str(o.passes)) or int(o.passes) - 1 < 0:
+        error_exit("The number of passes supplied by -p must be a positive integer")
+    if not re.match(r"^-?[0-9]+$", str(o.kmer)) or int(o.kmer) - 1 < 0:
+        error_exit("The k-mer size supplied by -k must be a positive integer")
+    passes, kmer = int(o.passes), int(o.kmer)
+    last_it = passes - 1
+    qfn = o.query_fn
+    contigs = None
+
+    if not os.path.exists("jasper.split.success"):                      # :152-159
+        log("Splitting query into batches for parallel execution")
+        for p in glob.glob("%s.batch.*.fa" % glob.escape(qfn)):
+            os.remove(p)
+        try:
+            contigs = read_assembly(o.query)
+            split_batches(contigs, batch_size, qfn)
+        except OSError:
+            error_exit("Splitting files failed, do you have enough disk space?")
+        if os.path.exists("jasper.correct.success"):
+            os.remove("jasper.correct.success")
+        open("jasper.split.success", "w").close()
+
+    table = None
+    histo_file = "jfhisto%d.csv" % kmer
+    if o.jf_db is None:                                                 # :162-185
+        reads = o.reads.split()
+        for fn in reads:
+            if not (os.path.isfile(fn) and os.path.getsize(fn) > 0):
+                error_exit("The reads file  %s does not exist. Please supply a series of valid reads files separated by space and wrapped in one pair of quotation marks." % fn)
+        log("Creating jellyfish database mer_counts%d.jf" % kmer)
+        table = KmerTable(kmer, min_slots=max(1 << 20, 2 * o.jf_size), device=o.device)
+        table.count_files(reads)
+        with open(histo_file + ".tmp", "w") as f:
+            for m, n in table.histo_rows():
+                f.write("%d %d\n" % (m, n))
+        os.replace(histo_file + ".tmp", histo_file)
+        open("jasper.no_cat.success", "w").close()
+        open("jasper.histo.success", "w").close()
+        if os.path.exists("jasper.correct.success"):
+            os.remove("jasper.correct.success")
+    else:
+        error_exit("Reading an existing Jellyfish database (-j) is not implemented in this build; pass the reads with -r")
+
+    if not os.path.exists("jasper.correct.success"):                    # :195-216
+        log("Polishing")
+        txt, status = polisher.threshold_from_histo_file(histo_file)
+        if status == 0:
+            with open("threshold.txt.tmp", "w") as f:
+                f.write(txt)
+            os.replace("threshold.txt.tmp", "threshold.txt")
+        if not (os.path.isfile("threshold.txt") and os.path.getsize("threshold.txt") > 0):
+            error_exit("Local min of kmer counts is smaller than 4. The input read data is not suitable for polishing.")
+        thresh = int(open("threshold.txt").read().split()[0])
+        log("Lower threshold for unreliable kmers is %d" % thresh)
+        batch_files = sorted(glob.glob("%s.batch.*.fa" % glob.escape(qfn)))   # `ls` order
+        for bf in batch_files:
+            polisher.main(None, bf, kmer, True, True, bf + ".fix.csv", bf + ".fixed.fa.tmp", table, thresh, passes)
+            os.replace("_iter%d_%s.fixed.fa.tmp" % (last_it, bf), "_iter%d_%s.fixed.fa" % (last_it, bf))
+        if os.path.exists("jasper.join.success"):
+            os.remove("jasper.join.success")
+        open("jasper.correct.success", "w").close()
+
+    if not os.path.exists("jasper.join.success"):                       # :218-232
+        log("Joining")
+        if contigs is None:
+            contigs = read_assembly(o.query)
+        fixed_files = sorted(glob.glob("_iter%d_%s.batch.*.fa.fixed.fa" % (last_it, glob.escape(qfn))))
+        text = join_polished(fixed_files, batch_size, [c[0] for c in contigs])
+        with open(qfn + ".fixed.fasta.tmp", "w") as f:
+            f.write(text)
+        os.replace(qfn + ".fixed.fasta.tmp", qfn + ".polished.fasta")
+        for p in glob.glob("_iter*_%s.batch.*.fa.fixed.fa" % glob.escape(qfn)) + glob.glob("_iter*_%s.batch.*.fa.fixed.fa.tmp" % glob.escape(qfn)):
+            os.remove(p)
+        csvs = sorted(glob.glob("_iter*_%s.batch.*.fa.fix.csv" % glob.escape(qfn)))
+        with open(qfn + ".fixes.csv.tmp", "w", newline="") as f:
+            f.write(merge_fix_csvs(csvs))
+        os.replace(qfn + ".fixes.csv.tmp", qfn + ".fixes.csv")
+        open("jasper.join.success", "w").close()
+        if not o.debug:
+            for p in csvs + glob.glob("%s.batch.*.fa" % glob.escape(qfn)):
+                if os.path.exists(p):
+                    os.remove(p)
+
+    # QV (:235-257)
+    def colsum(path):
+        a = b = 0
+        with open(path) as f:
+            for ln in f:
+                F = ln.split()
+                if len(F) >= 2:
+                    a += int(F[0]); b += int(F[1])
+        return a, b
+    if os.path.exists("0qValCalcHelper.csv") and os.path.exists("%dqValCalcHelper.csv" % passes):
+        b0, t0 = colsum("0qValCalcHelper.csv")
+        b1, t1 = colsum("%dqValCalcHelper.csv" % passes)
+        log("Before Polishing: Q value = %s" % qv.q_value(b0, t0, kmer))
+        log("After Polishing: Q value = %s" % qv.q_value(b1, t1, kmer))
+        for p in glob.glob("*qValCalcHelper.csv"):
+            os.remove(p)
+    log("Polished sequence is in %s.polished.fasta" % qfn)
+    if table is not None:
+        table.close()
+    return 0
+
+
+def main():
+    sys.exit(run(sys.argv[1:]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,766 @@
+// polish.hip -- the assembly scan / lookup / fix loop on the GPU.
+//
+// One 64-lane wavefront walks one chunk record (">name:offset", src/jasper.sh:155) through one pass of
+// src/jasper.py:iteration.  The walk is sequential by definition (the next position depends on the last
+// repair), so parallelism comes from three places:
+//   * chunks are independent (the reference's own xargs -P parallelism, src/jasper.sh:212): one wave each;
+//   * inside a chunk the wave evaluates 64 stride positions i, i+(k-1), ... at once, ballots "needs
+//     attention" and jumps to the first such position (positions that are plainly good only ever do
+//     `i += k-1`, src/jasper.py:97,100);
+//   * inside a repair the independent lookups (backward/forward run scans, check_sequence samples, dense
+//     bad-k-mer counts, the four extensions of every live path) are spread over the lanes and reduced by
+//     ballot / popcount.
+// Everything else is executed uniformly by all 64 lanes (same values in every lane), i.e. as scalar code.
+// The chunk text lives in a gap buffer in HBM so that `seq = seq[:a] + patch + seq[b:]` costs O(distance).
+//
+// Reference lines are cited as src/jasper.py:N.  Lookups go to the HBM table with the truncate-and-pad
+// semantics of MerDNA(str) (Appendix A.3 of SURVEY.md; JF::include/jellyfish/mer_dna.hpp:525-542).
+#include "polish.hpp"
+
+namespace jk {
+
+constexpr int SMAX = 384;  // longest trial string kept in LDS (k <= 64: < 4k + 64)
+
+__device__ __forceinline__ void pyslice(int64_t len, int64_t a, int64_t b, int64_t &lo, int64_t &hi) {
+    if (a < 0) { a += len; if (a < 0) a = 0; } else if (a > len) a = len;
+    if (b < 0) { b += len; if (b < 0) b = 0; } else if (b > len) b = len;
+    if (b < a) b = a;
+    lo = a; hi = b;
+}
+
+// Python round(): half-to-even on the double (device rint under the default rounding mode)
+__device__ __forceinline__ int64_t pyround(double x) { return (int64_t)rint(x); }
+
+struct FrontEntry {       // live path of the extension search
+    uint32_t node;        // trie node of its last base
+    uint16_t tlen;        // valid bytes in tail
+    uint8_t alive;
+    uint8_t pad;
+    uint8_t tail[72];     // last min(len, k+3) bytes of start_km1 + path
+};
+static_assert(sizeof(FrontEntry) == 80, "FrontEntry layout");
+
+struct Walker {
+    TableDev T;
+    int k, step, lane;
+    uint32_t solid;
+    uint8_t *buf;
+    int64_t len, gs, glen, cap;
+    ChunkDev *C;
+    uint32_t chunk_id;
+    uint32_t nrec, naux, seqno;
+    int pass;
+    int status;
+    uint64_t nlook;
+    uint8_t *s_tbf, *s_t1, *s_t2, *s_gkb, *s_gka;
+
+    // ---------------- text access ----------------
+    __device__ __forceinline__ uint8_t at(int64_t p) const { return buf[p < gs ? p : p + glen]; }
+
+    // qf[jf.MerDNA(seq[a:b]).get_canonical()] -- python slice semantics, per lane
+    __device__ __forceinline__ uint32_t cnt_seq(int64_t a, int64_t b) const {
+        int64_t lo, hi;
+        pyslice(len, a, b, lo, hi);
+        const u128 m = encode_padded(k, (long)(hi - lo), [&](int q) { return at(lo + q); });
+        return clamp32(table_get(T, mix(canonical(m, k), T.B)));
+    }
+    // same for a string in LDS / global scratch
+    __device__ __forceinline__ uint32_t cnt_str(const uint8_t *p, int n) const {
+        const u128 m = encode_padded(k, (long)n, [&](int q) { return p[q]; });
+        return clamp32(table_get(T, mix(canonical(m, k), T.B)));
+    }
+
+    // ---------------- gap buffer ----------------
+    __device__ void move_gap(int64_t to) {
+        if (to == gs) return;
+        if (to > gs) {  // bytes [gs+glen, to+glen) slide down to [gs, to)
+            const int64_t n = to - gs;
+            for (int64_t off = 0; off < n; off += 256) {
+                uint8_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { int64_t q = off + u * 64 + lane; v[u] = q < n ? buf[gs + glen + q] : 0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { int64_t q = off + u * 64 + lane; if (q < n) buf[gs + q] = v[u]; }
+            }
+        } else {        // bytes [to, gs) slide up to [to+glen, gs+glen), highest first
+            const int64_t n = gs - to;
+            for (int64_t off = 0; off < n; off += 256) {
+                uint8_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { int64_t q = off + u * 64 + lane; v[u] = q < n ? buf[gs - 1 - q] : 0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { int64_t q = off + u * 64 + lane; if (q < n) buf[gs + glen - 1 - q] = v[u]; }
+            }
+        }
+        gs = to;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    // seq = seq[:a] + patch + seq[b:]   (0 <= a <= b <= len), patch readable by every lane
+    __device__ void replace(int64_t a, int64_t b, const uint8_t *patch, int64_t plen) {
+        move_gap(a);
+        glen += (b - a);
+        if (glen < plen) { status = PS_GAP_EXHAUSTED; return; }
+        for (int64_t q = lane; q < plen; q += 64) buf[gs + q] = patch[q];
+        gs += plen;
+        glen -= plen;
+        len += plen - (b - a);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+
+    // ---------------- LDS string helpers (lane-parallel copies, then a wave barrier) ----------------
+    __device__ __forceinline__ void cp_seq(uint8_t *dst, int64_t lo, int64_t hi) const {
+        for (int64_t q = lane; q < hi - lo; q += 64) dst[q] = at(lo + q);
+    }
+    __device__ __forceinline__ void cp_mem(uint8_t *dst, const uint8_t *src, int n) const {
+        for (int q = lane; q < n; q += 64) dst[q] = src[q];
+    }
+    __device__ __forceinline__ void put(uint8_t *dst, uint8_t c) const { if (lane == 0) *dst = c; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+
+    // ---------------- src/jasper.py:585-599 check_sequence ----------------
+    // samples: trial[:k], trial[-k:], trial[i:i+k] for i in range(step, len-k, step); all must be >= thr
+    __device__ bool check_sequence(const uint8_t *t, int n, uint32_t thr) {
+        const int nmid = (n - k > step) ? (n - k - step + step - 1) / step : 0;  // len(range(step, n-k, step))
+        const int jobs = 2 + nmid;
+        bool ok = true;
+        for (int base = 0; base < jobs; base += 64) {
+            const int j = base + lane;
+            bool bad = false;
+            if (j < jobs) {
+                uint32_t c;
+                if (j == 0) c = cnt_str(t, n < k ? n : k);
+                else if (j == 1) { int lo = n > k ? n - k : 0; c = cnt_str(t + lo, n - lo); }
+                else { int i = step * (j - 1); c = cnt_str(t + i, k); }
+                bad = c < thr;
+            }
+            if (__ballot(bad)) ok = false;
+        }
+        nlook += (uint64_t)jobs;
+        return ok;
+    }
+    // number of windows of t (all n-k+1 of them) whose count is below thr
+    __device__ int dense_bad(const uint8_t *t, int n, uint32_t thr) {
+        int bad = 0;
+        const int nw = n - k + 1;
+        for (int base = 0; base < nw; base += 64) {
+            const int i = base + lane;
+            bool b = false;
+            if (i < nw) b = cnt_str(t + i, k) < thr;
+            bad += __popcll(__ballot(b));
+        }
+        if (nw > 0) nlook += (uint64_t)nw;
+        return bad;
+    }
+
+    // ---------------- fix records ----------------
+    __device__ void emit(uint8_t kind, int64_t index, uint8_t newc, uint8_t oldc, uint32_t rep, uint32_t aux_off, uint32_t aux_len) {
+        if (nrec >= C->rec_cap) { status = PS_REC_OVERFLOW; return; }
+        if (lane == 0) {
+            FixRec r;
+            r.index = index; r.chunk = chunk_id; r.seqno = seqno; r.pass = (uint8_t)pass; r.kind = kind;
+            r.newc = newc; r.oldc = oldc; r.rep = rep; r.aux_off = aux_off; r.aux_len = aux_len;
+            C->recs[nrec] = r;
+        }
+        nrec++;
+        seqno++;
+    }
+
+    // ---------------- repairs (src/jasper.py:392-524). tbf = to_be_fixed in s_tbf, length L. Output in s_t1. --------
+    // fix_k_case_sub :392-406
+    __device__ uint8_t fix_k_case_sub(int L, uint32_t thr, int &outlen) {
+        const uint8_t bad = s_tbf[k - 1];
+        const char *order = "ACTG";
+        for (int b = 0; b < 4; ++b) {
+            if ((uint8_t)order[b] == bad) continue;
+            cp_mem(s_t1, s_tbf, L);
+            sync();
+            put(s_t1 + k - 1, (uint8_t)order[b]);
+            sync();
+            if (check_sequence(s_t1, L, thr)) { outlen = L; return (uint8_t)order[b]; }
+            sync();
+        }
+        return 0;
+    }
+    // fix_insert :409-419
+    __device__ uint8_t fix_insert(int L, uint32_t thr, int &outlen) {
+        cp_mem(s_t1, s_tbf, k - 1);
+        cp_mem(s_t1 + k - 1, s_tbf + k, L - k);
+        sync();
+        if (check_sequence(s_t1, L - 1, thr)) { outlen = L - 1; return s_tbf[k - 1]; }
+        sync();
+        return 0;
+    }
+    // fix_del :422-431
+    __device__ uint8_t fix_del(int L, uint32_t thr, int &outlen) {
+        const char *order = "ATCG";
+        for (int a = 0; a < 4; ++a) {
+            cp_mem(s_t1, s_tbf, k - 1);
+            cp_mem(s_t1 + k, s_tbf + k - 1, L - (k - 1));
+            put(s_t1 + k - 1, (uint8_t)order[a]);
+            sync();
+            if (check_sequence(s_t1, L + 1, thr)) { outlen = L + 1; return (uint8_t)order[a]; }
+            sync();
+        }
+        return 0;
+    }
+    // fixdiploid :340-382. returns 0, 's' or 'e'
+    __device__ uint8_t fixdiploid(int L, uint32_t thr, int64_t gb, int64_t ga, uint8_t &left, uint8_t &right, int &outlen) {
+        const uint8_t left_bad = s_tbf[L - k], right_bad = s_tbf[k - 1];
+        int64_t gbsi = gb - k + 1; if (gbsi < 0) gbsi = 0;
+        const int64_t h = (int64_t)((double)(k - 1 - L + k) / 2.0);
+        int64_t alo, ahi, blo, bhi;
+        if (ga + k - 1 + h < len) pyslice(len, ga + k - 1, ga + k - 1 + h, alo, ahi);
+        else { int64_t st = ga + k - 1; if (st > len - 1) st = len - 1; pyslice(len, st, len, alo, ahi); }
+        const int64_t before_len = ahi - alo;
+        int64_t bs = gbsi - before_len + 1; if (bs < 0) bs = 0;
+        pyslice(len, bs, gbsi + 1, blo, bhi);
+        const int nb = (int)(bhi - blo), na = (int)(ahi - alo);
+        if (nb + L + na > SMAX) { status = PS_STRING_TOO_LONG; return 0; }
+        const char *order = "ACTG";
+        for (int xi = 0; xi < 4; ++xi)
+            for (int yi = 0; yi < 4; ++yi) {
+                const uint8_t x = (uint8_t)order[xi], y = (uint8_t)order[yi];
+                if (x == left_bad && y == right_bad) continue;
+                if (x != left_bad && y != right_bad) continue;
+                // trial = tbf[:L-k] + x + tbf[L-k+1:k-1] + y + tbf[k:]   (python slices; L-k+1 <= k-1 here)
+                int n = 0;
+                int64_t a0, a1;
+                pyslice(L, 0, L - k, a0, a1); cp_mem(s_t1 + n, s_tbf + a0, (int)(a1 - a0)); n += (int)(a1 - a0);
+                put(s_t1 + n, x); n += 1;
+                pyslice(L, L - k + 1, k - 1, a0, a1); cp_mem(s_t1 + n, s_tbf + a0, (int)(a1 - a0)); n += (int)(a1 - a0);
+                put(s_t1 + n, y); n += 1;
+                pyslice(L, k, L, a0, a1); cp_mem(s_t1 + n, s_tbf + a0, (int)(a1 - a0)); n += (int)(a1 - a0);
+                sync();
+                cp_seq(s_t2, blo, bhi);
+                cp_mem(s_t2 + nb, s_t1, n);
+                cp_seq(s_t2 + nb + n, alo, ahi);
+                sync();
+                const bool ok = check_sequence(s_t2, nb + n + na, thr);
+                sync();
+                if (ok) { left = x; right = y; outlen = n; return (x == left_bad) ? (uint8_t)'e' : (uint8_t)'s'; }
+            }
+        return 0;
+    }
+    // fix_same_base_del :434-477. returns true; ridx, rbase, rrep; output in s_t1
+    __device__ bool fix_same_base_del(int L, uint32_t thr, int &ridx, uint8_t &rbase, int &rrep, int &outlen) {
+        if (thr > solid) return false;
+        const uint8_t sb = s_tbf[k - 2];
+        int inserted = 0;
+        const int original_bad = L - k + 1;
+        int current_bad = original_bad;
+        const int max_ins = original_bad;
+        if (L + max_ins > SMAX) { status = PS_STRING_TOO_LONG; return false; }
+        while (inserted < max_ins) {
+            // trial = tbf[:k-1] + sb*(inserted+1) + tbf[k-1:]
+            inserted++;
+            const int n = L + inserted;
+            cp_mem(s_t1, s_tbf, k - 1);
+            for (int q = lane; q < inserted; q += 64) s_t1[k - 1 + q] = sb;
+            cp_mem(s_t1 + k - 1 + inserted, s_tbf + k - 1, L - (k - 1));
+            sync();
+            const int new_bad = dense_bad(s_t1, n, thr);
+            sync();
+            if (new_bad == 0) { ridx = k - 1; rbase = sb; rrep = inserted; outlen = n; return true; }
+            if (new_bad >= current_bad) break;
+            current_bad = new_bad;
+        }
+        const char *order = "ATCG";
+        for (int a = 0; a < 4; ++a) {
+            cp_mem(s_t1, s_tbf, k - 2);
+            put(s_t1 + k - 2, (uint8_t)order[a]);
+            cp_mem(s_t1 + k - 1, s_tbf + k - 2, L - (k - 2));
+            sync();
+            const bool ok = check_sequence(s_t1, L + 1, thr);
+            sync();
+            if (ok) { ridx = k - 2; rbase = (uint8_t)order[a]; rrep = 1; outlen = L + 1; return true; }
+        }
+        return false;
+    }
+    // fix_same_base_insertion :479-524
+    __device__ bool fix_same_base_insertion(int L, uint32_t thr, int &ridx, uint8_t &rbase, int &rrep, int &outlen) {
+        if (thr > solid) return false;
+        const uint8_t sb = s_tbf[k - 1];
+        int deleted = 0;
+        const int original_bad = L - k + 1;
+        int current_bad = original_bad;
+        const int max_del = original_bad;
+        while (deleted < max_del) {  // (tbf[k-1] == sb is always true, :494)
+            current_bad -= 1;
+            deleted += 1;
+            // local = tbf[:k-1] + tbf[k-1+deleted:]
+            const int n = L - deleted;
+            if (n < k - 1) break;
+            cp_mem(s_t1, s_tbf, k - 1);
+            cp_mem(s_t1 + k - 1, s_tbf + k - 1 + deleted, n - (k - 1));
+            sync();
+            if (n == k) { sync(); break; }
+            const int new_bad = dense_bad(s_t1, n, thr);
+            sync();
+            if (new_bad == 0) { ridx = k - 1; rbase = sb; rrep = deleted; outlen = n; return true; }
+            if (new_bad >= current_bad) break;
+            current_bad = new_bad;
+        }
+        for (int i = L - k; i < L - 1; ++i) {
+            if (i < 0) continue;
+            cp_mem(s_t1, s_tbf, i);
+            cp_mem(s_t1 + i, s_tbf + i + 1, L - i - 1);
+            sync();
+            const bool ok = check_sequence(s_t1, L - 1, thr);
+            sync();
+            if (ok) { ridx = i; rbase = s_tbf[i]; rrep = 1; outlen = L - 1; return true; }
+        }
+        return false;
+    }
+
+    // ---------------- src/jasper.py:527-583 base_extension ----------------
+    // gkb / gka in s_gkb / s_gka (lengths nb, na). Returns patch length (patch in C->patch) or -1 for None.
+    __device__ int64_t base_extension(int64_t Ltbf, int nb, int na, uint32_t thr) {
+        if (nb < k || na < k || thr > solid) return -1;
+        const int64_t min_overlap = 5, slack = 10;
+        const int64_t max_ext = pyround((double)(Ltbf - 2 * k) * 1.2) + min_overlap + slack;
+        const int64_t min_patch_len = pyround((double)(Ltbf - 2 * k) / 1.2) - slack;
+        FrontEntry *F = reinterpret_cast<FrontEntry *>(C->front);
+        const uint32_t fcap = C->front_cap;
+        uint32_t *nodes = C->nodes;
+        uint32_t nn = 1;            // node 0 = the initial one-base path (last base of the good k-mer before)
+        uint32_t np = 1;
+        const int TCAP = k + 3;
+        if (lane == 0) {
+            nodes[0] = 0;
+            F[0].node = 0; F[0].tlen = (uint16_t)k; F[0].alive = 1; F[0].pad = 0;
+        }
+        for (int q = lane; q < k; q += 64) F[0].tail[q] = s_gkb[q];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const int glo = (k > 5) ? 5 : (k == 5 ? 0 : 5 - k);   // good_k_mer_after[-(k-5):]
+        for (int64_t i = 1; i < max_ext; ++i) {
+            // paths = [l for l in paths if len(l) > 0]   (:542) -- order-preserving in-place compaction
+            uint32_t w = 0;
+            for (uint32_t base = 0; base < np; base += 64) {
+                const uint32_t e = base + lane;
+                FrontEntry fe;
+                bool alive = false;
+                if (e < np) { fe = F[e]; alive = fe.alive != 0; }
+                const uint64_t m = __ballot(alive);
+                const uint32_t dst = w + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (alive && dst != e) F[dst] = fe;
+                w += (uint32_t)__popcll(m);
+            }
+            np = w;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (np > 5000) return -1;                                            // :543-546
+            if (np == 0) continue;  // nothing left: the python loop just spins to max_ext and returns None
+            const uint32_t last_path = np;
+            for (uint32_t g = 0; g < last_path; g += 16) {
+                // 16 paths x 4 bases per round: score = qf[km1 + bases[j]]     (:551-554)
+                const uint32_t pp = g + (uint32_t)(lane >> 2);
+                const int jj = lane & 3;
+                uint32_t score = 0;
+                if (pp < last_path) {
+                    const FrontEntry *fe = &F[pp];
+                    const int tl = fe->tlen;
+                    const uint8_t bj = (uint8_t)("ACGT"[jj]);
+                    const u128 m = encode_padded(k, (long)k, [&](int q) { return q < k - 1 ? fe->tail[tl - (k - 1) + q] : bj; });
+                    score = clamp32(table_get(T, mix(canonical(m, k), T.B)));
+                }
+                const uint32_t gend = (last_path - g) < 16u ? (last_path - g) : 16u;
+                nlook += 4ull * gend;
+                for (uint32_t q = 0; q < gend; ++q) {
+                    const uint32_t p = g + q;
+                    int ext = -1;                      // first base that extended this path
+                    const uint32_t pnode = F[p].node;  // uniform loads
+                    const int tl = F[p].tlen;
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t sc = __shfl(score, (int)(q * 4 + j));
+                        if (sc < thr) continue;
+                        const uint8_t bj = (uint8_t)("ACGT"[j]);
+                        if (i >= min_overlap && i >= min_patch_len) {           // :557
+                            // last_bases[-5:] == good_k_mer_after[0:5]         (:558) ; last_bases = km1 + base
+                            bool same = true;
+                            for (int u = 0; u < 4; ++u) same = same && (F[p].tail[tl - 4 + u] == s_gka[u]);
+                            same = same && (bj == s_gka[4]);
+                            if (same) {
+                                // path_connected = (start_km1 + path_before + base + gka[-(k-5):])[-(2k-1):]  (:560/:563)
+                                int n = 0;
+                                const int take = tl < TCAP ? tl : TCAP;
+                                cp_mem(s_t1, F[p].tail + (tl - take), take); n += take;
+                                put(s_t1 + n, bj); n += 1;
+                                cp_mem(s_t1 + n, s_gka + glo, k - glo); n += k - glo;
+                                sync();
+                                const int off = n > 2 * k - 1 ? n - (2 * k - 1) : 0;
+                                const bool ok = check_sequence(s_t1 + off, n - off, thr);   // :567
+                                sync();
+                                if (ok) {
+                                    if (i == min_overlap) return -1;                          // :568-571 "patch empty"
+                                    // return_path = (path_before + base)[1:-5]  = path_before[1 : i-4]   (:561/:564)
+                                    const int64_t plen = i - 5;
+                                    if (plen > (int64_t)C->patch_cap) { status = PS_BFS_ARENA; return -1; }
+                                    if (lane == 0) {
+                                        uint32_t nd = pnode;
+                                        for (int u = 0; u < 4; ++u) nd = nodes[nd] >> 2;          // drop path[i-1..i-4]
+                                        for (int64_t u = plen - 1; u >= 0; --u) {
+                                            C->patch[u] = (uint8_t)("ACGT"[nodes[nd] & 3u]);
+                                            nd = nodes[nd] >> 2;
+                                        }
+                                    }
+                                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                                    return plen;
+                                }
+                            }
+                        }
+                        if (ext < 0) {
+                            ext = j;                                                          // :576-578 (applied below)
+                        } else {                                                              // :579-580 sibling
+                            if (np >= fcap || nn >= C->node_cap) { status = PS_BFS_ARENA; return -1; }
+                            if (lane == 0) nodes[nn] = (pnode << 2) | (uint32_t)j;
+                            // sibling tail = tail_before + base
+                            const int keep = tl < TCAP ? tl : TCAP - 1;
+                            for (int u = lane; u < keep; u += 64) F[np].tail[u] = F[p].tail[tl - keep + u];
+                            if (lane == 0) {
+                                F[np].tail[keep] = bj;
+                                F[np].tlen = (uint16_t)(keep + 1); F[np].node = nn; F[np].alive = 1; F[np].pad = 0;
+                            }
+                            nn++; np++;
+                        }
+                    }
+                    // apply the first extension to the path itself, or kill it                (:576-578,:581-582)
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    if (ext >= 0) {
+                        if (nn >= C->node_cap) { status = PS_BFS_ARENA; return -1; }
+                        const uint8_t bj = (uint8_t)("ACGT"[ext]);
+                        if (lane == 0) nodes[nn] = (pnode << 2) | (uint32_t)ext;
+                        if (tl < TCAP) {
+                            if (lane == 0) { F[p].tail[tl] = bj; F[p].tlen = (uint16_t)(tl + 1); F[p].node = nn; }
+                        } else {
+                            uint8_t v = 0;
+                            if (lane < TCAP - 1) v = F[p].tail[lane + 1];   // k+3 <= 67 > 64 lanes only when k > 61
+                            uint8_t v2 = 0;
+                            if (lane + 64 < TCAP - 1) v2 = F[p].tail[lane + 65];
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                            if (lane < TCAP - 1) F[p].tail[lane] = v;
+                            if (lane + 64 < TCAP - 1) F[p].tail[lane + 64] = v2;
+                            if (lane == 0) { F[p].tail[TCAP - 1] = bj; F[p].node = nn; }
+                        }
+                        nn++;
+                    } else if (lane == 0) {
+                        F[p].alive = 0;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                }
+            }
+        }
+        return -1;
+    }
+
+    // ---------------- src/jasper.py:226-332 fixing_sid ----------------
+    // tbf in s_tbf (only when n <= k), L = len(to_be_fixed). Emits records, splices the chunk.
+    __device__ void fixing_sid(int64_t L64, uint32_t thr, int64_t n, int64_t gb, int64_t ga) {
+        int64_t s0 = gb - k + 2; if (s0 < 0) s0 = 0;
+        const int L = (int)L64;
+        int outlen = 0;
+        if (n == k) {                                                          // :232
+            uint8_t b = fix_k_case_sub(L, thr, outlen);
+            if (b) {
+                emit('s', ga - 1, b, at(ga - 1), 1, 0, 0);                    // :235-237
+                replace(s0, ga + k - 1, s_t1, outlen);                        // :238
+            } else {
+                b = fix_insert(L, thr, outlen);
+                if (b) {
+                    emit('i', ga - 1, '-', at(ga - 1), 1, 0, 0);              // :242-244
+                    replace(s0, ga + k - 1, s_t1, outlen);
+                }
+            }
+        } else if (n == k - 1) {                                               // :247
+            uint8_t b = fix_del(L, thr, outlen);
+            if (b) {
+                emit('d', ga, b, '-', 1, 0, 0);                               // :250-253
+                replace(s0, ga + k - 1, s_t1, outlen);
+            } else {
+                uint8_t left = 0, right = 0;
+                const uint8_t lr = fixdiploid(L, thr, gb, ga, left, right, outlen);
+                if (lr) {
+                    if (lr == 's') emit('s', ga - 1, left, at(ga - 1), 1, 0, 0);   // :257-260
+                    else emit('s', gb + 1, right, at(gb + 1), 1, 0, 0);            // :262-264
+                    replace(s0, ga + k - 1, s_t1, outlen);
+                } else if (status == PS_OK) {
+                    int idx = 0, rep = 0; uint8_t bs = 0;
+                    if (fix_same_base_insertion(L, thr, idx, bs, rep, outlen)) {    // :267-272
+                        emit('i', idx + s0, '-', bs, (uint32_t)rep, 0, 0);
+                        replace(s0, ga + k - 1, s_t1, outlen);
+                    }
+                }
+            }
+        } else if (n < k - 1 && n > 1 && L64 >= k) {                           // :274
+            int idx = 0, rep = 0; uint8_t bs = 0;
+            if (fix_same_base_del(L, thr, idx, bs, rep, outlen)) {             // :275-280
+                emit('d', idx + s0, bs, '-', (uint32_t)rep, 0, 0);
+                replace(s0, ga + k - 1, s_t1, outlen);
+            } else if (status == PS_OK) {
+                uint8_t left = 0, right = 0;
+                const uint8_t lr = fixdiploid(L, thr, gb, ga, left, right, outlen);
+                if (lr) {
+                    if (lr == 's') emit('s', ga - 1, left, at(ga - 1), 1, 0, 0);
+                    else emit('s', gb + 1, right, at(gb + 1), 1, 0, 0);
+                    replace(s0, ga + k - 1, s_t1, outlen);
+                } else if (status == PS_OK && fix_same_base_insertion(L, thr, idx, bs, rep, outlen)) {  // :294-299
+                    emit('i', idx + s0, '-', bs, (uint32_t)rep, 0, 0);
+                    replace(s0, ga + k - 1, s_t1, outlen);
+                }
+            }
+        } else if (n > k) {                                                    // :301
+            int64_t blo, bhi, alo, ahi;
+            pyslice(len, gb - k + 1, gb + 1, blo, bhi);                        // :302
+            pyslice(len, ga, ga + k, alo, ahi);                                // :303
+            cp_seq(s_gkb, blo, bhi);
+            cp_seq(s_gka, alo, ahi);
+            sync();
+            const int64_t plen = base_extension(L64, (int)(bhi - blo), (int)(ahi - alo), thr);
+            sync();
+            if (plen >= 0 && status == PS_OK) {
+                // record: patch ++ original segment seq[gb+1:ga]; the host aligns them (src/jasper.py:309-329)
+                int64_t olo, ohi;
+                pyslice(len, gb + 1, ga, olo, ohi);
+                const int64_t on = ohi - olo;
+                if ((uint64_t)naux + (uint64_t)plen + (uint64_t)on > (uint64_t)C->aux_cap) { status = PS_AUX_OVERFLOW; return; }
+                for (int64_t q = lane; q < plen; q += 64) C->aux[naux + q] = C->patch[q];
+                for (int64_t q = lane; q < on; q += 64) C->aux[naux + plen + q] = at(olo + q);
+                emit('x', gb + 1, 0, 0, (uint32_t)on, naux, (uint32_t)plen);
+                naux += (uint32_t)(plen + on);
+                replace(gb + 1, ga, C->patch, plen);                           // :312
+            }
+        }
+    }
+
+    // ---------------- src/jasper.py:150-223 handle_bad_kmers ----------------
+    __device__ int64_t handle_bad_kmers(int64_t i, int64_t &wrong, bool fix, int64_t rolling_thre, bool &brk) {
+        brk = false;
+        uint32_t thre = solid;
+        if (rolling_thre > 0) thre = (uint32_t)rolling_thre;                   // :151-153
+        // backward: j = i-1; while cnt(seq[j:j+k]) < thre and j >= 0: j -= 1      (:155-159), 64 candidates per round
+        int64_t j = i - 1;
+        for (;;) {
+            const int64_t jl = j - lane;
+            bool stop = true;
+            if (jl >= 0) stop = !(cnt_seq(jl, jl + k) < thre);
+            // jl == -1 stops the loop whatever the count; jl < -1 is never reached
+            const uint64_t m = __ballot(stop);
+            nlook += 64;
+            if (m) { j = j - (int64_t)__builtin_ctzll(m); break; }
+            j -= 64;
+        }
+        if (j < -1) j = -1;
+        int64_t gb = j + k - 1;                                                // :160
+        uint32_t prev = cnt_seq(j, k + j);                                     // :161
+        if (j == -1) gb = -1;                                                  // :164
+        // forward (:167-178)
+        for (;;) {
+            const int64_t il = i + lane;
+            bool cont = false;
+            if (il < len - k + 1) cont = cnt_seq(il, il + k) < thre;
+            const bool giveup = cont && rolling_thre != 0 && (il - j > k);     // :173-176
+            const uint64_t m = __ballot(!cont || giveup);
+            nlook += 64;
+            if (m) {
+                const int f = (int)__builtin_ctzll(m);
+                const bool g = __shfl((int)giveup, f) != 0;
+                i += f;
+                if (g) return i + 1;
+                break;
+            }
+            i += 64;
+        }
+        int64_t ga = i;                                                        // :179
+        nlook += 4;
+        if (2ull * cnt_seq(gb - k + 2, gb + 2) < (uint64_t)solid && 2ull * cnt_seq(gb - k + 3, gb + 3) < (uint64_t)solid) {
+            // too_low_flag only (:182-183)
+        } else if (rolling_thre == 0) {                                        // :184
+            while (2ull * cnt_seq(gb - k + 2, gb + 2) >= (uint64_t)prev && gb - k + 1 < ga) {   // :185
+                if (gb == -1) break;
+                if (2ull * prev >= (uint64_t)thre && 2ull * cnt_seq(gb - k + 2, gb + 2) < (uint64_t)thre &&
+                    2ull * cnt_seq(gb - k + 3, gb + 3) < (uint64_t)thre) break;                  // :188-190
+                prev = cnt_seq(gb - k + 2, gb + 2);                            // :192
+                gb++;
+                nlook += 4;
+            }
+            if (gb >= len - 1) { brk = true; return i; }                       // :194-195
+        }
+        int64_t s0 = gb - k + 2; if (s0 < 0) s0 = 0;
+        if (s0 + k + k >= len) { brk = true; return s0 + k + k; }              // :197-198
+        {
+            // four independent lookups (:199-205), one per lane
+            uint32_t c = 0;
+            if (lane == 0) c = cnt_seq(s0 + 1, s0 + k + 1);
+            else if (lane == 1) c = cnt_seq(s0 + k - 2, s0 + k + k - 2);
+            else if (lane == 2) c = cnt_seq(s0 + k - 1, s0 + k + k - 1);
+            else if (lane == 3) c = cnt_seq(s0 + k, s0 + k + k);
+            const uint64_t lowm = __ballot(lane < 4 && c < thre) & 0xFull;
+            nlook += 4;
+            if (lowm == 0x7ull) ga = s0 + k;
+        }
+        int64_t tlo, thi;
+        pyslice(len, s0, ga + k - 1, tlo, thi);                                // :206
+        int64_t n = ga - s0; if (n < 0) n = 0;                                 // :207
+        wrong += n;
+        if (fix) {
+            if (gb < 0) return i;                                              // :211-212
+            const int64_t L = thi - tlo;
+            if (n <= k) {
+                if (L > SMAX) { status = PS_STRING_TOO_LONG; return i; }
+                cp_seq(s_tbf, tlo, thi);
+                sync();
+            }
+            fixing_sid(L, thre, n, gb, ga);                                    // :213
+            sync();
+        }
+        return i;                                                              // :223
+    }
+
+    // first position >= i on the stride i, i+(k-1), ... that is not a plain "good k-mer, i += k-1" step
+    // (src/jasper.py:97,100), or a position >= len-k+1
+    __device__ int64_t skip_good(int64_t i) {
+        const int64_t end = len - k + 1;
+        for (;;) {
+            const int64_t p = i + (int64_t)lane * (k - 1);
+            bool ev = true;
+            if (p < end) {
+                // one pass over the window: 2-bit encode + validity
+                u128 m = mk(0, 0);
+                bool valid = true;
+                for (int q = 0; q < k; ++q) {
+                    const int c = code(at(p + q));
+                    valid = valid && (c >= 0);
+                    m = bor(shl(m, 2), mk(0, (uint64_t)(c & 3)));
+                }
+                if (valid) {
+                    const uint32_t occ = clamp32(table_get(T, mix(canonical(m, k), T.B)));
+                    ev = occ < solid;
+                    if (!ev && p > 0) {
+                        const int64_t a = p - k > 0 ? p - k : 0;
+                        const int64_t b = p > k ? p : k;
+                        ev = 50ull * occ < (uint64_t)cnt_seq(a, b);            // :80
+                    }
+                }
+            }
+            const uint64_t mask = __ballot(ev);
+            nlook += 128;
+            if (mask) return i + (int64_t)__builtin_ctzll(mask) * (k - 1);
+            i += 64ll * (k - 1);
+        }
+    }
+
+    // ---------------- src/jasper.py:50-104, one chunk, one pass ----------------
+    __device__ void walk(bool fix, int64_t &wrong_out) {
+        int64_t i = 0, wrong = 0;
+        while (i < len - k + 1 && status == PS_OK) {                           // :55
+            i = skip_good(i);
+            if (i >= len - k + 1) break;
+            // the reference's own loop body at position i
+            uint8_t ch = 'A';
+            if (lane < k) ch = at(i + lane);
+            const uint64_t inwin = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+            const uint64_t mN = __ballot(ch == 'N') & inwin;                   // :57-60
+            if (mN) {
+                const int f = (int)__builtin_ctzll(mN);
+                i += f + 1;
+                if (f == 0) {  // a run of N: every further step is again "N at offset 0 -> i += 1"
+                    for (;;) {
+                        const int64_t q = i + lane;
+                        const bool stop = !(q < len - k + 1 && at(q) == 'N');
+                        const uint64_t m = __ballot(stop);
+                        if (m) { i += (int64_t)__builtin_ctzll(m); break; }
+                        i += 64;
+                    }
+                }
+                continue;
+            }
+            const uint64_t mn = __ballot(ch == 'n') & inwin;                   // :61-64
+            if (mn) { i += (int64_t)__builtin_ctzll(mn) + 1; continue; }
+            const uint64_t mo = __ballot(code(ch) < 0) & inwin;                // :65-68
+            if (mo) { i += 1; continue; }
+            const uint32_t occ = cnt_seq(i, i + k);                            // :70-71
+            nlook += 1;
+            bool brk = false;
+            if (occ < solid) {                                                 // :73
+                i = handle_bad_kmers(i, wrong, fix, 0, brk);
+                if (brk) break;
+                continue;
+            }
+            bool cond2 = false;
+            if (i > 0) {                                                       // :80
+                const int64_t a = i - k > 0 ? i - k : 0;
+                const int64_t b = i > k ? i : k;
+                cond2 = 50ull * occ < (uint64_t)cnt_seq(a, b);
+                nlook += 1;
+            }
+            if (!cond2) { i += k - 1; continue; }                              // :100
+            // rolling mean of the counts sampled every `step` over the previous k positions (:82-89)
+            int64_t ind0 = i - k > 0 ? i - k : 0;
+            int64_t num = (i - ind0 + step - 1) / step;                        // iterations of `while ind < i`
+            double sum = 0.0;
+            for (int64_t base = 0; base < num; base += 64) {
+                const int64_t t = base + lane;
+                unsigned long long c = 0;
+                if (t < num) { const int64_t ind = ind0 + (t + 1) * step; c = cnt_seq(ind, ind + k); }
+                // exact integer sum across lanes
+                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+                sum += (double)c;
+            }
+            nlook += (uint64_t)num;
+            const int64_t rolling = pyround(sum / (double)num / 50.0);        // :89
+            if ((int64_t)occ < rolling) {                                      // :90
+                i = handle_bad_kmers(i, wrong, fix, pyround(sum / (double)num / 2.0), brk);   // :93
+                if (brk) break;
+            } else {
+                i += k - 1;                                                    // :97
+            }
+        }
+        wrong_out = wrong;
+    }
+};
+
+__global__ __launch_bounds__(64) void polish_kernel(TableDev T, ChunkDev *chunks, int n_chunks, PolishParams P, int pass) {
+    __shared__ uint8_t s_tbf[SMAX], s_t1[SMAX], s_t2[SMAX], s_gkb[64], s_gka[64];
+    const int c = blockIdx.x;
+    if (c >= n_chunks) return;
+    ChunkDev *C = &chunks[c];
+    if (C->status != PS_OK) return;
+    Walker w;
+    w.T = T; w.k = P.k; w.step = P.step; w.lane = threadIdx.x; w.solid = P.solid;
+    w.buf = C->buf; w.len = C->len; w.gs = C->gs; w.glen = C->glen; w.cap = C->cap;
+    w.C = C; w.chunk_id = (uint32_t)c; w.nrec = C->nrec; w.naux = C->naux; w.seqno = 0; w.pass = pass;
+    w.status = PS_OK; w.nlook = 0;
+    w.s_tbf = s_tbf; w.s_t1 = s_t1; w.s_t2 = s_t2; w.s_gkb = s_gkb; w.s_gka = s_gka;
+    const bool fix = P.fix && pass < P.passes;                                 // src/jasper.py:37-38
+    const int64_t total = w.len - P.k + 1;                                     // :51 (may be negative)
+    int64_t wrong = 0;
+    w.walk(fix, wrong);
+    if (threadIdx.x == 0) {
+        C->len = w.len; C->gs = w.gs; C->glen = w.glen;
+        C->nrec = w.nrec; C->naux = w.naux; C->status = w.status;
+        C->lookups += w.nlook;
+        if (pass == 0) { C->wrong[0] = wrong; C->total[0] = total; }           // :107-111
+        if (pass == P.passes) { C->wrong[1] = wrong; C->total[1] = total; }
+    }
+}
+
+// gather every chunk's logical text (left part ++ right part of its gap buffer) into one output buffer
+__global__ __launch_bounds__(256) void pack_kernel(const ChunkDev *chunks, int n_chunks, uint8_t *out, const int64_t *out_off) {
+    for (int c = blockIdx.y; c < n_chunks; c += gridDim.y) {
+        const ChunkDev C = chunks[c];
+        uint8_t *dst = out + out_off[c];
+        for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < C.len; q += (int64_t)gridDim.x * blockDim.x)
+            dst[q] = C.buf[q < C.gs ? q : q + C.glen];
+    }
+}
+
+void launch_polish_pass(const TableDev &T, ChunkDev *d_chunks, int n_chunks, PolishParams pp, int pass, hipStream_t stream) {
+    if (n_chunks <= 0) return;
+    hipLaunchKernelGGL(polish_kernel, dim3(n_chunks), dim3(64), 0, stream, T, d_chunks, n_chunks, pp, pass);
+}
+
+void launch_pack(ChunkDev *d_chunks, int n_chunks, uint8_t *d_out, const int64_t *d_out_off, hipStream_t stream) {
+    if (n_chunks <= 0) return;
+    dim3 grid(64, n_chunks < 1024 ? n_chunks : 1024);
+    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, stream, d_chunks, n_chunks, d_out, d_out_off);
+}
+
+}  // namespace jk

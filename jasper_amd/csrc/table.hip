@@ -1,0 +1,468 @@
+// table.hip -- kernels and host logic of the HBM k-mer count table (see table.hpp for what it replaces).
+//
+// Kernels (all integer / byte work, HBM-bound, no MFMA):
+//   count_kernel     K1+K2  bases -> rolling canonical k-mers -> insert-or-increment
+//   lookup_kernel    K4     strings -> padded canonical k-mer -> exact count (clamped to 2^32-1)
+//   histo_kernel     K3     slots -> 10002-bin multiplicity histogram (LDS-privatised bins)
+//   export / import  C1     table <-> list of (hash, count) for growth and for the multi-GPU merge
+#include "table.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace jk {
+
+#define HIPCHK(x)                                                                     \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            err = std::string(#x) + ": " + hipGetErrorString(e_);                     \
+            return -1;                                                                \
+        }                                                                             \
+    } while (0)
+
+// --------------------------------------------------------------------------------------------------
+// K1+K2: counting.  One block stages a tile of TILE bases (+64 bases of left halo) into LDS as 2-bit
+// codes and an "invalid" bit per base; thread t then owns the 16 windows that END at tile bases
+// 16t..16t+15 and rolls the forward and reverse-complement k-mers across them, exactly the recurrence of
+// JF::include/jellyfish/mer_iterator.hpp:66-77 (valid code -> shift both mers, anything else -> reset).
+// Global reads are 16 B per lane, fully coalesced; table traffic is one random 16-B slot per k-mer.
+// --------------------------------------------------------------------------------------------------
+constexpr int CT_THREADS = 256;
+constexpr int CT_GROUP = 16;                       // bases per thread
+constexpr int CT_TILE = CT_THREADS * CT_GROUP;     // 4096 bases per block iteration
+constexpr int CT_HALO = 4;                         // 4 groups = 64 bases >= k-1
+
+__device__ __forceinline__ void pack16(const uint8_t *b16, uint32_t &codes, uint32_t &inv) {
+    codes = 0;
+    inv = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        int c = code(b16[j]);
+        codes = (codes << 2) | (uint32_t)(c & 3);
+        inv = (inv << 1) | (uint32_t)(c < 0);
+    }
+}
+
+// load group g (16 bases starting at absolute position pos, may be negative / beyond n) and pack it
+__device__ __forceinline__ void stage_group(const uint8_t *__restrict__ bases, int64_t pos, uint64_t n, bool aligned,
+                                            uint32_t &codes, uint32_t &inv) {
+    uint8_t b[16];
+    if (pos >= 0 && (uint64_t)pos + 16 <= n && aligned) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(bases + pos);
+        *reinterpret_cast<uint4 *>(b) = v;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int64_t p = pos + j;
+            b[j] = (p >= 0 && (uint64_t)p < n) ? bases[p] : (uint8_t)'N';
+        }
+    }
+    pack16(b, codes, inv);
+}
+
+// `emit_from`: only windows ENDING at piece position >= emit_from are counted (pieces overlap by k-1 bases
+// plus alignment padding; the overlap belongs to the previous piece).
+__global__ __launch_bounds__(CT_THREADS) void count_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t ntiles,
+                                                            uint64_t emit_from, TableDev T) {
+    __shared__ uint32_t s_code[CT_THREADS + CT_HALO];
+    __shared__ uint32_t s_inv[CT_THREADS + CT_HALO];
+    const int t = threadIdx.x;
+    const int k = T.k;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
+    const u128 kmask = maskbits(2 * k);
+    unsigned long long added = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base0 = (int64_t)(tile * CT_TILE);
+        uint32_t c, iv;
+        stage_group(bases, base0 + (int64_t)t * CT_GROUP, n, aligned, c, iv);
+        s_code[t + CT_HALO] = c;
+        s_inv[t + CT_HALO] = iv;
+        if (t < CT_HALO) {
+            uint32_t hc, hiv;
+            stage_group(bases, base0 - (int64_t)(CT_HALO - t) * CT_GROUP, n, aligned, hc, hiv);
+            s_code[t] = hc;
+            s_inv[t] = hiv;
+        }
+        __syncthreads();
+        // the 64 bases before my group, oldest in the high bits
+        const uint32_t w4 = s_code[t], w3 = s_code[t + 1], w2 = s_code[t + 2], w1 = s_code[t + 3];
+        const uint64_t ivprev = ((uint64_t)s_inv[t] << 48) | ((uint64_t)s_inv[t + 1] << 32) | ((uint64_t)s_inv[t + 2] << 16) |
+                                (uint64_t)s_inv[t + 3];
+        const uint32_t own = c, owninv = iv;
+        __syncthreads();  // LDS is free for the next tile from here on
+        u128 fwd = band(mk(((uint64_t)w4 << 32) | w3, ((uint64_t)w2 << 32) | w1), kmask);
+        u128 rc = revcomp(fwd, k);
+        int run = ivprev ? (int)__builtin_ctzll(ivprev) : 64;  // valid bases in a row ending just before my group
+        if (owninv == 0xFFFFu) continue;                       // nothing but separators / padding here
+#pragma unroll 4
+        for (int j = 0; j < CT_GROUP; ++j) {
+            const uint32_t cj = (own >> (30 - 2 * j)) & 3u;
+            const bool bad = (owninv >> (15 - j)) & 1u;
+            fwd = band(bor(shl(fwd, 2), mk(0, cj)), kmask);
+            rc = bor(shr(rc, 2), shl(mk(0, 3u - cj), 2 * (k - 1)));
+            run = bad ? 0 : run + 1;
+            if (run >= k && (uint64_t)(base0 + t * CT_GROUP + j) >= emit_from) {
+                const u128 canon = lt(rc, fwd) ? rc : fwd;
+                table_add_or_spill(T, mix(canon, T.B), 1ull);
+                ++added;
+            }
+        }
+    }
+    if (added) atomicAdd(&T.stats[ST_OCCURRENCES], added);
+}
+
+// --------------------------------------------------------------------------------------------------
+// K4: lookups of arbitrary strings with the reference's truncate-and-pad semantics (qf[MerDNA(s).get_canonical()],
+// JF::swig/mer_file.i:41 + JF::swig/mer_dna.i:15).
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lookup_kernel(const char *__restrict__ chars, const int64_t *__restrict__ offs, uint64_t n,
+                                                     uint32_t *__restrict__ out, TableDev T) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const char *s = chars + offs[i];
+        const long len = (long)(offs[i + 1] - offs[i]);
+        const u128 m = encode_padded(T.k, len, [&](int q) { return (unsigned char)s[q]; });
+        out[i] = clamp32(table_get(T, mix(canonical(m, T.k), T.B)));
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// K3: histogram (JF::sub_commands/histo_main.cc:34-44): bucket = min(count, 10001) on the clamped count.
+// One coalesced 16-B read per slot; bins are privatised in LDS (40 KB) and flushed once per block.
+// --------------------------------------------------------------------------------------------------
+constexpr int HISTO_BINS = 10002;
+__global__ __launch_bounds__(256) void histo_kernel(TableDev T, unsigned long long *__restrict__ out) {
+    __shared__ unsigned int bins[HISTO_BINS];
+    for (int i = threadIdx.x; i < HISTO_BINS; i += blockDim.x) bins[i] = 0;
+    __syncthreads();
+    const uint64_t nslots = T.mask + 1;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < nslots; i += (uint64_t)gridDim.x * blockDim.x) {
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * i);
+        if (e.x != 0ull && e.y != 0ull) {
+            const uint32_t c = clamp32(e.y);
+            atomicAdd(&bins[c > 10001u ? 10001u : c], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HISTO_BINS; i += blockDim.x)
+        if (bins[i]) atomicAdd(&out[i], (unsigned long long)bins[i]);
+}
+
+// --------------------------------------------------------------------------------------------------
+// C1 building blocks: table -> (hash.hi, hash.lo, count) entries and back.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void export_kernel(TableDev T, unsigned long long *__restrict__ entries,
+                                                     unsigned long long *__restrict__ counter, uint64_t cap) {
+    const uint64_t nslots = T.mask + 1;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < nslots; i += (uint64_t)gridDim.x * blockDim.x) {
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * i);
+        if (e.x == 0ull) continue;
+        const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
+        const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
+        const uint64_t home = (i - off) & T.mask;
+        const u128 h = hash_from(home, rem, T.B, T.s);
+        const unsigned long long idx = atomicAdd(counter, 1ull);
+        if (idx < cap) {
+            entries[3 * idx + 0] = h.hi;
+            entries[3 * idx + 1] = h.lo;
+            entries[3 * idx + 2] = e.y;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void import_kernel(const unsigned long long *__restrict__ entries, uint64_t n, TableDev T) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const u128 h = mk(entries[3 * i + 0], entries[3 * i + 1]);
+        const unsigned long long c = entries[3 * i + 2];
+        if (c) table_add_or_spill(T, h, c);
+    }
+}
+
+// rehash straight from an old slot array into a (larger) table
+__global__ __launch_bounds__(256) void rehash_kernel(TableDev oldT, TableDev newT) {
+    const uint64_t nslots = oldT.mask + 1;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < nslots; i += (uint64_t)gridDim.x * blockDim.x) {
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(oldT.slots + 2 * i);
+        if (e.x == 0ull) continue;
+        const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
+        const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
+        const uint64_t home = (i - off) & oldT.mask;
+        table_add_or_spill(newT, hash_from(home, rem, oldT.B, oldT.s), e.y);
+    }
+}
+
+// ==================================================================================================
+// host side
+// ==================================================================================================
+static int grid_for(uint64_t work_items, int per_block) {
+    uint64_t b = (work_items + per_block - 1) / per_block;
+    const uint64_t cap = 256ull * 8;  // 256 CUs x 8 blocks: fills the chip, rest is grid-stride
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int Table::min_log2_slots(int k) {
+    int need = 2 * k - (63 - OFFBITS);  // B - s <= 63 - OFFBITS
+    return std::max(need, 10);
+}
+
+int Table::init(int k_, uint64_t min_slots, int device_, std::string &err) {
+    if (k_ < 1 || k_ > 64) { err = "k must be in [1,64]"; return -1; }
+    k = k_;
+    device = device_;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    int s = min_log2_slots(k);
+    while ((1ull << s) < min_slots) ++s;
+    if (s > 2 * k) s = 2 * k;                 // never more slots than possible keys ...
+    if (s < min_log2_slots(k)) {              // ... unless the tag format needs them
+        err = "internal: slot count below tag-format minimum"; return -1;
+    }
+    nslots = 1ull << s;
+    d = TableDev{};
+    d.s = s; d.B = 2 * k; d.k = k; d.mask = nslots - 1;
+    d.spill_cap = 1u << 16;
+    HIPCHK(hipMalloc((void **)&d.slots, nslots * 16));
+    HIPCHK(hipMalloc((void **)&d.stats, ST_WORDS * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&d.spill, d.spill_cap * 3 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d.slots, 0, nslots * 16, stream));
+    HIPCHK(hipMemsetAsync(d.stats, 0, ST_WORDS * sizeof(unsigned long long), stream));
+    HIPCHK(hipHostMalloc((void **)&h_stats, ST_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(hipEventCreate(&ev_k0));
+    HIPCHK(hipEventCreate(&ev_k1));
+    memset(h_stats, 0, ST_WORDS * sizeof(unsigned long long));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+}
+
+void Table::destroy() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (int i = 0; i < 2; ++i) {
+        if (d_stage[i]) (void)hipFree(d_stage[i]);
+        if (h_stage[i]) (void)hipHostFree(h_stage[i]);
+        if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]);
+    }
+    if (d.slots) (void)hipFree(d.slots);
+    if (d.stats) (void)hipFree(d.stats);
+    if (d.spill) (void)hipFree(d.spill);
+    if (h_stats) (void)hipHostFree(h_stats);
+    if (ev_k0) (void)hipEventDestroy(ev_k0);
+    if (ev_k1) (void)hipEventDestroy(ev_k1);
+    if (stream) (void)hipStreamDestroy(stream);
+    d = TableDev{};
+    stream = nullptr;
+}
+
+int Table::read_stats(std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpyAsync(h_stats, d.stats, ST_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int Table::grow(int new_s, std::string &err) {
+    if (new_s > d.B) new_s = d.B;
+    if (new_s <= d.s) return 0;
+    TableDev nt = d;
+    nt.s = new_s;
+    nt.mask = (1ull << new_s) - 1;
+    HIPCHK(hipMalloc((void **)&nt.slots, (1ull << new_s) * 16));
+    HIPCHK(hipMemsetAsync(nt.slots, 0, (1ull << new_s) * 16, stream));
+    // distinct is recounted by the re-insertion
+    HIPCHK(hipMemsetAsync(d.stats + ST_DISTINCT, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, stream, d, nt);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipFree(d.slots));
+    d = nt;
+    nslots = 1ull << new_s;
+    return 0;
+}
+
+// after a batch of insertions: re-insert spilled k-mers into a bigger table, grow when past the load limit
+int Table::after_batch(std::string &err) {
+    for (int round = 0; round < 8; ++round) {
+        if (read_stats(err)) return -1;
+        if (h_stats[ST_FATAL]) { err = "k-mer table overflow (spill buffer exhausted): pass a larger size hint"; return -2; }
+        const uint64_t spilled = h_stats[ST_SPILL];
+        const bool too_full = (double)h_stats[ST_DISTINCT] > grow_at * (double)nslots && d.s < d.B;
+        if (!spilled && !too_full) return 0;
+        std::vector<unsigned long long> sp;
+        if (spilled) {
+            sp.resize(3 * spilled);
+            HIPCHK(hipMemcpy(sp.data(), d.spill, sp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemsetAsync(d.stats + ST_SPILL, 0, sizeof(unsigned long long), stream));
+        }
+        int ns = d.s + 1;
+        while ((double)h_stats[ST_DISTINCT] > 0.5 * grow_at * (double)(1ull << ns) && ns < d.B) ++ns;
+        if (d.s >= d.B && spilled) { err = "k-mer table cannot grow further"; return -2; }
+        if (grow(ns, err)) return -1;
+        if (spilled) {
+            unsigned long long *tmp = nullptr;
+            HIPCHK(hipMalloc((void **)&tmp, sp.size() * sizeof(unsigned long long)));
+            HIPCHK(hipMemcpy(tmp, sp.data(), sp.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(import_kernel, dim3(grid_for(spilled, 256)), dim3(256), 0, stream, tmp, spilled, d);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(hipFree(tmp));
+        }
+    }
+    err = "k-mer table did not settle after growth";
+    return -2;
+}
+
+int Table::ensure_capacity(uint64_t upcoming_kmers, std::string &err) {
+    // keep the worst case (every upcoming k-mer new) under 3/4 full so probe runs stay far below MAXPROBE
+    if (read_stats(err)) return -1;
+    int ns = d.s;
+    while ((double)(h_stats[ST_DISTINCT] + upcoming_kmers) > 0.75 * (double)(1ull << ns) && ns < d.B) ++ns;
+    if (ns != d.s) return grow(ns, err);
+    return 0;
+}
+
+int Table::launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, std::string &err) {
+    const uint64_t ntiles = (len + CT_TILE - 1) / CT_TILE;
+    HIPCHK(hipEventRecord(ev_k0, stream));
+    hipLaunchKernelGGL(count_kernel, dim3(grid_for(ntiles, 1)), dim3(CT_THREADS), 0, stream, d_piece, len, ntiles, emit_from, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ev_k1, stream));
+    return 0;
+}
+
+// bases already in HBM. Processed in launches of at most nslots/4 bases so that the load factor is re-checked
+// (and the table grown) between launches. A piece starts k-1 bases early, rounded down to 16 bytes so the
+// kernel keeps its 16-byte vector loads; emit_from keeps every window counted exactly once.
+int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    const uint64_t halo = (uint64_t)(k - 1);
+    const uint64_t misalign = reinterpret_cast<uintptr_t>(d_bases) & 15;
+    uint64_t pos = 0;
+    while (pos < n) {
+        uint64_t piece = std::max<uint64_t>(nslots / 4, 1u << 20);
+        piece = std::min<uint64_t>(piece, 1ull << 31);
+        uint64_t start = pos >= halo ? pos - halo : 0;
+        // round the start down so that (d_bases + start) is 16-byte aligned
+        const uint64_t a = (start + misalign) & 15;
+        start = start >= a ? start - a : 0;
+        const uint64_t end = std::min<uint64_t>(n, pos + piece);
+        if (launch_count(d_bases + start, end - start, pos - start, err)) return -1;
+        pos = end;
+        int rc = after_batch(err);
+        if (rc) return rc;
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ev_k0, ev_k1));
+        count_kernel_ms += ms;
+        count_launches += 1;
+    }
+    return 0;
+}
+
+// bases in host memory: double-buffered pinned staging; the copy of piece i+1 overlaps the kernel of piece i
+int Table::count_host(const char *bases, uint64_t n, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    if (!stage_bytes) {
+        stage_bytes = 64u << 20;
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipMalloc((void **)&d_stage[i], stage_bytes + 64));
+            HIPCHK(hipHostMalloc((void **)&h_stage[i], stage_bytes + 64, hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&ev_stage[i], hipEventDisableTiming));
+        }
+    }
+    const uint64_t halo = (uint64_t)(k - 1);
+    uint64_t pos = 0;
+    int buf = 0;
+    while (pos < n) {
+        const uint64_t piece = std::min<uint64_t>(stage_bytes - halo, std::max<uint64_t>(nslots / 4, 1u << 20));
+        const uint64_t start = pos >= halo ? pos - halo : 0;
+        const uint64_t end = std::min<uint64_t>(n, pos + piece);
+        const uint64_t len = end - start;
+        HIPCHK(hipEventSynchronize(ev_stage[buf]));  // staging buffer free again?
+        memcpy(h_stage[buf], bases + start, len);
+        HIPCHK(hipMemcpyAsync(d_stage[buf], h_stage[buf], len, hipMemcpyHostToDevice, stream));
+        if (launch_count(d_stage[buf], len, pos - start, err)) return -1;
+        HIPCHK(hipEventRecord(ev_stage[buf], stream));
+        pos = end;
+        buf ^= 1;
+        int rc = after_batch(err);
+        if (rc) return rc;
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ev_k0, ev_k1));
+        count_kernel_ms += ms;
+        count_launches += 1;
+    }
+    return 0;
+}
+
+int Table::histogram(uint64_t *out, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    unsigned long long *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_out, HISTO_BINS * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d_out, 0, HISTO_BINS * sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(histo_kernel, dim3(grid_for(nslots, 256 * 16)), dim3(256), 0, stream, d, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, HISTO_BINS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipFree(d_out));
+    return 0;
+}
+
+int Table::lookup_strings(const char *chars, const int64_t *offsets, uint64_t n, uint32_t *out, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    if (n == 0) return 0;
+    const uint64_t nchars = (uint64_t)offsets[n];
+    char *d_chars = nullptr;
+    int64_t *d_offs = nullptr;
+    uint32_t *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_chars, nchars + 16));
+    HIPCHK(hipMalloc((void **)&d_offs, (n + 1) * sizeof(int64_t)));
+    HIPCHK(hipMalloc((void **)&d_out, n * sizeof(uint32_t)));
+    HIPCHK(hipMemcpyAsync(d_chars, chars, nchars, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_offs, offsets, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(lookup_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_chars, d_offs, n, d_out, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipFree(d_chars));
+    HIPCHK(hipFree(d_offs));
+    HIPCHK(hipFree(d_out));
+    return 0;
+}
+
+int Table::export_entries(uint64_t *n_out, unsigned long long **d_entries_out, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    if (read_stats(err)) return -1;
+    const uint64_t cap = h_stats[ST_DISTINCT];
+    unsigned long long *d_e = nullptr, *d_ctr = nullptr;
+    HIPCHK(hipMalloc((void **)&d_e, (cap ? cap : 1) * 3 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&d_ctr, sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d_ctr, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(export_kernel, dim3(grid_for(nslots, 256 * 16)), dim3(256), 0, stream, d, d_e, d_ctr, cap);
+    HIPCHK(hipGetLastError());
+    unsigned long long got = 0;
+    HIPCHK(hipMemcpyAsync(&got, d_ctr, sizeof got, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipFree(d_ctr));
+    if (got != cap) { (void)hipFree(d_e); err = "export: entry count changed under us"; return -1; }
+    *n_out = got;
+    *d_entries_out = d_e;
+    return 0;
+}
+
+int Table::import_entries(const unsigned long long *d_entries, uint64_t n, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    uint64_t pos = 0;
+    while (pos < n) {
+        uint64_t piece = std::min<uint64_t>(n - pos, std::max<uint64_t>(nslots / 4, 1u << 20));
+        hipLaunchKernelGGL(import_kernel, dim3(grid_for(piece, 256)), dim3(256), 0, stream, d_entries + 3 * pos, piece, d);
+        HIPCHK(hipGetLastError());
+        pos += piece;
+        int rc = after_batch(err);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // namespace jk

@@ -1,0 +1,135 @@
+// table.hpp -- the k-mer count table resident in HBM and its host-side owner.
+//
+// Replaces (function, not layout) Jellyfish's lock-free hash + sorted DB + mmap query:
+//   JF::include/jellyfish/large_hash_array.hpp:291,509-597,674-752  (add / claim_key / add_val)
+//   JF::include/jellyfish/hash_counter.hpp:91-115,200-238             (add, double_size)
+//   JF::include/jellyfish/binary_dumper.hpp:148-199                   (query: exact count or 0)
+//   JF::sub_commands/histo_main.cc:34-44                              (histogram)
+#pragma once
+#include "kmer.hpp"
+#include <string>
+
+namespace jk {
+
+// what kernels receive (by value)
+struct TableDev {
+    unsigned long long *slots;  // 2 words per slot: tag, count
+    uint64_t mask;              // nslots - 1
+    int s;                      // log2(nslots)
+    int B;                      // 2k
+    int k;
+    unsigned long long *stats;  // [0] distinct keys  [1] spilled insertions  [2] k-mer occurrences added  [3] fatal
+    unsigned long long *spill;  // 3 words per spilled insertion: hash.hi, hash.lo, increment
+    uint64_t spill_cap;
+};
+
+enum { ST_DISTINCT = 0, ST_SPILL = 1, ST_OCCURRENCES = 2, ST_FATAL = 3, ST_WORDS = 8 };
+
+// insert-or-add `inc` for the key whose mixed hash is h. Returns false if no slot within MAXPROBE.
+__device__ __forceinline__ bool table_add(const TableDev &T, u128 h, unsigned long long inc) {
+    const uint64_t home = home_of(h, T.B, T.s);
+    const uint64_t rem = rem_of(h, T.B, T.s);
+    for (uint32_t off = 0; off < MAXPROBE; ++off) {
+        const uint64_t slot = (home + off) & T.mask;
+        const unsigned long long want = tag_of(rem, off);
+        unsigned long long *p = T.slots + 2 * slot;
+        // a stale (L1) view can only show "empty" where a tag has since been written; the CAS below
+        // then returns the real occupant, so plain loads are safe here.
+        unsigned long long cur = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0ull) {
+            cur = atomicCAS(p, 0ull, want);
+            if (cur == 0ull) {
+                atomicAdd(&T.stats[ST_DISTINCT], 1ull);
+                cur = want;
+            }
+        }
+        if (cur == want) {
+            __hip_atomic_fetch_add(p + 1, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
+    }
+    return false;
+}
+
+__device__ __forceinline__ void table_add_or_spill(const TableDev &T, u128 h, unsigned long long inc) {
+    if (!table_add(T, h, inc)) {
+        unsigned long long idx = atomicAdd(&T.stats[ST_SPILL], 1ull);
+        if (idx < T.spill_cap) {
+            T.spill[3 * idx + 0] = h.hi;
+            T.spill[3 * idx + 1] = h.lo;
+            T.spill[3 * idx + 2] = inc;
+        } else {
+            atomicExch(&T.stats[ST_FATAL], 1ull);
+        }
+    }
+}
+
+// exact 64-bit count of the key whose mixed hash is h, or 0
+__device__ __forceinline__ unsigned long long table_get(const TableDev &T, u128 h) {
+    const uint64_t home = home_of(h, T.B, T.s);
+    const uint64_t rem = rem_of(h, T.B, T.s);
+    for (uint32_t off = 0; off < MAXPROBE; ++off) {
+        const uint64_t slot = (home + off) & T.mask;
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * slot);  // tag + count, one 16-B load
+        if (e.x == tag_of(rem, off)) return e.y;
+        if (e.x == 0ull) return 0ull;
+    }
+    return 0ull;
+}
+
+// count as the reference's DB file reports it: min(count, 2^32-1)  (JF::include/jellyfish/binary_dumper.hpp:36-40)
+__device__ __forceinline__ uint32_t clamp32(unsigned long long c) { return c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c; }
+
+// H2 / Appendix A.3: k-mer of a string cut at the first non-ACGTacgt byte (or at k) and right-filled with 'A'
+// (JF::include/jellyfish/mer_dna.hpp:525-542).  `get(i)` returns byte i of the string, n = its length.
+template <typename Get>
+__device__ __forceinline__ u128 encode_padded(int k, long n, Get get) {
+    u128 m = mk(0, 0);
+    int t = 0;
+    const int lim = n < k ? (int)n : k;
+    for (; t < lim; ++t) {
+        int c = code(get(t));
+        if (c < 0) break;
+        m = bor(shl(m, 2), mk(0, (uint64_t)c));
+    }
+    if (t < k) m = shl(m, 2 * (k - t));
+    return m;
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+struct Table {
+    int device = 0;
+    int k = 0;
+    hipStream_t stream = nullptr;
+    TableDev d{};
+    uint64_t nslots = 0;
+    // staging for host -> device streaming
+    uint8_t *d_stage[2] = {nullptr, nullptr};
+    uint8_t *h_stage[2] = {nullptr, nullptr};
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    unsigned long long *h_stats = nullptr;  // pinned mirror of stats
+    double grow_at = 0.5;
+    // HIP-event timing of the counting kernels since reset_timing() (for bench.py's roofline leg)
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+    double count_kernel_ms = 0;
+    uint64_t count_launches = 0;
+    void reset_timing() { count_kernel_ms = 0; count_launches = 0; }
+    int launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, std::string &err);
+
+    static int min_log2_slots(int k);
+    int init(int k, uint64_t min_slots, int device, std::string &err);
+    void destroy();
+    int read_stats(std::string &err);                 // stream sync + copy stats to h_stats
+    int ensure_capacity(uint64_t upcoming_kmers, std::string &err);
+    int grow(int new_s, std::string &err);            // rehash into 2^new_s slots
+    int after_batch(std::string &err);                // spill / fatal / growth handling
+    int count_device(const uint8_t *d_bases, uint64_t n, std::string &err);
+    int count_host(const char *bases, uint64_t n, std::string &err);
+    int histogram(uint64_t *out10002, std::string &err);
+    int lookup_strings(const char *chars, const int64_t *offsets, uint64_t n, uint32_t *out, std::string &err);
+    int export_entries(uint64_t *n_out, unsigned long long **d_entries_out, std::string &err);  // 3 words each
+    int import_entries(const unsigned long long *d_entries, uint64_t n, std::string &err);
+};
+
+}  // namespace jk

@@ -1,0 +1,220 @@
+"""Host-side mirror of the reference's per-batch polisher `src/jasper.py` and of `src/jellyfish.py`.
+
+Same names, argument meaning, output files and error behaviour as the reference; the scan/lookup/fix loop itself
+runs on the GPU (libjasper_hip.so: jasper_polish_batch).  Reference lines are cited as src/jasper.py:N.
+"""
+import csv
+import io
+import math
+import os
+import sys
+
+from .table import KmerTable
+
+FIX_FIELDS = ['Contig', 'Base_coord', 'Original', 'Mutation']  # src/jasper.py:115
+
+
+def parse_fasta(query_file):
+    """src/jasper.py:615-631 -- ordered dict name -> sequence; name = first token without '>', only '\\n' stripped"""
+    seq = {}
+    name = None
+    temp = []
+    with open(query_file, "r") as f:
+        for line in f:
+            if line.startswith(">"):
+                if name is not None:
+                    seq[name] = "".join(temp)
+                name = line.split()[0][1:]
+                temp = []
+            else:
+                if name is None:
+                    # the reference stores this under "placeholder" and pops it again (:619,629)
+                    continue
+                temp.append(line.replace('\n', ''))
+    if name is not None:
+        seq[name] = "".join(temp)
+    return seq
+
+
+def split_output(seq, num_per_line=60):
+    """src/jasper.py:142-147"""
+    return [seq[num_per_line * i:num_per_line * (i + 1)] for i in range(math.ceil(len(seq) / num_per_line))]
+
+
+def globalms_first(a, b):
+    """Stand-in for Bio.pairwise2.align.globalms(a, b, 0, -1, -1, -1)[0][:2]  (src/jasper.py:309).
+
+    PARITY UNPINNED: Biopython is a third-party dependency that is not part of the reference tree. Global alignment
+    with match 0 and mismatch/gap -1; traceback from the end preferring gap-in-a, then diagonal, then gap-in-b, never
+    a gap-in-a directly after a gap-in-b, first complete path wins.  It only decides which rows the ">k bad k-mers"
+    branch writes to the fix CSV, never the polished sequence or the QV counters.
+    """
+    n, m = len(a), len(b)
+    S = [[0] * (m + 1) for _ in range(n + 1)]
+    for i in range(1, n + 1):
+        S[i][0] = -i
+    for j in range(1, m + 1):
+        S[0][j] = -j
+    for i in range(1, n + 1):
+        ai = a[i - 1]
+        Si, Sp = S[i], S[i - 1]
+        for j in range(1, m + 1):
+            d = Sp[j - 1] + (0 if ai == b[j - 1] else -1)
+            u = Sp[j] - 1
+            l = Si[j - 1] - 1
+            Si[j] = d if d >= u and d >= l else (u if u >= l else l)
+    stack = [(n, m, 0, False, 0)]
+    oa, ob = [], []
+    while stack:
+        i, j, opt, colgap, olen = stack.pop()
+        del oa[olen:], ob[olen:]
+        if i == 0 and j == 0:
+            break
+        cur = S[i][j]
+        pushed = False
+        while opt < 3 and not pushed:
+            o = opt
+            opt += 1
+            if o == 0 and j > 0 and cur == S[i][j - 1] - 1 and not colgap:
+                stack.append((i, j, opt, colgap, olen))
+                oa.append('-'); ob.append(b[j - 1])
+                stack.append((i, j - 1, 0, False, olen + 1)); pushed = True
+            elif o == 1 and i > 0 and j > 0 and cur == S[i - 1][j - 1] + (0 if a[i - 1] == b[j - 1] else -1):
+                stack.append((i, j, opt, colgap, olen))
+                oa.append(a[i - 1]); ob.append(b[j - 1])
+                stack.append((i - 1, j - 1, 0, False, olen + 1)); pushed = True
+            elif o == 2 and i > 0 and cur == S[i - 1][j] - 1:
+                stack.append((i, j, opt, colgap, olen))
+                oa.append(a[i - 1]); ob.append('-')
+                stack.append((i - 1, j, 0, True, olen + 1)); pushed = True
+    return "".join(reversed(oa)), "".join(reversed(ob))
+
+
+def rows_from_record(seqname, r):
+    """fix records of one handle_bad_kmers call -> rows appended to fixed_bases_list (src/jasper.py:218-222,232-329)"""
+    kind = r["kind"]
+    if kind == "s":
+        return [[seqname, r["index"], r["newc"], "s" + r["oldc"]]]
+    if kind == "i":
+        return [[seqname, r["index"], "-", "i" + r["oldc"] * r["rep"]]]
+    if kind == "d":
+        return [[seqname, r["index"], r["newc"] * r["rep"], "d-"]]
+    if kind == "x":
+        fixed_seq_rep, original_rep = globalms_first(r["patch"], r["orig"])
+        fixed_ind, fixed_base, original = [], [], []
+        for index in range(len(fixed_seq_rep)):                      # :313-329
+            ori = original_rep[index]
+            changed = fixed_seq_rep[index]
+            if changed == ori:
+                continue
+            elif changed == "-":
+                fixed_base.append('-'); original.append("i" + ori); fixed_ind.append(index + r["index"])
+            elif ori == "-":
+                original.append("d-"); fixed_ind.append(index + r["index"]); fixed_base.append(changed)
+            else:
+                original.append("s" + ori); fixed_base.append(changed); fixed_ind.append(index + r["index"])
+        if len(fixed_ind) == 1:                                       # :218-219 (python lists end up in the row)
+            return [[seqname, fixed_ind[0], fixed_base, original]]
+        # :221-222 -- IndexError on an empty list makes the reference print and sys.exit(1)
+        return [[seqname, fixed_ind[0], fixed_base[0], original[0]], [seqname, fixed_ind[1], fixed_base[1], original[1]]]
+    raise ValueError("unknown fix record kind %r" % kind)
+
+
+def fix_csv_text(rows):
+    """what csv.writer(f, delimiter=' ') writes for header + rows (src/jasper.py:116-119)"""
+    buf = io.StringIO(newline="")
+    w = csv.writer(buf, delimiter=' ')
+    w.writerow(FIX_FIELDS)
+    w.writerows(rows)
+    return buf.getvalue()
+
+
+def polish_batch(table, names, seqs, thre, num_iter, fix=True):
+    """run one batch; returns (polished seqs, [rows of pass 0, rows of pass 1, ...], (bad0,total0,badP,totalP), result)"""
+    res = table.polish_batch(seqs, thre, num_iter, fix=fix)
+    rows = [[] for _ in range(num_iter)]
+    for r in res.records:  # already ordered by chunk, then pass, then emission
+        rows[r["pass_"]].append((r["chunk"], r["seqno"], rows_from_record(names[r["chunk"]], r)))
+    out_rows = []
+    for p in range(num_iter):
+        flat = []
+        for _, _, rr in sorted(rows[p], key=lambda x: (x[0], x[1])):
+            flat.extend(rr)
+        out_rows.append(flat)
+    return res.seqs, out_rows, res.qv, res
+
+
+def main(contigs, query_path, k, test, fix, fout, fixedout, db, thre, num_iter):
+    """src/jasper.py:12-32 main() + :35-137 iteration(): same arguments; `db` is a KmerTable (HBM) instead of a .jf path.
+
+    Writes, in the current directory, exactly the files the reference writes:
+      _iter{i}_<fout> (CSV, CRLF), _iter{P-1}_<fixedout> (FASTA, 60 columns), {0,P}qValCalcHelper.csv (appended).
+    Any failure prints and exits 1 like the reference's bare `except` (:27-32).
+    """
+    try:
+        if not isinstance(db, KmerTable):
+            raise TypeError("db must be a jasper_amd.KmerTable resident in HBM")
+        if db.k != k:
+            # QueryMerFile sets the global k from the DB header (JF::swig/mer_file.i:23): the DB wins
+            k = db.k
+        seq_dict = parse_fasta(query_path)
+        names = list(seq_dict.keys())
+        seqs = [seq_dict[n] for n in names]
+        do_fix = bool(fix)
+        fixed, rows, qv, _ = polish_batch(db, names, seqs, thre, num_iter, fix=do_fix)
+        if test:                                                            # :107-111
+            with open("0qValCalcHelper.csv", 'a') as f:
+                f.write("{} {}\n".format(qv[0], qv[1]))
+            if num_iter != 0:
+                with open(str(num_iter) + "qValCalcHelper.csv", 'a') as f:
+                    f.write("{} {}\n".format(qv[2], qv[3]))
+        if do_fix:
+            fo = os.path.split(fout)
+            for ite in range(num_iter):                                     # :48-49,114-119
+                with open(fo[0] + "_iter" + str(ite) + "_" + fo[1], 'w', newline='') as csvf:
+                    csvf.write(fix_csv_text(rows[ite]))
+            ff = os.path.split(fixedout)                                    # :39-40
+            out_path = ff[0] + "_iter" + str(num_iter - 1) + "_" + ff[1]
+            with open(out_path, 'w') as of:                                 # :120-128
+                for seqname, seq in zip(names, fixed):
+                    of.write(">{}\n".format(seqname))
+                    for l in split_output(seq, 60):
+                        of.write(l + "\n")
+            return out_path
+        return None
+    except SystemExit:
+        raise
+    except BaseException:
+        exception_type, exception_object, exception_traceback = sys.exc_info()
+        print(exception_traceback.tb_lineno)
+        print(sys.exc_info())
+        sys.exit(1)
+
+
+def threshold_from_histo_rows(rows):
+    """src/jellyfish.py:8-22 on rows (multiplicity, n_distinct).
+
+    Returns the text the script writes to stdout ('' if it prints nothing) and its exit status.
+    """
+    count = -1
+    threshold = 0
+    for row in rows:
+        if count == -1:
+            count = int(row[-1])
+        else:
+            if count >= int(row[-1]):
+                count = int(row[-1])
+                threshold = int(int(row[0]) / 2)
+            else:
+                if threshold < 2:
+                    return "", 1
+                return str(threshold), 0
+    return "", 0
+
+
+def threshold_from_histo_file(path):
+    rows = []
+    with open(path, 'r') as histo:
+        for row in csv.reader(histo, delimiter=' '):
+            rows.append(row)
+    return threshold_from_histo_rows(rows)

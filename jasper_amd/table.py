@@ -1,0 +1,178 @@
+"""KmerTable: the HBM-resident canonical k-mer count table and the operations of the hot path on it.
+
+Host-side mirror of what the reference does through `jellyfish count/histo` (src/jasper.sh:177,189) and the SWIG
+module `dna_jellyfish` (JF::swig/mer_file.i, JF::swig/mer_dna.i).  All compute happens in libjasper_hip.so;
+nothing here falls back to the CPU.
+"""
+import ctypes as C
+
+from . import _lib
+from ._lib import FixRec, check
+
+
+class PolishResult:
+    """what one `jasper.py` process produces for one batch file (src/jasper.py:107-128)"""
+
+    def __init__(self, seqs, records, aux, qv, lookups, seconds):
+        self.seqs = seqs            # polished chunk sequences, batch order
+        self.records = records      # list of dicts (chunk, pass, seqno, kind, index, newc, oldc, rep, patch, orig)
+        self.aux = aux
+        self.qv = qv                # (bad0, total0, badP, totalP)
+        self.lookups = lookups
+        self.seconds = seconds
+
+
+class KmerTable:
+    def __init__(self, k, min_slots=1 << 20, device=0):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        self.k = int(k)
+        self.device = int(device)
+        check(self._L.jasper_table_create(self.k, int(min_slots), self.device, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.jasper_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- counting (jellyfish count -C) -------------------------------------------------------------
+    def count_files(self, paths):
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        check(self._L.jasper_count_reads_files(self._h, arr, len(paths)))
+
+    def count_text(self, text):
+        if isinstance(text, str):
+            text = text.encode()
+        check(self._L.jasper_count_reads_text(self._h, text, len(text)))
+
+    def count_bases(self, bases):
+        if isinstance(bases, str):
+            bases = bases.encode()
+        check(self._L.jasper_count_bases(self._h, bases, len(bases)))
+
+    def count_bases_device(self, dev_ptr, n):
+        check(self._L.jasper_count_bases_device(self._h, C.c_void_p(dev_ptr), int(n)))
+
+    def count_timing(self):
+        ms = C.c_double(0)
+        n = C.c_uint64(0)
+        check(self._L.jasper_last_count_timing(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def sync(self):
+        check(self._L.jasper_table_sync(self._h))
+
+    def info(self):
+        k = C.c_int(0)
+        slots = C.c_uint64(0)
+        distinct = C.c_uint64(0)
+        occ = C.c_uint64(0)
+        check(self._L.jasper_table_info(self._h, C.byref(k), C.byref(slots), C.byref(distinct), C.byref(occ)))
+        return dict(k=k.value, slots=slots.value, distinct=distinct.value, occurrences=occ.value)
+
+    # ---- jellyfish histo ---------------------------------------------------------------------------
+    def histogram(self):
+        out = (C.c_uint64 * 10002)()
+        check(self._L.jasper_histogram(self._h, out))
+        return list(out)
+
+    def histo_rows(self):
+        """non-zero rows (multiplicity, n_distinct) as `jellyfish histo` prints them (JF::sub_commands/histo_main.cc:82-84)"""
+        h = self.histogram()
+        return [(m, h[m]) for m in range(1, 10002) if h[m]]
+
+    # ---- qf[MerDNA(s).get_canonical()] -------------------------------------------------------------
+    def lookup(self, strings):
+        n = len(strings)
+        if n == 0:
+            return []
+        bs = [s.encode() if isinstance(s, str) else bytes(s) for s in strings]
+        offs = (C.c_int64 * (n + 1))()
+        tot = 0
+        for i, b in enumerate(bs):
+            offs[i] = tot
+            tot += len(b)
+        offs[n] = tot
+        out = (C.c_uint32 * n)()
+        check(self._L.jasper_lookup(self._h, b"".join(bs), offs, n, out))
+        return list(out)
+
+    # ---- merge support -----------------------------------------------------------------------------
+    def export_entries(self):
+        """numpy uint64 array [n,3]: mixed-hash hi, lo, count"""
+        import numpy as np
+        n = C.c_uint64(0)
+        check(self._L.jasper_table_export(self._h, C.byref(n), None))
+        arr = np.zeros((max(int(n.value), 1), 3), dtype=np.uint64)
+        cap = C.c_uint64(arr.shape[0])
+        check(self._L.jasper_table_export(self._h, C.byref(cap), arr.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return arr[: int(cap.value)]
+
+    def import_entries(self, arr):
+        import numpy as np
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        if arr.size == 0:
+            return
+        check(self._L.jasper_table_import(self._h, arr.ctypes.data_as(C.POINTER(C.c_uint64)), arr.shape[0]))
+
+    def export_device(self):
+        n = C.c_uint64(0)
+        p = C.c_void_p()
+        check(self._L.jasper_table_export_device(self._h, C.byref(n), C.byref(p)))
+        return p.value, int(n.value)
+
+    def import_device(self, dev_ptr, n):
+        check(self._L.jasper_table_import_device(self._h, C.c_void_p(dev_ptr), int(n)))
+
+    def device_free(self, dev_ptr):
+        check(self._L.jasper_device_free(self._h, C.c_void_p(dev_ptr)))
+
+    # ---- one batch through the polisher -------------------------------------------------------------
+    def polish_batch(self, seqs, solid_thre, passes, fix=True):
+        n = len(seqs)
+        bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        cs = (C.c_char_p * max(n, 1))(*bs)
+        lens = (C.c_int64 * max(n, 1))(*[len(b) for b in bs])
+        res = C.c_void_p()
+        rc = self._L.jasper_polish_batch(self._h, n, cs, lens, int(solid_thre), int(passes), 1 if fix else 0, C.byref(res))
+        try:
+            check(rc)
+            out = []
+            aux = []
+            for i in range(n):
+                p = C.c_void_p()
+                ln = C.c_int64(0)
+                check(self._L.jasper_result_seq(res, i, C.byref(p), C.byref(ln)))
+                out.append(C.string_at(p, ln.value).decode("latin-1") if ln.value else "")
+                ap = C.c_void_p()
+                an = C.c_uint64(0)
+                check(self._L.jasper_result_aux(res, i, C.byref(ap), C.byref(an)))
+                aux.append(C.string_at(ap, an.value) if an.value else b"")
+            rp = C.POINTER(FixRec)()
+            rn = C.c_uint64(0)
+            check(self._L.jasper_result_records(res, C.byref(rp), C.byref(rn)))
+            recs = []
+            for i in range(rn.value):
+                r = rp[i]
+                d = dict(chunk=r.chunk, pass_=r.pass_, seqno=r.seqno, kind=chr(r.kind), index=r.index,
+                         newc=chr(r.newc), oldc=chr(r.oldc), rep=r.rep)
+                if d["kind"] == "x":
+                    a = aux[r.chunk]
+                    d["patch"] = a[r.aux_off:r.aux_off + r.aux_len].decode("latin-1")
+                    d["orig"] = a[r.aux_off + r.aux_len:r.aux_off + r.aux_len + r.rep].decode("latin-1")
+                recs.append(d)
+            qv = (C.c_int64 * 4)()
+            check(self._L.jasper_result_qv(res, qv))
+            nl = C.c_uint64(0)
+            check(self._L.jasper_result_lookups(res, C.byref(nl)))
+            secs = self._L.jasper_result_seconds(res)
+            return PolishResult(out, recs, aux, tuple(qv), nl.value, secs)
+        finally:
+            if res:
+                self._L.jasper_result_free(res)
