@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X: assembly Mbp/s polished + Gk-mers/s counted, k=37.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One STEP = one pass of the whole hot path over one batch of synthetic input that is already resident in HBM:
+    new table -> count canonical 37-mers of the read shard (K1+K2) -> [N>1: key-wise merge of the per-GPU tables
+    over RCCL] -> histogram (K3) -> threshold (src/jellyfish.py) -> P fixing passes + 1 QV pass over this rank's
+    chunk records (K4-K6) -> polished text + fix records back on the host.
+Workload at N=1 = BASELINE.json configs[1]: "human chr21"-sized synthetic genome (47 Mb) + 30x 150-bp reads, k=37,
+2 passes, chunked as `jasper.sh -t 16` would (BATCH_SIZE = int(47e6/16*.9)).  For N>1 the genome, the reads and
+the assembly grow with N (weak scaling): every rank counts 1/N of the reads of the N x 47 Mb genome and polishes
+its share of the chunks, with the table merge in between.
+
+Prints ONE JSON line (rank 0). `value` = assembly bases polished per second of whole-job wall time (Mbp/s);
+the counting rate, the polishing-only rate, the roofline of the dominant kernel (count_kernel, HIP-event timed
+on the table's own stream) and a CPU baseline (the C oracle on a bounded sample, rank 0 at N=1 only) ride along.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K = 37
+PASSES = 2
+THREADS_FOR_BATCH_RULE = 16
+READ_LEN = 150
+COVERAGE = 30
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_KMER = 33            # 1 B base + 16 B slot read + 16 B slot write
+
+
+def build_workload(torch, dev, rank, world, genome_mb, seed):
+    from jasper_amd import synth
+    import numpy as np
+    G = int(genome_mb * 1e6)
+    # every rank builds the same N genomes (same seeds) so that read shards come from the whole genome
+    genomes = []
+    for j in range(world):
+        gen = torch.Generator(device=dev).manual_seed(seed * 1000 + j)
+        genomes.append(synth.torch_genome(gen, G, dev))
+    whole = torch.cat(genomes) if world > 1 else genomes[0]
+    nreads_total = int(G * world * COVERAGE / READ_LEN)
+    lo = rank * nreads_total // world
+    hi = (rank + 1) * nreads_total // world
+    gen = torch.Generator(device=dev).manual_seed(seed * 1000 + 500 + rank)
+    reads = synth.torch_reads_stream(gen, whole, hi - lo, READ_LEN, 0.003)
+    # this rank's draft assembly = its own genome with planted errors; chunked like jasper.sh -t 16
+    rng = np.random.default_rng(seed * 1000 + 900 + rank)
+    asm = synth.make_assembly(rng, genomes[rank].cpu().numpy())
+    del genomes, whole
+    bs = synth.jasper_batch_size(len(asm), THREADS_FOR_BATCH_RULE)
+    recs = synth.chunk_records(">chr%d" % rank, len(asm), bs)
+    asm_b = asm.tobytes()
+    names = [r[0][1:] for r in recs]
+    seqs = [asm_b[a:b] for _, a, b in recs]
+    torch.cuda.synchronize(dev)
+    return reads, names, seqs, len(asm), bs, hi - lo
+
+
+def one_step(torch, dev_index, reads, seqs, min_slots, world, timers):
+    from jasper_amd import KmerTable, polisher, dist as jdist
+    t0 = time.perf_counter()
+    table = KmerTable(K, min_slots=min_slots, device=dev_index)
+    table.count_bases_device(reads.data_ptr(), reads.numel())
+    table.sync()
+    t1 = time.perf_counter()
+    kms, launches = table.count_timing()
+    merged = 0
+    if world > 1:
+        merged = jdist.merge_tables(table, torch.device("cuda", dev_index))
+        table.sync()
+    t2 = time.perf_counter()
+    rows = table.histo_rows()
+    txt, status = polisher.threshold_from_histo_rows(rows)
+    if status != 0 or not txt:
+        raise RuntimeError("synthetic histogram has no usable local minimum (threshold script would abort)")
+    thr = int(txt)
+    t3 = time.perf_counter()
+    res = table.polish_batch(seqs, thr, PASSES, fix=True)
+    t4 = time.perf_counter()
+    info = table.info()
+    table.close()
+    timers.append(dict(count=t1 - t0, merge=t2 - t1, histo=t3 - t2, polish=t4 - t3, kernel_ms=kms, launches=launches,
+                       polish_dev=res.seconds, thr=thr, qv=res.qv, nfix=len(res.records), merged=merged,
+                       distinct=info["distinct"], occurrences=info["occurrences"], slots=info["slots"], lookups=res.lookups))
+    return res
+
+
+def cpu_baseline(seed):
+    """the C oracle (a port of the reference's algorithm) on a bounded sample of the same workload, 1 thread"""
+    import numpy as np
+    from jasper_amd import synth, polisher
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    G = 600_000
+    genome = synth.make_genome(rng, G)
+    reads = synth.make_reads_stream(rng, genome, COVERAGE, READ_LEN, 0.003)
+    asm = synth.make_assembly(rng, genome, err=1e-4, n_every=10_000_000)
+    t0 = time.perf_counter()
+    db = O.OracleDB(K)
+    nk = db.count_bases(reads.tobytes())
+    t1 = time.perf_counter()
+    h = db.histo()
+    txt, status = polisher.threshold_from_histo_rows([(m, h[m]) for m in range(1, 10002) if h[m]])
+    thr = int(txt) if (status == 0 and txt) else 2
+    bs = synth.jasper_batch_size(len(asm), THREADS_FOR_BATCH_RULE)
+    recs = synth.chunk_records("s", len(asm), bs)
+    b = asm.tobytes().decode()
+    db.polish_batch([r[0] for r in recs], [b[a:e] for _, a, e in recs], thr, PASSES)
+    t2 = time.perf_counter()
+    return dict(value=round(len(asm) / 1e6 / (t2 - t0), 4), unit="Mbp/s", cores=1, kind="port",
+                sample="%.1f Mb synthetic genome, 30x 150-bp reads (%d k-mers), k=37, 2 passes; oracle/jasper_oracle.c, 1 thread"
+                       % (G / 1e6, nk),
+                count_Mkmers_per_s=round(nk / 1e6 / (t1 - t0), 3), polish_Mbp_per_s=round(len(asm) / 1e6 / (t2 - t1), 3),
+                seconds=round(t2 - t0, 2))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mb", type=float, default=47.0, help="assembly size per GPU in Mb (47 = chr21-sized, BASELINE configs[1])")
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.stderr.write("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`\n" % (a.gpus, a.gpus))
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        sys.stderr.write("bench.py: no GPU visible; the product has no CPU path\n")
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    reads, names, seqs, asm_len, bs, nreads = build_workload(torch, dev, rank, world, a.genome_mb, a.seed)
+    # size hint like jasper.sh: JF_SIZE = FASTQ bytes / 10 (src/jasper.sh:82); FASTQ ~ 2.1 bytes per base
+    jf_size = int(nreads * world * READ_LEN * 2.1 / 10)
+    min_slots = max(1 << 21, 2 * jf_size)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    timers = []
+    for _ in range(a.warmup):
+        one_step(torch, local, reads, seqs, min_slots, world, timers)
+    timers.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = one_step(torch, local, reads, seqs, min_slots, world, timers)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        tot = torch.tensor([asm_len, timers[-1]["occurrences"] if world == 1 else 0, reads.numel()], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        asm_total = int(tot[0].item())
+    else:
+        asm_total = asm_len
+    steps = max(a.steps, 1)
+    ms_per_step = dt / steps * 1e3
+    T = timers[-1]
+    mean = lambda key: sum(t[key] for t in timers) / len(timers)
+    # k-mer occurrences this rank counted per step (own shard): reads x (READ_LEN - K + 1)
+    kmers_rank = nreads * (READ_LEN - K + 1)
+    kernel_s = mean("kernel_ms") * 1e-3
+    launches = max(int(T["launches"]), 1)
+    achieved = BYTES_PER_KMER * kmers_rank / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    out = {
+        "metric": "assembly Mbp/s polished + Gk-mers/s counted, k=37",
+        "value": round(asm_total / 1e6 / (dt / steps), 3),
+        "unit": "Mbp/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "configs[1] chr21-sized: %.0f Mb synthetic genome x %d GPU(s) + %dx %d-bp reads, k=%d, %d passes, "
+                               "chunked as jasper.sh -t %d (BATCH_SIZE %d)" % (a.genome_mb, world, COVERAGE, READ_LEN, K, PASSES,
+                                                                               THREADS_FOR_BATCH_RULE, bs),
+                   "chunks_per_gpu": len(seqs), "reads_per_gpu": nreads, "table_slots": T["slots"], "distinct_kmers": T["distinct"],
+                   "threshold": T["thr"], "parallelism": "read shards + chunk shards, table merge over RCCL" if world > 1 else "single GPU"},
+        "kmers_counted_Gk_per_s": round(kmers_rank * world / mean("count") / 1e9, 3),
+        "polish_only_Mbp_per_s": round(asm_total / 1e6 / mean("polish"), 3),
+        "phase_ms": {k: round(mean(k) * 1e3, 2) for k in ("count", "merge", "histo", "polish")},
+        "polish_device_ms": round(mean("polish_dev") * 1e3, 2),
+        "qv_counters": list(T["qv"]), "fix_records": T["nfix"], "polish_lookups": T["lookups"],
+        "roofline": {"bound": "hbm", "kernel": "count_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": int(BYTES_PER_KMER * kmers_rank / launches),
+                     "launches_per_step": launches, "avg_launch_ms": round(mean("kernel_ms") / launches, 3)},
+    }
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(a.seed)
+            except Exception as e:  # the baseline is a report, never a reason to lose the measurement
+                out["cpu_baseline"] = {"value": None, "unit": "Mbp/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,8 @@ int jasper_table_export(jasper_table *t, uint64_t *n_entries, uint64_t *host_ent
 int jasper_table_import(jasper_table *t, const uint64_t *host_entries, uint64_t n_entries);
 int jasper_table_export_device(jasper_table *t, uint64_t *n_entries, void **d_entries);
 int jasper_table_import_device(jasper_table *t, const void *d_entries, uint64_t n_entries);
+/* export into caller-owned device memory (e.g. a torch tensor handed to RCCL); cap_entries = room in d_dst */
+int jasper_table_export_to(jasper_table *t, void *d_dst, uint64_t cap_entries, uint64_t *n_entries);
 int jasper_device_free(jasper_table *t, void *d_ptr);
 
 /* one batch of chunk records through `passes` fixing passes + the final QV pass (src/jasper.py:25-26) */

@@ -127,6 +127,18 @@ int jasper_table_export_device(jasper_table *t, uint64_t *n_entries, void **d_en
     return JASPER_OK;
 }
 
+int jasper_table_export_to(jasper_table *t, void *d_dst, uint64_t cap_entries, uint64_t *n_entries) {
+    unsigned long long *p = nullptr;
+    uint64_t n = 0;
+    int rc = t->t.export_entries(&n, &p, g_err);
+    if (rc) return rc;
+    if (n > cap_entries) { (void)hipFree(p); g_err = "export buffer too small"; return JASPER_ERR_CAPACITY; }
+    if (n) CHK(hipMemcpy(d_dst, p, n * 24, hipMemcpyDeviceToDevice));
+    CHK(hipFree(p));
+    *n_entries = n;
+    return JASPER_OK;
+}
+
 int jasper_table_import_device(jasper_table *t, const void *d_entries, uint64_t n_entries) {
     return t->t.import_entries((const unsigned long long *)d_entries, n_entries, g_err);
 }

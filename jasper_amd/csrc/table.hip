@@ -72,7 +72,7 @@ __global__ __launch_bounds__(CT_THREADS) void count_kernel(const uint8_t *__rest
     const int k = T.k;
     const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
     const u128 kmask = maskbits(2 * k);
-    unsigned long long added = 0;
+    unsigned long long added = 0, fresh = 0;
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base0 = (int64_t)(tile * CT_TILE);
         uint32_t c, iv;
@@ -105,12 +105,17 @@ __global__ __launch_bounds__(CT_THREADS) void count_kernel(const uint8_t *__rest
             run = bad ? 0 : run + 1;
             if (run >= k && (uint64_t)(base0 + t * CT_GROUP + j) >= emit_from) {
                 const u128 canon = lt(rc, fwd) ? rc : fwd;
-                table_add_or_spill(T, mix(canon, T.B), 1ull);
+                fresh += table_add_or_spill(T, mix(canon, T.B), 1ull);
                 ++added;
             }
         }
     }
-    if (added) atomicAdd(&T.stats[ST_OCCURRENCES], added);
+    // one pair of counter updates per wave
+    for (int o = 32; o > 0; o >>= 1) { added += __shfl_xor(added, o); fresh += __shfl_xor(fresh, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (added) atomicAdd(&T.stats[ST_OCCURRENCES], added);
+        if (fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+    }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -172,15 +177,19 @@ __global__ __launch_bounds__(256) void export_kernel(TableDev T, unsigned long l
 }
 
 __global__ __launch_bounds__(256) void import_kernel(const unsigned long long *__restrict__ entries, uint64_t n, TableDev T) {
+    unsigned long long fresh = 0;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const u128 h = mk(entries[3 * i + 0], entries[3 * i + 1]);
         const unsigned long long c = entries[3 * i + 2];
-        if (c) table_add_or_spill(T, h, c);
+        if (c) fresh += table_add_or_spill(T, h, c);
     }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
 }
 
 // rehash straight from an old slot array into a (larger) table
 __global__ __launch_bounds__(256) void rehash_kernel(TableDev oldT, TableDev newT) {
+    unsigned long long fresh = 0;
     const uint64_t nslots = oldT.mask + 1;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < nslots; i += (uint64_t)gridDim.x * blockDim.x) {
         const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(oldT.slots + 2 * i);
@@ -188,8 +197,10 @@ __global__ __launch_bounds__(256) void rehash_kernel(TableDev oldT, TableDev new
         const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
         const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
         const uint64_t home = (i - off) & oldT.mask;
-        table_add_or_spill(newT, hash_from(home, rem, oldT.B, oldT.s), e.y);
+        fresh += table_add_or_spill(newT, hash_from(home, rem, oldT.B, oldT.s), e.y);
     }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&newT.stats[ST_DISTINCT], fresh);
 }
 
 // ==================================================================================================

@@ -25,8 +25,10 @@ struct TableDev {
 
 enum { ST_DISTINCT = 0, ST_SPILL = 1, ST_OCCURRENCES = 2, ST_FATAL = 3, ST_WORDS = 8 };
 
-// insert-or-add `inc` for the key whose mixed hash is h. Returns false if no slot within MAXPROBE.
-__device__ __forceinline__ bool table_add(const TableDev &T, u128 h, unsigned long long inc) {
+// insert-or-add `inc` for the key whose mixed hash is h. Returns 0 if no slot within MAXPROBE, 1 if the key
+// existed, 2 if this call claimed a new slot (callers batch the distinct-key counter: one same-address atomic
+// per new key would serialise the whole chip on a single L2 channel).
+__device__ __forceinline__ int table_add(const TableDev &T, u128 h, unsigned long long inc) {
     const uint64_t home = home_of(h, T.B, T.s);
     const uint64_t rem = rem_of(h, T.B, T.s);
     for (uint32_t off = 0; off < MAXPROBE; ++off) {
@@ -36,23 +38,27 @@ __device__ __forceinline__ bool table_add(const TableDev &T, u128 h, unsigned lo
         // a stale (L1) view can only show "empty" where a tag has since been written; the CAS below
         // then returns the real occupant, so plain loads are safe here.
         unsigned long long cur = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int fresh = 1;
         if (cur == 0ull) {
             cur = atomicCAS(p, 0ull, want);
             if (cur == 0ull) {
-                atomicAdd(&T.stats[ST_DISTINCT], 1ull);
+                fresh = 2;
                 cur = want;
             }
         }
         if (cur == want) {
             __hip_atomic_fetch_add(p + 1, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return true;
+            return fresh;
         }
     }
-    return false;
+    return 0;
 }
 
-__device__ __forceinline__ void table_add_or_spill(const TableDev &T, u128 h, unsigned long long inc) {
-    if (!table_add(T, h, inc)) {
+// returns 1 when a new distinct key was created
+__device__ __forceinline__ unsigned table_add_or_spill(const TableDev &T, u128 h, unsigned long long inc) {
+    const int r = table_add(T, h, inc);
+    if (r == 2) return 1u;
+    if (r == 0) {
         unsigned long long idx = atomicAdd(&T.stats[ST_SPILL], 1ull);
         if (idx < T.spill_cap) {
             T.spill[3 * idx + 0] = h.hi;
@@ -62,6 +68,7 @@ __device__ __forceinline__ void table_add_or_spill(const TableDev &T, u128 h, un
             atomicExch(&T.stats[ST_FATAL], 1ull);
         }
     }
+    return 0u;
 }
 
 // exact 64-bit count of the key whose mixed hash is h, or 0

@@ -1,0 +1,159 @@
+"""Synthetic workloads of SURVEY.md 8(d): genome, Illumina-like reads, draft assembly with planted errors.
+
+Two generators with the same statistical recipe:
+  * numpy (CPU)  -- small inputs for tests and for the bounded cpu_baseline sample
+  * torch (GPU)  -- the bench workload, generated straight into HBM so the timed region starts with the inputs
+                    resident (there is no network for real genomes; sizes match BASELINE.json configs)
+Recipe: genome = i.i.d. uniform ACGT, 3 % of bases overwritten by copies of 40 repeat units (300-6000 bp, 1 %
+divergence); reads = 150 bp, uniform start, random strand, 0.3 % uniform substitutions, one 'N' between reads
+(what Jellyfish's parser inserts, JF::include/jellyfish/mer_overlap_sequence_parser.hpp:175,205); assembly =
+genome with errors at 1e-4/base (60 % substitutions, 20 % 1-bp insertions, 20 % 1-bp deletions) and a 500-bp
+N-run every 10 Mb.
+"""
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[_a] = _b
+
+
+def make_genome(rng, n, repeat_frac=0.03):
+    g = ACGT[rng.integers(0, 4, n)]
+    if n >= 20000 and repeat_frac > 0:
+        units = [ACGT[rng.integers(0, 4, int(rng.integers(300, 6001)))] for _ in range(40)]
+        target = int(n * repeat_frac)
+        placed = 0
+        while placed < target:
+            u = units[int(rng.integers(0, 40))].copy()
+            if len(u) >= n:
+                break
+            mut = rng.random(len(u)) < 0.01
+            u[mut] = ACGT[rng.integers(0, 4, int(mut.sum()))]
+            p = int(rng.integers(0, n - len(u)))
+            g[p:p + len(u)] = u
+            placed += len(u)
+    return g
+
+
+def make_reads_stream(rng, genome, coverage, read_len=150, err=0.003):
+    """uint8 array: read_0 'N' read_1 'N' ...   (k-mers never span reads)"""
+    n = len(genome)
+    nreads = int(n * coverage / read_len)
+    out = np.empty((nreads, read_len + 1), dtype=np.uint8)
+    out[:, read_len] = ord("N")
+    bs = 200000
+    ar = np.arange(read_len)
+    for a in range(0, nreads, bs):
+        m = min(bs, nreads - a)
+        starts = rng.integers(0, n - read_len + 1, m)
+        r = genome[starts[:, None] + ar[None, :]]
+        e = rng.random((m, read_len)) < err
+        ne = int(e.sum())
+        if ne:
+            # substitute with a different base
+            cur = r[e]
+            code = np.searchsorted(ACGT, cur) % 4
+            r[e] = ACGT[(code + rng.integers(1, 4, ne)) % 4]
+        flip = rng.random(m) < 0.5
+        r[flip] = _COMP[r[flip][:, ::-1]]
+        out[a:a + m, :read_len] = r
+    return out.reshape(-1)
+
+
+def make_assembly(rng, genome, err=1e-4, n_every=10_000_000, n_len=500):
+    g = genome.copy()
+    n = len(g)
+    for p in range(n_every, n - n_len, n_every):
+        g[p:p + n_len] = ord("N")
+    ne = int(rng.poisson(n * err))
+    pos = np.sort(rng.choice(n, size=min(ne, n), replace=False)) if ne else np.zeros(0, dtype=np.int64)
+    kind = rng.random(len(pos))
+    pieces = []
+    last = 0
+    for p, kd in zip(pos.tolist(), kind.tolist()):
+        if g[p] == ord("N"):
+            continue
+        pieces.append(g[last:p])
+        if kd < 0.6:      # substitution
+            c = int(np.searchsorted(ACGT, g[p]))
+            pieces.append(ACGT[[(c + int(rng.integers(1, 4))) % 4]])
+            last = p + 1
+        elif kd < 0.8:    # insertion before p
+            pieces.append(ACGT[[int(rng.integers(0, 4))]])
+            last = p
+        else:             # deletion of p
+            last = p + 1
+    pieces.append(g[last:])
+    return np.concatenate(pieces)
+
+
+def chunk_records(name, seq_len, batch_size):
+    """(record name, start, end) of src/jasper.sh:155 for one contig"""
+    return [("%s:%d" % (name, ci), ci, min(seq_len, ci + batch_size)) for ci in range(0, seq_len, batch_size)]
+
+
+def jasper_batch_size(total_bases, threads, user_batch=0, max_batch=25000000):
+    """src/jasper.sh:132-138"""
+    bs = int(total_bases / threads * .9)
+    b = user_batch
+    if bs > b:
+        b = bs
+        if b > max_batch:
+            b = max_batch
+    return b
+
+
+# ---- torch / GPU versions (bench) ---------------------------------------------------------------------
+def torch_genome(gen, n, device, repeat_frac=0.03):
+    import torch
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    g = lut[torch.randint(0, 4, (n,), generator=gen, device=device)]
+    if n >= 20000 and repeat_frac > 0:
+        cpu = torch.Generator().manual_seed(int(torch.randint(0, 2**31 - 1, (1,), generator=gen, device=device).item()))
+        ulen = torch.randint(300, 6001, (40,), generator=cpu).tolist()
+        units = [lut[torch.randint(0, 4, (l,), generator=gen, device=device)] for l in ulen]
+        target, placed = int(n * repeat_frac), 0
+        choice = torch.randint(0, 40, (target // 300 + 1,), generator=cpu).tolist()
+        ci = 0
+        while placed < target and ci < len(choice):
+            u = units[choice[ci]].clone()
+            ci += 1
+            if len(u) >= n:
+                break
+            mut = torch.rand(len(u), generator=gen, device=device) < 0.01
+            u[mut] = lut[torch.randint(0, 4, (int(mut.sum().item()),), generator=gen, device=device)]
+            p = int(torch.randint(0, n - len(u), (1,), generator=cpu).item())
+            g[p:p + len(u)] = u
+            placed += len(u)
+    return g
+
+
+def torch_reads_stream(gen, genome, nreads, read_len=150, err=0.003, block=1 << 20):
+    """uint8 tensor of nreads*(read_len+1) bytes in HBM: read 'N' read 'N' ..."""
+    import torch
+    dev = genome.device
+    n = genome.numel()
+    out = torch.empty((nreads, read_len + 1), dtype=torch.uint8, device=dev)
+    out[:, read_len] = ord("N")
+    ar = torch.arange(read_len, device=dev)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    code = torch.full((256,), 0, dtype=torch.int64, device=dev)
+    comp = torch.arange(256, dtype=torch.uint8, device=dev)
+    for i, (a, b) in enumerate(zip(b"ACGT", b"TGCA")):
+        code[a] = i
+        comp[a] = b
+    for a in range(0, nreads, block):
+        m = min(block, nreads - a)
+        starts = torch.randint(0, n - read_len + 1, (m,), generator=gen, device=dev)
+        r = genome[starts[:, None] + ar[None, :]]
+        e = torch.rand((m, read_len), generator=gen, device=dev) < err
+        shift = torch.randint(1, 4, (m, read_len), generator=gen, device=dev)
+        sub = lut[(code[r.long()] + shift) % 4]
+        isb = (r != ord("N"))
+        r = torch.where(e & isb, sub, r)
+        flip = torch.rand(m, generator=gen, device=dev) < 0.5
+        rc = comp[r.flip(1).long()]
+        r = torch.where(flip[:, None], rc, r)
+        out[a:a + m, :read_len] = r
+    return out.reshape(-1)

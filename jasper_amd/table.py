@@ -127,6 +127,11 @@ class KmerTable:
         check(self._L.jasper_table_export_device(self._h, C.byref(n), C.byref(p)))
         return p.value, int(n.value)
 
+    def export_to(self, dev_ptr, cap_entries):
+        n = C.c_uint64(0)
+        check(self._L.jasper_table_export_to(self._h, C.c_void_p(dev_ptr), int(cap_entries), C.byref(n)))
+        return int(n.value)
+
     def import_device(self, dev_ptr, n):
         check(self._L.jasper_table_import_device(self._h, C.c_void_p(dev_ptr), int(n)))
 
