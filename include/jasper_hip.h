@@ -61,6 +61,8 @@ int jasper_table_create(int k, uint64_t min_slots, int device, jasper_table **ou
 void jasper_table_destroy(jasper_table *t);
 int jasper_table_info(jasper_table *t, int *k, uint64_t *slots, uint64_t *distinct, uint64_t *occurrences);
 int jasper_table_sync(jasper_table *t);
+/* forget every k-mer (slots and counters zeroed in place; capacity kept) */
+int jasper_table_clear(jasper_table *t);
 
 /* bases: concatenated read sequences, records separated by any non-ACGTacgt byte; windows do not span calls */
 int jasper_count_bases(jasper_table *t, const char *bases, uint64_t n);

@@ -32,6 +32,7 @@ SYMBOLS = {
     "jasper_table_destroy": (None, [_P]),
     "jasper_table_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "jasper_table_sync": (C.c_int, [_P]),
+    "jasper_table_clear": (C.c_int, [_P]),
     "jasper_count_bases": (C.c_int, [_P, C.c_char_p, C.c_uint64]),
     "jasper_count_bases_device": (C.c_int, [_P, _P, C.c_uint64]),
     "jasper_count_reads_text": (C.c_int, [_P, C.c_char_p, C.c_uint64]),

@@ -77,6 +77,13 @@ int jasper_table_sync(jasper_table *t) {
     return JASPER_OK;
 }
 
+int jasper_table_clear(jasper_table *t) {
+    CHK(hipSetDevice(t->t.device));
+    CHK(hipMemsetAsync(t->t.d.slots, 0, t->t.nslots * 16, t->t.stream));
+    CHK(hipMemsetAsync(t->t.d.stats, 0, ST_WORDS * sizeof(unsigned long long), t->t.stream));
+    return JASPER_OK;
+}
+
 int jasper_count_bases(jasper_table *t, const char *bases, uint64_t n) {
     t->t.reset_timing();
     return t->t.count_host(bases, n, g_err);

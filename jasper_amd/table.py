@@ -65,6 +65,9 @@ class KmerTable:
         check(self._L.jasper_last_count_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def clear(self):
+        check(self._L.jasper_table_clear(self._h))
+
     def sync(self):
         check(self._L.jasper_table_sync(self._h))
 
