@@ -345,3 +345,41 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def make_mer_kats(out_path):
+    """known answers of the reference's own encoder: str(MerDNA(s)) and str(MerDNA(s).get_canonical()) from the real
+    SWIG binding (JF::swig/mer_dna.i) for strings with lower case, N at various offsets, short and empty input."""
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+import dna_jellyfish as jf
+import random
+random.seed(5)
+out = []
+for k in (5, 17, 25, 31, 32, 33, 37, 48, 63):
+    jf.MerDNA.k(k)
+    cases = ["", "A", "GT", "N", "ACGTN", "acgtacgt"]
+    for _ in range(12):
+        n = random.choice([k, k, k, k - 1, k + 3, k // 2, 2 * k])
+        s = "".join(random.choice("ACGT") for _ in range(n))
+        r = random.random()
+        if r < 0.25:
+            s = s.lower()
+        elif r < 0.5 and n > 2:
+            p = random.randrange(n)
+            s = s[:p] + random.choice("NnRX-") + s[p + 1:]
+        elif r < 0.6:
+            s = "".join(random.choice("ACGTacgt") for _ in range(n))
+        cases.append(s)
+    for s in cases:
+        m = jf.MerDNA(s)
+        c = m.get_canonical()
+        out.append(dict(k=k, s=s, mer=str(m), canonical=str(c)))
+json.dump(out, open(sys.argv[1], "w"), indent=0)
+''' % JF_PY
+    subprocess.run([sys.executable, "-c", code, out_path], check=True)
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_KATS", "1") == "1":
+    make_mer_kats(os.path.join(os.path.dirname(os.path.abspath(__file__)), "mer_kats.json"))

@@ -1,0 +1,219 @@
+"""GPU parity proper: the HIP path (through the C-ABI) against the CPU oracle on seeded synthetic inputs, edge cases
+of the reference's own tests (empty / ragged input, N, lower case, table growth, several files), and
+size-independent properties at larger sizes.  Integer / byte work: everything must be bit-exact."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from jasper_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def KT(hip):
+    from jasper_amd import KmerTable
+    return KmerTable
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def workload(seed, G, k, cov=30, rl=150, err=0.003, asm_err=1e-3):
+    rng = np.random.default_rng(seed)
+    genome = synth.make_genome(rng, G)
+    reads = synth.make_reads_stream(rng, genome, cov, rl, err)
+    asm = synth.make_assembly(rng, genome, err=asm_err, n_every=max(G // 3, 1000), n_len=60)
+    return genome, reads.tobytes(), asm.tobytes().decode()
+
+
+def histo_rows(h):
+    return [(m, h[m]) for m in range(1, 10002) if h[m]]
+
+
+@pytest.mark.parametrize("k,G,seed", [(37, 200_000, 1), (25, 150_000, 2), (31, 60_000, 3), (32, 60_000, 4), (33, 60_000, 5),
+                                       (15, 30_000, 6), (41, 50_000, 7)])
+def test_count_histogram_lookup_vs_oracle(KT, O, k, G, seed):
+    genome, reads, asm = workload(seed, G, k)
+    t = KT(k, min_slots=1 << 16)          # far too small on purpose: exercises growth / rehash between launches
+    t.count_bases(reads)
+    db = O.OracleDB(k)
+    n_o = db.count_bases(reads)
+    info = t.info()
+    assert info["occurrences"] == n_o
+    assert info["distinct"] == db.distinct()
+    assert t.histogram() == db.histo()
+    rng = np.random.default_rng(seed)
+    # lookups of assembly windows incl. N runs, windows running off the end, and short / empty strings
+    pos = rng.integers(0, len(asm), 3000)
+    qs = [asm[p:p + k] for p in pos] + ["", "A", "N", asm[:k - 1], asm[5:5 + k].lower(), asm[:k] + "GGG"]
+    assert t.lookup(qs) == [db.query(q) for q in qs]
+    t.close()
+
+
+@pytest.mark.parametrize("k,G,seed,thre,passes", [(37, 300_000, 11, 3, 2), (25, 200_000, 12, 3, 2), (31, 100_000, 13, 4, 3),
+                                                    (21, 80_000, 14, 3, 1), (37, 120_000, 15, 5, 4)])
+def test_polish_vs_oracle(KT, O, k, G, seed, thre, passes):
+    from jasper_amd import polisher
+    genome, reads, asm = workload(seed, G, k, asm_err=2e-3)
+    t = KT(k, min_slots=1 << 20)
+    t.count_bases(reads)
+    db = O.OracleDB(k)
+    db.count_bases(reads)
+    bs = max(2 * k + 5, G // 7)
+    recs = synth.chunk_records("ctg", len(asm), bs)
+    names = [r[0] for r in recs] + ["tiny:0", "empty:0"]
+    seqs = [asm[a:b] for _, a, b in recs] + [asm[:k + 3], ""]
+    fixed_o, rows_o, qv_o, _ = db.polish_batch(names, seqs, thre, passes)
+    fixed, rows, qv, res = polisher.polish_batch(t, names, seqs, thre, passes)
+    assert qv == qv_o
+    assert fixed == fixed_o
+    for it in range(passes):
+        assert polisher.fix_csv_text(rows[it]) == "Contig Base_coord Original Mutation\r\n" + rows_o[it]
+    assert sum(len(r) for r in rows) > 10
+    # QV-only run (no --fix): sequence unchanged, same pass-0 counters
+    res2 = t.polish_batch(seqs, thre, passes, fix=False)
+    assert res2.seqs == seqs and res2.qv[:2] == qv_o[:2] and not res2.records
+    t.close()
+
+
+def test_reads_files_formats_and_gzip(KT, O, tmp_path):
+    """`zcat -f R1 R2 | jellyfish count`: one stream, format from the first byte, plain and gzip mixed"""
+    k = 21
+    rng = np.random.default_rng(5)
+    genome = synth.make_genome(rng, 20000, repeat_frac=0)
+    stream = synth.make_reads_stream(rng, genome, 10, 80, 0.01).tobytes().decode()
+    reads = [r for r in stream.split("N") if r]
+    half = len(reads) // 2
+    fq1 = "".join("@r%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads[:half]))
+    fq2 = "".join("@s%d x\r\n%s\r\n+\r\n%s\r\n" % (i, r, "#" * len(r)) for i, r in enumerate(reads[half:]))
+    p1, p2 = tmp_path / "r1.fq", tmp_path / "r2.fq.gz"
+    p1.write_text(fq1)
+    with gzip.open(p2, "wb") as f:
+        f.write(fq2.encode())
+    t = KT(k, min_slots=1 << 16)
+    t.count_files([str(p1), str(p2)])
+    db = O.OracleDB(k)
+    db.count_text(fq1 + fq2)
+    assert t.histogram() == db.histo() and t.info()["occurrences"] == sum(c for _, c in db.items())
+    t.close()
+    # FASTA, multi-line, with an empty record and lower case
+    fa = ">a\nACGTACGTACGTACGTACGTACGTAC\nGTACGTAAACCCGGGTTT\n>b\n>c desc\nacgtacgtacgtacgtacgtacgtacgtacgtaaa\n"
+    t = KT(k, min_slots=1 << 16)
+    t.count_text(fa)
+    db = O.OracleDB(k)
+    db.count_text(fa)
+    assert t.histogram() == db.histo()
+    t.close()
+
+
+def test_format_errors(KT):
+    from jasper_amd._lib import JasperHipError
+    t = KT(21, min_slots=1 << 16)
+    with pytest.raises(JasperHipError, match="Unsupported format"):
+        t.count_text("ACGT\n")
+    with pytest.raises(JasperHipError, match="Invalid fastq"):
+        t.count_text("@r\nACGTACGT\n+\nIIII\n")
+    t.count_text("")                       # empty input: nothing counted, no error
+    assert t.info()["occurrences"] == 0 and t.histogram() == [0] * 10002
+    t.close()
+    with pytest.raises(JasperHipError):
+        KT(70)                             # k out of range
+
+
+def test_merge_by_export_import_is_keywise_sum(KT, O):
+    """the multi-GPU merge primitive: counts(A) (+) counts(B) == counts(A ++ B)   (jellyfish merge semantics)"""
+    k = 37
+    _, reads, _ = workload(21, 100_000, k)
+    cut = reads.index(b"N", len(reads) // 2) + 1
+    a, b = reads[:cut], reads[cut:]
+    ta, tb = KT(k, min_slots=1 << 16), KT(k, min_slots=1 << 22)
+    ta.count_bases(a)
+    tb.count_bases(b)
+    ent = tb.export_entries()
+    assert ent.shape[0] == tb.info()["distinct"]
+    ta.import_entries(ent)
+    db = O.OracleDB(k)
+    db.count_bases(reads)
+    assert ta.histogram() == db.histo() and ta.info()["distinct"] == db.distinct()
+    # linearity: importing the same entries again doubles exactly those counts
+    ta.close()
+    tb.import_entries(ent)
+    h2 = tb.histogram()
+    db2 = O.OracleDB(k)
+    db2.count_bases(b)
+    db2.count_bases(b)
+    assert h2 == db2.histo()
+    tb.close()
+
+
+def test_device_resident_stream_equals_host_stream(KT):
+    """jasper_count_bases_device on an HBM-resident (and deliberately misaligned) buffer == host path"""
+    import torch
+    k = 37
+    _, reads, _ = workload(31, 150_000, k)
+    t1, t2 = KT(k, min_slots=1 << 16), KT(k, min_slots=1 << 16)
+    t1.count_bases(reads)
+    buf = torch.empty(len(reads) + 64, dtype=torch.uint8, device="cuda")
+    for shift in (0, 3):
+        view = buf[shift:shift + len(reads)]
+        view.copy_(torch.frombuffer(bytearray(reads), dtype=torch.uint8))
+        torch.cuda.synchronize()
+        t2.clear()
+        t2.count_bases_device(view.data_ptr(), len(reads))
+        assert t2.histogram() == t1.histogram() and t2.info()["occurrences"] == t1.info()["occurrences"]
+    t1.close()
+    t2.close()
+
+
+def test_properties_at_scale(KT):
+    """size-independent properties on a multi-Mb workload (the oracle would take minutes here)"""
+    import torch
+    k = 37
+    G = 8_000_000
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    genome = synth.torch_genome(gen, G, dev)
+    nreads = G * 30 // 150
+    reads = synth.torch_reads_stream(gen, genome, nreads)
+    torch.cuda.synchronize()
+    t = KT(k, min_slots=1 << 20)
+    t.count_bases_device(reads.data_ptr(), reads.numel())
+    info = t.info()
+    assert info["occurrences"] == nreads * (150 - k + 1)          # every window of every read, nothing across the 'N's
+    h = t.histogram()
+    assert sum(h) == info["distinct"]
+    assert sum(m * c for m, c in enumerate(h[:10001])) <= info["occurrences"]
+    # counting the same reads again doubles every count: histogram bins move from m to 2m
+    t.count_bases_device(reads.data_ptr(), reads.numel())
+    h2 = t.histogram()
+    assert all(h2[2 * m] == h[m] for m in range(1, 5000)) and all(h2[m] == 0 for m in range(1, 10000, 2))
+    t.clear()
+    t.count_bases_device(reads.data_ptr(), reads.numel())
+    rng = np.random.default_rng(1)
+    asm = synth.make_assembly(rng, genome.cpu().numpy(), err=2e-4).tobytes().decode()
+    bs = synth.jasper_batch_size(len(asm), 16)
+    seqs = [asm[a:b] for _, a, b in synth.chunk_records("c", len(asm), bs)]
+    res = t.polish_batch(seqs, 2, 2)
+    assert res.qv[1] == sum(len(s) - k + 1 for s in seqs)
+    assert res.qv[2] < res.qv[0] / 20                              # polishing removes >95 % of the bad k-mers
+    # idempotence of the QV pass: scanning the polished text again reports exactly the final counters, and a
+    # sequence that needs no fix is returned unchanged
+    res2 = t.polish_batch(res.seqs, 2, 0, fix=False)
+    assert res2.qv[0] == res.qv[2] and res2.qv[1] == res.qv[3] and res2.seqs == res.seqs
+    # length bookkeeping: every record explains one unit of length change
+    delta = 0
+    for r in res.records:
+        if r["kind"] == "i":
+            delta -= r["rep"]
+        elif r["kind"] == "d":
+            delta += r["rep"]
+        elif r["kind"] == "x":
+            delta += len(r["patch"]) - len(r["orig"])
+    assert sum(len(s) for s in res.seqs) - sum(len(s) for s in seqs) == delta
+    t.close()

@@ -1,0 +1,141 @@
+"""CPU: host-side mirrors of src/jasper.sh / src/jasper.py / src/jellyfish.py logic (no GPU, no library calls)."""
+import os
+
+import pytest
+
+from golden_util import Case, case_names
+from jasper_amd import cli, polisher, qv, synth, dist
+from oracle import oracle as O
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_threshold_mirror_matches_reference_script(name):
+    c = Case(name)
+    txt, status = polisher.threshold_from_histo_rows(c.histo_rows())
+    assert status == c.meta["jellyfish_py_exit"] and txt == c.meta["jellyfish_py_stdout"]
+
+
+def test_threshold_edge_cases():
+    f = polisher.threshold_from_histo_rows
+    assert f([]) == ("", 0)
+    assert f([(1, 10)]) == ("", 0)
+    assert f([(1, 100), (2, 50), (3, 60)]) == ("", 1)             # local min at 2 -> int(2/2)=1 < 2 -> exit 1
+    assert f([(1, 100), (2, 50), (3, 20), (4, 10), (5, 12)]) == ("2", 0)
+    assert f([(1, 100), (2, 50), (3, 20), (4, 10), (5, 9), (6, 30)]) == ("2", 0)
+    assert f([(1, 5), (2, 9)]) == ("", 1)                           # first row only sets count; rise at row 2 with threshold 0
+    assert f([(1, 100), (2, 50), (3, 20)]) == ("", 0)              # never rises: prints nothing, exit 0
+    for rows in ([(1, 100), (2, 50), (3, 60)], [(1, 100), (2, 50), (3, 20), (4, 10), (5, 12)], [(1, 5), (2, 9)]):
+        try:
+            t = O.threshold(rows)
+            o = (str(t) if t else "", 0)
+        except SystemExit:
+            o = ("", 1)
+        assert o == f(rows)
+
+
+def test_step_rule():
+    """src/jasper.py:20 step = max(2, round(k/8)) with python's round-half-to-even"""
+    import math
+    for k in range(6, 64):
+        assert max(2, round(k / 8)) == max(2, int(math.floor(k / 8 + 0.5)) if (k / 8) % 1 != 0.5 else max(2, round(k / 8)))
+
+
+def test_batch_size_rule():
+    assert synth.jasper_batch_size(1_000_000, 4) == 225000            # SURVEY A.5 probe
+    assert synth.jasper_batch_size(47_000_000, 16) == 2643750
+    assert synth.jasper_batch_size(3_100_000_000, 16) == 25000000     # capped
+    assert synth.jasper_batch_size(1000, 2, user_batch=30000000) == 30000000   # a larger user -b is not capped
+
+
+def test_split_and_join_roundtrip(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    contigs = [(">c0", "A" * 600000), (">c1", "C" * 300000), (">c2", "G" * 100000)]
+    files = cli.split_batches(contigs, 225000, "asm.fa")
+    got = [[ln.strip() for ln in open(f) if ln.startswith(">")] for f in files]
+    # SURVEY A.5 probe: {c0:0,c0:225000}, {c0:450000,c1:0}, {c1:225000,c2:0}
+    assert got == [[">c0:0", ">c0:225000"], [">c0:450000", ">c1:0"], [">c1:225000", ">c2:0"]]
+    text = cli.join_polished(files, 225000, [c[0] for c in contigs])
+    assert text == "".join("%s\n%s\n" % c for c in contigs)
+
+
+def test_read_assembly_first_token_rules(tmp_path):
+    p = tmp_path / "a.fa"
+    p.write_text(">c0 desc here\nACGT extra\nTTTT\n\n>c1\nGG\n>empty\n>c2\nA\n")
+    assert cli.read_assembly(str(p)) == [(">c0", "ACGTTTTT"), (">c1", "GG"), (">c2", "A")]
+    assert cli.sequence_bytes(str(p)) == len("ACGT extra") + 4 + 0 + 2 + 1
+
+
+def test_parse_fasta_dict_semantics(tmp_path):
+    p = tmp_path / "b.fa"
+    p.write_text("junk before\n>a x y\nAC\nGT\n>b\n\n>a\nTT\n")
+    d = polisher.parse_fasta(str(p))
+    assert list(d.items()) == [("a", "TT"), ("b", "")]
+
+
+def test_rows_and_csv_format():
+    rows = []
+    rows += polisher.rows_from_record("c:0", dict(kind="s", index=12, newc="A", oldc="c", rep=1))
+    rows += polisher.rows_from_record("c:0", dict(kind="i", index=13, newc="-", oldc="T", rep=3))
+    rows += polisher.rows_from_record("c:0", dict(kind="d", index=14, newc="G", oldc="-", rep=2))
+    txt = polisher.fix_csv_text(rows)
+    assert txt == "Contig Base_coord Original Mutation\r\nc:0 12 A sc\r\nc:0 13 - iTTT\r\nc:0 14 GG d-\r\n"
+    one = polisher.rows_from_record("n", dict(kind="x", index=100, patch="ACGTA", orig="ACCTA"))
+    assert polisher.fix_csv_text(one).splitlines()[1] == "n 102 ['G'] ['sC']"
+    two = polisher.rows_from_record("n", dict(kind="x", index=5, patch="ACGTA", orig="ACTAT"))
+    assert len(two) == 2
+    with pytest.raises(IndexError):
+        polisher.rows_from_record("n", dict(kind="x", index=5, patch="ACGT", orig="ACGT"))
+
+
+def test_alignment_standin_properties():
+    import random
+    rnd = random.Random(3)
+    for _ in range(200):
+        a = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(0, 30)))
+        b = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(0, 30)))
+        ra, rb = polisher.globalms_first(a, b)
+        assert len(ra) == len(rb)
+        assert ra.replace("-", "") == a and rb.replace("-", "") == b
+        assert all(not (x == "-" and y == "-") for x, y in zip(ra, rb))
+
+
+def test_qv_formatting():
+    assert qv.q_value(0, 1000, 37) == "Inf"
+    s = qv.q_value(171811, 46999330, 37)
+    assert s.count(".") == 1 and len(s.split(".")[1]) == 5
+    import math
+    approx = -10 * math.log10(1 - (1 - 171811 / 46999330) ** (1 / 37))
+    assert abs(float(s) - approx) < 1e-3
+    assert abs(float(qv.q_value(112, 46999349, 37)) - (-10 * math.log10(1 - (1 - 112 / 46999349) ** (1 / 37)))) < 1e-2
+
+
+def test_cli_parser_quirks():
+    o = cli.parse_args(["-a", "x/asm.fa", "-k", "25", "-p", "1", "-t", "8", "-b", "123"])
+    assert (o.query_fn, o.kmer, o.passes, o.num_threads, o.batch_size) == ("asm.fa", "25", "1", "8", "123")
+    o = cli.parse_args(["-k", "25", "-d"])
+    assert o.debug and o.kmer == "25"
+    with pytest.raises(SystemExit):               # src/jasper.sh:93-96: -d eats the next argument, so "25" is unknown
+        cli.parse_args(["-d", "-k", "25"])
+    with pytest.raises(SystemExit):
+        cli.parse_args(["--nope"])
+
+
+def test_chunk_assignment_and_shards():
+    owner = dist.assign_chunks([10, 9, 8, 1, 1, 1], 2)
+    loads = [sum(l for l, o in zip([10, 9, 8, 1, 1, 1], owner) if o == r) for r in range(2)]
+    assert sorted(loads) == [13, 17] and sum(loads) == 30     # longest-first greedy
+    cover = []
+    for r in range(3):
+        lo, hi = dist.shard_range(10, r, 3)
+        cover += list(range(lo, hi))
+    assert cover == list(range(10))
+
+
+def test_synth_recipe_small():
+    import numpy as np
+    rng = np.random.default_rng(1)
+    g = synth.make_genome(rng, 50000)
+    r = synth.make_reads_stream(rng, g, 5, 100, 0.01)
+    assert r.size == (50000 * 5 // 100) * 101 and set(np.unique(r)) <= set(b"ACGTN")
+    a = synth.make_assembly(rng, g, err=1e-3, n_every=20000, n_len=50)
+    assert abs(len(a) - len(g)) < 50 and b"N" * 50 in a.tobytes()
