@@ -66,12 +66,37 @@ class JasperHipError(RuntimeError):
         self.code = code
 
 
+def _share_hip_runtime_with_torch():
+    """One process must use ONE HIP/HSA runtime. PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64;
+    if libjasper_hip.so pulled in /opt/rocm's copies first, a later `import torch` finds "No HIP GPUs" (the second
+    HSA runtime cannot open the device). So when torch is installed but not imported yet, load ITS runtime first;
+    libjasper_hip.so's NEEDED libamdhip64.so.7 then resolves to the already-loaded copy. Without torch the system
+    ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """load libjasper_hip.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')"""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s not built: run `make -C jasper_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)  # AttributeError if the library does not export a declared symbol

@@ -354,6 +354,9 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
     while (pos < n) {
         uint64_t piece = std::max<uint64_t>(nslots / 4, 1u << 20);
         piece = std::min<uint64_t>(piece, 1ull << 31);
+        if (piece > nslots / 4) {   // small table: make room for a whole piece of new keys up front
+            if (ensure_capacity(std::min<uint64_t>(piece, n - pos), err)) return -1;
+        }
         uint64_t start = pos >= halo ? pos - halo : 0;
         // round the start down so that (d_bases + start) is 16-byte aligned
         const uint64_t a = (start + misalign) & 15;
@@ -387,6 +390,9 @@ int Table::count_host(const char *bases, uint64_t n, std::string &err) {
     int buf = 0;
     while (pos < n) {
         const uint64_t piece = std::min<uint64_t>(stage_bytes - halo, std::max<uint64_t>(nslots / 4, 1u << 20));
+        if (piece > nslots / 4) {
+            if (ensure_capacity(std::min<uint64_t>(piece, n - pos), err)) return -1;
+        }
         const uint64_t start = pos >= halo ? pos - halo : 0;
         const uint64_t end = std::min<uint64_t>(n, pos + piece);
         const uint64_t len = end - start;
@@ -467,6 +473,9 @@ int Table::import_entries(const unsigned long long *d_entries, uint64_t n, std::
     uint64_t pos = 0;
     while (pos < n) {
         uint64_t piece = std::min<uint64_t>(n - pos, std::max<uint64_t>(nslots / 4, 1u << 20));
+        if (piece > nslots / 4) {
+            if (ensure_capacity(piece, err)) return -1;
+        }
         hipLaunchKernelGGL(import_kernel, dim3(grid_for(piece, 256)), dim3(256), 0, stream, d_entries + 3 * pos, piece, d);
         HIPCHK(hipGetLastError());
         pos += piece;
