@@ -383,3 +383,81 @@ json.dump(out, open(sys.argv[1], "w"), indent=0)
 
 if __name__ == "__main__" and os.environ.get("GOLDEN_KATS", "1") == "1":
     make_mer_kats(os.path.join(os.path.dirname(os.path.abspath(__file__)), "mer_kats.json"))
+
+
+def make_e2e(outdir):
+    """one run of the REAL src/jasper.sh (bash + perl + jellyfish + jasper.py) -> tests/golden/e2e/*.
+    QV lines are not captured: `bc` is not installed in the build container."""
+    import glob as _glob
+    rng = np.random.default_rng(77)
+    k = 25
+    contigs = [("ctgA some description", rand_seq(rng, 9000)), ("ctgB", rand_seq(rng, 5000)), ("ctgC:x", rand_seq(rng, 2500))]
+    truth = {n.split()[0]: s for n, s in contigs}
+    asm = {}
+    for n, s in truth.items():
+        L = len(s)
+        plan = [(int(p), ["sub", "ins", "del"][int(rng.integers(0, 3))], None) for p in sorted(rng.choice(L - 200, max(3, L // 700), replace=False) + 100)]
+        plan = [(p, kd, {"sub": 1 + int(rng.integers(0, 3)), "ins": "ACGT"[int(rng.integers(0, 4))], "del": 1}[kd]) for p, kd, _ in plan]
+        asm[n] = mutate(rng, s, plan)
+    reads = sample_reads(rng, [(s, 1.0) for s in truth.values()], 40, 100, 0.002)
+    work = tempfile.mkdtemp(prefix="golden_e2e_")
+    half = len(reads) // 2
+    write_reads(os.path.join(work, "r1.fq"), reads[:half], "fq", rng)
+    write_reads(os.path.join(work, "r2.fq"), reads[half:], "fq", rng)
+    with open(os.path.join(work, "asm.fa"), "w") as f:
+        for (hdr, _), (n, s) in zip(contigs, asm.items()):
+            f.write(">%s\n" % hdr)
+            for a in range(0, len(s), 70):
+                f.write(s[a:a + 70] + "\n")
+    # PYTHONPATH must be ONE directory holding jellyfish.py, dna_jellyfish and Bio (src/jasper.sh:115)
+    pp = os.path.join(work, "pp")
+    os.makedirs(os.path.join(pp, "Bio"))
+    for fn in ("dna_jellyfish.py", "_dna_jellyfish.so"):
+        shutil.copy(os.path.join(JF_PY, fn), pp)
+    shutil.copy(os.path.join(REF, "jellyfish.py"), pp)
+    open(os.path.join(pp, "Bio", "__init__.py"), "w").write("")
+    stub = DRIVER.split("# --- stand-in")[1].split("Bio = types.ModuleType")[0]
+    open(os.path.join(pp, "Bio", "pairwise2.py"), "w").write(
+        "# stand-in" + stub + "\nimport types\nalign = types.SimpleNamespace(globalms=_globalms)\ndef format_alignment(*a, **k): return ''\n")
+    # jasper.sh wants jasper.py executable next to itself: run a private copy of the two scripts from a temp bin dir
+    bindir = os.path.join(work, "bin")
+    os.makedirs(bindir)
+    for fn in ("jasper.sh", "jasper.py", "jellyfish.py"):
+        shutil.copy(os.path.join(REF, fn), bindir)
+        os.chmod(os.path.join(bindir, fn), 0o755)
+    env = dict(os.environ, PATH=bindir + ":" + os.path.dirname(JF_BIN) + ":" + os.environ["PATH"], PYTHONPATH=pp)
+    run_dir = os.path.join(work, "run")
+    os.makedirs(run_dir)
+    for fn in ("r1.fq", "r2.fq", "asm.fa"):
+        shutil.copy(os.path.join(work, fn), run_dir)
+    p = subprocess.run(["bash", os.path.join(bindir, "jasper.sh"), "-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(k), "-t", "4", "-p", "2", "-d"],
+                       cwd=run_dir, env=env, capture_output=True, text=True)
+    if os.path.isdir(outdir):
+        shutil.rmtree(outdir)
+    os.makedirs(outdir)
+    for fn in ("asm.fa",):
+        shutil.copy(os.path.join(run_dir, fn), outdir)
+    for fn in ("r1.fq", "r2.fq"):
+        with gzip.GzipFile(os.path.join(outdir, fn + ".gz"), "wb", mtime=0) as f:
+            f.write(open(os.path.join(run_dir, fn), "rb").read())
+    for fn in ("asm.fa.polished.fasta", "asm.fa.fixes.csv", "jfhisto%d.csv" % k, "threshold.txt"):
+        shutil.copy(os.path.join(run_dir, fn), outdir)
+    batches = {}
+    for bf in sorted(_glob.glob(os.path.join(run_dir, "asm.fa.batch.*.fa"))):
+        batches[os.path.basename(bf)] = [ln.strip() for ln in open(bf) if ln.startswith(">")]
+    log_lines = [re_sub_date(ln) for ln in p.stdout.splitlines()]
+    meta = dict(k=k, threads=4, passes=2, exit=p.returncode, batches=batches, stdout=log_lines,
+                sentinels=sorted(os.path.basename(x) for x in _glob.glob(os.path.join(run_dir, "jasper.*.success"))))
+    json.dump(meta, open(os.path.join(outdir, "meta.json"), "w"), indent=1, sort_keys=True)
+    shutil.rmtree(work)
+    return meta
+
+
+def re_sub_date(line):
+    import re
+    return re.sub(r"^\[[^\]]*\]", "[DATE]", line)
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_E2E", "1") == "1":
+    m = make_e2e(os.path.join(os.path.dirname(os.path.abspath(__file__)), "e2e"))
+    print("e2e exit", m["exit"], m["batches"], m["stdout"])

@@ -1,0 +1,71 @@
+"""GPU: the drop-in driver (jasper_amd.cli) against one run of the REAL src/jasper.sh (tests/golden/e2e, produced by
+tests/golden/make_golden.py:make_e2e with bash + perl + Jellyfish 2.3.0 + unmodified jasper.py)."""
+import gzip
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+E2E = os.path.join(HERE, "golden", "e2e")
+ROOT = os.path.dirname(HERE)
+
+
+def fasta_records(path):
+    d, name = {}, None
+    for ln in open(path):
+        if ln.startswith(">"):
+            name = ln.strip()
+            d[name] = ""
+        else:
+            d[name] += ln.strip()
+    return d
+
+
+def test_cli_matches_jasper_sh(hip, tmp_path):
+    meta = json.load(open(os.path.join(E2E, "meta.json")))
+    for fn in ("r1.fq", "r2.fq"):
+        with open(tmp_path / fn, "wb") as f:
+            f.write(gzip.open(os.path.join(E2E, fn + ".gz")).read())
+    shutil.copy(os.path.join(E2E, "asm.fa"), tmp_path)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(meta["k"]),
+                        "-t", str(meta["threads"]), "-p", str(meta["passes"]), "-d"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    # artefacts of src/jasper.sh
+    assert open(tmp_path / "threshold.txt").read() == open(os.path.join(E2E, "threshold.txt")).read()
+    assert open(tmp_path / "jfhisto25.csv").read() == open(os.path.join(E2E, "jfhisto25.csv")).read()
+    # contig order in the reference is perl-hash order: compare per record
+    assert fasta_records(tmp_path / "asm.fa.polished.fasta") == fasta_records(os.path.join(E2E, "asm.fa.polished.fasta"))
+    assert open(tmp_path / "asm.fa.fixes.csv", newline="").read() == open(os.path.join(E2E, "asm.fa.fixes.csv"), newline="").read()
+    # batch file layout (kept because of -d)
+    got = {}
+    for fn in sorted(os.listdir(tmp_path)):
+        if re.match(r"asm\.fa\.batch\.\d+\.fa$", fn):
+            got[fn] = [ln.strip() for ln in open(tmp_path / fn) if ln.startswith(">")]
+    assert got == meta["batches"]
+    assert sorted(fn for fn in os.listdir(tmp_path) if re.match(r"jasper\..*\.success$", fn)) == meta["sentinels"]
+    # log lines: same messages in the same order (the reference's Q values read "Inf" there only because bc is missing)
+    mine = [re.sub(r"^\[[^\]]*\]", "[DATE]", ln) for ln in p.stdout.splitlines()]
+    strip_q = lambda ls: [re.sub(r"Q value = .*", "Q value =", ln) for ln in ls]
+    assert strip_q(mine) == strip_q(meta["stdout"])
+    # a second run in the same directory resumes from the sentinels and leaves the result untouched
+    p2 = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", "25", "-t", "4", "-p", "2"],
+                        cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert p2.returncode == 0
+    assert fasta_records(tmp_path / "asm.fa.polished.fasta") == fasta_records(os.path.join(E2E, "asm.fa.polished.fasta"))
+
+
+def test_cli_errors(hip, tmp_path):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-a", "missing.fa"], cwd=tmp_path, env=env, capture_output=True, text=True)
+    assert p.returncode == 1 and "The query file does not exist" in p.stderr
+    (tmp_path / "a.fa").write_text(">c\nACGT\n")
+    p = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-a", "a.fa", "-r", "nope.fq"], cwd=tmp_path, env=env, capture_output=True, text=True)
+    assert p.returncode == 1 and "does not exist" in p.stderr
