@@ -227,24 +227,28 @@ def merge_fix_csvs(csv_files):
         for fnr, ln in enumerate(content, start=1):
             if (n == 0 and fnr == 1) or fnr > 1:
                 lines.append(ln)
-    rows = []
-    for ln in lines:
-        parts = ln.split(":")
-        s = parts[0] + " " + (parts[1] if len(parts) > 1 else "")
-        rows.append(s)
+    def awk_fields(rec):
+        """awk's default field splitting: runs of blank/tab/newline separate fields ('\r' is NOT a separator)"""
+        t = rec.strip(" \t\n")
+        return re.split(r"[ \t\n]+", t) if t else []
 
-    def num(x):
-        m = re.match(r"\s*-?\d+", x)
+    rows = []
+    for ln in lines:                                   # awk -F ':' '{print $1" "$2}'
+        parts = ln.split(":")
+        rows.append(parts[0] + " " + (parts[1] if len(parts) > 1 else ""))
+
+    def num(x):                                        # sort -n: leading integer, 0 if none
+        m = re.match(r"[ \t]*-?\d+", x)
         return int(m.group(0)) if m else 0
 
-    def key(s):
-        F = s.split()
-        return (F[0].encode() if F else b"", num(F[1]) if len(F) > 1 else 0, num(F[2]) if len(F) > 2 else 0)
+    def key(s):                                        # sort -k1,1 -k2,2n -k3,3n, last resort: whole line
+        F = awk_fields(s)
+        return (F[0].encode() if F else b"", num(F[1]) if len(F) > 1 else 0, num(F[2]) if len(F) > 2 else 0, s.encode())
 
     rows.sort(key=key)
     out = []
-    for s in rows:
-        F = s.split()
+    for s in rows:                                     # awk '{print $1":"$2" "$3" "$4" "$5}'
+        F = awk_fields(s)
         F += [""] * (5 - len(F))
         out.append("%s:%s %s %s %s\n" % (F[0], F[1], F[2], F[3], F[4]))
     return "".join(out)
