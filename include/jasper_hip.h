@@ -94,6 +94,8 @@ int jasper_result_aux(const jasper_result *r, int chunk, const char **aux, uint6
 int jasper_result_qv(const jasper_result *r, int64_t out4[4]); /* bad0,total0,badP,totalP  (src/jasper.py:107-111) */
 int jasper_result_lookups(const jasper_result *r, uint64_t *n);
 double jasper_result_seconds(const jasper_result *r);         /* device time of the passes (HIP events) */
+/* how the batch was parallelised: segments walked over all passes, chunks redone unsegmented after a failed speculation */
+int jasper_result_segments(const jasper_result *r, uint64_t *n_segments, uint64_t *n_respeculated);
 void jasper_result_free(jasper_result *r);
 
 /* kernel timing for bench.py: HIP-event time of the last counting call on this table, and its launch count */

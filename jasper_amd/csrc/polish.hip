@@ -1,9 +1,15 @@
 // polish.hip -- the assembly scan / lookup / fix loop on the GPU.
 //
-// One 64-lane wavefront walks one chunk record (">name:offset", src/jasper.sh:155) through one pass of
-// src/jasper.py:iteration.  The walk is sequential by definition (the next position depends on the last
-// repair), so parallelism comes from three places:
-//   * chunks are independent (the reference's own xargs -P parallelism, src/jasper.sh:212): one wave each;
+// One 64-lane wavefront walks one SEGMENT of a chunk record (">name:offset", src/jasper.sh:155) through one pass
+// of src/jasper.py:iteration.  The walk is sequential by definition (the next position depends on the last
+// repair), so parallelism comes from these places:
+//   * chunks are independent (the reference's own xargs -P parallelism, src/jasper.sh:212);
+//   * a chunk is cut at sync points -- starts of runs of >= k-1 bad k-mers preceded by >= 4k clean positions, found
+//     by a dense scan (scan_kernel / classify_kernel / find_sync_kernel).  Any stride phase lands inside such a run
+//     and handle_bad_kmers() then finds the same run bounds, so the walk right of a sync point is independent of
+//     everything left of it except a coordinate shift: segments are walked concurrently and stitched afterwards.
+//     A walk that touches text outside what its segment may assume raises spec_fail and the chunk is redone as one
+//     segment (= the plain sequential walk);
 //   * inside a chunk the wave evaluates 64 stride positions i, i+(k-1), ... at once, ballots "needs
 //     attention" and jumps to the first such position (positions that are plainly good only ever do
 //     `i += k-1`, src/jasper.py:97,100);
@@ -46,20 +52,39 @@ struct Walker {
     uint32_t solid;
     uint8_t *buf;
     int64_t len, gs, glen, cap;
-    ChunkDev *C;
+    SegDev *C;
     uint32_t chunk_id;
     uint32_t nrec, naux, seqno;
     int pass;
     int status;
     uint64_t nlook;
     uint8_t *s_tbf, *s_t1, *s_t2, *s_gkb, *s_gka;
+    // segment context
+    int64_t delta;        // len - len0: how far text right of the last edit has shifted
+    int64_t dirty_end;    // local positions >= dirty_end hold pass-start text (shifted by delta)
+    int64_t glo;          // reads below this local position are outside what a non-first segment may assume
+    bool is_first, is_last;
+    int spec_fail;
+    const uint8_t *cls;
+    int64_t cls_n, seg_lo, stop_orig;
+    ScratchPool pool;
+    // path-search scratch (valid while a pool slot is held)
+    uint32_t *bfs_nodes;
+    uint8_t *bfs_front, *bfs_patch;
+    int bfs_slot;
+
+    // a read of local range [lo, hi) (pre-clamp bounds) must stay inside what this segment knows to be true text
+    __device__ __forceinline__ void guard(int64_t lo, int64_t hi) {
+        if ((!is_first && lo < glo) || (!is_last && hi > len)) spec_fail = 1;
+    }
 
     // ---------------- text access ----------------
     __device__ __forceinline__ uint8_t at(int64_t p) const { return buf[p < gs ? p : p + glen]; }
 
     // qf[jf.MerDNA(seq[a:b]).get_canonical()] -- python slice semantics, per lane
-    __device__ __forceinline__ uint32_t cnt_seq(int64_t a, int64_t b) const {
+    __device__ __forceinline__ uint32_t cnt_seq(int64_t a, int64_t b) {
         int64_t lo, hi;
+        guard(a, b);
         pyslice(len, a, b, lo, hi);
         const u128 m = encode_padded(k, (long)(hi - lo), [&](int q) { return at(lo + q); });
         return clamp32(table_get(T, mix(canonical(m, k), T.B)));
@@ -104,11 +129,14 @@ struct Walker {
         gs += plen;
         glen -= plen;
         len += plen - (b - a);
+        delta += plen - (b - a);
+        dirty_end = a + plen;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
 
     // ---------------- LDS string helpers (lane-parallel copies, then a wave barrier) ----------------
-    __device__ __forceinline__ void cp_seq(uint8_t *dst, int64_t lo, int64_t hi) const {
+    __device__ __forceinline__ void cp_seq(uint8_t *dst, int64_t lo, int64_t hi) {
+        guard(lo, hi);
         for (int64_t q = lane; q < hi - lo; q += 64) dst[q] = at(lo + q);
     }
     __device__ __forceinline__ void cp_mem(uint8_t *dst, const uint8_t *src, int n) const {
@@ -210,7 +238,10 @@ struct Walker {
         const int64_t h = (int64_t)((double)(k - 1 - L + k) / 2.0);
         int64_t alo, ahi, blo, bhi;
         if (ga + k - 1 + h < len) pyslice(len, ga + k - 1, ga + k - 1 + h, alo, ahi);
-        else { int64_t st = ga + k - 1; if (st > len - 1) st = len - 1; pyslice(len, st, len, alo, ahi); }
+        else {
+            if (!is_last) spec_fail = 1;   // only the true chunk end may take this branch
+            int64_t st = ga + k - 1; if (st > len - 1) st = len - 1; pyslice(len, st, len, alo, ahi);
+        }
         const int64_t before_len = ahi - alo;
         int64_t bs = gbsi - before_len + 1; if (bs < 0) bs = 0;
         pyslice(len, bs, gbsi + 1, blo, bhi);
@@ -313,15 +344,42 @@ struct Walker {
     }
 
     // ---------------- src/jasper.py:527-583 base_extension ----------------
-    // gkb / gka in s_gkb / s_gka (lengths nb, na). Returns patch length (patch in C->patch) or -1 for None.
+    // gkb / gka in s_gkb / s_gka (lengths nb, na). Returns patch length (patch in bfs_patch, slot kept until
+    // release_scratch()) or -1 for None.
     __device__ int64_t base_extension(int64_t Ltbf, int nb, int na, uint32_t thr) {
         if (nb < k || na < k || thr > solid) return -1;
+        // take a scratch slot (searches are rare; a wave holds a slot only while it searches and splices)
+        uint32_t slot = (uint32_t)((blockIdx.x * 2654435761u) % pool.nslots);
+        for (;;) {
+            unsigned int old = 1;
+            if (lane == 0) old = atomicCAS(&pool.locks[slot], 0u, 1u);
+            old = __shfl(old, 0);
+            if (old == 0u) break;
+            slot = (slot + 1) % pool.nslots;
+            __builtin_amdgcn_s_sleep(16);
+        }
+        bfs_slot = (int)slot;
+        uint8_t *sb = pool.base + (size_t)slot * pool.stride;
+        bfs_nodes = reinterpret_cast<uint32_t *>(sb);
+        bfs_front = sb + pool.off_front;
+        bfs_patch = sb + pool.off_patch;
+        const int64_t r = base_extension_impl(Ltbf, thr);
+        if (r < 0) release_scratch();
+        return r;
+    }
+    __device__ void release_scratch() {
+        if (bfs_slot < 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (lane == 0) atomicExch(&pool.locks[bfs_slot], 0u);
+        bfs_slot = -1;
+    }
+    __device__ int64_t base_extension_impl(int64_t Ltbf, uint32_t thr) {
         const int64_t min_overlap = 5, slack = 10;
         const int64_t max_ext = pyround((double)(Ltbf - 2 * k) * 1.2) + min_overlap + slack;
         const int64_t min_patch_len = pyround((double)(Ltbf - 2 * k) / 1.2) - slack;
-        FrontEntry *F = reinterpret_cast<FrontEntry *>(C->front);
-        const uint32_t fcap = C->front_cap;
-        uint32_t *nodes = C->nodes;
+        FrontEntry *F = reinterpret_cast<FrontEntry *>(bfs_front);
+        const uint32_t fcap = pool.front_cap;
+        uint32_t *nodes = bfs_nodes;
         uint32_t nn = 1;            // node 0 = the initial one-base path (last base of the good k-mer before)
         uint32_t np = 1;
         const int TCAP = k + 3;
@@ -348,7 +406,7 @@ struct Walker {
             np = w;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             if (np > 5000) return -1;                                            // :543-546
-            if (np == 0) continue;  // nothing left: the python loop just spins to max_ext and returns None
+            if (np == 0) return -1;  // nothing left: the python loop just spins to max_ext and returns None
             const uint32_t last_path = np;
             for (uint32_t g = 0; g < last_path; g += 16) {
                 // 16 paths x 4 bases per round: score = qf[km1 + bases[j]]     (:551-554)
@@ -393,12 +451,12 @@ struct Walker {
                                     if (i == min_overlap) return -1;                          // :568-571 "patch empty"
                                     // return_path = (path_before + base)[1:-5]  = path_before[1 : i-4]   (:561/:564)
                                     const int64_t plen = i - 5;
-                                    if (plen > (int64_t)C->patch_cap) { status = PS_BFS_ARENA; return -1; }
+                                    if (plen > (int64_t)pool.patch_cap) { status = PS_BFS_ARENA; return -1; }
                                     if (lane == 0) {
                                         uint32_t nd = pnode;
                                         for (int u = 0; u < 4; ++u) nd = nodes[nd] >> 2;          // drop path[i-1..i-4]
                                         for (int64_t u = plen - 1; u >= 0; --u) {
-                                            C->patch[u] = (uint8_t)("ACGT"[nodes[nd] & 3u]);
+                                            bfs_patch[u] = (uint8_t)("ACGT"[nodes[nd] & 3u]);
                                             nd = nodes[nd] >> 2;
                                         }
                                     }
@@ -410,7 +468,7 @@ struct Walker {
                         if (ext < 0) {
                             ext = j;                                                          // :576-578 (applied below)
                         } else {                                                              // :579-580 sibling
-                            if (np >= fcap || nn >= C->node_cap) { status = PS_BFS_ARENA; return -1; }
+                            if (np >= fcap || nn >= pool.node_cap) { status = PS_BFS_ARENA; return -1; }
                             if (lane == 0) nodes[nn] = (pnode << 2) | (uint32_t)j;
                             // sibling tail = tail_before + base
                             const int keep = tl < TCAP ? tl : TCAP - 1;
@@ -425,7 +483,7 @@ struct Walker {
                     // apply the first extension to the path itself, or kill it                (:576-578,:581-582)
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     if (ext >= 0) {
-                        if (nn >= C->node_cap) { status = PS_BFS_ARENA; return -1; }
+                        if (nn >= pool.node_cap) { status = PS_BFS_ARENA; return -1; }
                         const uint8_t bj = (uint8_t)("ACGT"[ext]);
                         if (lane == 0) nodes[nn] = (pnode << 2) | (uint32_t)ext;
                         if (tl < TCAP) {
@@ -508,6 +566,8 @@ struct Walker {
             }
         } else if (n > k) {                                                    // :301
             int64_t blo, bhi, alo, ahi;
+            guard(gb - k + 1, gb + 1);
+            guard(ga, ga + k);
             pyslice(len, gb - k + 1, gb + 1, blo, bhi);                        // :302
             pyslice(len, ga, ga + k, alo, ahi);                                // :303
             cp_seq(s_gkb, blo, bhi);
@@ -520,13 +580,14 @@ struct Walker {
                 int64_t olo, ohi;
                 pyslice(len, gb + 1, ga, olo, ohi);
                 const int64_t on = ohi - olo;
-                if ((uint64_t)naux + (uint64_t)plen + (uint64_t)on > (uint64_t)C->aux_cap) { status = PS_AUX_OVERFLOW; return; }
-                for (int64_t q = lane; q < plen; q += 64) C->aux[naux + q] = C->patch[q];
+                if ((uint64_t)naux + (uint64_t)plen + (uint64_t)on > (uint64_t)C->aux_cap) { status = PS_AUX_OVERFLOW; release_scratch(); return; }
+                for (int64_t q = lane; q < plen; q += 64) C->aux[naux + q] = bfs_patch[q];
                 for (int64_t q = lane; q < on; q += 64) C->aux[naux + plen + q] = at(olo + q);
                 emit('x', gb + 1, 0, 0, (uint32_t)on, naux, (uint32_t)plen);
                 naux += (uint32_t)(plen + on);
-                replace(gb + 1, ga, C->patch, plen);                           // :312
+                replace(gb + 1, ga, bfs_patch, plen);                          // :312
             }
+            release_scratch();
         }
     }
 
@@ -539,12 +600,18 @@ struct Walker {
         int64_t j = i - 1;
         for (;;) {
             const int64_t jl = j - lane;
-            bool stop = true;
-            if (jl >= 0) stop = !(cnt_seq(jl, jl + k) < thre);
+            bool stop = true, oob = false;
+            if (!is_first && jl < glo) oob = true;                 // left of what this segment may assume
+            else if (jl >= 0) stop = !(cnt_seq(jl, jl + k) < thre);
             // jl == -1 stops the loop whatever the count; jl < -1 is never reached
             const uint64_t m = __ballot(stop);
             nlook += 64;
-            if (m) { j = j - (int64_t)__builtin_ctzll(m); break; }
+            if (m) {
+                const int f = (int)__builtin_ctzll(m);
+                if (__shfl((int)oob, f)) spec_fail = 1;
+                j = j - (int64_t)f;
+                break;
+            }
             j -= 64;
         }
         if (j < -1) j = -1;
@@ -563,6 +630,7 @@ struct Walker {
                 const int f = (int)__builtin_ctzll(m);
                 const bool g = __shfl((int)giveup, f) != 0;
                 i += f;
+                if (!is_last && i >= len - k + 1) spec_fail = 1;
                 if (g) return i + 1;
                 break;
             }
@@ -581,10 +649,10 @@ struct Walker {
                 gb++;
                 nlook += 4;
             }
-            if (gb >= len - 1) { brk = true; return i; }                       // :194-195
+            if (gb >= len - 1) { if (!is_last) spec_fail = 1; brk = true; return i; }   // :194-195
         }
         int64_t s0 = gb - k + 2; if (s0 < 0) s0 = 0;
-        if (s0 + k + k >= len) { brk = true; return s0 + k + k; }              // :197-198
+        if (s0 + k + k >= len) { if (!is_last) spec_fail = 1; brk = true; return s0 + k + k; }   // :197-198
         {
             // four independent lookups (:199-205), one per lane
             uint32_t c = 0;
@@ -621,7 +689,12 @@ struct Walker {
         for (;;) {
             const int64_t p = i + (int64_t)lane * (k - 1);
             bool ev = true;
-            if (p < end) {
+            bool known = false;
+            if (p < end && cls != nullptr && p >= dirty_end + k) {
+                const int64_t o = p - delta + seg_lo;              // pass-start chunk coordinate
+                if (o >= 0 && o < cls_n) { known = true; ev = cls[o] != PC_CLEAN; }
+            }
+            if (p < end && !known) {
                 // one pass over the window: 2-bit encode + validity
                 u128 m = mk(0, 0);
                 bool valid = true;
@@ -649,10 +722,14 @@ struct Walker {
 
     // ---------------- src/jasper.py:50-104, one chunk, one pass ----------------
     __device__ void walk(bool fix, int64_t &wrong_out) {
-        int64_t i = 0, wrong = 0;
+        int64_t i = C->start_i, wrong = 0;
+        bool handed_over = false;
         while (i < len - k + 1 && status == PS_OK) {                           // :55
+            if (__ballot(spec_fail != 0)) { spec_fail = 1; break; }
             i = skip_good(i);
-            if (i >= len - k + 1) break;
+            if (i >= len - k + 1) { if (!is_last) spec_fail = 1; break; }
+            // arriving at the next sync point: the next segment takes over from here
+            if (!is_last && (i - delta + seg_lo) >= stop_orig) { handed_over = true; break; }
             // the reference's own loop body at position i
             uint8_t ch = 'A';
             if (lane < k) ch = at(i + lane);
@@ -713,54 +790,217 @@ struct Walker {
                 i += k - 1;                                                    // :97
             }
         }
+        if (!is_last && !handed_over && status == PS_OK) spec_fail = 1;   // ran off the segment instead of reaching the sync point
+        if (__ballot(spec_fail != 0)) spec_fail = 1;
         wrong_out = wrong;
     }
 };
 
-__global__ __launch_bounds__(64) void polish_kernel(TableDev T, ChunkDev *chunks, int n_chunks, PolishParams P, int pass) {
+__global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, int n_segs, PolishParams P, int pass, ScratchPool pool) {
     __shared__ uint8_t s_tbf[SMAX], s_t1[SMAX], s_t2[SMAX], s_gkb[64], s_gka[64];
     const int c = blockIdx.x;
-    if (c >= n_chunks) return;
-    ChunkDev *C = &chunks[c];
+    if (c >= n_segs) return;
+    SegDev *C = &segs[c];
     if (C->status != PS_OK) return;
     Walker w;
     w.T = T; w.k = P.k; w.step = P.step; w.lane = threadIdx.x; w.solid = P.solid;
     w.buf = C->buf; w.len = C->len; w.gs = C->gs; w.glen = C->glen; w.cap = C->cap;
-    w.C = C; w.chunk_id = (uint32_t)c; w.nrec = C->nrec; w.naux = C->naux; w.seqno = 0; w.pass = pass;
+    w.C = C; w.chunk_id = C->chunk; w.nrec = 0; w.naux = 0; w.seqno = 0; w.pass = pass;
     w.status = PS_OK; w.nlook = 0;
     w.s_tbf = s_tbf; w.s_t1 = s_t1; w.s_t2 = s_t2; w.s_gkb = s_gkb; w.s_gka = s_gka;
+    w.delta = 0; w.dirty_end = INT64_MIN / 2; w.glo = P.k;
+    w.is_first = C->first != 0; w.is_last = C->last != 0; w.spec_fail = 0;
+    w.cls = C->cls; w.cls_n = C->cls_n; w.seg_lo = C->seg_lo; w.stop_orig = C->stop_orig;
+    w.pool = pool; w.bfs_slot = -1; w.bfs_nodes = nullptr; w.bfs_front = nullptr; w.bfs_patch = nullptr;
     const bool fix = P.fix && pass < P.passes;                                 // src/jasper.py:37-38
-    const int64_t total = w.len - P.k + 1;                                     // :51 (may be negative)
     int64_t wrong = 0;
     w.walk(fix, wrong);
+    w.release_scratch();
     if (threadIdx.x == 0) {
         C->len = w.len; C->gs = w.gs; C->glen = w.glen;
-        C->nrec = w.nrec; C->naux = w.naux; C->status = w.status;
-        C->lookups += w.nlook;
-        if (pass == 0) { C->wrong[0] = wrong; C->total[0] = total; }           // :107-111
-        if (pass == P.passes) { C->wrong[1] = wrong; C->total[1] = total; }
+        C->nrec = w.nrec; C->naux = w.naux; C->status = w.status; C->spec_fail = w.spec_fail;
+        C->wrong = wrong;
+        C->lookups = w.nlook;
     }
 }
 
-// gather every chunk's logical text (left part ++ right part of its gap buffer) into one output buffer
-__global__ __launch_bounds__(256) void pack_kernel(const ChunkDev *chunks, int n_chunks, uint8_t *out, const int64_t *out_off) {
-    for (int c = blockIdx.y; c < n_chunks; c += gridDim.y) {
-        const ChunkDev C = chunks[c];
-        uint8_t *dst = out + out_off[c];
-        for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < C.len; q += (int64_t)gridDim.x * blockDim.x)
-            dst[q] = C.buf[q < C.gs ? q : q + C.glen];
+// ---------------------------------------------------------------------------------------------------------
+// Dense scan (K4/K5): count of EVERY window of a contiguous text.  Same LDS staging and rolling recurrence as
+// count_kernel (table.hip); a window that contains a non-ACGT byte gets valid = 0.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SC_THREADS = 256, SC_GROUP = 16, SC_TILE = SC_THREADS * SC_GROUP, SC_HALO = 4;
+
+__global__ __launch_bounds__(SC_THREADS) void scan_kernel(const uint8_t *__restrict__ text, int64_t n, int64_t ntiles,
+                                                           uint32_t *__restrict__ cnt, uint8_t *__restrict__ valid, TableDev T) {
+    __shared__ uint32_t s_code[SC_THREADS + SC_HALO];
+    __shared__ uint32_t s_inv[SC_THREADS + SC_HALO];
+    const int t = threadIdx.x;
+    const int k = T.k;
+    const u128 kmask = maskbits(2 * k);
+    auto stage = [&](int64_t pos, uint32_t &codes, uint32_t &inv) {
+        codes = 0; inv = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t p = pos + j;
+            const int c = (p >= 0 && p < n) ? code(text[p]) : -1;
+            codes = (codes << 2) | (uint32_t)(c & 3);
+            inv = (inv << 1) | (uint32_t)(c < 0);
+        }
+    };
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base0 = tile * SC_TILE;
+        uint32_t c, iv;
+        stage(base0 + (int64_t)t * SC_GROUP, c, iv);
+        s_code[t + SC_HALO] = c;
+        s_inv[t + SC_HALO] = iv;
+        if (t < SC_HALO) {
+            uint32_t hc, hiv;
+            stage(base0 - (int64_t)(SC_HALO - t) * SC_GROUP, hc, hiv);
+            s_code[t] = hc;
+            s_inv[t] = hiv;
+        }
+        __syncthreads();
+        const uint32_t w4 = s_code[t], w3 = s_code[t + 1], w2 = s_code[t + 2], w1 = s_code[t + 3];
+        const uint64_t ivprev = ((uint64_t)s_inv[t] << 48) | ((uint64_t)s_inv[t + 1] << 32) | ((uint64_t)s_inv[t + 2] << 16) |
+                                (uint64_t)s_inv[t + 3];
+        const uint32_t own = c, owninv = iv;
+        __syncthreads();
+        u128 fwd = band(mk(((uint64_t)w4 << 32) | w3, ((uint64_t)w2 << 32) | w1), kmask);
+        u128 rc = revcomp(fwd, k);
+        int run = ivprev ? (int)__builtin_ctzll(ivprev) : 64;
+#pragma unroll 4
+        for (int j = 0; j < SC_GROUP; ++j) {
+            const uint32_t cj = (own >> (30 - 2 * j)) & 3u;
+            const bool bad = (owninv >> (15 - j)) & 1u;
+            fwd = band(bor(shl(fwd, 2), mk(0, cj)), kmask);
+            rc = bor(shr(rc, 2), shl(mk(0, 3u - cj), 2 * (k - 1)));
+            run = bad ? 0 : run + 1;
+            const int64_t e = base0 + (int64_t)t * SC_GROUP + j;    // window end
+            const int64_t p = e - k + 1;                            // window start
+            if (p >= 0 && e < n) {
+                if (run >= k) {
+                    const u128 canon = lt(rc, fwd) ? rc : fwd;
+                    cnt[p] = clamp32(table_get(T, mix(canon, T.B)));
+                    valid[p] = 1;
+                } else {
+                    cnt[p] = 0;
+                    valid[p] = 0;
+                }
+            }
+        }
     }
 }
 
-void launch_polish_pass(const TableDev &T, ChunkDev *d_chunks, int n_chunks, PolishParams pp, int pass, hipStream_t stream) {
-    if (n_chunks <= 0) return;
-    hipLaunchKernelGGL(polish_kernel, dim3(n_chunks), dim3(64), 0, stream, T, d_chunks, n_chunks, pp, pass);
+// class of every window start (see PosClass): what the walk's main loop (src/jasper.py:56-100) does there
+__global__ __launch_bounds__(256) void classify_kernel(const uint32_t *__restrict__ cnt, const uint8_t *__restrict__ valid, int64_t nwin,
+                                                       int k, uint32_t solid, uint8_t *__restrict__ cls) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nwin; p += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t c;
+        if (!valid[p]) c = PC_OTHER;
+        else if (cnt[p] < solid) c = PC_BAD;
+        else if (p > 0) {
+            const int64_t q = p - k > 0 ? p - k : 0;               // seq[max(0,i-k):max(k,i)]  (:80)
+            c = (!valid[q] || 50ull * cnt[p] < (unsigned long long)cnt[q]) ? PC_OTHER : PC_CLEAN;
+        } else c = PC_CLEAN;
+        cls[p] = c;
+    }
 }
 
-void launch_pack(ChunkDev *d_chunks, int n_chunks, uint8_t *d_out, const int64_t *d_out_off, hipStream_t stream) {
-    if (n_chunks <= 0) return;
-    dim3 grid(64, n_chunks < 1024 ? n_chunks : 1024);
-    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, stream, d_chunks, n_chunks, d_out, d_out_off);
+// sync points: p with cls[p-4k .. p) all CLEAN and cls[p .. p+k-1) all BAD
+__global__ __launch_bounds__(256) void find_sync_kernel(const uint8_t *__restrict__ cls, int64_t nwin, int k, int64_t *__restrict__ out,
+                                                        unsigned int *__restrict__ count, unsigned int cap) {
+    const int64_t W = 4ll * k;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nwin; p += (int64_t)gridDim.x * blockDim.x) {
+        if (p < W || p + k - 1 > nwin) continue;
+        if (cls[p] != PC_BAD || cls[p - 1] != PC_CLEAN) continue;
+        bool ok = true;
+        for (int64_t q = 1; q < k - 1 && ok; ++q) ok = cls[p + q] == PC_BAD;
+        for (int64_t q = 2; q <= W && ok; ++q) ok = cls[p - q] == PC_CLEAN;
+        if (!ok) continue;
+        const unsigned int idx = atomicAdd(count, 1u);
+        if (idx < cap) out[idx] = p;
+    }
+}
+
+// copy each segment's text range out of its chunk into the segment's gap buffer (text right of the gap)
+__global__ __launch_bounds__(256) void seg_init_kernel(SegDev *segs, int n_segs, const uint8_t *const *chunk_text) {
+    for (int s = blockIdx.y; s < n_segs; s += gridDim.y) {
+        const SegDev S = segs[s];
+        const uint8_t *src = chunk_text[S.chunk] + S.seg_lo;
+        uint8_t *dst = S.buf + S.glen;
+        for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < S.len0; q += (int64_t)gridDim.x * blockDim.x) dst[q] = src[q];
+    }
+}
+
+// write each segment's owned part of the polished text into the chunk's new text
+__global__ __launch_bounds__(256) void seg_stitch_kernel(const SegDev *segs, int n_segs, uint8_t *const *chunk_out) {
+    for (int s = blockIdx.y; s < n_segs; s += gridDim.y) {
+        const SegDev S = segs[s];
+        uint8_t *dst = chunk_out[S.chunk] + S.out_off;
+        const int64_t n = S.own_hi - S.own_lo;
+        for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t p = S.own_lo + q;
+            dst[q] = S.buf[p < S.gs ? p : p + S.glen];
+        }
+    }
+}
+
+// pack the fix records (and aux bytes) of all segments of a pass into compact arrays, turning segment-local
+// coordinates into chunk coordinates: index += idx_base, seqno += seq_base, aux_off += aux_base
+__global__ __launch_bounds__(64) void seg_gather_kernel(const SegDev *segs, int n_segs, const int64_t *idx_base, const uint32_t *seq_base,
+                                                        const uint32_t *rec_off, const uint32_t *aux_off, FixRec *out_recs, uint8_t *out_aux) {
+    const int s = blockIdx.x;
+    if (s >= n_segs) return;
+    const SegDev S = segs[s];
+    for (uint32_t r = threadIdx.x; r < S.nrec; r += blockDim.x) {
+        FixRec f = S.recs[r];
+        f.index += idx_base[s];
+        f.seqno += seq_base[s];
+        if (f.kind == 'x') f.aux_off += aux_off[s];
+        out_recs[rec_off[s] + r] = f;
+    }
+    for (uint32_t q = threadIdx.x; q < S.naux; q += blockDim.x) out_aux[aux_off[s] + q] = S.aux[q];
+}
+
+static int blocks_for(int64_t items, int per_block) {
+    int64_t b = (items + per_block - 1) / per_block;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+void launch_scan(const TableDev &T, const uint8_t *d_text, int64_t len, uint32_t *d_cnt, uint8_t *d_valid, hipStream_t stream) {
+    if (len <= 0) return;
+    const int64_t ntiles = (len + SC_TILE - 1) / SC_TILE;
+    hipLaunchKernelGGL(scan_kernel, dim3(blocks_for(ntiles, 1)), dim3(SC_THREADS), 0, stream, d_text, len, ntiles, d_cnt, d_valid, T);
+}
+void launch_classify(const uint32_t *d_cnt, const uint8_t *d_valid, int64_t nwin, int k, uint32_t solid, uint8_t *d_cls, hipStream_t stream) {
+    if (nwin <= 0) return;
+    hipLaunchKernelGGL(classify_kernel, dim3(blocks_for(nwin, 256 * 8)), dim3(256), 0, stream, d_cnt, d_valid, nwin, k, solid, d_cls);
+}
+void launch_find_sync(const uint8_t *d_cls, int64_t nwin, int k, int64_t *d_out, unsigned int *d_count, unsigned int cap,
+                      hipStream_t stream) {
+    if (nwin <= 0) return;
+    hipLaunchKernelGGL(find_sync_kernel, dim3(blocks_for(nwin, 256 * 8)), dim3(256), 0, stream, d_cls, nwin, k, d_out, d_count, cap);
+}
+void launch_seg_init(SegDev *d_segs, int n_segs, const uint8_t *const *d_chunk_text, hipStream_t stream) {
+    if (n_segs <= 0) return;
+    dim3 grid(n_segs >= 512 ? 4 : 64, n_segs < 4096 ? n_segs : 4096);
+    hipLaunchKernelGGL(seg_init_kernel, grid, dim3(256), 0, stream, d_segs, n_segs, d_chunk_text);
+}
+void launch_seg_walk(const TableDev &T, SegDev *d_segs, int n_segs, PolishParams pp, int pass, ScratchPool pool, hipStream_t stream) {
+    if (n_segs <= 0) return;
+    hipLaunchKernelGGL(seg_walk_kernel, dim3(n_segs), dim3(64), 0, stream, T, d_segs, n_segs, pp, pass, pool);
+}
+void launch_seg_gather(const SegDev *d_segs, int n_segs, const int64_t *idx_base, const uint32_t *seq_base, const uint32_t *rec_off,
+                       const uint32_t *aux_off, FixRec *out_recs, uint8_t *out_aux, hipStream_t stream) {
+    if (n_segs <= 0) return;
+    hipLaunchKernelGGL(seg_gather_kernel, dim3(n_segs), dim3(64), 0, stream, d_segs, n_segs, idx_base, seq_base, rec_off, aux_off, out_recs, out_aux);
+}
+void launch_seg_stitch(const SegDev *d_segs, int n_segs, uint8_t *const *d_chunk_out, hipStream_t stream) {
+    if (n_segs <= 0) return;
+    dim3 grid(n_segs >= 512 ? 4 : 64, n_segs < 4096 ? n_segs : 4096);
+    hipLaunchKernelGGL(seg_stitch_kernel, grid, dim3(256), 0, stream, d_segs, n_segs, d_chunk_out);
 }
 
 }  // namespace jk

@@ -15,14 +15,14 @@ struct FixRec {
     uint8_t newc;      // 's': new base; 'd': restored base (repeated `rep` times)
     uint8_t oldc;      // 's': old base; 'i': removed base (repeated `rep` times)
     uint32_t rep;      // 'x': length of the original segment
-    uint32_t aux_off;  // 'x': offset of  patch ++ original segment  in the chunk's aux bytes
+    uint32_t aux_off;  // 'x': offset of  patch ++ original segment  in the aux bytes
     uint32_t aux_len;  // 'x': length of the patch
 };
 static_assert(sizeof(FixRec) == 32, "FixRec layout");
 
 enum PolishStatus {
     PS_OK = 0,
-    PS_GAP_EXHAUSTED = 1,   // chunk grew beyond its slack
+    PS_GAP_EXHAUSTED = 1,   // text grew beyond its slack
     PS_REC_OVERFLOW = 2,    // more fix records than reserved
     PS_AUX_OVERFLOW = 3,
     PS_BFS_ARENA = 4,       // path-extension search ran out of scratch
@@ -30,30 +30,53 @@ enum PolishStatus {
     PS_STRING_TOO_LONG = 6
 };
 
-// per chunk state in HBM
-struct ChunkDev {
-    uint8_t *buf;        // gap buffer: logical text = buf[0,gs) ++ buf[gs+glen, cap)
+// position classes written by the dense scan (one byte per window start of a chunk, per pass)
+enum PosClass : uint8_t {
+    PC_CLEAN = 0,  // valid window, count >= solid_thre, and not (count < count(window k back)/50): the walk does `i += k-1`
+    PC_BAD = 1,    // valid window, count < solid_thre
+    PC_OTHER = 2   // non-ACGT window, or the k-back test fires / cannot be decided densely: evaluate exactly
+};
+
+// scratch of the path-extension search (src/jasper.py:527-583), pooled: a wave takes a slot only while it searches
+struct ScratchPool {
+    unsigned int *locks;   // 0 free, 1 taken
+    uint8_t *base;
+    size_t stride;         // bytes per slot
+    uint32_t nslots;
+    uint32_t node_cap;     // trie arena entries (uint32)
+    uint32_t front_cap;    // frontier entries (80 B)
+    uint32_t patch_cap;    // bytes
+    size_t off_front, off_patch;
+};
+
+// One SEGMENT of a chunk record for one pass.  A chunk is cut at "sync points": starts of runs of >= k-1 bad k-mers
+// that are preceded by >= 4k clean positions.  Whatever stride phase the reference's walk arrives with, it lands inside
+// such a run and handle_bad_kmers() then does the same thing -- so the walk to the right of a sync point does not
+// depend on anything to its left except a coordinate shift, and segments can be walked concurrently.
+struct SegDev {
+    uint8_t *buf;        // gap buffer holding a private copy of the segment's text (local coordinates)
     int64_t cap;
-    int64_t len;         // logical length
-    int64_t gs;          // gap start
-    int64_t glen;        // gap length
-    FixRec *recs;        // this chunk's records (all passes), capacity rec_cap
-    uint32_t rec_cap;
-    uint32_t nrec;
-    uint8_t *aux;        // bytes referenced by 'x' records
-    uint32_t aux_cap;
-    uint32_t naux;
-    // scratch for the path-extension search (src/jasper.py:527-583)
-    uint32_t *nodes;     // trie arena: parent << 2 | base
-    uint32_t node_cap;
-    uint8_t *front;      // frontier entries
-    uint32_t front_cap;  // entries
-    uint8_t *patch;      // reconstructed patch
-    uint32_t patch_cap;
+    int64_t len;         // logical length (local)
+    int64_t gs, glen;    // gap start / length
+    int64_t len0;        // logical length before the pass
+    int64_t seg_lo;      // chunk coordinate (at pass start) of local position 0
+    int64_t start_i;     // local position where the walk starts (0 for the first segment of a chunk)
+    int64_t stop_orig;   // the walk ends when it arrives at an event whose pass-start chunk coordinate is >= this
+    int32_t first, last; // first / last segment of its chunk: chunk-start / chunk-end semantics are real there
+    const uint8_t *cls;  // PosClass per window start of the chunk at pass start (chunk coordinates), cls_n entries
+    int64_t cls_n;
+    FixRec *recs;
+    uint32_t rec_cap, nrec;
+    uint8_t *aux;
+    uint32_t aux_cap, naux;
+    uint32_t chunk;
     int32_t status;
-    int64_t wrong[2];    // bad k-mers counted in pass 0 and in the final (QV) pass
-    int64_t total[2];    // total k-mers (len-k+1) in pass 0 and in the final pass
-    uint64_t lookups;    // table probes issued (informational)
+    int32_t spec_fail;   // the walk touched text outside what the segment may assume -> redo the chunk unsegmented
+    int64_t wrong;       // bad k-mers counted in this segment during this pass
+    uint64_t lookups;
+    // filled by the host before stitching
+    int64_t own_lo, own_hi;   // local range of the polished text this segment contributes
+    int64_t out_off;          // where it goes in the chunk's new text
 };
 
 struct PolishParams {
@@ -64,7 +87,16 @@ struct PolishParams {
     int fix;
 };
 
-void launch_polish_pass(const TableDev &T, ChunkDev *d_chunks, int n_chunks, PolishParams pp, int pass, hipStream_t stream);
-void launch_pack(ChunkDev *d_chunks, int n_chunks, uint8_t *d_out, const int64_t *d_out_off, hipStream_t stream);
+// dense scan of one contiguous text: count of every window (0xFFFFFFFF clamp as in lookups) + validity
+void launch_scan(const TableDev &T, const uint8_t *d_text, int64_t len, uint32_t *d_cnt, uint8_t *d_valid, hipStream_t stream);
+void launch_classify(const uint32_t *d_cnt, const uint8_t *d_valid, int64_t nwin, int k, uint32_t solid, uint8_t *d_cls, hipStream_t stream);
+// sync-point candidates of one chunk: appends chunk coordinates to d_out (unsorted), count in *d_count
+void launch_find_sync(const uint8_t *d_cls, int64_t nwin, int k, int64_t *d_out, unsigned int *d_count, unsigned int cap,
+                      hipStream_t stream);
+void launch_seg_init(SegDev *d_segs, int n_segs, const uint8_t *const *d_chunk_text, hipStream_t stream);
+void launch_seg_walk(const TableDev &T, SegDev *d_segs, int n_segs, PolishParams pp, int pass, ScratchPool pool, hipStream_t stream);
+void launch_seg_stitch(const SegDev *d_segs, int n_segs, uint8_t *const *d_chunk_out, hipStream_t stream);
+void launch_seg_gather(const SegDev *d_segs, int n_segs, const int64_t *idx_base, const uint32_t *seq_base, const uint32_t *rec_off,
+                       const uint32_t *aux_off, FixRec *out_recs, uint8_t *out_aux, hipStream_t stream);
 
 }  // namespace jk

@@ -1,0 +1,354 @@
+// polish_host.hip -- host orchestration of one batch of chunk records through P fixing passes + the QV pass
+// (src/jasper.py:25-26 `for ite in range(num_iter+1): iteration(...)`).
+//
+// Per pass:  dense scan + classes (all chunks)  ->  sync points  ->  segments  ->  concurrent segment walks
+//            ->  [redo chunks whose speculation failed as one segment]  ->  gather fix records, stitch the new text.
+#include "polish_host.hpp"
+#include <algorithm>
+#include <cstring>
+
+namespace jk {
+
+#define HIPCHK(x)                                                                     \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            err = std::string(#x) + ": " + hipGetErrorString(e_);                     \
+            return -1;                                                                \
+        }                                                                             \
+    } while (0)
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+namespace {
+struct DevBuf {  // frees on scope exit
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <typename T> T *as() { return reinterpret_cast<T *>(p); }
+};
+}  // namespace
+
+int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *lens, int solid_thre, int passes, int fix,
+               PolishOut &R, std::string &err) {
+    const int k = T.k;
+    const int64_t W = 4ll * k;        // clean window required left of a sync point
+    const int64_t M = 3ll * k;        // text kept right of the next sync point
+    const int64_t TMIN = 4096;        // minimum distance between sync points
+    hipStream_t st = T.stream;
+    HIPCHK(hipSetDevice(T.device));
+    R.seqs.assign(n_chunks, std::string());
+    R.aux.assign(n_chunks, std::string());
+    R.recs.clear();
+    R.qv[0] = R.qv[1] = R.qv[2] = R.qv[3] = 0;
+    R.lookups = 0;
+    R.seconds = 0;
+    R.n_segments = 0;
+    R.n_respeculated = 0;
+    if (n_chunks == 0) return 0;
+
+    // ---------------- layout ----------------
+    std::vector<int64_t> len(lens, lens + n_chunks), cap(n_chunks);
+    std::vector<size_t> off_text(n_chunks), off_pos(n_chunks), off_cand(n_chunks);
+    std::vector<uint32_t> cand_cap(n_chunks);
+    size_t text_bytes = 0, pos_items = 0, cand_items = 0, seg_text_bound = 0, seg_rec_bound = 0, seg_aux_bound = 0;
+    int64_t max_segs = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        cap[c] = len[c] + std::max<int64_t>(4096, len[c] / 8) + 64;
+        off_text[c] = text_bytes;  text_bytes += al256((size_t)cap[c]);
+        off_pos[c] = pos_items;    pos_items += al256((size_t)cap[c]);
+        cand_cap[c] = (uint32_t)std::min<int64_t>(1 << 28, cap[c] / (4 * k) + 16);
+        off_cand[c] = cand_items;  cand_items += cand_cap[c];
+        const int64_t ms = cap[c] / TMIN + 2;
+        max_segs += ms;
+        const int64_t tb = cap[c] + ms * (W + M + 64);
+        seg_text_bound += (size_t)(tb + tb / 8 + ms * 1280);
+        seg_rec_bound += (size_t)(2 * tb / k + 16 * ms);
+        seg_aux_bound += (size_t)(2 * tb + 1024 * ms);
+    }
+    DevBuf b_textA, b_textB, b_cnt, b_valid, b_cls, b_cand, b_ccount, b_ptrA, b_ptrB, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks;
+    auto dmalloc = [&](DevBuf &b, size_t bytes) -> bool {
+        hipError_t e = hipMalloc(&b.p, bytes ? bytes : 256);
+        if (e != hipSuccess) { err = std::string("polish: device allocation failed: ") + hipGetErrorString(e); return false; }
+        return true;
+    };
+    if (!dmalloc(b_textA, text_bytes) || !dmalloc(b_textB, text_bytes) || !dmalloc(b_cnt, pos_items * 4) || !dmalloc(b_valid, pos_items) ||
+        !dmalloc(b_cls, pos_items) || !dmalloc(b_cand, cand_items * 8) || !dmalloc(b_ccount, n_chunks * 4) ||
+        !dmalloc(b_ptrA, n_chunks * sizeof(void *)) || !dmalloc(b_ptrB, n_chunks * sizeof(void *)) ||
+        !dmalloc(b_segs, (size_t)max_segs * sizeof(SegDev)) || !dmalloc(b_segtext, seg_text_bound) ||
+        !dmalloc(b_segrec, seg_rec_bound * sizeof(FixRec)) || !dmalloc(b_segaux, seg_aux_bound))
+        return -2;
+    ScratchPool pool;
+    pool.nslots = 256;
+    pool.node_cap = 1u << 18;
+    pool.front_cap = 20480;
+    pool.patch_cap = 1u << 16;
+    pool.off_front = al256((size_t)pool.node_cap * 4);
+    pool.off_patch = pool.off_front + al256((size_t)pool.front_cap * 80);
+    pool.stride = pool.off_patch + al256(pool.patch_cap);
+    if (!dmalloc(b_pool, pool.stride * pool.nslots) || !dmalloc(b_locks, pool.nslots * 4)) return -2;
+    pool.base = b_pool.as<uint8_t>();
+    pool.locks = b_locks.as<unsigned int>();
+    HIPCHK(hipMemsetAsync(pool.locks, 0, pool.nslots * 4, st));
+
+    uint8_t *textIn = b_textA.as<uint8_t>(), *textOut = b_textB.as<uint8_t>();
+    std::vector<uint8_t *> hptrA(n_chunks), hptrB(n_chunks);
+    for (int c = 0; c < n_chunks; ++c) {
+        hptrA[c] = b_textA.as<uint8_t>() + off_text[c];
+        hptrB[c] = b_textB.as<uint8_t>() + off_text[c];
+        if (len[c]) HIPCHK(hipMemcpyAsync(hptrA[c], seqs[c], (size_t)len[c], hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipMemcpyAsync(b_ptrA.p, hptrA.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b_ptrB.p, hptrB.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
+    uint8_t **ptrIn = b_ptrA.as<uint8_t *>(), **ptrOut = b_ptrB.as<uint8_t *>();
+
+    PolishParams pp;
+    pp.k = k;
+    pp.step = std::max(2, (int)std::nearbyint((double)k / 8.0));   // src/jasper.py:20 (python round = half-to-even)
+    pp.solid = (uint32_t)solid_thre;
+    pp.passes = passes;
+    pp.fix = fix ? 1 : 0;
+
+    hipEvent_t ev0, ev1;
+    HIPCHK(hipEventCreate(&ev0));
+    HIPCHK(hipEventCreate(&ev1));
+    HIPCHK(hipEventRecord(ev0, st));
+
+    std::vector<SegDev> segs;
+    std::vector<unsigned int> ccount(n_chunks);
+    std::vector<int64_t> cands;
+    std::vector<uint32_t> aux_total(n_chunks, 0);   // aux bytes gathered so far per chunk (all passes)
+    std::vector<std::vector<uint8_t>> aux_pass;      // raw aux bytes per pass, regrouped per chunk at the end
+    std::vector<size_t> rec_pass_begin;
+    int rc = 0;
+
+    for (int pass = 0; pass <= passes && rc == 0; ++pass) {                                   // src/jasper.py:25
+        // ---- 1. dense scan, classes, sync-point candidates
+        HIPCHK(hipMemsetAsync(b_ccount.p, 0, n_chunks * 4, st));
+        for (int c = 0; c < n_chunks; ++c) {
+            const int64_t nwin = len[c] - k + 1;
+            if (nwin <= 0) continue;
+            uint8_t *text = textIn + off_text[c];
+            launch_scan(T.d, text, len[c], b_cnt.as<uint32_t>() + off_pos[c], b_valid.as<uint8_t>() + off_pos[c], st);
+            launch_classify(b_cnt.as<uint32_t>() + off_pos[c], b_valid.as<uint8_t>() + off_pos[c], nwin, k, pp.solid,
+                            b_cls.as<uint8_t>() + off_pos[c], st);
+            if (nwin > 2 * TMIN)
+                launch_find_sync(b_cls.as<uint8_t>() + off_pos[c], nwin, k, b_cand.as<int64_t>() + off_cand[c],
+                                 b_ccount.as<unsigned int>() + c, cand_cap[c], st);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ccount.data(), b_ccount.p, n_chunks * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+
+        // ---- 2. segments
+        auto build_segments = [&](const std::vector<int> &chunks, bool speculate, std::vector<SegDev> &out, std::string &e2) -> int {
+            out.clear();
+            size_t tpos = 0, rpos = 0, apos = 0;
+            for (int c : chunks) {
+                std::vector<int64_t> sync;
+                if (speculate && ccount[c] > 0) {
+                    const unsigned int nc = std::min(ccount[c], cand_cap[c]);
+                    cands.resize(nc);
+                    if (hipMemcpy(cands.data(), b_cand.as<int64_t>() + off_cand[c], nc * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+                        e2 = "polish: reading sync candidates failed"; return -1;
+                    }
+                    std::sort(cands.begin(), cands.end());
+                    int64_t last = 0;
+                    for (int64_t p : cands)
+                        if (p - last >= TMIN && len[c] - p >= TMIN) { sync.push_back(p); last = p; }
+                }
+                const int m = (int)sync.size();
+                for (int j = 0; j <= m; ++j) {
+                    SegDev S;
+                    memset(&S, 0, sizeof S);
+                    S.chunk = (uint32_t)c;
+                    S.first = (j == 0);
+                    S.last = (j == m);
+                    S.seg_lo = j == 0 ? 0 : sync[j - 1] - W;
+                    S.start_i = j == 0 ? 0 : W;
+                    S.stop_orig = j == m ? INT64_MAX : sync[j];
+                    const int64_t seg_hi = j == m ? len[c] : std::min<int64_t>(len[c], sync[j] + M);
+                    S.len0 = seg_hi - S.seg_lo;
+                    S.len = S.len0;
+                    S.cap = S.len0 + std::max<int64_t>(1024, S.len0 / 8);
+                    S.gs = 0;
+                    S.glen = S.cap - S.len0;
+                    S.cls = (len[c] - k + 1 > 0) ? b_cls.as<uint8_t>() + off_pos[c] : nullptr;
+                    S.cls_n = std::max<int64_t>(0, len[c] - k + 1);
+                    S.rec_cap = (uint32_t)std::min<int64_t>(0x7fffffff, 2 * S.len0 / k + 16);
+                    S.aux_cap = (uint32_t)std::min<int64_t>(0x7fffffff, 2 * S.len0 + 1024);
+                    S.buf = b_segtext.as<uint8_t>() + tpos;            tpos += al256((size_t)S.cap);
+                    S.recs = b_segrec.as<FixRec>() + rpos;             rpos += S.rec_cap;
+                    S.aux = b_segaux.as<uint8_t>() + apos;             apos += al256(S.aux_cap);
+                    // owned part of the text: chunk coordinates [B_j, B_{j+1}), B = sync - 2k
+                    S.own_lo = j == 0 ? 0 : 2ll * k;                   // local (no edit can precede it)
+                    S.own_hi = j == m ? -1 : (sync[j] - 2ll * k) - S.seg_lo;   // local, before adding this segment's delta
+                    out.push_back(S);
+                }
+            }
+            if (tpos > seg_text_bound || rpos > seg_rec_bound || apos > seg_aux_bound || (int64_t)out.size() > max_segs) {
+                e2 = "polish: internal segment arena bound exceeded"; return -2;
+            }
+            return 0;
+        };
+        auto run_segments = [&](std::vector<SegDev> &sv, std::string &e2) -> int {
+            if (sv.empty()) return 0;
+            if (hipMemcpyAsync(b_segs.p, sv.data(), sv.size() * sizeof(SegDev), hipMemcpyHostToDevice, st) != hipSuccess) { e2 = "polish: H2D segs"; return -1; }
+            launch_seg_init(b_segs.as<SegDev>(), (int)sv.size(), (const uint8_t *const *)ptrIn, st);
+            launch_seg_walk(T.d, b_segs.as<SegDev>(), (int)sv.size(), pp, pass, pool, st);
+            if (hipGetLastError() != hipSuccess) { e2 = "polish: kernel launch failed"; return -1; }
+            if (hipMemcpyAsync(sv.data(), b_segs.p, sv.size() * sizeof(SegDev), hipMemcpyDeviceToHost, st) != hipSuccess) { e2 = "polish: D2H segs"; return -1; }
+            if (hipStreamSynchronize(st) != hipSuccess) { e2 = "polish: kernel execution failed"; return -1; }
+            return 0;
+        };
+        std::vector<int> all(n_chunks);
+        for (int c = 0; c < n_chunks; ++c) all[c] = c;
+        if ((rc = build_segments(all, true, segs, err))) break;
+        if ((rc = run_segments(segs, err))) break;
+        R.n_segments += segs.size();
+
+        // ---- 3. chunks whose speculation failed are redone as a single segment (= the plain sequential walk)
+        std::vector<char> failed(n_chunks, 0);
+        bool any_failed = false;
+        for (const SegDev &S : segs)
+            if (S.spec_fail && S.status == PS_OK) { failed[S.chunk] = 1; any_failed = true; }
+        if (any_failed) {
+            std::vector<int> redo;
+            for (int c = 0; c < n_chunks; ++c) if (failed[c]) redo.push_back(c);
+            R.n_respeculated += redo.size();
+            // results of the good chunks must survive: stitch / gather them first, then reuse the arenas for the redo
+            std::vector<SegDev> good, bad;
+            for (const SegDev &S : segs) if (!failed[S.chunk]) good.push_back(S);
+            // (the redo gets fresh arena space; the good segments' buffers stay untouched because run_segments
+            // only writes through the SegDev table it uploads -- so place the redo segments BEHIND the good ones)
+            size_t tpos = 0, rpos = 0, apos = 0;
+            for (const SegDev &S : segs) { tpos += al256((size_t)S.cap); rpos += S.rec_cap; apos += al256(S.aux_cap); }
+            std::vector<SegDev> redo_segs;
+            if ((rc = build_segments(redo, false, redo_segs, err))) break;
+            size_t t2 = tpos, r2 = rpos, a2 = apos;
+            for (SegDev &S : redo_segs) {
+                S.buf = b_segtext.as<uint8_t>() + t2;  t2 += al256((size_t)S.cap);
+                S.recs = b_segrec.as<FixRec>() + r2;   r2 += S.rec_cap;
+                S.aux = b_segaux.as<uint8_t>() + a2;   a2 += al256(S.aux_cap);
+            }
+            if (t2 > seg_text_bound || r2 > seg_rec_bound || a2 > seg_aux_bound) {
+                // not enough spare room: fall back to redoing EVERYTHING unsegmented (always fits)
+                if ((rc = build_segments(all, false, segs, err))) break;
+                if ((rc = run_segments(segs, err))) break;
+            } else {
+                if ((rc = run_segments(redo_segs, err))) break;
+                segs = good;
+                segs.insert(segs.end(), redo_segs.begin(), redo_segs.end());
+                std::stable_sort(segs.begin(), segs.end(), [](const SegDev &a, const SegDev &b) {
+                    return a.chunk != b.chunk ? a.chunk < b.chunk : a.seg_lo < b.seg_lo;
+                });
+            }
+        }
+
+        // ---- 4. bookkeeping per chunk: status, counters, coordinates of the stitched text
+        const size_t ns = segs.size();
+        std::vector<int64_t> idx_base(ns);
+        std::vector<uint32_t> seq_base(ns), rec_off(ns), aux_off(ns);
+        std::vector<int64_t> newlen(n_chunks, 0), shift(n_chunks, 0);
+        std::vector<uint32_t> seqc(n_chunks, 0);
+        size_t nrec_pass = 0, naux_pass = 0;
+        for (size_t s = 0; s < ns && rc == 0; ++s) {
+            SegDev &S = segs[s];
+            const int c = (int)S.chunk;
+            if (S.status != PS_OK) {
+                static const char *names[] = {"ok", "text grew beyond its slack", "fix-record buffer overflow", "aux buffer overflow",
+                                              "path-extension scratch exhausted", "reference IndexError (src/jasper.py:221)",
+                                              "trial string too long"};
+                err = std::string("polish: chunk ") + std::to_string(c) + ": " + names[S.status];
+                rc = S.status == PS_REF_INDEXERROR ? -4 : -2;
+                break;
+            }
+            const int64_t d = S.len - S.len0;
+            if (S.last) S.own_hi = S.len; else S.own_hi += d;
+            S.out_off = newlen[c];
+            newlen[c] += S.own_hi - S.own_lo;
+            idx_base[s] = S.seg_lo + shift[c];
+            shift[c] += d;
+            seq_base[s] = seqc[c];
+            seqc[c] += S.nrec;
+            rec_off[s] = (uint32_t)nrec_pass;
+            aux_off[s] = (uint32_t)naux_pass;
+            nrec_pass += S.nrec;
+            naux_pass += S.naux;
+            R.lookups += S.lookups;
+            if (pass == 0) R.qv[0] += S.wrong;
+            if (pass == passes) R.qv[2] += S.wrong;
+        }
+        if (rc) break;
+        for (int c = 0; c < n_chunks; ++c) {
+            if (pass == 0) R.qv[1] += len[c] - k + 1;                                           // src/jasper.py:51,107-111
+            if (pass == passes) R.qv[3] += len[c] - k + 1;
+            if (newlen[c] > cap[c]) { err = "polish: chunk grew beyond its slack"; rc = -2; }
+        }
+        if (rc) break;
+
+        // ---- 5. gather records / aux, stitch the new text
+        HIPCHK(hipMemcpyAsync(b_segs.p, segs.data(), ns * sizeof(SegDev), hipMemcpyHostToDevice, st));
+        rec_pass_begin.push_back(R.recs.size());
+        aux_pass.emplace_back();
+        if (nrec_pass) {
+            DevBuf d_idx, d_seq, d_ro, d_ao, d_recs, d_aux;
+            if (!dmalloc(d_idx, ns * 8) || !dmalloc(d_seq, ns * 4) || !dmalloc(d_ro, ns * 4) || !dmalloc(d_ao, ns * 4) ||
+                !dmalloc(d_recs, nrec_pass * sizeof(FixRec)) || !dmalloc(d_aux, naux_pass)) { rc = -2; break; }
+            HIPCHK(hipMemcpyAsync(d_idx.p, idx_base.data(), ns * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_seq.p, seq_base.data(), ns * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_ro.p, rec_off.data(), ns * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_ao.p, aux_off.data(), ns * 4, hipMemcpyHostToDevice, st));
+            launch_seg_gather(b_segs.as<SegDev>(), (int)ns, d_idx.as<int64_t>(), d_seq.as<uint32_t>(), d_ro.as<uint32_t>(),
+                              d_ao.as<uint32_t>(), d_recs.as<FixRec>(), d_aux.as<uint8_t>(), st);
+            HIPCHK(hipGetLastError());
+            const size_t r0 = R.recs.size();
+            R.recs.resize(r0 + nrec_pass);
+            HIPCHK(hipMemcpyAsync(&R.recs[r0], d_recs.p, nrec_pass * sizeof(FixRec), hipMemcpyDeviceToHost, st));
+            aux_pass.back().resize(naux_pass);
+            if (naux_pass) HIPCHK(hipMemcpyAsync(aux_pass.back().data(), d_aux.p, naux_pass, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        launch_seg_stitch(b_segs.as<SegDev>(), (int)ns, (uint8_t *const *)ptrOut, st);
+        HIPCHK(hipGetLastError());
+        for (int c = 0; c < n_chunks; ++c) len[c] = newlen[c];
+        std::swap(textIn, textOut);
+        std::swap(ptrIn, ptrOut);
+    }
+    if (rc == 0) {
+        HIPCHK(hipEventRecord(ev1, st));
+        // ---- results to the host
+        for (int c = 0; c < n_chunks; ++c) {
+            R.seqs[c].resize((size_t)len[c]);
+            if (len[c]) HIPCHK(hipMemcpyAsync(&R.seqs[c][0], textIn + off_text[c], (size_t)len[c], hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+        R.seconds = ms * 1e-3;
+        // records: order by chunk, pass, emission; regroup the aux bytes of 'x' records per chunk
+        for (size_t p = 0; p < rec_pass_begin.size(); ++p) {
+            const size_t b = rec_pass_begin[p], e = p + 1 < rec_pass_begin.size() ? rec_pass_begin[p + 1] : R.recs.size();
+            for (size_t i = b; i < e; ++i) {
+                FixRec &f = R.recs[i];
+                if (f.kind == 'x') {
+                    std::string &a = R.aux[f.chunk];
+                    const size_t n = (size_t)f.aux_len + f.rep;
+                    const uint32_t no = (uint32_t)a.size();
+                    a.append(reinterpret_cast<const char *>(aux_pass[p].data()) + f.aux_off, n);
+                    f.aux_off = no;
+                }
+            }
+        }
+        std::stable_sort(R.recs.begin(), R.recs.end(), [](const FixRec &a, const FixRec &b) {
+            if (a.chunk != b.chunk) return a.chunk < b.chunk;
+            if (a.pass != b.pass) return a.pass < b.pass;
+            return a.seqno < b.seqno;
+        });
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    return rc;
+}
+
+}  // namespace jk

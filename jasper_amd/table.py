@@ -180,7 +180,11 @@ class KmerTable:
             nl = C.c_uint64(0)
             check(self._L.jasper_result_lookups(res, C.byref(nl)))
             secs = self._L.jasper_result_seconds(res)
-            return PolishResult(out, recs, aux, tuple(qv), nl.value, secs)
+            nseg, nredo = C.c_uint64(0), C.c_uint64(0)
+            check(self._L.jasper_result_segments(res, C.byref(nseg), C.byref(nredo)))
+            pr = PolishResult(out, recs, aux, tuple(qv), nl.value, secs)
+            pr.segments, pr.respeculated = nseg.value, nredo.value
+            return pr
         finally:
             if res:
                 self._L.jasper_result_free(res)
