@@ -21,9 +21,10 @@ namespace jk {
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 namespace {
-struct DevBuf {  // frees on scope exit
+struct DevBuf {  // a slot of the table's grow-only workspace (not owned) or a temporary (owned)
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool owned = false;
+    ~DevBuf() { if (p && owned) (void)hipFree(p); }
     template <typename T> T *as() { return reinterpret_cast<T *>(p); }
 };
 }  // namespace
@@ -66,9 +67,16 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         seg_aux_bound += (size_t)(2 * tb + 1024 * ms);
     }
     DevBuf b_textA, b_textB, b_cnt, b_valid, b_cls, b_cand, b_ccount, b_ptrA, b_ptrB, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks;
-    auto dmalloc = [&](DevBuf &b, size_t bytes) -> bool {
+    int ws_next = 0;
+    auto dmalloc = [&](DevBuf &b, size_t bytes) -> bool {      // persistent: slot of the table's workspace
+        b.p = T.workspace(ws_next++, bytes, err);
+        b.owned = false;
+        return b.p != nullptr;
+    };
+    auto tmalloc = [&](DevBuf &b, size_t bytes) -> bool {      // per-pass temporary
         hipError_t e = hipMalloc(&b.p, bytes ? bytes : 256);
-        if (e != hipSuccess) { err = std::string("polish: device allocation failed: ") + hipGetErrorString(e); return false; }
+        b.owned = true;
+        if (e != hipSuccess) { b.p = nullptr; err = std::string("polish: device allocation failed: ") + hipGetErrorString(e); return false; }
         return true;
     };
     if (!dmalloc(b_textA, text_bytes) || !dmalloc(b_textB, text_bytes) || !dmalloc(b_cnt, pos_items * 4) || !dmalloc(b_valid, pos_items) ||
@@ -292,8 +300,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         aux_pass.emplace_back();
         if (nrec_pass) {
             DevBuf d_idx, d_seq, d_ro, d_ao, d_recs, d_aux;
-            if (!dmalloc(d_idx, ns * 8) || !dmalloc(d_seq, ns * 4) || !dmalloc(d_ro, ns * 4) || !dmalloc(d_ao, ns * 4) ||
-                !dmalloc(d_recs, nrec_pass * sizeof(FixRec)) || !dmalloc(d_aux, naux_pass)) { rc = -2; break; }
+            if (!tmalloc(d_idx, ns * 8) || !tmalloc(d_seq, ns * 4) || !tmalloc(d_ro, ns * 4) || !tmalloc(d_ao, ns * 4) ||
+                !tmalloc(d_recs, nrec_pass * sizeof(FixRec)) || !tmalloc(d_aux, naux_pass)) { rc = -2; break; }
             HIPCHK(hipMemcpyAsync(d_idx.p, idx_base.data(), ns * 8, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(d_seq.p, seq_base.data(), ns * 4, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(d_ro.p, rec_off.data(), ns * 4, hipMemcpyHostToDevice, st));

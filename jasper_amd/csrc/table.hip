@@ -248,9 +248,27 @@ int Table::init(int k_, uint64_t min_slots, int device_, std::string &err) {
     return 0;
 }
 
+void *Table::workspace(int id, size_t bytes, std::string &err) {
+    if (bytes == 0) bytes = 256;
+    WsBuf &b = ws[id];
+    if (b.bytes >= bytes) return b.p;
+    if (b.p) { (void)hipStreamSynchronize(stream); (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    const size_t want = bytes + bytes / 8;   // a little headroom so that slightly larger batches do not reallocate
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        e = hipMalloc(&b.p, bytes);
+        if (e != hipSuccess) { err = std::string("device workspace allocation failed: ") + hipGetErrorString(e); b.p = nullptr; return nullptr; }
+        b.bytes = bytes;
+        return b.p;
+    }
+    b.bytes = want;
+    return b.p;
+}
+
 void Table::destroy() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
+    for (WsBuf &b : ws) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
     for (int i = 0; i < 2; ++i) {
         if (d_stage[i]) (void)hipFree(d_stage[i]);
         if (h_stage[i]) (void)hipHostFree(h_stage[i]);
@@ -348,13 +366,17 @@ int Table::launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from
 // kernel keeps its 16-byte vector loads; emit_from keeps every window counted exactly once.
 int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
     HIPCHK(hipSetDevice(device));
+    if (read_stats(err)) return -1;
     const uint64_t halo = (uint64_t)(k - 1);
     const uint64_t misalign = reinterpret_cast<uintptr_t>(d_bases) & 15;
     uint64_t pos = 0;
     while (pos < n) {
-        uint64_t piece = std::max<uint64_t>(nslots / 4, 1u << 20);
+        // a launch may add at most as many new keys as keep the table under 3/4 full in the worst case (every
+        // base a new k-mer); h_stats holds the distinct count of the last check
+        const uint64_t room = (uint64_t)(0.75 * (double)nslots) > h_stats[ST_DISTINCT] ? (uint64_t)(0.75 * (double)nslots) - h_stats[ST_DISTINCT] : 0;
+        uint64_t piece = std::max<uint64_t>(room, 1u << 20);
         piece = std::min<uint64_t>(piece, 1ull << 31);
-        if (piece > nslots / 4) {   // small table: make room for a whole piece of new keys up front
+        if (piece > room) {   // small table: make room for a whole piece of new keys up front
             if (ensure_capacity(std::min<uint64_t>(piece, n - pos), err)) return -1;
         }
         uint64_t start = pos >= halo ? pos - halo : 0;
@@ -377,6 +399,7 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
 // bases in host memory: double-buffered pinned staging; the copy of piece i+1 overlaps the kernel of piece i
 int Table::count_host(const char *bases, uint64_t n, std::string &err) {
     HIPCHK(hipSetDevice(device));
+    if (read_stats(err)) return -1;
     if (!stage_bytes) {
         stage_bytes = 64u << 20;
         for (int i = 0; i < 2; ++i) {
@@ -389,8 +412,9 @@ int Table::count_host(const char *bases, uint64_t n, std::string &err) {
     uint64_t pos = 0;
     int buf = 0;
     while (pos < n) {
-        const uint64_t piece = std::min<uint64_t>(stage_bytes - halo, std::max<uint64_t>(nslots / 4, 1u << 20));
-        if (piece > nslots / 4) {
+        const uint64_t room = (uint64_t)(0.75 * (double)nslots) > h_stats[ST_DISTINCT] ? (uint64_t)(0.75 * (double)nslots) - h_stats[ST_DISTINCT] : 0;
+        const uint64_t piece = std::min<uint64_t>(stage_bytes - halo, std::max<uint64_t>(room, 1u << 20));
+        if (piece > room) {
             if (ensure_capacity(std::min<uint64_t>(piece, n - pos), err)) return -1;
         }
         const uint64_t start = pos >= halo ? pos - halo : 0;
@@ -470,10 +494,12 @@ int Table::export_entries(uint64_t *n_out, unsigned long long **d_entries_out, s
 
 int Table::import_entries(const unsigned long long *d_entries, uint64_t n, std::string &err) {
     HIPCHK(hipSetDevice(device));
+    if (read_stats(err)) return -1;
     uint64_t pos = 0;
     while (pos < n) {
-        uint64_t piece = std::min<uint64_t>(n - pos, std::max<uint64_t>(nslots / 4, 1u << 20));
-        if (piece > nslots / 4) {
+        const uint64_t room = (uint64_t)(0.75 * (double)nslots) > h_stats[ST_DISTINCT] ? (uint64_t)(0.75 * (double)nslots) - h_stats[ST_DISTINCT] : 0;
+        uint64_t piece = std::min<uint64_t>(n - pos, std::max<uint64_t>(room, 1u << 20));
+        if (piece > room) {
             if (ensure_capacity(piece, err)) return -1;
         }
         hipLaunchKernelGGL(import_kernel, dim3(grid_for(piece, 256)), dim3(256), 0, stream, d_entries + 3 * pos, piece, d);

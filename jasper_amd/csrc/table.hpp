@@ -123,6 +123,10 @@ struct Table {
     uint64_t count_launches = 0;
     void reset_timing() { count_kernel_ms = 0; count_launches = 0; }
     int launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, std::string &err);
+    // grow-only device workspace reused by the polisher across calls (hipMalloc of GBs costs far more than the kernels)
+    struct WsBuf { void *p = nullptr; size_t bytes = 0; };
+    WsBuf ws[24];
+    void *workspace(int id, size_t bytes, std::string &err);
 
     static int min_log2_slots(int k);
     int init(int k, uint64_t min_slots, int device, std::string &err);

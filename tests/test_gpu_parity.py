@@ -76,6 +76,8 @@ def test_polish_vs_oracle(KT, O, k, G, seed, thre, passes):
     for it in range(passes):
         assert polisher.fix_csv_text(rows[it]) == "Contig Base_coord Original Mutation\r\n" + rows_o[it]
     assert sum(len(r) for r in rows) > 10
+    if G >= 200_000:   # chunks long enough to be cut at sync points: the walk really ran as concurrent segments
+        assert res.segments > (passes + 1) * len(seqs), (res.segments, res.respeculated)
     # without --fix (src/jasper.py:114,120: nothing is written, nothing is changed; counters still differ from the
     # fixing run because that one re-scans the text it has just edited)
     res2 = t.polish_batch(seqs, thre, passes, fix=False)
@@ -202,6 +204,7 @@ def test_properties_at_scale(KT):
     bs = synth.jasper_batch_size(len(asm), 16)
     seqs = [asm[a:b] for _, a, b in synth.chunk_records("c", len(asm), bs)]
     res = t.polish_batch(seqs, 2, 2)
+    assert res.segments > 100 and res.respeculated <= len(seqs)
     assert res.qv[1] == sum(len(s) - k + 1 for s in seqs)
     assert res.qv[2] < res.qv[0] / 20                              # polishing removes >95 % of the bad k-mers
     # idempotence of the QV pass: scanning the polished text again reports exactly the final counters, and a
