@@ -87,7 +87,8 @@ def one_step(torch, dev_index, table, reads, seqs, world, timers):
     info = table.info()
     timers.append(dict(count=t1 - t0, merge=t2 - t1, histo=t3 - t2, polish=t4 - t3, kernel_ms=kms, launches=launches,
                        polish_dev=res.seconds, thr=thr, qv=res.qv, nfix=len(res.records), merged=merged,
-                       distinct=info["distinct"], occurrences=info["occurrences"], slots=info["slots"], lookups=res.lookups))
+                       distinct=info["distinct"], occurrences=info["occurrences"], slots=info["slots"], lookups=res.lookups,
+                       segments=res.segments, respeculated=res.respeculated))
     return res
 
 
@@ -205,6 +206,7 @@ def main():
         "phase_ms": {k: round(mean(k) * 1e3, 2) for k in ("count", "merge", "histo", "polish")},
         "polish_device_ms": round(mean("polish_dev") * 1e3, 2),
         "qv_counters": list(T["qv"]), "fix_records": T["nfix"], "polish_lookups": T["lookups"],
+        "polish_segments": T["segments"], "polish_chunks_redone_unsegmented": T["respeculated"],
         "roofline": {"bound": "hbm", "kernel": "count_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": int(BYTES_PER_KMER * kmers_rank / launches),

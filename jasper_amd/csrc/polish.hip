@@ -96,25 +96,47 @@ struct Walker {
     }
 
     // ---------------- gap buffer ----------------
+    // 16 bytes at an arbitrary byte address (gfx950 runs with unaligned global access enabled)
+    struct __attribute__((packed, aligned(1))) U16 { uint32_t w[4]; };
     __device__ void move_gap(int64_t to) {
         if (to == gs) return;
-        if (to > gs) {  // bytes [gs+glen, to+glen) slide down to [gs, to)
+        if (to > gs) {  // bytes [gs+glen, to+glen) slide down to [gs, to): ascending, loads of a step before its stores
             const int64_t n = to - gs;
-            for (int64_t off = 0; off < n; off += 256) {
-                uint8_t v[4];
+            const uint8_t *src = buf + gs + glen;
+            uint8_t *dst = buf + gs;
+            int64_t off = 0;
+            for (; off + 4096 <= n; off += 4096) {          // 64 lanes x 4 x 16 B per step
+                U16 v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { int64_t q = off + u * 64 + lane; v[u] = q < n ? buf[gs + glen + q] : 0; }
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const U16 *>(src + off + (u * 64 + lane) * 16);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { int64_t q = off + u * 64 + lane; if (q < n) buf[gs + q] = v[u]; }
+                for (int u = 0; u < 4; ++u) *reinterpret_cast<U16 *>(dst + off + (u * 64 + lane) * 16) = v[u];
             }
-        } else {        // bytes [to, gs) slide up to [to+glen, gs+glen), highest first
-            const int64_t n = gs - to;
-            for (int64_t off = 0; off < n; off += 256) {
+            for (; off < n; off += 256) {
                 uint8_t v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { int64_t q = off + u * 64 + lane; v[u] = q < n ? buf[gs - 1 - q] : 0; }
+                for (int u = 0; u < 4; ++u) { int64_t q = off + u * 64 + lane; v[u] = q < n ? src[q] : 0; }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { int64_t q = off + u * 64 + lane; if (q < n) buf[gs + glen - 1 - q] = v[u]; }
+                for (int u = 0; u < 4; ++u) { int64_t q = off + u * 64 + lane; if (q < n) dst[q] = v[u]; }
+            }
+        } else {        // bytes [to, gs) slide up to [to+glen, gs+glen): descending from the top
+            const int64_t n = gs - to;
+            const uint8_t *src_end = buf + gs;               // one past the last source byte
+            uint8_t *dst_end = buf + gs + glen;
+            int64_t off = 0;                                 // bytes already moved, counted from the top
+            for (; off + 4096 <= n; off += 4096) {
+                U16 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const U16 *>(src_end - off - (u * 64 + lane + 1) * 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *reinterpret_cast<U16 *>(dst_end - off - (u * 64 + lane + 1) * 16) = v[u];
+            }
+            for (; off < n; off += 256) {
+                uint8_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { int64_t q = off + u * 64 + lane; v[u] = q < n ? src_end[-1 - q] : 0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { int64_t q = off + u * 64 + lane; if (q < n) dst_end[-1 - q] = v[u]; }
             }
         }
         gs = to;
@@ -814,9 +836,11 @@ __global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, 
     w.pool = pool; w.bfs_slot = -1; w.bfs_nodes = nullptr; w.bfs_front = nullptr; w.bfs_patch = nullptr;
     const bool fix = P.fix && pass < P.passes;                                 // src/jasper.py:37-38
     int64_t wrong = 0;
+    const uint64_t t0 = wall_clock64();
     w.walk(fix, wrong);
     w.release_scratch();
     if (threadIdx.x == 0) {
+        C->ticks = wall_clock64() - t0;
         C->len = w.len; C->gs = w.gs; C->glen = w.glen;
         C->nrec = w.nrec; C->naux = w.naux; C->status = w.status; C->spec_fail = w.spec_fail;
         C->wrong = wrong;

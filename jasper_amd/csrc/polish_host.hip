@@ -5,6 +5,8 @@
 //            ->  [redo chunks whose speculation failed as one segment]  ->  gather fix records, stitch the new text.
 #include "polish_host.hpp"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace jk {
@@ -250,6 +252,21 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                     return a.chunk != b.chunk ? a.chunk < b.chunk : a.seg_lo < b.seg_lo;
                 });
             }
+        }
+
+        if (getenv("JASPER_POLISH_DEBUG")) {
+            uint64_t mx = 0, sum = 0, mxl = 0; int64_t mxlen = 0; size_t nrecs = 0, mxrec = 0;
+            for (const SegDev &S : segs) {
+                sum += S.ticks; nrecs += S.nrec;
+                if (S.ticks > mx) { mx = S.ticks; mxl = S.lookups; mxlen = S.len0; mxrec = S.nrec; }
+            }
+            fprintf(stderr, "[polish] pass %d: %zu segments, %zu records, walk ticks(10ns): mean %.0f max %llu (that segment: len %lld, %llu lookups, %zu records)\n",
+                    pass, segs.size(), nrecs, segs.empty() ? 0.0 : (double)sum / segs.size(), (unsigned long long)mx, (long long)mxlen,
+                    (unsigned long long)mxl, mxrec);
+            // histogram of segment times in ms buckets
+            int hb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (const SegDev &S : segs) { double ms = S.ticks * 1e-5; int b = ms < 0.1 ? 0 : ms < 0.3 ? 1 : ms < 1 ? 2 : ms < 2 ? 3 : ms < 4 ? 4 : ms < 8 ? 5 : ms < 16 ? 6 : 7; hb[b]++; }
+            fprintf(stderr, "[polish]   segments by walk time: <0.1ms %d, <0.3 %d, <1 %d, <2 %d, <4 %d, <8 %d, <16 %d, more %d\n", hb[0], hb[1], hb[2], hb[3], hb[4], hb[5], hb[6], hb[7]);
         }
 
         // ---- 4. bookkeeping per chunk: status, counters, coordinates of the stitched text
