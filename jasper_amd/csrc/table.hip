@@ -8,6 +8,7 @@
 #include "table.hpp"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -33,6 +34,7 @@ constexpr int CT_THREADS = 256;
 constexpr int CT_GROUP = 16;                       // bases per thread
 constexpr int CT_TILE = CT_THREADS * CT_GROUP;     // 4096 bases per block iteration
 constexpr int CT_HALO = 4;                         // 4 groups = 64 bases >= k-1
+constexpr int CT_BATCH = 4;                        // first probes kept in flight per thread
 
 __device__ __forceinline__ void pack16(const uint8_t *b16, uint32_t &codes, uint32_t &inv) {
     codes = 0;
@@ -64,6 +66,8 @@ __device__ __forceinline__ void stage_group(const uint8_t *__restrict__ bases, i
 
 // `emit_from`: only windows ENDING at piece position >= emit_from are counted (pieces overlap by k-1 bases
 // plus alignment padding; the overlap belongs to the previous piece).
+// MODE 0 = product; 1 = hashing only, 2 = hashing + home-slot load only (tuning experiments, tools/bench_resident.py)
+template <int MODE>
 __global__ __launch_bounds__(CT_THREADS) void count_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t ntiles,
                                                             uint64_t emit_from, TableDev T) {
     __shared__ uint32_t s_code[CT_THREADS + CT_HALO];
@@ -96,17 +100,45 @@ __global__ __launch_bounds__(CT_THREADS) void count_kernel(const uint8_t *__rest
         u128 rc = revcomp(fwd, k);
         int run = ivprev ? (int)__builtin_ctzll(ivprev) : 64;  // valid bases in a row ending just before my group
         if (owninv == 0xFFFFu) continue;                       // nothing but separators / padding here
-#pragma unroll 4
-        for (int j = 0; j < CT_GROUP; ++j) {
-            const uint32_t cj = (own >> (30 - 2 * j)) & 3u;
-            const bool bad = (owninv >> (15 - j)) & 1u;
-            fwd = band(bor(shl(fwd, 2), mk(0, cj)), kmask);
-            rc = bor(shr(rc, 2), shl(mk(0, 3u - cj), 2 * (k - 1)));
-            run = bad ? 0 : run + 1;
-            if (run >= k && (uint64_t)(base0 + t * CT_GROUP + j) >= emit_from) {
-                const u128 canon = lt(rc, fwd) ? rc : fwd;
-                fresh += table_add_or_spill(T, mix(canon, T.B), 1ull);
-                ++added;
+        // four windows at a time: hash all four, put their four home-slot loads in flight together, then resolve
+        for (int jb = 0; jb < CT_GROUP; jb += CT_BATCH) {
+            u128 h[CT_BATCH];
+            bool val[CT_BATCH];
+            unsigned long long cur0[CT_BATCH];
+#pragma unroll
+            for (int u = 0; u < CT_BATCH; ++u) {
+                const int j = jb + u;
+                const uint32_t cj = (own >> (30 - 2 * j)) & 3u;
+                const bool bad = (owninv >> (15 - j)) & 1u;
+                fwd = band(bor(shl(fwd, 2), mk(0, cj)), kmask);
+                rc = bor(shr(rc, 2), shl(mk(0, 3u - cj), 2 * (k - 1)));
+                run = bad ? 0 : run + 1;
+                val[u] = run >= k && (uint64_t)(base0 + t * CT_GROUP + j) >= emit_from;
+                h[u] = mix(lt(rc, fwd) ? rc : fwd, T.B);
+            }
+            if (MODE == 1) {
+#pragma unroll
+                for (int u = 0; u < CT_BATCH; ++u) if (val[u]) { fresh ^= h[u].lo ^ h[u].hi; ++added; }
+                continue;
+            }
+#pragma unroll
+            for (int u = 0; u < CT_BATCH; ++u) {
+                cur0[u] = 0;
+                if (val[u]) cur0[u] = __hip_atomic_load(T.slots + 2 * (home_of(h[u], T.B, T.s) & T.mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (MODE == 2) {
+#pragma unroll
+                for (int u = 0; u < CT_BATCH; ++u) if (val[u]) { fresh ^= cur0[u]; ++added; }
+                continue;
+            }
+#pragma unroll
+            for (int u = 0; u < CT_BATCH; ++u) {
+                if (val[u]) {
+                    const int r = table_add_prefetched(T, h[u], 1ull, cur0[u]);
+                    if (r == 2) ++fresh;
+                    else if (r == 0) table_spill(T, h[u], 1ull);
+                    ++added;
+                }
             }
         }
     }
@@ -114,7 +146,7 @@ __global__ __launch_bounds__(CT_THREADS) void count_kernel(const uint8_t *__rest
     for (int o = 32; o > 0; o >>= 1) { added += __shfl_xor(added, o); fresh += __shfl_xor(fresh, o); }
     if ((threadIdx.x & 63) == 0) {
         if (added) atomicAdd(&T.stats[ST_OCCURRENCES], added);
-        if (fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+        if (fresh) atomicAdd(&T.stats[MODE == 0 ? ST_DISTINCT : 7], fresh);
     }
 }
 
@@ -355,7 +387,10 @@ int Table::ensure_capacity(uint64_t upcoming_kmers, std::string &err) {
 int Table::launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, std::string &err) {
     const uint64_t ntiles = (len + CT_TILE - 1) / CT_TILE;
     HIPCHK(hipEventRecord(ev_k0, stream));
-    hipLaunchKernelGGL(count_kernel, dim3(grid_for(ntiles, 1)), dim3(CT_THREADS), 0, stream, d_piece, len, ntiles, emit_from, d);
+    static const int mode = getenv("JASPER_EXPERIMENT_MODE") ? atoi(getenv("JASPER_EXPERIMENT_MODE")) : 0;
+    if (mode == 1) hipLaunchKernelGGL(count_kernel<1>, dim3(grid_for(ntiles, 1)), dim3(CT_THREADS), 0, stream, d_piece, len, ntiles, emit_from, d);
+    else if (mode == 2) hipLaunchKernelGGL(count_kernel<2>, dim3(grid_for(ntiles, 1)), dim3(CT_THREADS), 0, stream, d_piece, len, ntiles, emit_from, d);
+    else hipLaunchKernelGGL(count_kernel<0>, dim3(grid_for(ntiles, 1)), dim3(CT_THREADS), 0, stream, d_piece, len, ntiles, emit_from, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_k1, stream));
     return 0;
@@ -376,7 +411,8 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
         const uint64_t room = (uint64_t)(0.75 * (double)nslots) > h_stats[ST_DISTINCT] ? (uint64_t)(0.75 * (double)nslots) - h_stats[ST_DISTINCT] : 0;
         uint64_t piece = std::max<uint64_t>(room, 1u << 20);
         piece = std::min<uint64_t>(piece, 1ull << 31);
-        if (piece > room) {   // small table: make room for a whole piece of new keys up front
+        if (const char *e = getenv("JASPER_EXPERIMENT_PIECE")) piece = strtoull(e, nullptr, 10);   // tuning experiments only
+        if (piece > room && !getenv("JASPER_EXPERIMENT_PIECE")) {   // small table: make room for a whole piece of new keys up front
             if (ensure_capacity(std::min<uint64_t>(piece, n - pos), err)) return -1;
         }
         uint64_t start = pos >= halo ? pos - halo : 0;

@@ -54,6 +54,39 @@ __device__ __forceinline__ int table_add(const TableDev &T, u128 h, unsigned lon
     return 0;
 }
 
+// same as table_add, but the tag of the home slot has already been loaded (`cur0`): lets a thread keep several
+// first probes in flight before resolving them
+__device__ __forceinline__ int table_add_prefetched(const TableDev &T, u128 h, unsigned long long inc, unsigned long long cur0) {
+    const uint64_t home = home_of(h, T.B, T.s);
+    const uint64_t rem = rem_of(h, T.B, T.s);
+    for (uint32_t off = 0; off < MAXPROBE; ++off) {
+        const uint64_t slot = (home + off) & T.mask;
+        const unsigned long long want = tag_of(rem, off);
+        unsigned long long *p = T.slots + 2 * slot;
+        unsigned long long cur = off == 0 ? cur0 : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int fresh = 1;
+        if (cur == 0ull) {
+            cur = atomicCAS(p, 0ull, want);
+            if (cur == 0ull) { fresh = 2; cur = want; }
+        }
+        if (cur == want) {
+            __hip_atomic_fetch_add(p + 1, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return fresh;
+        }
+    }
+    return 0;
+}
+__device__ __forceinline__ void table_spill(const TableDev &T, u128 h, unsigned long long inc) {
+    unsigned long long idx = atomicAdd(&T.stats[ST_SPILL], 1ull);
+    if (idx < T.spill_cap) {
+        T.spill[3 * idx + 0] = h.hi;
+        T.spill[3 * idx + 1] = h.lo;
+        T.spill[3 * idx + 2] = inc;
+    } else {
+        atomicExch(&T.stats[ST_FATAL], 1ull);
+    }
+}
+
 // returns 1 when a new distinct key was created
 __device__ __forceinline__ unsigned table_add_or_spill(const TableDev &T, u128 h, unsigned long long inc) {
     const int r = table_add(T, h, inc);

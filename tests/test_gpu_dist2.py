@@ -1,0 +1,91 @@
+"""GPU, 2 processes sharing the one GPU of the test box: the N>1 data path end to end (read shard -> count -> export ->
+exchange -> import -> identical merged tables -> chunk shard -> polish) with gloo as the transport, because RCCL refuses
+two ranks on one device.  Everything except the transport is what bench.py / the 8-GPU run executes."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from jasper_amd import KmerTable, synth, dist as jd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k = 37
+        rng = np.random.default_rng(42)                     # same workload on every rank
+        genome = synth.make_genome(rng, 150_000)
+        reads = synth.make_reads_stream(rng, genome, 30, 150, 0.003)
+        asm = synth.make_assembly(rng, genome, err=1e-3, n_every=10**9).tobytes().decode()
+        nrec = reads.size // 151
+        lo, hi = jd.shard_range(nrec, rank, world)          # read shard of this rank
+        mine = reads[lo * 151:hi * 151].tobytes()
+        t = KmerTable(k, min_slots=1 << 21, device=0)
+        t.count_bases(mine)
+        dev = torch.device("cuda", 0)
+        merged = jd.merge_tables(t, dev)
+        h = t.histogram()
+        info = t.info()
+        # chunk shard
+        bs = 20_000
+        recs = synth.chunk_records("c", len(asm), bs)
+        owner = jd.assign_chunks([b - a for _, a, b in recs], world)
+        my = [i for i, o in enumerate(owner) if o == rank]
+        res = t.polish_batch([asm[recs[i][1]:recs[i][2]] for i in my], 3, 2)
+        qv = jd.all_reduce_ints(list(res.qv), device=dev)
+        q.put((rank, h, info["distinct"], merged, my, res.seqs, qv))
+        t.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu(hip):
+    import torch.multiprocessing as mp
+    from jasper_amd import KmerTable, synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in ps], key=lambda x: x[0])
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single-table reference on the same workload
+    k = 37
+    rng = np.random.default_rng(42)
+    genome = synth.make_genome(rng, 150_000)
+    reads = synth.make_reads_stream(rng, genome, 30, 150, 0.003)
+    asm = synth.make_assembly(rng, genome, err=1e-3, n_every=10**9).tobytes().decode()
+    t = KmerTable(k, min_slots=1 << 21, device=0)
+    t.count_bases(reads.tobytes())
+    h = t.histogram()
+    assert res[0][1] == h and res[1][1] == h                      # both ranks hold the full counts after the merge
+    assert res[0][2] == res[1][2] == t.info()["distinct"]
+    assert res[0][3] > 0 and res[1][3] > 0
+    recs = synth.chunk_records("c", len(asm), 20_000)
+    full = t.polish_batch([asm[a:b] for _, a, b in recs], 3, 2)
+    got = [None] * len(recs)
+    for r in res:
+        for i, s in zip(r[4], r[5]):
+            got[i] = s
+    assert got == full.seqs                                       # chunk shards together == unsharded run
+    assert tuple(res[0][6]) == tuple(res[1][6]) == full.qv        # QV counters all-reduced
+    t.close()
