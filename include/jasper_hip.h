@@ -83,6 +83,14 @@ int jasper_table_import_device(jasper_table *t, const void *d_entries, uint64_t 
 /* export into caller-owned device memory (e.g. a torch tensor handed to RCCL); cap_entries = room in d_dst */
 int jasper_table_export_to(jasper_table *t, void *d_dst, uint64_t cap_entries, uint64_t *n_entries);
 int jasper_device_free(jasper_table *t, void *d_ptr);
+/* multi-GPU exchange format: 16-byte entries { hash.lo, hash.hi | count << max(0, 2k-64) } in device memory.
+ * export: keys whose home slot lies in slot-range partition `part` of `nparts` (nparts = 1: all); *n_entries is the
+ * number that exists (may exceed cap_entries: call once with cap 0 to size the buffer).  import mode 0 adds the
+ * counts (key-wise sum), mode 1 sets them (an owner's final counts replace this table's partial ones). */
+int jasper_table_export_packed(jasper_table *t, void *d_dst, uint64_t cap_entries, uint64_t *n_entries, uint32_t part, uint32_t nparts);
+int jasper_table_import_packed(jasper_table *t, const void *d_src, uint64_t n_entries, int mode);
+/* grow to at least min_slots slots (ranks agree on one geometry before exchanging slot-range partitions) */
+int jasper_table_reserve(jasper_table *t, uint64_t min_slots);
 
 /* one batch of chunk records through `passes` fixing passes + the final QV pass (src/jasper.py:25-26) */
 int jasper_polish_batch(jasper_table *t, int n_chunks, const char *const *seqs, const int64_t *lens,

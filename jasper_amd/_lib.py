@@ -45,6 +45,9 @@ SYMBOLS = {
     "jasper_table_import_device": (C.c_int, [_P, _P, C.c_uint64]),
     "jasper_table_export_to": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "jasper_device_free": (C.c_int, [_P, _P]),
+    "jasper_table_export_packed": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32]),
+    "jasper_table_import_packed": (C.c_int, [_P, _P, C.c_uint64, C.c_int]),
+    "jasper_table_reserve": (C.c_int, [_P, C.c_uint64]),
     "jasper_polish_batch": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "jasper_result_num_chunks": (C.c_int, [_P]),
     "jasper_result_seq": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64)]),

@@ -150,6 +150,15 @@ int jasper_table_import_device(jasper_table *t, const void *d_entries, uint64_t 
     return t->t.import_entries((const unsigned long long *)d_entries, n_entries, g_err);
 }
 
+int jasper_table_export_packed(jasper_table *t, void *d_dst, uint64_t cap_entries, uint64_t *n_entries, uint32_t part, uint32_t nparts) {
+    if (nparts == 0 || part >= nparts) { g_err = "bad partition"; return JASPER_ERR; }
+    return t->t.export_packed(d_dst, cap_entries, n_entries, part, nparts, g_err);
+}
+int jasper_table_import_packed(jasper_table *t, const void *d_src, uint64_t n_entries, int mode) {
+    return t->t.import_packed(d_src, n_entries, mode, g_err);
+}
+int jasper_table_reserve(jasper_table *t, uint64_t min_slots) { return t->t.reserve(min_slots, g_err); }
+
 int jasper_device_free(jasper_table *t, void *d_ptr) {
     CHK(hipSetDevice(t->t.device));
     CHK(hipFree(d_ptr));

@@ -219,6 +219,72 @@ __global__ __launch_bounds__(256) void import_kernel(const unsigned long long *_
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
 }
 
+// ---- 16-byte packed entries (multi-GPU exchange) ------------------------------------------------------------
+__device__ __forceinline__ int packed_count_shift(int B) { return B > 64 ? B - 64 : 0; }
+
+// scans slots [first, first+span) (mod table size): a key homed in partition `part` sits at most MAXPROBE-1 slots
+// behind its home, so one partition costs 1/nparts of a table pass
+__global__ __launch_bounds__(256) void export_packed_kernel(TableDev T, ulonglong2 *__restrict__ out, unsigned long long *__restrict__ counter,
+                                                            uint64_t cap, uint32_t part, uint32_t nparts, uint64_t first, uint64_t span) {
+    const int sh = packed_count_shift(T.B);
+    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < span; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = (first + q) & T.mask;
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * i);
+        if (e.x == 0ull) continue;
+        const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
+        const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
+        const uint64_t home = (i - off) & T.mask;
+        if (nparts > 1 && (uint32_t)(((unsigned __int128)home * nparts) >> T.s) != part) continue;
+        const u128 h = hash_from(home, rem, T.B, T.s);
+        if (sh && (e.y >> (64 - sh)) != 0ull) { atomicExch(&T.stats[ST_FATAL], 2ull); continue; }   // count does not fit the packing
+        const unsigned long long idx = atomicAdd(counter, 1ull);
+        if (idx < cap) out[idx] = make_ulonglong2(h.lo, h.hi | (sh ? (e.y << sh) : 0ull));
+    }
+}
+
+// insert-or-assign: the key's count becomes `val` (used when an owner's final counts replace a rank's partial ones)
+__device__ __forceinline__ int table_set(const TableDev &T, u128 h, unsigned long long val) {
+    const uint64_t home = home_of(h, T.B, T.s);
+    const uint64_t rem = rem_of(h, T.B, T.s);
+    for (uint32_t off = 0; off < MAXPROBE; ++off) {
+        const uint64_t slot = (home + off) & T.mask;
+        const unsigned long long want = tag_of(rem, off);
+        unsigned long long *p = T.slots + 2 * slot;
+        unsigned long long cur = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int fresh = 1;
+        if (cur == 0ull) {
+            cur = atomicCAS(p, 0ull, want);
+            if (cur == 0ull) { fresh = 2; cur = want; }
+        }
+        if (cur == want) {
+            __hip_atomic_store(p + 1, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return fresh;
+        }
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void import_packed_kernel(const ulonglong2 *__restrict__ in, uint64_t n, TableDev T, int mode) {
+    unsigned long long fresh = 0;
+    const int sh = packed_count_shift(T.B);
+    const unsigned long long himask = sh ? ((1ull << sh) - 1ull) : 0ull;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const ulonglong2 e = in[i];
+        const u128 h = mk(e.y & himask, e.x);
+        const unsigned long long c = sh ? (e.y >> sh) : e.y;
+        // (B <= 64 keeps the count in the whole second word)
+        if (!c) continue;
+        if (mode == 0) fresh += table_add_or_spill(T, h, c);
+        else {
+            const int r = table_set(T, h, c);
+            if (r == 2) ++fresh;
+            else if (r == 0) table_spill(T, h, c);   // re-inserted additively after growth: only ever reached for NEW keys
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+}
+
 // rehash straight from an old slot array into a (larger) table
 __global__ __launch_bounds__(256) void rehash_kernel(TableDev oldT, TableDev newT) {
     unsigned long long fresh = 0;
@@ -539,6 +605,57 @@ int Table::import_entries(const unsigned long long *d_entries, uint64_t n, std::
             if (ensure_capacity(piece, err)) return -1;
         }
         hipLaunchKernelGGL(import_kernel, dim3(grid_for(piece, 256)), dim3(256), 0, stream, d_entries + 3 * pos, piece, d);
+        HIPCHK(hipGetLastError());
+        pos += piece;
+        int rc = after_batch(err);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int Table::reserve(uint64_t min_slots, std::string &err) {
+    int ns = d.s;
+    while ((1ull << ns) < min_slots && ns < d.B) ++ns;
+    if (ns > d.s) return grow(ns, err);
+    return 0;
+}
+
+int Table::export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t part, uint32_t nparts, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    unsigned long long *d_ctr = nullptr;
+    HIPCHK(hipMalloc((void **)&d_ctr, sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d_ctr, 0, sizeof(unsigned long long), stream));
+    uint64_t first = 0, span = nslots;
+    if (nparts > 1) {
+        // partition p holds the keys with floor(home * nparts / nslots) == p, i.e. homes in [ceil(p*S/n), ceil((p+1)*S/n))
+        first = ((unsigned __int128)part * nslots + nparts - 1) / nparts;
+        const uint64_t next = ((unsigned __int128)(part + 1) * nslots + nparts - 1) / nparts;
+        span = std::min<uint64_t>(nslots, next - first + MAXPROBE);
+    }
+    hipLaunchKernelGGL(export_packed_kernel, dim3(grid_for(span, 256 * 16)), dim3(256), 0, stream, d, (ulonglong2 *)d_dst, d_ctr, cap, part, nparts,
+                       first, span);
+    HIPCHK(hipGetLastError());
+    unsigned long long got = 0;
+    HIPCHK(hipMemcpyAsync(&got, d_ctr, sizeof got, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipFree(d_ctr));
+    if (read_stats(err)) return -1;
+    if (h_stats[ST_FATAL] == 2) { err = "a count does not fit the packed exchange format"; return -2; }
+    *n_out = got;   // may exceed cap: the caller sizes its buffer with a first call (cap = 0) or from info()
+    return 0;
+}
+
+int Table::import_packed(const void *d_src, uint64_t n, int mode, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    if (read_stats(err)) return -1;
+    uint64_t pos = 0;
+    while (pos < n) {
+        const uint64_t room = (uint64_t)(0.75 * (double)nslots) > h_stats[ST_DISTINCT] ? (uint64_t)(0.75 * (double)nslots) - h_stats[ST_DISTINCT] : 0;
+        uint64_t piece = std::min<uint64_t>(n - pos, std::max<uint64_t>(room, 1u << 20));
+        if (piece > room) {
+            if (ensure_capacity(piece, err)) return -1;
+        }
+        hipLaunchKernelGGL(import_packed_kernel, dim3(grid_for(piece, 256)), dim3(256), 0, stream, (const ulonglong2 *)d_src + pos, piece, d, mode);
         HIPCHK(hipGetLastError());
         pos += piece;
         int rc = after_batch(err);

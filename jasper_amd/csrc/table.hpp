@@ -174,6 +174,11 @@ struct Table {
     int lookup_strings(const char *chars, const int64_t *offsets, uint64_t n, uint32_t *out, std::string &err);
     int export_entries(uint64_t *n_out, unsigned long long **d_entries_out, std::string &err);  // 3 words each
     int import_entries(const unsigned long long *d_entries, uint64_t n, std::string &err);
+    // 16-byte entries for the multi-GPU exchange: { hash.lo, hash.hi | count << (B-64) }; only keys whose home slot
+    // falls into partition `part` of `nparts` equal slot ranges; mode 0 = add counts, 1 = set counts
+    int export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t part, uint32_t nparts, std::string &err);
+    int import_packed(const void *d_src, uint64_t n, int mode, std::string &err);
+    int reserve(uint64_t min_slots, std::string &err);
 };
 
 }  // namespace jk

@@ -69,21 +69,88 @@ def all_gather_entries(entries, group=None):
     return torch.cat(others, dim=0).contiguous()
 
 
-def merge_tables(table, device):
-    """key-wise sum of the per-GPU tables: afterwards every rank's table holds the counts of ALL reads"""
+def _all_to_all_rows(send, group=None):
+    """send[dst] goes to rank dst; returns recv with recv[src] = what rank src sent to this rank.
+    RCCL: one all_to_all_single (point-to-point over every xGMI link at once). gloo has no all_to_all for device
+    tensors, so the CPU/rehearsal path gathers everything and picks its column -- same result, more traffic."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if dist.get_backend(group) == "nccl":
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
+        return recv
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send, group=group)
+    return torch.stack([parts[src][rank] for src in range(world)])
+
+
+def merge_tables(table, device, group=None):
+    """key-wise sum of the per-GPU tables; afterwards every rank's table holds the counts of ALL reads.
+
+    Owner-partitioned (reduce-scatter + all-gather by key range) instead of all-gathering whole tables:
+      1. ranks agree on one table geometry (all_reduce MAX of the slot count, local rehash if needed);
+      2. the key space is cut into `world` slot ranges; every rank sends the entries it holds of range o to rank o
+         (all_to_all of 16-byte packed entries) and rank o adds them to its own counts -> range o is final on rank o;
+      3. every rank publishes its final range (all_gather) and the others SET those counts in their tables.
+    Per rank this moves about (1 + (world-1)/world) x its own entries plus the merged table once, instead of
+    (world-1) x all entries.  Returns the number of entries received.
+    """
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 0
-    info = table.info()
-    mine = torch.empty((max(info["distinct"], 1), 3), dtype=torch.int64, device=device)
-    n = table.export_to(mine.data_ptr(), mine.shape[0])
-    torch.cuda.synchronize(device)
-    others = all_gather_entries(mine[:n])
-    torch.cuda.synchronize(device)
-    if others.shape[0]:
-        table.import_device(others.data_ptr(), others.shape[0])
-    return int(others.shape[0])
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    # 1. common geometry
+    slots = torch.tensor([table.info()["slots"]], dtype=torch.int64, device=device)
+    dist.all_reduce(slots, op=dist.ReduceOp.MAX, group=group)
+    table.reserve(int(slots.item()))
+    # 2. what I hold of every owner's range
+    counts = torch.tensor([table.export_packed(0, 0, o, world) for o in range(world)], dtype=torch.int64, device=device)
+    allc = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(allc, counts, group=group)
+    allc = torch.stack(allc).cpu()                     # allc[src][dst]
+    mx = max(int(allc.max().item()), 1)
+    send = torch.zeros((world, mx, 2), dtype=torch.int64, device=device)   # zero rows (count 0) are ignored by import
+    for o in range(world):
+        if o != rank and int(allc[rank][o]):
+            table.export_packed(send[o].data_ptr(), mx, o, world)
+    torch.cuda.synchronize(device) if device.type == "cuda" else None
+    recv = _all_to_all_rows(send, group)
+    torch.cuda.synchronize(device) if device.type == "cuda" else None
+    del send
+    received = 0
+    for src in range(world):
+        n = int(allc[src][rank])
+        if src != rank and n:
+            table.import_packed(recv[src].data_ptr(), n, 0)        # add: my range becomes final
+            received += n
+    del recv
+    # 3. publish my final range, take the others'
+    n_mine = table.export_packed(0, 0, rank, world)
+    nm = torch.tensor([n_mine], dtype=torch.int64, device=device)
+    alln = [torch.zeros_like(nm) for _ in range(world)]
+    dist.all_gather(alln, nm, group=group)
+    alln = [int(x.item()) for x in alln]
+    mx2 = max(max(alln), 1)
+    mine = torch.zeros((mx2, 2), dtype=torch.int64, device=device)
+    table.export_packed(mine.data_ptr(), mx2, rank, world)
+    torch.cuda.synchronize(device) if device.type == "cuda" else None
+    full = torch.empty((world, mx2, 2), dtype=torch.int64, device=device)
+    try:
+        dist.all_gather_into_tensor(full.view(world * mx2, 2), mine, group=group)
+    except (RuntimeError, NotImplementedError):
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        full = torch.stack(parts)
+    torch.cuda.synchronize(device) if device.type == "cuda" else None
+    for src in range(world):
+        if src != rank and alln[src]:
+            table.import_packed(full[src].data_ptr(), alln[src], 1)  # set: the owner's final counts replace my partial ones
+            received += alln[src]
+    return received
 
 
 def all_reduce_ints(values, device=None):

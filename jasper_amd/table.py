@@ -135,6 +135,18 @@ class KmerTable:
         check(self._L.jasper_table_export_to(self._h, C.c_void_p(dev_ptr), int(cap_entries), C.byref(n)))
         return int(n.value)
 
+    def export_packed(self, dev_ptr, cap_entries, part=0, nparts=1):
+        """16-byte exchange entries of slot-range partition part/nparts into device memory; returns how many exist"""
+        n = C.c_uint64(0)
+        check(self._L.jasper_table_export_packed(self._h, C.c_void_p(dev_ptr), int(cap_entries), C.byref(n), int(part), int(nparts)))
+        return int(n.value)
+
+    def import_packed(self, dev_ptr, n, mode=0):
+        check(self._L.jasper_table_import_packed(self._h, C.c_void_p(dev_ptr), int(n), int(mode)))
+
+    def reserve(self, min_slots):
+        check(self._L.jasper_table_reserve(self._h, int(min_slots)))
+
     def import_device(self, dev_ptr, n):
         check(self._L.jasper_table_import_device(self._h, C.c_void_p(dev_ptr), int(n)))
 

@@ -156,6 +156,40 @@ def test_merge_by_export_import_is_keywise_sum(KT, O):
     tb.close()
 
 
+def test_packed_partition_exchange_primitives(KT, O):
+    """the pieces of dist.merge_tables on one GPU: slot-range partitions are a disjoint cover; add-import sums; set-import
+    overwrites partial counts with final ones"""
+    import torch
+    k = 37
+    _, reads, _ = workload(23, 120_000, k)
+    cut = reads.index(b"N", len(reads) // 2) + 1
+    ta, tb, full = KT(k, min_slots=1 << 21), KT(k, min_slots=1 << 21), KT(k, min_slots=1 << 21)
+    ta.count_bases(reads[:cut])
+    tb.count_bases(reads[cut:])
+    full.count_bases(reads)
+    nparts = 3
+    sizes = [tb.export_packed(0, 0, p, nparts) for p in range(nparts)]
+    assert sum(sizes) == tb.info()["distinct"] == tb.export_packed(0, 0)
+    # "rank a" owns partition 1: it receives b's entries of partition 1 (add) -> final there
+    buf = torch.zeros((max(sizes), 2), dtype=torch.int64, device="cuda")
+    assert tb.export_packed(buf.data_ptr(), buf.shape[0], 1, nparts) == sizes[1]
+    ta.import_packed(buf.data_ptr(), sizes[1], 0)
+    # then publishes its final partition 1 and b SETs it
+    n1 = ta.export_packed(0, 0, 1, nparts)
+    out = torch.zeros((n1, 2), dtype=torch.int64, device="cuda")
+    ta.export_packed(out.data_ptr(), n1, 1, nparts)
+    tb.import_packed(out.data_ptr(), n1, 1)
+    # partition 1 of b now equals partition 1 of the full table
+    ref = torch.zeros((n1, 2), dtype=torch.int64, device="cuda")
+    assert full.export_packed(ref.data_ptr(), n1, 1, nparts) == n1
+    got = torch.zeros((n1, 2), dtype=torch.int64, device="cuda")
+    assert tb.export_packed(got.data_ptr(), n1, 1, nparts) == n1
+    key = lambda x: sorted(map(tuple, x.cpu().tolist()))
+    assert key(got) == key(ref) == key(out)
+    for t in (ta, tb, full):
+        t.close()
+
+
 def test_device_resident_stream_equals_host_stream(KT):
     """jasper_count_bases_device on an HBM-resident (and deliberately misaligned) buffer == host path"""
     import torch
