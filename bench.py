@@ -98,7 +98,7 @@ def cpu_baseline(seed):
     from jasper_amd import synth, polisher
     from oracle import oracle as O
     rng = np.random.default_rng(seed)
-    G = 600_000
+    G = 4_000_000      # ~90 M k-mer insertions + 3 scans of 4 Mb: roughly 15-30 s of one host core
     genome = synth.make_genome(rng, G)
     reads = synth.make_reads_stream(rng, genome, COVERAGE, READ_LEN, 0.003)
     asm = synth.make_assembly(rng, genome, err=1e-4, n_every=10_000_000)

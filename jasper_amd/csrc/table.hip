@@ -221,6 +221,12 @@ __global__ __launch_bounds__(256) void import_kernel(const unsigned long long *_
 
 // ---- 16-byte packed entries (multi-GPU exchange) ------------------------------------------------------------
 __device__ __forceinline__ int packed_count_shift(int B) { return B > 64 ? B - 64 : 0; }
+// owner partition of a key: by the top 32 bits of its mixed hash, so it does not depend on the table size
+// (ranks may hold tables of different sizes while they exchange)
+__host__ __device__ __forceinline__ uint32_t part_of(u128 h, int B, uint32_t nparts) {
+    const uint64_t top32 = B >= 32 ? shr(h, B - 32).lo : (h.lo << (32 - B));
+    return (uint32_t)((top32 * (uint64_t)nparts) >> 32);
+}
 
 // scans slots [first, first+span) (mod table size): a key homed in partition `part` sits at most MAXPROBE-1 slots
 // behind its home, so one partition costs 1/nparts of a table pass
@@ -234,8 +240,8 @@ __global__ __launch_bounds__(256) void export_packed_kernel(TableDev T, ulonglon
         const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
         const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
         const uint64_t home = (i - off) & T.mask;
-        if (nparts > 1 && (uint32_t)(((unsigned __int128)home * nparts) >> T.s) != part) continue;
         const u128 h = hash_from(home, rem, T.B, T.s);
+        if (nparts > 1 && part_of(h, T.B, nparts) != part) continue;
         if (sh && (e.y >> (64 - sh)) != 0ull) { atomicExch(&T.stats[ST_FATAL], 2ull); continue; }   // count does not fit the packing
         const unsigned long long idx = atomicAdd(counter, 1ull);
         if (idx < cap) out[idx] = make_ulonglong2(h.lo, h.hi | (sh ? (e.y << sh) : 0ull));
@@ -627,10 +633,17 @@ int Table::export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t pa
     HIPCHK(hipMemsetAsync(d_ctr, 0, sizeof(unsigned long long), stream));
     uint64_t first = 0, span = nslots;
     if (nparts > 1) {
-        // partition p holds the keys with floor(home * nparts / nslots) == p, i.e. homes in [ceil(p*S/n), ceil((p+1)*S/n))
-        first = ((unsigned __int128)part * nslots + nparts - 1) / nparts;
-        const uint64_t next = ((unsigned __int128)(part + 1) * nslots + nparts - 1) / nparts;
-        span = std::min<uint64_t>(nslots, next - first + MAXPROBE);
+        // partition p = keys whose top-32 hash bits t satisfy floor(t * nparts / 2^32) == p, i.e. t in [t_lo, t_hi);
+        // their home slots are a contiguous range, and an entry sits < MAXPROBE slots behind its home
+        const uint64_t t_lo = (((uint64_t)part << 32) + nparts - 1) / nparts;
+        const uint64_t t_hi = ((((uint64_t)part + 1) << 32) + nparts - 1) / nparts;   // exclusive
+        const int s_ = d.s;
+        uint64_t last_excl;
+        if (d.B >= 32) {
+            if (s_ <= 32) { first = t_lo >> (32 - s_); last_excl = ((t_hi - 1) >> (32 - s_)) + 1; }
+            else { first = t_lo << (s_ - 32); last_excl = t_hi << (s_ - 32); }
+            span = std::min<uint64_t>(nslots, last_excl - first + MAXPROBE);
+        }   // (B < 32: tiny key space, scan everything)
     }
     hipLaunchKernelGGL(export_packed_kernel, dim3(grid_for(span, 256 * 16)), dim3(256), 0, stream, d, (ulonglong2 *)d_dst, d_ctr, cap, part, nparts,
                        first, span);
