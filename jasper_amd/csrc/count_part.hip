@@ -1,0 +1,343 @@
+// count_part.hip -- counting without global atomics on the table ("partitioned" path of K1+K2).
+//
+// Why: the direct kernel (table.hip: count_kernel) issues one scattered 64-bit atomic per k-mer, and MI355X retires
+// only ~20 G scattered atomics/s chip-wide whatever the working set (measured: hashing alone 190 Gk-mers/s, hashing +
+// one random 8-B load 48 Gk-mers/s, full insert 18 Gk-mers/s, unchanged when the touched slots fit in L2; see
+// DESIGN.md 6).  Here the table is updated with LDS atomics instead:
+//
+//   part1_kernel   bases -> mixed hash -> bucket = top p1 hash bits; the remaining (2k-p1 <= 64) bits go, as one
+//                  8-byte record, into the bucket's list.  Per 16 K-record tile: LDS histogram (returning LDS
+//                  atomics give every record its rank), ONE global reservation per non-empty bucket, scattered 8-B
+//                  stores that the XCD's L2 merges into full lines.
+//   part2_kernel   same scheme on each bucket, by the next p2 hash bits  ->  2^(p1+p2) lists, one per table REGION
+//                  of 2^rbits <= 8192 consecutive slots (home slot = top hash bits, so a region is a hash range).
+//   lds_insert_kernel  one workgroup per region: region (+128-slot halo so a probe may run past the region end) is
+//                  loaded into LDS (130 KB), records are inserted with LDS compare-and-swap / add, image written back.
+//                  Even and odd regions run in two launches, so no two resident images overlap.
+//   A record that finds no room (bucket list full, probe beyond the halo) takes the direct path: immediately during
+//   part1/part2 (no LDS image exists yet), deferred to a list that import_kernel drains after the last lds_insert.
+//
+// The table layout, tags and probe order are exactly those of the direct path, so lookups, histogram, export, growth
+// and the polisher do not know which path filled the table.  HBM traffic per k-mer: 1 B base + 8 B x 2 (part1 list)
+// + 8 B x 2 (part2 list) + the table once in, once out -- all of it streaming.
+#include "table.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace jk {
+
+#define HIPCHK(x)                                                                     \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            err = std::string(#x) + ": " + hipGetErrorString(e_);                     \
+            return -1;                                                                \
+        }                                                                             \
+    } while (0)
+
+constexpr int PT_THREADS = 1024;
+constexpr int PT_GROUP = 16;
+constexpr int PT_TILE = PT_THREADS * PT_GROUP;   // 16384 records per block iteration
+constexpr int PT_HALO = 4;
+constexpr int PT_MAXBUCKETS = 2048;              // p1, p2 <= 11
+constexpr int RG_MAXBITS = 13;                   // region <= 8192 slots = 128 KB of LDS
+constexpr int RG_HALO = 128;                     // slots of the next region a probe may run into
+
+struct PartGeom {
+    int p1, p2, rbits;       // p1 + p2 + rbits == s
+    int recbits;             // 2k - p1  (<= 64): bits kept in a record
+    uint32_t nblk1;          // part1 grid: every block owns one SLICE of every level-1 list
+    uint32_t nblk2;          // part2 blocks per level-1 bucket: every one owns a slice of each of the bucket's region lists
+    uint32_t cap1, cap2;     // slice capacities (records)
+};
+// level-1 list of bucket b = slices  out1[(b * nblk1 + blk) * cap1 ...], filled counts cnt1[b * nblk1 + blk]
+// region list of region r  = slices  out2[(r * nblk2 + x) * cap2 ...],   filled counts cnt2[r * nblk2 + x]
+
+__device__ __forceinline__ uint64_t rec_of(u128 h, int recbits) { return recbits >= 64 ? h.lo : (h.lo & ((1ull << recbits) - 1ull)); }
+__device__ __forceinline__ u128 hash_of(uint64_t b1, uint64_t rec, int recbits) { return bor(shl(mk(0, b1), recbits), mk(0, rec)); }
+
+__device__ __forceinline__ void pt_stage(const uint8_t *__restrict__ bases, int64_t pos, uint64_t n, bool aligned, uint32_t &codes, uint32_t &inv) {
+    uint8_t b[16];
+    if (pos >= 0 && (uint64_t)pos + 16 <= n && aligned) {
+        *reinterpret_cast<uint4 *>(b) = *reinterpret_cast<const uint4 *>(bases + pos);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int64_t p = pos + j; b[j] = (p >= 0 && (uint64_t)p < n) ? bases[p] : (uint8_t)'N'; }
+    }
+    codes = 0; inv = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const int c = code(b[j]); codes = (codes << 2) | (uint32_t)(c & 3); inv = (inv << 1) | (uint32_t)(c < 0); }
+}
+
+// ---- level 1: bases -> records in 2^p1 bucket lists --------------------------------------------------------
+// Every block keeps one write cursor per bucket in LDS for its own slice of that bucket's list: a record's place is
+// one returning LDS atomic, there is no global atomic and no second pass.  Stores are 8-B scattered; records of one
+// slice are consecutive, so the L2 of the block's XCD merges them into full lines.
+__global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t ntiles, uint64_t emit_from,
+                                                            TableDev T, PartGeom G, uint64_t *__restrict__ out1, unsigned int *__restrict__ cnt1) {
+    __shared__ uint32_t s_code[PT_THREADS + PT_HALO];
+    __shared__ uint32_t s_inv[PT_THREADS + PT_HALO];
+    __shared__ unsigned int s_cur[PT_MAXBUCKETS];
+    const int t = threadIdx.x;
+    const int k = T.k;
+    const int nb = 1 << G.p1;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
+    const u128 kmask = maskbits(2 * k);
+    unsigned long long added = 0, fresh = 0;
+    for (int i = t; i < nb; i += PT_THREADS) s_cur[i] = 0;
+    __syncthreads();
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base0 = (int64_t)(tile * PT_TILE);
+        uint32_t c, iv;
+        pt_stage(bases, base0 + (int64_t)t * PT_GROUP, n, aligned, c, iv);
+        s_code[t + PT_HALO] = c;
+        s_inv[t + PT_HALO] = iv;
+        if (t < PT_HALO) {
+            uint32_t hc, hiv;
+            pt_stage(bases, base0 - (int64_t)(PT_HALO - t) * PT_GROUP, n, aligned, hc, hiv);
+            s_code[t] = hc;
+            s_inv[t] = hiv;
+        }
+        __syncthreads();
+        const uint32_t w4 = s_code[t], w3 = s_code[t + 1], w2 = s_code[t + 2], w1 = s_code[t + 3];
+        const uint64_t ivprev = ((uint64_t)s_inv[t] << 48) | ((uint64_t)s_inv[t + 1] << 32) | ((uint64_t)s_inv[t + 2] << 16) | (uint64_t)s_inv[t + 3];
+        __syncthreads();   // staging arrays are free for the next tile
+        u128 fwd = band(mk(((uint64_t)w4 << 32) | w3, ((uint64_t)w2 << 32) | w1), kmask);
+        u128 rc = revcomp(fwd, k);
+        int run = ivprev ? (int)__builtin_ctzll(ivprev) : 64;
+        if (iv == 0xFFFFu) continue;
+#pragma unroll 4
+        for (int j = 0; j < PT_GROUP; ++j) {
+            const uint32_t cj = (c >> (30 - 2 * j)) & 3u;
+            const bool bad = (iv >> (15 - j)) & 1u;
+            fwd = band(bor(shl(fwd, 2), mk(0, cj)), kmask);
+            rc = bor(shr(rc, 2), shl(mk(0, 3u - cj), 2 * (k - 1)));
+            run = bad ? 0 : run + 1;
+            if (run >= k && (uint64_t)(base0 + t * PT_GROUP + j) >= emit_from) {
+                const u128 h = mix(lt(rc, fwd) ? rc : fwd, T.B);
+                const uint32_t b = (uint32_t)shr(h, G.recbits).lo;
+                const uint64_t rec = rec_of(h, G.recbits);
+                const unsigned int pos = atomicAdd(&s_cur[b], 1u);          // LDS: place in my slice of bucket b
+                if (pos < G.cap1) out1[((uint64_t)b * G.nblk1 + blockIdx.x) * G.cap1 + pos] = rec;
+                else fresh += table_add_or_spill(T, h, 1ull);               // slice full: direct path (no LDS image exists yet)
+                ++added;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < nb; i += PT_THREADS) cnt1[(uint64_t)i * G.nblk1 + blockIdx.x] = s_cur[i] < G.cap1 ? s_cur[i] : G.cap1;
+    for (int o = 32; o > 0; o >>= 1) { added += __shfl_xor(added, o); fresh += __shfl_xor(fresh, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (added) atomicAdd(&T.stats[ST_OCCURRENCES], added);
+        if (fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+    }
+}
+
+// ---- level 2: every bucket list -> 2^p2 region lists ---------------------------------------------------------
+// grid (nblk2, buckets): block (x, b1) reads the level-1 slices x, x+nblk2, ... of bucket b1 and appends to ITS slice
+// of each of the bucket's 2^p2 region lists, again with LDS cursors only.
+__global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__restrict__ out1, const unsigned int *__restrict__ cnt1, TableDev T,
+                                                            PartGeom G, uint64_t *__restrict__ out2, unsigned int *__restrict__ cnt2) {
+    __shared__ unsigned int s_cur[PT_MAXBUCKETS];
+    const int t = threadIdx.x;
+    const int nb2 = 1 << G.p2;
+    const int shift2 = G.recbits - G.p2;               // the p2 bits right below the level-1 bucket bits
+    unsigned long long fresh = 0;
+    for (uint32_t b1 = blockIdx.y; b1 < (1u << G.p1); b1 += gridDim.y) {
+        for (int i = t; i < nb2; i += PT_THREADS) s_cur[i] = 0;
+        __syncthreads();
+        for (uint32_t sl = blockIdx.x; sl < G.nblk1; sl += G.nblk2) {
+            const uint32_t n1 = cnt1[(uint64_t)b1 * G.nblk1 + sl];
+            const uint64_t *src = out1 + ((uint64_t)b1 * G.nblk1 + sl) * G.cap1;
+            for (uint32_t idx = t; idx < n1; idx += PT_THREADS) {         // coalesced 8-B loads
+                const uint64_t rec = src[idx];
+                const uint32_t b2 = (uint32_t)(rec >> shift2) & (uint32_t)(nb2 - 1);
+                const unsigned int pos = atomicAdd(&s_cur[b2], 1u);
+                const uint64_t region = ((uint64_t)b1 << G.p2) + b2;
+                if (pos < G.cap2) out2[(region * G.nblk2 + blockIdx.x) * G.cap2 + pos] = rec;
+                else fresh += table_add_or_spill(T, hash_of(b1, rec, G.recbits), 1ull);
+            }
+        }
+        __syncthreads();
+        for (int i = t; i < nb2; i += PT_THREADS)
+            cnt2[(((uint64_t)b1 << G.p2) + i) * G.nblk2 + blockIdx.x] = s_cur[i] < G.cap2 ? s_cur[i] : G.cap2;
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+}
+
+// ---- final: region lists -> LDS image of the region -> table ------------------------------------------------------
+// lists: slices  lists[(region * nsl + x) * cap + i], i < cnt[region * nsl + x].  `parity`: regions with (region & 1) == parity.
+__global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *__restrict__ lists, const unsigned int *__restrict__ cnt, uint32_t cap,
+                                                                 uint32_t nsl, TableDev T, PartGeom G, uint32_t nregions, uint32_t parity,
+                                                                 unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
+                                                                 uint64_t deferred_cap) {
+    extern __shared__ __align__(16) unsigned long long s_img[];    // 2 words per slot: (R + halo) slots
+    const int t = threadIdx.x;
+    const uint32_t R = 1u << G.rbits;
+    const uint32_t halo = nregions > 1 ? (uint32_t)RG_HALO : 0u;     // a single region is the whole table: probes wrap inside it
+    const uint32_t span = R + halo;
+    unsigned long long fresh = 0;
+    for (uint32_t region = blockIdx.x * 2 + parity; region < nregions; region += gridDim.x * 2) {
+        uint32_t total = 0;
+        for (uint32_t x = 0; x < nsl; ++x) total += cnt[(uint64_t)region * nsl + x];
+        if (total == 0) continue;                                  // block-uniform
+        const uint64_t first = (uint64_t)region << G.rbits;        // first slot of the region
+        // image in: coalesced 16-B loads (the halo wraps around the end of the table)
+        for (uint32_t i = t; i < span; i += PT_THREADS) {
+            const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * ((first + i) & T.mask));
+            s_img[2 * i] = e.x;
+            s_img[2 * i + 1] = e.y;
+        }
+        __syncthreads();
+        const uint64_t b1 = region >> G.p2;
+        for (uint32_t x = 0; x < nsl; ++x) {
+            const uint32_t nrec = cnt[(uint64_t)region * nsl + x];
+            const uint64_t *src = lists + ((uint64_t)region * nsl + x) * cap;
+            for (uint32_t i = t; i < nrec; i += PT_THREADS) {
+                const uint64_t rec = src[i];
+                const u128 h = hash_of(b1, rec, G.recbits);
+                const uint64_t home = home_of(h, T.B, T.s);
+                const uint64_t rem = rem_of(h, T.B, T.s);
+                const uint32_t local = (uint32_t)(home - first);   // < R
+                bool done = false;
+                for (uint32_t off = 0; off < MAXPROBE && !done; ++off) {
+                    uint32_t idx = local + off;
+                    if (nregions == 1) idx &= (R - 1);             // whole table in LDS: wrap like the global probe
+                    else if (idx >= span) break;                   // beyond the halo: deferred to the direct path
+                    const unsigned long long want = tag_of(rem, off);
+                    unsigned long long cur = s_img[2 * idx];
+                    if (cur == 0ull) {
+                        cur = atomicCAS(&s_img[2 * idx], 0ull, want);   // LDS compare-and-swap
+                        if (cur == 0ull) { ++fresh; cur = want; }
+                    }
+                    if (cur == want) {
+                        atomicAdd(&s_img[2 * idx + 1], 1ull);      // LDS add
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    const unsigned long long di = atomicAdd(deferred_n, 1ull);
+                    if (di < deferred_cap) { deferred[3 * di] = h.hi; deferred[3 * di + 1] = h.lo; deferred[3 * di + 2] = 1ull; }
+                    else atomicExch(&T.stats[ST_FATAL], 1ull);
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < span; i += PT_THREADS)
+            *reinterpret_cast<ulonglong2 *>(T.slots + 2 * ((first + i) & T.mask)) = make_ulonglong2(s_img[2 * i], s_img[2 * i + 1]);
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+}
+
+__global__ __launch_bounds__(256) void import3_kernel(const unsigned long long *__restrict__ entries, const unsigned long long *__restrict__ n_ptr,
+                                                      uint64_t cap, TableDev T) {
+    const uint64_t n = *n_ptr < cap ? *n_ptr : cap;
+    unsigned long long fresh = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        fresh += table_add_or_spill(T, mk(entries[3 * i], entries[3 * i + 1]), entries[3 * i + 2]);
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+}
+
+// ==================================================================================================
+static uint32_t list_cap(double avg) { return (uint32_t)std::min<double>(4.0e9, avg * 1.25 + 8.0 * std::sqrt(avg) + 64.0); }
+
+// can this piece take the partitioned path, and with which geometry?
+bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
+    PartGeom &G = *reinterpret_cast<PartGeom *>(geom_out);
+    if (getenv("JASPER_COUNT_DIRECT")) return false;
+    if (piece_bases < (8u << 20)) return false;          // small pieces: the direct kernel is already latency-hidden
+    const int B = d.B, s = d.s;
+    const int need_p1 = B > 64 ? B - 64 : 0;              // records are 8 bytes
+    int p1 = std::max(need_p1, (s - RG_MAXBITS + 1) / 2);
+    if (p1 < 1) p1 = 1;
+    if (p1 > 11 || p1 > s - 8) return false;              // (k >= 38, or a table too small to be worth it)
+    int p2 = s - RG_MAXBITS - p1;
+    if (p2 < 0) p2 = 0;
+    if (p2 > 11) return false;
+    G.p1 = p1; G.p2 = p2; G.rbits = s - p1 - p2; G.recbits = B - p1;
+    // slices should hold >= ~512 records on average so that their 1.25x + 8 sigma capacity wastes little
+    const uint64_t ntiles = (piece_bases + PT_TILE - 1) / PT_TILE;
+    uint64_t nblk1 = piece_bases / ((uint64_t)(1u << p1) * 512);
+    nblk1 = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(nblk1, ntiles), 512));   // two 1024-thread blocks per CU
+    G.nblk1 = (uint32_t)nblk1;
+    G.cap1 = list_cap((double)piece_bases / ((double)(1u << p1) * (double)nblk1));
+    G.nblk2 = p2 ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nblk1, 8)) : 1;
+    G.cap2 = p2 ? list_cap((double)piece_bases / ((double)(1ull << (p1 + p2)) * (double)G.nblk2)) : 0;
+    return true;
+}
+
+int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, const void *geom, std::string &err) {
+    const PartGeom G = *reinterpret_cast<const PartGeom *>(geom);
+    const uint32_t nb1 = 1u << G.p1, nregions = 1u << (G.p1 + G.p2);
+    const uint64_t deferred_cap = std::max<uint64_t>(1u << 16, len / 16);
+    const size_t n_cnt1 = (size_t)nb1 * G.nblk1, n_cnt2 = G.p2 ? (size_t)nregions * G.nblk2 : 0;
+    uint64_t *out1 = (uint64_t *)workspace(16, n_cnt1 * G.cap1 * 8, err);
+    uint64_t *out2 = G.p2 ? (uint64_t *)workspace(17, n_cnt2 * G.cap2 * 8, err) : nullptr;
+    unsigned int *cur = (unsigned int *)workspace(18, (n_cnt1 + n_cnt2 + 4) * 4, err);
+    unsigned long long *defer = (unsigned long long *)workspace(19, deferred_cap * 24 + 64, err);
+    if (!out1 || (G.p2 && !out2) || !cur || !defer) return -2;
+    unsigned int *cnt1 = cur, *cnt2 = cur + n_cnt1;
+    unsigned long long *defer_n = defer;                    // first 8 bytes: counter; entries start 64 bytes in
+    unsigned long long *defer_e = defer + 8;
+    HIPCHK(hipMemsetAsync(defer_n, 0, 64, stream));
+    const uint64_t ntiles = (len + PT_TILE - 1) / PT_TILE;
+    for (int i = 0; i < 6; ++i) if (!ev_stage_t[i]) HIPCHK(hipEventCreate(&ev_stage_t[i]));
+    HIPCHK(hipEventRecord(ev_k0, stream));
+    HIPCHK(hipEventRecord(ev_stage_t[0], stream));
+    hipLaunchKernelGGL(part1_kernel, dim3(G.nblk1), dim3(PT_THREADS), 0, stream, d_piece, len, ntiles, emit_from, d, G, out1, cnt1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ev_stage_t[1], stream));
+    const uint64_t *lists = out1;
+    const unsigned int *lcnt = cnt1;
+    uint32_t lcap = G.cap1, nsl = G.nblk1;
+    if (G.p2) {
+        dim3 grid(G.nblk2, std::min<uint32_t>(nb1, 2048));
+        hipLaunchKernelGGL(part2_kernel, grid, dim3(PT_THREADS), 0, stream, out1, cnt1, d, G, out2, cnt2);
+        HIPCHK(hipGetLastError());
+        lists = out2; lcnt = cnt2; lcap = G.cap2; nsl = G.nblk2;
+    }
+    HIPCHK(hipEventRecord(ev_stage_t[2], stream));
+    const size_t lds = ((size_t)(1u << G.rbits) + RG_HALO) * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_insert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    for (uint32_t parity = 0; parity < 2; ++parity) {
+        if (!(nregions == 1 && parity == 1)) {
+            const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
+            hipLaunchKernelGGL(lds_insert_kernel, dim3(nblk), dim3(PT_THREADS), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, parity, defer_e,
+                               defer_n, deferred_cap);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(ev_stage_t[3 + parity], stream));
+    }
+    hipLaunchKernelGGL(import3_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, deferred_cap, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ev_k1, stream));
+    HIPCHK(hipEventRecord(ev_stage_t[5], stream));
+    part_stage_pending = true;
+    if (getenv("JASPER_COUNT_DEBUG")) {
+        HIPCHK(hipStreamSynchronize(stream));
+        unsigned long long dn = 0;
+        HIPCHK(hipMemcpy(&dn, defer_n, 8, hipMemcpyDeviceToHost));
+        std::vector<unsigned int> hc(n_cnt1 + n_cnt2);
+        HIPCHK(hipMemcpy(hc.data(), cur, hc.size() * 4, hipMemcpyDeviceToHost));
+        unsigned int mx1 = 0, mx2 = 0;
+        for (size_t i = 0; i < n_cnt1; ++i) mx1 = std::max(mx1, hc[i]);
+        for (size_t i = 0; i < n_cnt2; ++i) mx2 = std::max(mx2, hc[n_cnt1 + i]);
+        fprintf(stderr, "[count] partitioned piece %llu bases: p1 %d p2 %d rbits %d nblk1 %u nblk2 %u cap1 %u cap2 %u | fullest slice1 %u slice2 %u deferred %llu\n",
+                (unsigned long long)len, G.p1, G.p2, G.rbits, G.nblk1, G.nblk2, G.cap1, G.cap2, mx1, mx2, dn);
+    }
+    return 0;
+}
+
+}  // namespace jk

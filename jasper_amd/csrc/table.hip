@@ -7,6 +7,7 @@
 //   export / import  C1     table <-> list of (hash, count) for growth and for the multi-GPU merge
 #include "table.hpp"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -421,6 +422,7 @@ int Table::after_batch(std::string &err) {
         if (read_stats(err)) return -1;
         if (h_stats[ST_FATAL]) { err = "k-mer table overflow (spill buffer exhausted): pass a larger size hint"; return -2; }
         const uint64_t spilled = h_stats[ST_SPILL];
+        if (getenv("JASPER_COUNT_DEBUG") && spilled) fprintf(stderr, "[count] after_batch: %llu spilled insertions\n", (unsigned long long)spilled);
         const bool too_full = (double)h_stats[ST_DISTINCT] > grow_at * (double)nslots && d.s < d.B;
         if (!spilled && !too_full) return 0;
         std::vector<unsigned long long> sp;
@@ -457,6 +459,13 @@ int Table::ensure_capacity(uint64_t upcoming_kmers, std::string &err) {
 }
 
 int Table::launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, std::string &err) {
+    alignas(16) char geom[64];
+    // the partitioned path streams the whole table once per piece: worth it only for pieces that are large relative
+    // to the table (host-staged 64 MiB pieces stay on the direct kernel and are PCIe-bound anyway)
+    if (len >= nslots / 2 && partition_geometry(len, geom)) {
+        ++count_partitioned_launches;
+        return launch_count_partitioned(d_piece, len, emit_from, geom, err);
+    }
     const uint64_t ntiles = (len + CT_TILE - 1) / CT_TILE;
     HIPCHK(hipEventRecord(ev_k0, stream));
     static const int mode = getenv("JASPER_EXPERIMENT_MODE") ? atoi(getenv("JASPER_EXPERIMENT_MODE")) : 0;
@@ -482,20 +491,50 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
         // base a new k-mer); h_stats holds the distinct count of the last check
         const uint64_t room = (uint64_t)(0.75 * (double)nslots) > h_stats[ST_DISTINCT] ? (uint64_t)(0.75 * (double)nslots) - h_stats[ST_DISTINCT] : 0;
         uint64_t piece = std::max<uint64_t>(room, 1u << 20);
+        // after the first piece the measured share of NEW keys per k-mer (x1.5 safety) replaces the worst case "every base
+        // a new key"; the spill list / deferred list / growth still catch a piece that turns out less repetitive
+        if (pos > 0 && dup_ratio < 0.6) piece = std::max<uint64_t>(piece, (uint64_t)((double)room / std::max(0.05, 1.5 * dup_ratio)));
+        {   // partition lists need ~20 bytes of workspace per base
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                size_t have = free_b;
+                for (int w = 16; w <= 19; ++w) have += ws[w].bytes;
+                piece = std::min<uint64_t>(piece, std::max<uint64_t>(have / 28, 1u << 20));
+            }
+        }
         piece = std::min<uint64_t>(piece, 1ull << 31);
+        // do not leave a small tail for a separate launch (the 1.5x safety factor covers a quarter more)
+        if (pos > 0 && dup_ratio < 0.6 && n - pos <= piece + piece / 4 && n - pos <= (1ull << 31)) piece = n - pos;
         if (const char *e = getenv("JASPER_EXPERIMENT_PIECE")) piece = strtoull(e, nullptr, 10);   // tuning experiments only
-        if (piece > room && !getenv("JASPER_EXPERIMENT_PIECE")) {   // small table: make room for a whole piece of new keys up front
-            if (ensure_capacity(std::min<uint64_t>(piece, n - pos), err)) return -1;
+        {   // make room up front for the new keys this piece is expected to bring (worst case for the first piece)
+            const uint64_t todo = std::min<uint64_t>(piece, n - pos);
+            // (the share of new keys only falls as coverage accumulates, so the last piece's ratio is already an upper
+            // estimate; spill list, deferred list and growth after the piece remain the safety net)
+            const uint64_t expect = pos > 0 && dup_ratio < 0.6 ? (uint64_t)((double)todo * std::min(1.0, dup_ratio)) : todo;
+            if (expect > room && !getenv("JASPER_EXPERIMENT_PIECE")) {
+                if (ensure_capacity(expect, err)) return -1;
+            }
         }
         uint64_t start = pos >= halo ? pos - halo : 0;
         // round the start down so that (d_bases + start) is 16-byte aligned
         const uint64_t a = (start + misalign) & 15;
         start = start >= a ? start - a : 0;
         const uint64_t end = std::min<uint64_t>(n, pos + piece);
+        const uint64_t distinct_before = h_stats[ST_DISTINCT], occ_before = h_stats[ST_OCCURRENCES];
         if (launch_count(d_bases + start, end - start, pos - start, err)) return -1;
         pos = end;
         int rc = after_batch(err);
         if (rc) return rc;
+        if (h_stats[ST_OCCURRENCES] > occ_before)
+            dup_ratio = (double)(h_stats[ST_DISTINCT] - distinct_before) / (double)(h_stats[ST_OCCURRENCES] - occ_before);
+        if (part_stage_pending) {
+            for (int i = 0; i < 5; ++i) { float m = 0; if (hipEventElapsedTime(&m, ev_stage_t[i], ev_stage_t[i + 1]) == hipSuccess) part_stage_ms[i] += m; }
+            part_stage_pending = false;
+        }
+        if (getenv("JASPER_COUNT_DEBUG"))
+            fprintf(stderr, "[count] piece done: pos %llu / %llu, distinct %llu, slots 2^%d, dup_ratio %.3f, stage ms so far %.2f %.2f %.2f %.2f %.2f\n",
+                    (unsigned long long)pos, (unsigned long long)n, (unsigned long long)h_stats[ST_DISTINCT], d.s, dup_ratio,
+                    part_stage_ms[0], part_stage_ms[1], part_stage_ms[2], part_stage_ms[3], part_stage_ms[4]);
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, ev_k0, ev_k1));
         count_kernel_ms += ms;

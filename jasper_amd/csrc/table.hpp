@@ -156,6 +156,14 @@ struct Table {
     uint64_t count_launches = 0;
     void reset_timing() { count_kernel_ms = 0; count_launches = 0; }
     int launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, std::string &err);
+    // partitioned (atomic-free) path, count_part.hip; `geom` is an opaque PartGeom
+    bool partition_geometry(uint64_t piece_bases, void *geom_out) const;
+    int launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, const void *geom, std::string &err);
+    uint64_t count_partitioned_launches = 0;
+    hipEvent_t ev_stage_t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries of the partitioned path
+    double part_stage_ms[5] = {0, 0, 0, 0, 0};                                          // part1, part2, lds even, lds odd, deferred
+    bool part_stage_pending = false;
+    double dup_ratio = 1.0;   // new distinct keys per k-mer of the last piece (sizes the next piece)
     // grow-only device workspace reused by the polisher across calls (hipMalloc of GBs costs far more than the kernels)
     struct WsBuf { void *p = nullptr; size_t bytes = 0; };
     WsBuf ws[24];
