@@ -71,6 +71,7 @@ def one_step(torch, dev_index, table, reads, seqs, world, timers):
     table.sync()
     t1 = time.perf_counter()
     kms, launches = table.count_timing()
+    stages, part_launches = table.count_stages()
     merged = 0
     if world > 1:
         merged = jdist.merge_tables(table, torch.device("cuda", dev_index))
@@ -85,7 +86,7 @@ def one_step(torch, dev_index, table, reads, seqs, world, timers):
     res = table.polish_batch(seqs, thr, PASSES, fix=True)
     t4 = time.perf_counter()
     info = table.info()
-    timers.append(dict(count=t1 - t0, merge=t2 - t1, histo=t3 - t2, polish=t4 - t3, kernel_ms=kms, launches=launches,
+    timers.append(dict(count=t1 - t0, merge=t2 - t1, histo=t3 - t2, polish=t4 - t3, kernel_ms=kms, launches=launches, stages=stages, part_launches=part_launches,
                        polish_dev=res.seconds, thr=thr, qv=res.qv, nfix=len(res.records), merged=merged,
                        distinct=info["distinct"], occurrences=info["occurrences"], slots=info["slots"], lookups=res.lookups,
                        segments=res.segments, respeculated=res.respeculated))
@@ -207,10 +208,17 @@ def main():
         "polish_device_ms": round(mean("polish_dev") * 1e3, 2),
         "qv_counters": list(T["qv"]), "fix_records": T["nfix"], "polish_lookups": T["lookups"],
         "polish_segments": T["segments"], "polish_chunks_redone_unsegmented": T["respeculated"],
-        "roofline": {"bound": "hbm", "kernel": "count_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm",
+                     "kernel": "k-mer counting = part1_kernel + part2_kernel + lds_insert_kernel (even, odd) per piece"
+                               if T["part_launches"] else "count_kernel",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": int(BYTES_PER_KMER * kmers_rank / launches),
-                     "launches_per_step": launches, "avg_launch_ms": round(mean("kernel_ms") / launches, 3)},
+                     "launches_per_step": launches, "partitioned_launches": T["part_launches"],
+                     "avg_launch_ms": round(mean("kernel_ms") / launches, 3),
+                     "kernel_ms_per_step": {n: round(sum(t["stages"][i] for t in timers) / len(timers), 3)
+                                            for i, n in enumerate(("part1_kernel", "part2_kernel", "lds_insert_kernel_even",
+                                                                   "lds_insert_kernel_odd", "deferred_import3_kernel"))}},
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:

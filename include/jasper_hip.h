@@ -108,6 +108,9 @@ void jasper_result_free(jasper_result *r);
 
 /* kernel timing for bench.py: HIP-event time of the last counting call on this table, and its launch count */
 int jasper_last_count_timing(jasper_table *t, double *kernel_ms, uint64_t *launches);
+/* the same split by kernel of the partitioned path: part1, part2, lds_insert (even regions), lds_insert (odd), deferred
+ * direct inserts; *partitioned_launches of the counted launches took that path (the others ran count_kernel) */
+int jasper_last_count_stages(jasper_table *t, double stage_ms[5], uint64_t *partitioned_launches);
 
 #ifdef __cplusplus
 }

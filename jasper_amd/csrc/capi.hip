@@ -120,6 +120,12 @@ int jasper_last_count_timing(jasper_table *t, double *kernel_ms, uint64_t *launc
     return JASPER_OK;
 }
 
+int jasper_last_count_stages(jasper_table *t, double stage_ms[5], uint64_t *partitioned_launches) {
+    for (int i = 0; i < 5; ++i) stage_ms[i] = t->t.part_stage_ms[i];
+    if (partitioned_launches) *partitioned_launches = t->t.count_partitioned_launches;
+    return JASPER_OK;
+}
+
 int jasper_histogram(jasper_table *t, uint64_t *out10002) { return t->t.histogram(out10002, g_err); }
 
 int jasper_lookup(jasper_table *t, const char *chars, const int64_t *offsets, uint64_t n, uint32_t *out) {

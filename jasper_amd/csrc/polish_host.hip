@@ -5,6 +5,7 @@
 //            ->  [redo chunks whose speculation failed as one segment]  ->  gather fix records, stitch the new text.
 #include "polish_host.hpp"
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,6 +50,9 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     R.n_respeculated = 0;
     if (n_chunks == 0) return 0;
 
+    const bool dbg = getenv("JASPER_POLISH_DEBUG") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     // ---------------- layout ----------------
     std::vector<int64_t> len(lens, lens + n_chunks), cap(n_chunks);
     std::vector<size_t> off_text(n_chunks), off_pos(n_chunks), off_cand(n_chunks);
@@ -111,6 +115,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     HIPCHK(hipMemcpyAsync(b_ptrB.p, hptrB.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
     uint8_t **ptrIn = b_ptrA.as<uint8_t *>(), **ptrOut = b_ptrB.as<uint8_t *>();
 
+    if (dbg) { (void)hipStreamSynchronize(st); fprintf(stderr, "[polish] setup + H2D: %.2f ms\n", now() - t_begin); }
+    const double t_loop = now();
     PolishParams pp;
     pp.k = k;
     pp.step = std::max(2, (int)std::nearbyint((double)k / 8.0));   // src/jasper.py:20 (python round = half-to-even)
@@ -339,6 +345,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         std::swap(textIn, textOut);
         std::swap(ptrIn, ptrOut);
     }
+    if (dbg) { (void)hipStreamSynchronize(st); fprintf(stderr, "[polish] passes: %.2f ms\n", now() - t_loop); }
+    const double t_out = now();
     if (rc == 0) {
         HIPCHK(hipEventRecord(ev1, st));
         // ---- results to the host
@@ -371,6 +379,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         });
     }
     (void)hipStreamSynchronize(st);
+    if (dbg) fprintf(stderr, "[polish] D2H + record sort: %.2f ms; total %.2f ms\n", now() - t_out, now() - t_begin);
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     return rc;

@@ -154,7 +154,7 @@ struct Table {
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     double count_kernel_ms = 0;
     uint64_t count_launches = 0;
-    void reset_timing() { count_kernel_ms = 0; count_launches = 0; }
+    void reset_timing() { count_kernel_ms = 0; count_launches = 0; count_partitioned_launches = 0; for (double &m : part_stage_ms) m = 0; }
     int launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, std::string &err);
     // partitioned (atomic-free) path, count_part.hip; `geom` is an opaque PartGeom
     bool partition_geometry(uint64_t piece_bases, void *geom_out) const;

@@ -65,6 +65,13 @@ class KmerTable:
         check(self._L.jasper_last_count_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def count_stages(self):
+        """(ms per kernel of the partitioned counting path [part1, part2, lds even, lds odd, deferred], launches that took it)"""
+        ms = (C.c_double * 5)()
+        n = C.c_uint64(0)
+        check(self._L.jasper_last_count_stages(self._h, ms, C.byref(n)))
+        return list(ms), n.value
+
     def clear(self):
         check(self._L.jasper_table_clear(self._h))
 
@@ -156,7 +163,8 @@ class KmerTable:
     # ---- one batch through the polisher -------------------------------------------------------------
     def polish_batch(self, seqs, solid_thre, passes, fix=True):
         n = len(seqs)
-        bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        want_str = any(isinstance(s, str) for s in seqs)       # bytes in -> bytes out (no 1-byte-per-char round trip)
+        bs = [s.encode("latin-1") if isinstance(s, str) else (s if isinstance(s, bytes) else bytes(s)) for s in seqs]
         cs = (C.c_char_p * max(n, 1))(*bs)
         lens = (C.c_int64 * max(n, 1))(*[len(b) for b in bs])
         res = C.c_void_p()
@@ -169,7 +177,8 @@ class KmerTable:
                 p = C.c_void_p()
                 ln = C.c_int64(0)
                 check(self._L.jasper_result_seq(res, i, C.byref(p), C.byref(ln)))
-                out.append(C.string_at(p, ln.value).decode("latin-1") if ln.value else "")
+                raw = C.string_at(p, ln.value) if ln.value else b""
+                out.append(raw.decode("latin-1") if want_str else raw)
                 ap = C.c_void_p()
                 an = C.c_uint64(0)
                 check(self._L.jasper_result_aux(res, i, C.byref(ap), C.byref(an)))
