@@ -87,7 +87,7 @@ def one_step(torch, dev_index, table, reads, seqs, world, timers):
     t4 = time.perf_counter()
     info = table.info()
     timers.append(dict(count=t1 - t0, merge=t2 - t1, histo=t3 - t2, polish=t4 - t3, kernel_ms=kms, launches=launches, stages=stages, part_launches=part_launches,
-                       polish_dev=res.seconds, thr=thr, qv=res.qv, nfix=len(res.records), merged=merged,
+                       polish_dev=res.seconds, thr=thr, qv=res.qv, nfix=res.n_records, merged=merged,
                        distinct=info["distinct"], occurrences=info["occurrences"], slots=info["slots"], lookups=res.lookups,
                        segments=res.segments, respeculated=res.respeculated))
     return res
@@ -99,7 +99,7 @@ def cpu_baseline(seed):
     from jasper_amd import synth, polisher
     from oracle import oracle as O
     rng = np.random.default_rng(seed)
-    G = 4_000_000      # ~90 M k-mer insertions + 3 scans of 4 Mb: roughly 15-30 s of one host core
+    G = 12_000_000     # ~270 M k-mer insertions + 3 scans of 12 Mb: roughly 20 s of one host core
     genome = synth.make_genome(rng, G)
     reads = synth.make_reads_stream(rng, genome, COVERAGE, READ_LEN, 0.003)
     asm = synth.make_assembly(rng, genome, err=1e-4, n_every=10_000_000)

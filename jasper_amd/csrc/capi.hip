@@ -79,7 +79,7 @@ int jasper_table_sync(jasper_table *t) {
 
 int jasper_table_clear(jasper_table *t) {
     CHK(hipSetDevice(t->t.device));
-    CHK(hipMemsetAsync(t->t.d.slots, 0, t->t.nslots * 16, t->t.stream));
+    if (t->t.zero_slots(t->t.d.slots, t->t.nslots, g_err)) return JASPER_ERR;
     CHK(hipMemsetAsync(t->t.d.stats, 0, ST_WORDS * sizeof(unsigned long long), t->t.stream));
     return JASPER_OK;
 }

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <vector>
 
 namespace jk {
@@ -292,6 +293,12 @@ __global__ __launch_bounds__(256) void import_packed_kernel(const ulonglong2 *__
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
 }
 
+// hipMemsetAsync runs at ~1 TB/s on this stack; 16-B streaming stores reach the HBM write rate
+__global__ __launch_bounds__(256) void zero_kernel(ulonglong2 *__restrict__ p, uint64_t n16) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
+        p[i] = make_ulonglong2(0ull, 0ull);
+}
+
 // rehash straight from an old slot array into a (larger) table
 __global__ __launch_bounds__(256) void rehash_kernel(TableDev oldT, TableDev newT) {
     unsigned long long fresh = 0;
@@ -331,6 +338,7 @@ int Table::init(int k_, uint64_t min_slots, int device_, std::string &err) {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     int s = min_log2_slots(k);
+    size_hint = min_slots;
     while ((1ull << s) < min_slots) ++s;
     if (s > 2 * k) s = 2 * k;                 // never more slots than possible keys ...
     if (s < min_log2_slots(k)) {              // ... unless the tag format needs them
@@ -343,7 +351,7 @@ int Table::init(int k_, uint64_t min_slots, int device_, std::string &err) {
     HIPCHK(hipMalloc((void **)&d.slots, nslots * 16));
     HIPCHK(hipMalloc((void **)&d.stats, ST_WORDS * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&d.spill, d.spill_cap * 3 * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(d.slots, 0, nslots * 16, stream));
+    if (zero_slots(d.slots, nslots, err)) return -1;
     HIPCHK(hipMemsetAsync(d.stats, 0, ST_WORDS * sizeof(unsigned long long), stream));
     HIPCHK(hipHostMalloc((void **)&h_stats, ST_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     HIPCHK(hipEventCreate(&ev_k0));
@@ -390,6 +398,12 @@ void Table::destroy() {
     stream = nullptr;
 }
 
+int Table::zero_slots(unsigned long long *slots, uint64_t n, std::string &err) {
+    hipLaunchKernelGGL(zero_kernel, dim3(256 * 16), dim3(256), 0, stream, reinterpret_cast<ulonglong2 *>(slots), n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int Table::read_stats(std::string &err) {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipMemcpyAsync(h_stats, d.stats, ST_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
@@ -404,7 +418,7 @@ int Table::grow(int new_s, std::string &err) {
     nt.s = new_s;
     nt.mask = (1ull << new_s) - 1;
     HIPCHK(hipMalloc((void **)&nt.slots, (1ull << new_s) * 16));
-    HIPCHK(hipMemsetAsync(nt.slots, 0, (1ull << new_s) * 16, stream));
+    if (zero_slots(nt.slots, 1ull << new_s, err)) return -1;
     // distinct is recounted by the re-insertion
     HIPCHK(hipMemsetAsync(d.stats + ST_DISTINCT, 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, stream, d, nt);
@@ -486,6 +500,28 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
     const uint64_t halo = (uint64_t)(k - 1);
     const uint64_t misalign = reinterpret_cast<uintptr_t>(d_bases) & 15;
     uint64_t pos = 0;
+    // Before anything has been measured, the caller's size hint plays the role of `jellyfish count -s`: the expected
+    // number of distinct k-mers of this input.  hint / bases is then the expected share of new keys per k-mer; it is
+    // only trusted for sizing the pieces (x1.5 below) -- an input that is less repetitive than promised still ends up
+    // in the spill / deferred lists and a grown table, or in a clean error, never in wrong counts.
+    bool have_ratio = false;
+    if (size_hint > 0 && n > (1u << 24) && h_stats[ST_DISTINCT] == 0 && h_stats[ST_OCCURRENCES] == 0) {
+        dup_ratio = std::min(1.0, (double)size_hint / (double)n);
+        have_ratio = dup_ratio < 0.6;
+    }
+    const bool started_empty = h_stats[ST_DISTINCT] == 0 && h_stats[ST_OCCURRENCES] == 0;
+    size_t mem_have = 0;
+    {   // partition lists need ~20 bytes of workspace per base
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            mem_have = free_b;
+            for (int w = 16; w <= 19; ++w) mem_have += ws[w].bytes;
+        }
+    }
+    const bool dbg = getenv("JASPER_COUNT_DEBUG") != nullptr;
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t_call = now_ms();
+    if (dbg) fprintf(stderr, "[count] call start: %llu bases\n", (unsigned long long)n);
     while (pos < n) {
         // a launch may add at most as many new keys as keep the table under 3/4 full in the worst case (every
         // base a new k-mer); h_stats holds the distinct count of the last check
@@ -493,24 +529,17 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
         uint64_t piece = std::max<uint64_t>(room, 1u << 20);
         // after the first piece the measured share of NEW keys per k-mer (x1.5 safety) replaces the worst case "every base
         // a new key"; the spill list / deferred list / growth still catch a piece that turns out less repetitive
-        if (pos > 0 && dup_ratio < 0.6) piece = std::max<uint64_t>(piece, (uint64_t)((double)room / std::max(0.05, 1.5 * dup_ratio)));
-        {   // partition lists need ~20 bytes of workspace per base
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                size_t have = free_b;
-                for (int w = 16; w <= 19; ++w) have += ws[w].bytes;
-                piece = std::min<uint64_t>(piece, std::max<uint64_t>(have / 28, 1u << 20));
-            }
-        }
+        if ((pos > 0 || have_ratio) && dup_ratio < 0.6) piece = std::max<uint64_t>(piece, (uint64_t)((double)room / std::max(0.05, 1.5 * dup_ratio)));
+        if (mem_have) piece = std::min<uint64_t>(piece, std::max<uint64_t>(mem_have / 28, 1u << 20));
         piece = std::min<uint64_t>(piece, 1ull << 31);
         // do not leave a small tail for a separate launch (the 1.5x safety factor covers a quarter more)
-        if (pos > 0 && dup_ratio < 0.6 && n - pos <= piece + piece / 4 && n - pos <= (1ull << 31)) piece = n - pos;
+        if ((pos > 0 || have_ratio) && dup_ratio < 0.6 && n - pos <= piece + piece / 4 && n - pos <= (1ull << 31)) piece = n - pos;
         if (const char *e = getenv("JASPER_EXPERIMENT_PIECE")) piece = strtoull(e, nullptr, 10);   // tuning experiments only
         {   // make room up front for the new keys this piece is expected to bring (worst case for the first piece)
             const uint64_t todo = std::min<uint64_t>(piece, n - pos);
             // (the share of new keys only falls as coverage accumulates, so the last piece's ratio is already an upper
             // estimate; spill list, deferred list and growth after the piece remain the safety net)
-            const uint64_t expect = pos > 0 && dup_ratio < 0.6 ? (uint64_t)((double)todo * std::min(1.0, dup_ratio)) : todo;
+            const uint64_t expect = (pos > 0 || have_ratio) && dup_ratio < 0.6 ? (uint64_t)((double)todo * std::min(1.0, dup_ratio)) : todo;
             if (expect > room && !getenv("JASPER_EXPERIMENT_PIECE")) {
                 if (ensure_capacity(expect, err)) return -1;
             }
@@ -521,9 +550,27 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
         start = start >= a ? start - a : 0;
         const uint64_t end = std::min<uint64_t>(n, pos + piece);
         const uint64_t distinct_before = h_stats[ST_DISTINCT], occ_before = h_stats[ST_OCCURRENCES];
+        const double t_l0 = dbg ? now_ms() : 0;
+        if (dbg) fprintf(stderr, "[count] host: %.2f ms since call start (sizing, capacity)\n", t_l0 - t_call);
         if (launch_count(d_bases + start, end - start, pos - start, err)) return -1;
+        const double t_l1 = dbg ? now_ms() : 0;
         pos = end;
         int rc = after_batch(err);
+        if (dbg) fprintf(stderr, "[count] host: launch calls %.2f ms, wait + after_batch %.2f ms\n", t_l1 - t_l0, now_ms() - t_l1);
+        if (rc == -2 && have_ratio && started_empty) {
+            // The size hint promised a more repetitive input than this one: the piece sized from it overflowed the table.
+            // Nothing else was in the table when this call started, so start over with worst-case piece sizes.
+            if (dbg) fprintf(stderr, "[count] size hint too small for this input: restarting with worst-case sizing\n");
+            err.clear();
+            if (zero_slots(d.slots, nslots, err)) return -1;
+            HIPCHK(hipMemsetAsync(d.stats, 0, ST_WORDS * sizeof(unsigned long long), stream));
+            if (read_stats(err)) return -1;
+            if (grow(std::min(d.B, d.s + 2), err)) return -1;
+            have_ratio = false;
+            dup_ratio = 1.0;
+            pos = 0;
+            continue;
+        }
         if (rc) return rc;
         if (h_stats[ST_OCCURRENCES] > occ_before)
             dup_ratio = (double)(h_stats[ST_DISTINCT] - distinct_before) / (double)(h_stats[ST_OCCURRENCES] - occ_before);

@@ -164,6 +164,7 @@ struct Table {
     double part_stage_ms[5] = {0, 0, 0, 0, 0};                                          // part1, part2, lds even, lds odd, deferred
     bool part_stage_pending = false;
     double dup_ratio = 1.0;   // new distinct keys per k-mer of the last piece (sizes the next piece)
+    uint64_t size_hint = 0;   // caller's expected number of distinct k-mers (`jellyfish count -s`); 0 = none given
     // grow-only device workspace reused by the polisher across calls (hipMalloc of GBs costs far more than the kernels)
     struct WsBuf { void *p = nullptr; size_t bytes = 0; };
     WsBuf ws[24];
@@ -173,6 +174,7 @@ struct Table {
     int init(int k, uint64_t min_slots, int device, std::string &err);
     void destroy();
     int read_stats(std::string &err);                 // stream sync + copy stats to h_stats
+    int zero_slots(unsigned long long *slots, uint64_t n, std::string &err);
     int ensure_capacity(uint64_t upcoming_kmers, std::string &err);
     int grow(int new_s, std::string &err);            // rehash into 2^new_s slots
     int after_batch(std::string &err);                // spill / fatal / growth handling

@@ -13,13 +13,43 @@ from ._lib import FixRec, check
 class PolishResult:
     """what one `jasper.py` process produces for one batch file (src/jasper.py:107-128)"""
 
-    def __init__(self, seqs, records, aux, qv, lookups, seconds):
+    def __init__(self, seqs, raw_records, aux, qv, lookups, seconds):
         self.seqs = seqs            # polished chunk sequences, batch order
-        self.records = records      # list of dicts (chunk, pass, seqno, kind, index, newc, oldc, rep, patch, orig)
-        self.aux = aux
+        self._raw = raw_records     # numpy structured array (FixRec layout), ordered by chunk, pass, emission
+        self._records = None
+        self.aux = aux              # per chunk: bytes referenced by its 'x' records
         self.qv = qv                # (bad0, total0, badP, totalP)
         self.lookups = lookups
         self.seconds = seconds
+        self.segments = 0
+        self.respeculated = 0
+
+    @property
+    def n_records(self):
+        return len(self._raw)
+
+    @property
+    def records(self):
+        """list of dicts (chunk, pass_, seqno, kind, index, newc, oldc, rep[, patch, orig]); decoded on first use"""
+        if self._records is None:
+            out = []
+            r = self._raw
+            for i in range(len(r)):
+                e = r[i]
+                d = dict(chunk=int(e["chunk"]), pass_=int(e["pass_"]), seqno=int(e["seqno"]), kind=chr(int(e["kind"])), index=int(e["index"]),
+                         newc=chr(int(e["newc"])), oldc=chr(int(e["oldc"])), rep=int(e["rep"]))
+                if d["kind"] == "x":
+                    a = self.aux[d["chunk"]]
+                    o, n = int(e["aux_off"]), int(e["aux_len"])
+                    d["patch"] = a[o:o + n].decode("latin-1")
+                    d["orig"] = a[o + n:o + n + d["rep"]].decode("latin-1")
+                out.append(d)
+            self._records = out
+        return self._records
+
+
+FIXREC_DTYPE = [("index", "<i8"), ("chunk", "<u4"), ("seqno", "<u4"), ("pass_", "u1"), ("kind", "u1"), ("newc", "u1"), ("oldc", "u1"),
+                ("rep", "<u4"), ("aux_off", "<u4"), ("aux_len", "<u4")]
 
 
 class KmerTable:
@@ -183,19 +213,14 @@ class KmerTable:
                 an = C.c_uint64(0)
                 check(self._L.jasper_result_aux(res, i, C.byref(ap), C.byref(an)))
                 aux.append(C.string_at(ap, an.value) if an.value else b"")
+            import numpy as np
             rp = C.POINTER(FixRec)()
             rn = C.c_uint64(0)
             check(self._L.jasper_result_records(res, C.byref(rp), C.byref(rn)))
-            recs = []
-            for i in range(rn.value):
-                r = rp[i]
-                d = dict(chunk=r.chunk, pass_=r.pass_, seqno=r.seqno, kind=chr(r.kind), index=r.index,
-                         newc=chr(r.newc), oldc=chr(r.oldc), rep=r.rep)
-                if d["kind"] == "x":
-                    a = aux[r.chunk]
-                    d["patch"] = a[r.aux_off:r.aux_off + r.aux_len].decode("latin-1")
-                    d["orig"] = a[r.aux_off + r.aux_len:r.aux_off + r.aux_len + r.rep].decode("latin-1")
-                recs.append(d)
+            if rn.value:
+                raw = np.frombuffer(C.string_at(rp, rn.value * C.sizeof(FixRec)), dtype=FIXREC_DTYPE).copy()
+            else:
+                raw = np.zeros(0, dtype=FIXREC_DTYPE)
             qv = (C.c_int64 * 4)()
             check(self._L.jasper_result_qv(res, qv))
             nl = C.c_uint64(0)
@@ -203,7 +228,7 @@ class KmerTable:
             secs = self._L.jasper_result_seconds(res)
             nseg, nredo = C.c_uint64(0), C.c_uint64(0)
             check(self._L.jasper_result_segments(res, C.byref(nseg), C.byref(nredo)))
-            pr = PolishResult(out, recs, aux, tuple(qv), nl.value, secs)
+            pr = PolishResult(out, raw, aux, tuple(qv), nl.value, secs)
             pr.segments, pr.respeculated = nseg.value, nredo.value
             return pr
         finally:
