@@ -67,6 +67,8 @@ def one_step(torch, dev_index, table, reads, seqs, world, timers):
     from jasper_amd import polisher, dist as jdist
     t0 = time.perf_counter()
     table.clear()          # a step starts from an empty table (zeroing 16 B/slot is part of the timed path)
+    table.sync()
+    t0b = time.perf_counter()
     table.count_bases_device(reads.data_ptr(), reads.numel())
     table.sync()
     t1 = time.perf_counter()
@@ -84,9 +86,10 @@ def one_step(torch, dev_index, table, reads, seqs, world, timers):
     thr = int(txt)
     t3 = time.perf_counter()
     res = table.polish_batch(seqs, thr, PASSES, fix=True)
+    polished = sum(res.seq_len(i) for i in range(len(seqs)))   # results are on the host (C result object)
     t4 = time.perf_counter()
     info = table.info()
-    timers.append(dict(count=t1 - t0, merge=t2 - t1, histo=t3 - t2, polish=t4 - t3, kernel_ms=kms, launches=launches, stages=stages, part_launches=part_launches,
+    timers.append(dict(count=t1 - t0, clear=t0b - t0, merge=t2 - t1, histo=t3 - t2, polish=t4 - t3, kernel_ms=kms, launches=launches, stages=stages, part_launches=part_launches,
                        polish_dev=res.seconds, thr=thr, qv=res.qv, nfix=res.n_records, merged=merged,
                        distinct=info["distinct"], occurrences=info["occurrences"], slots=info["slots"], lookups=res.lookups,
                        segments=res.segments, respeculated=res.respeculated))
@@ -204,7 +207,7 @@ def main():
                    "threshold": T["thr"], "parallelism": "read shards + chunk shards, table merge over RCCL" if world > 1 else "single GPU"},
         "kmers_counted_Gk_per_s": round(kmers_rank * world / mean("count") / 1e9, 3),
         "polish_only_Mbp_per_s": round(asm_total / 1e6 / mean("polish"), 3),
-        "phase_ms": {k: round(mean(k) * 1e3, 2) for k in ("count", "merge", "histo", "polish")},
+        "phase_ms": {k: round(mean(k) * 1e3, 2) for k in ("clear", "count", "merge", "histo", "polish")},
         "polish_device_ms": round(mean("polish_dev") * 1e3, 2),
         "qv_counters": list(T["qv"]), "fix_records": T["nfix"], "polish_lookups": T["lookups"],
         "polish_segments": T["segments"], "polish_chunks_redone_unsegmented": T["respeculated"],

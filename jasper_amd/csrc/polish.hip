@@ -22,6 +22,7 @@
 // Reference lines are cited as src/jasper.py:N.  Lookups go to the HBM table with the truncate-and-pad
 // semantics of MerDNA(str) (Appendix A.3 of SURVEY.md; JF::include/jellyfish/mer_dna.hpp:525-542).
 #include "polish.hpp"
+#include <algorithm>
 
 namespace jk {
 
@@ -984,6 +985,125 @@ __global__ __launch_bounds__(64) void seg_gather_kernel(const SegDev *segs, int 
         out_recs[rec_off[s] + r] = f;
     }
     for (uint32_t q = threadIdx.x; q < S.naux; q += blockDim.x) out_aux[aux_off[s] + q] = S.aux[q];
+}
+
+// ---- batched variants: blockIdx.y walks the chunks of the batch ---------------------------------------------------
+__global__ __launch_bounds__(SC_THREADS) void scan_batch_kernel(const ScanChunk *__restrict__ chunks, int n_chunks, TableDev T) {
+    __shared__ uint32_t s_code[SC_THREADS + SC_HALO];
+    __shared__ uint32_t s_inv[SC_THREADS + SC_HALO];
+    const int t = threadIdx.x;
+    const int k = T.k;
+    const u128 kmask = maskbits(2 * k);
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const ScanChunk C = chunks[ci];
+        const uint8_t *__restrict__ text = C.text;
+        const int64_t n = C.len;
+        if (n - k + 1 <= 0) continue;
+        const int64_t ntiles = (n + SC_TILE - 1) / SC_TILE;
+        for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int64_t base0 = tile * SC_TILE;
+            uint32_t c = 0, iv = 0;
+            {
+                const int64_t pos = base0 + (int64_t)t * SC_GROUP;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int64_t p = pos + j;
+                    const int cc = (p < n) ? code(text[p]) : -1;
+                    c = (c << 2) | (uint32_t)(cc & 3);
+                    iv = (iv << 1) | (uint32_t)(cc < 0);
+                }
+            }
+            s_code[t + SC_HALO] = c;
+            s_inv[t + SC_HALO] = iv;
+            if (t < SC_HALO) {
+                uint32_t hc = 0, hiv = 0;
+                const int64_t pos = base0 - (int64_t)(SC_HALO - t) * SC_GROUP;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int64_t p = pos + j;
+                    const int cc = (p >= 0 && p < n) ? code(text[p]) : -1;
+                    hc = (hc << 2) | (uint32_t)(cc & 3);
+                    hiv = (hiv << 1) | (uint32_t)(cc < 0);
+                }
+                s_code[t] = hc;
+                s_inv[t] = hiv;
+            }
+            __syncthreads();
+            const uint32_t w4 = s_code[t], w3 = s_code[t + 1], w2 = s_code[t + 2], w1 = s_code[t + 3];
+            const uint64_t ivprev = ((uint64_t)s_inv[t] << 48) | ((uint64_t)s_inv[t + 1] << 32) | ((uint64_t)s_inv[t + 2] << 16) |
+                                    (uint64_t)s_inv[t + 3];
+            __syncthreads();
+            u128 fwd = band(mk(((uint64_t)w4 << 32) | w3, ((uint64_t)w2 << 32) | w1), kmask);
+            u128 rc = revcomp(fwd, k);
+            int run = ivprev ? (int)__builtin_ctzll(ivprev) : 64;
+#pragma unroll 4
+            for (int j = 0; j < SC_GROUP; ++j) {
+                const uint32_t cj = (c >> (30 - 2 * j)) & 3u;
+                const bool bad = (iv >> (15 - j)) & 1u;
+                fwd = band(bor(shl(fwd, 2), mk(0, cj)), kmask);
+                rc = bor(shr(rc, 2), shl(mk(0, 3u - cj), 2 * (k - 1)));
+                run = bad ? 0 : run + 1;
+                const int64_t e = base0 + (int64_t)t * SC_GROUP + j;
+                const int64_t p = e - k + 1;
+                if (p >= 0 && e < n) {
+                    if (run >= k) {
+                        const u128 canon = lt(rc, fwd) ? rc : fwd;
+                        C.cnt[p] = clamp32(table_get(T, mix(canon, T.B)));
+                        C.valid[p] = 1;
+                    } else {
+                        C.cnt[p] = 0;
+                        C.valid[p] = 0;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void classify_batch_kernel(const ScanChunk *__restrict__ chunks, int n_chunks, int k, uint32_t solid) {
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const ScanChunk C = chunks[ci];
+        const int64_t nwin = C.len - k + 1;
+        for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nwin; p += (int64_t)gridDim.x * blockDim.x) {
+            uint8_t c;
+            if (!C.valid[p]) c = PC_OTHER;
+            else if (C.cnt[p] < solid) c = PC_BAD;
+            else if (p > 0) {
+                const int64_t q = p - k > 0 ? p - k : 0;
+                c = (!C.valid[q] || 50ull * C.cnt[p] < (unsigned long long)C.cnt[q]) ? PC_OTHER : PC_CLEAN;
+            } else c = PC_CLEAN;
+            C.cls[p] = c;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void find_sync_batch_kernel(const ScanChunk *__restrict__ chunks, int n_chunks, int k) {
+    const int64_t W = 4ll * k;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const ScanChunk C = chunks[ci];
+        if (!C.want_sync) continue;
+        const int64_t nwin = C.len - k + 1;
+        const uint8_t *__restrict__ cls = C.cls;
+        for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nwin; p += (int64_t)gridDim.x * blockDim.x) {
+            if (p < W || p + k - 1 > nwin) continue;
+            if (cls[p] != PC_BAD || cls[p - 1] != PC_CLEAN) continue;
+            bool ok = true;
+            for (int64_t q = 1; q < k - 1 && ok; ++q) ok = cls[p + q] == PC_BAD;
+            for (int64_t q = 2; q <= W && ok; ++q) ok = cls[p - q] == PC_CLEAN;
+            if (!ok) continue;
+            const unsigned int idx = atomicAdd(C.cand_count, 1u);
+            if (idx < C.cand_cap) C.cand[idx] = p;
+        }
+    }
+}
+
+void launch_scan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunks, int k, uint32_t solid, hipStream_t stream) {
+    if (n_chunks <= 0) return;
+    const int gy = n_chunks < 1024 ? n_chunks : 1024;
+    const int gx = std::max(1, 4096 / gy);
+    hipLaunchKernelGGL(scan_batch_kernel, dim3(gx, gy), dim3(SC_THREADS), 0, stream, d_chunks, n_chunks, T);
+    hipLaunchKernelGGL(classify_batch_kernel, dim3(gx, gy), dim3(256), 0, stream, d_chunks, n_chunks, k, solid);
+    hipLaunchKernelGGL(find_sync_batch_kernel, dim3(gx, gy), dim3(256), 0, stream, d_chunks, n_chunks, k);
 }
 
 static int blocks_for(int64_t items, int per_block) {

@@ -88,6 +88,20 @@ struct PolishParams {
     int fix;
 };
 
+// per-chunk arguments of the dense scan / classify / sync-point kernels (one launch covers all chunks of a batch)
+struct ScanChunk {
+    const uint8_t *text;
+    int64_t len;
+    uint32_t *cnt;
+    uint8_t *valid;
+    uint8_t *cls;
+    int64_t *cand;
+    unsigned int *cand_count;
+    unsigned int cand_cap;
+    int32_t want_sync;
+};
+void launch_scan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunks, int k, uint32_t solid, hipStream_t stream);
+
 // dense scan of one contiguous text: count of every window (0xFFFFFFFF clamp as in lookups) + validity
 void launch_scan(const TableDev &T, const uint8_t *d_text, int64_t len, uint32_t *d_cnt, uint8_t *d_valid, hipStream_t stream);
 void launch_classify(const uint32_t *d_cnt, const uint8_t *d_valid, int64_t nwin, int k, uint32_t solid, uint8_t *d_cls, hipStream_t stream);

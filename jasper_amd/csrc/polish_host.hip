@@ -72,7 +72,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         seg_rec_bound += (size_t)(2 * tb / k + 16 * ms);
         seg_aux_bound += (size_t)(2 * tb + 1024 * ms);
     }
-    DevBuf b_textA, b_textB, b_cnt, b_valid, b_cls, b_cand, b_ccount, b_ptrA, b_ptrB, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks;
+    DevBuf b_textA, b_textB, b_cnt, b_valid, b_cls, b_cand, b_ccount, b_ptrA, b_ptrB, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks, b_scan;
     int ws_next = 0;
     auto dmalloc = [&](DevBuf &b, size_t bytes) -> bool {      // persistent: slot of the table's workspace
         b.p = T.workspace(ws_next++, bytes, err);
@@ -99,7 +99,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     pool.off_front = al256((size_t)pool.node_cap * 4);
     pool.off_patch = pool.off_front + al256((size_t)pool.front_cap * 80);
     pool.stride = pool.off_patch + al256(pool.patch_cap);
-    if (!dmalloc(b_pool, pool.stride * pool.nslots) || !dmalloc(b_locks, pool.nslots * 4)) return -2;
+    if (!dmalloc(b_pool, pool.stride * pool.nslots) || !dmalloc(b_locks, pool.nslots * 4) || !dmalloc(b_scan, sizeof(ScanChunk) * n_chunks)) return -2;
     pool.base = b_pool.as<uint8_t>();
     pool.locks = b_locks.as<unsigned int>();
     HIPCHK(hipMemsetAsync(pool.locks, 0, pool.nslots * 4, st));
@@ -140,16 +140,23 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     for (int pass = 0; pass <= passes && rc == 0; ++pass) {                                   // src/jasper.py:25
         // ---- 1. dense scan, classes, sync-point candidates
         HIPCHK(hipMemsetAsync(b_ccount.p, 0, n_chunks * 4, st));
-        for (int c = 0; c < n_chunks; ++c) {
-            const int64_t nwin = len[c] - k + 1;
-            if (nwin <= 0) continue;
-            uint8_t *text = textIn + off_text[c];
-            launch_scan(T.d, text, len[c], b_cnt.as<uint32_t>() + off_pos[c], b_valid.as<uint8_t>() + off_pos[c], st);
-            launch_classify(b_cnt.as<uint32_t>() + off_pos[c], b_valid.as<uint8_t>() + off_pos[c], nwin, k, pp.solid,
-                            b_cls.as<uint8_t>() + off_pos[c], st);
-            if (nwin > 2 * TMIN)
-                launch_find_sync(b_cls.as<uint8_t>() + off_pos[c], nwin, k, b_cand.as<int64_t>() + off_cand[c],
-                                 b_ccount.as<unsigned int>() + c, cand_cap[c], st);
+        {
+            std::vector<ScanChunk> sc(n_chunks);
+            for (int c = 0; c < n_chunks; ++c) {
+                ScanChunk &S = sc[c];
+                S.text = textIn + off_text[c];
+                S.len = len[c];
+                S.cnt = b_cnt.as<uint32_t>() + off_pos[c];
+                S.valid = b_valid.as<uint8_t>() + off_pos[c];
+                S.cls = b_cls.as<uint8_t>() + off_pos[c];
+                S.cand = b_cand.as<int64_t>() + off_cand[c];
+                S.cand_count = b_ccount.as<unsigned int>() + c;
+                S.cand_cap = cand_cap[c];
+                S.want_sync = (len[c] - k + 1) > 2 * TMIN;
+            }
+            HIPCHK(hipMemcpyAsync(b_scan.p, sc.data(), sizeof(ScanChunk) * n_chunks, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));   // `sc` is a stack vector: the copy must have read it before it goes away
+            launch_scan_batch(T.d, b_scan.as<ScanChunk>(), n_chunks, k, pp.solid, st);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ccount.data(), b_ccount.p, n_chunks * 4, hipMemcpyDeviceToHost, st));

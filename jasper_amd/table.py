@@ -11,10 +11,17 @@ from ._lib import FixRec, check
 
 
 class PolishResult:
-    """what one `jasper.py` process produces for one batch file (src/jasper.py:107-128)"""
+    """what one `jasper.py` process produces for one batch file (src/jasper.py:107-128).
 
-    def __init__(self, seqs, raw_records, aux, qv, lookups, seconds):
-        self.seqs = seqs            # polished chunk sequences, batch order
+    The polished texts stay in the C result object until asked for: `seq_view(i)` is a zero-copy memoryview,
+    `seqs` materialises python objects (str if the inputs were str, else bytes) on first use."""
+
+    def __init__(self, lib, handle, n_chunks, want_str, raw_records, aux, qv, lookups, seconds):
+        self._L = lib
+        self._h = handle
+        self._n = n_chunks
+        self._want_str = want_str
+        self._seqs = None
         self._raw = raw_records     # numpy structured array (FixRec layout), ordered by chunk, pass, emission
         self._records = None
         self.aux = aux              # per chunk: bytes referenced by its 'x' records
@@ -23,6 +30,38 @@ class PolishResult:
         self.seconds = seconds
         self.segments = 0
         self.respeculated = 0
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.jasper_result_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def seq_view(self, i):
+        p = C.c_void_p()
+        ln = C.c_int64(0)
+        check(self._L.jasper_result_seq(self._h, i, C.byref(p), C.byref(ln)))
+        if not ln.value:
+            return memoryview(b"")
+        return memoryview((C.c_char * ln.value).from_address(p.value)).cast("B")
+
+    def seq_len(self, i):
+        p = C.c_void_p()
+        ln = C.c_int64(0)
+        check(self._L.jasper_result_seq(self._h, i, C.byref(p), C.byref(ln)))
+        return ln.value
+
+    @property
+    def seqs(self):
+        if self._seqs is None:
+            out = []
+            for i in range(self._n):
+                raw = bytes(self.seq_view(i))
+                out.append(raw.decode("latin-1") if self._want_str else raw)
+            self._seqs = out
+        return self._seqs
 
     @property
     def n_records(self):
@@ -201,19 +240,13 @@ class KmerTable:
         rc = self._L.jasper_polish_batch(self._h, n, cs, lens, int(solid_thre), int(passes), 1 if fix else 0, C.byref(res))
         try:
             check(rc)
-            out = []
+            import numpy as np
             aux = []
             for i in range(n):
-                p = C.c_void_p()
-                ln = C.c_int64(0)
-                check(self._L.jasper_result_seq(res, i, C.byref(p), C.byref(ln)))
-                raw = C.string_at(p, ln.value) if ln.value else b""
-                out.append(raw.decode("latin-1") if want_str else raw)
                 ap = C.c_void_p()
                 an = C.c_uint64(0)
                 check(self._L.jasper_result_aux(res, i, C.byref(ap), C.byref(an)))
                 aux.append(C.string_at(ap, an.value) if an.value else b"")
-            import numpy as np
             rp = C.POINTER(FixRec)()
             rn = C.c_uint64(0)
             check(self._L.jasper_result_records(res, C.byref(rp), C.byref(rn)))
@@ -228,7 +261,8 @@ class KmerTable:
             secs = self._L.jasper_result_seconds(res)
             nseg, nredo = C.c_uint64(0), C.c_uint64(0)
             check(self._L.jasper_result_segments(res, C.byref(nseg), C.byref(nredo)))
-            pr = PolishResult(out, raw, aux, tuple(qv), nl.value, secs)
+            pr = PolishResult(self._L, res, n, want_str, raw, aux, tuple(qv), nl.value, secs)
+            res = None   # owned by the PolishResult from here on
             pr.segments, pr.respeculated = nseg.value, nredo.value
             return pr
         finally:
