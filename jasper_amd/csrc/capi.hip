@@ -73,16 +73,11 @@ int jasper_table_info(jasper_table *t, int *k, uint64_t *slots, uint64_t *distin
 
 int jasper_table_sync(jasper_table *t) {
     CHK(hipSetDevice(t->t.device));
-    CHK(hipStreamSynchronize(t->t.stream));
+    CHK(jk_stream_wait(t->t.stream));
     return JASPER_OK;
 }
 
-int jasper_table_clear(jasper_table *t) {
-    CHK(hipSetDevice(t->t.device));
-    if (t->t.zero_slots(t->t.d.slots, t->t.nslots, g_err)) return JASPER_ERR;
-    CHK(hipMemsetAsync(t->t.d.stats, 0, ST_WORDS * sizeof(unsigned long long), t->t.stream));
-    return JASPER_OK;
-}
+int jasper_table_clear(jasper_table *t) { return t->t.clear(g_err) ? JASPER_ERR : JASPER_OK; }
 
 int jasper_count_bases(jasper_table *t, const char *bases, uint64_t n) {
     t->t.reset_timing();

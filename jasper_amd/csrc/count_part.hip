@@ -59,6 +59,13 @@ struct PartGeom {
 __device__ __forceinline__ uint64_t rec_of(u128 h, int recbits) { return recbits >= 64 ? h.lo : (h.lo & ((1ull << recbits) - 1ull)); }
 __device__ __forceinline__ u128 hash_of(uint64_t b1, uint64_t rec, int recbits) { return bor(shl(mk(0, b1), recbits), mk(0, rec)); }
 
+// a record that found no room in its list waits for the direct path until every LDS image has been written back
+__device__ __forceinline__ void defer_record(const TableDev &T, u128 h, unsigned long long *deferred, unsigned long long *deferred_n, uint64_t deferred_cap) {
+    const unsigned long long di = atomicAdd(deferred_n, 1ull);
+    if (di < deferred_cap) { deferred[3 * di] = h.hi; deferred[3 * di + 1] = h.lo; deferred[3 * di + 2] = 1ull; }
+    else atomicExch(&T.stats[ST_FATAL], 1ull);
+}
+
 __device__ __forceinline__ void pt_stage(const uint8_t *__restrict__ bases, int64_t pos, uint64_t n, bool aligned, uint32_t &codes, uint32_t &inv) {
     uint8_t b[16];
     if (pos >= 0 && (uint64_t)pos + 16 <= n && aligned) {
@@ -80,7 +87,9 @@ __device__ __forceinline__ void pt_stage(const uint8_t *__restrict__ bases, int6
 // 1024 open lines per block x 2 blocks per CU do not stay in the 4 MiB L2 until they are full.)
 constexpr int P1_MAXB = 1024;          // part1 handles p1 <= 10; larger p1 falls back to the direct kernel
 __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t ntiles, uint64_t emit_from,
-                                                            TableDev T, PartGeom G, uint64_t *__restrict__ out1, unsigned int *__restrict__ cnt1) {
+                                                            TableDev T, PartGeom G, uint64_t *__restrict__ out1, unsigned int *__restrict__ cnt1,
+                                                            unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
+                                                            uint64_t deferred_cap) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_raw);                               // PT_TILE records
     uint32_t *s_code = reinterpret_cast<uint32_t *>(s_raw + (size_t)PT_TILE * 8);         // PT_THREADS + PT_HALO
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__rest
             const unsigned int pos = s_cur[lo] + (e - s_off[lo]);
             const uint64_t r = s_stage[e];
             if (pos < G.cap1) out1[((uint64_t)lo * G.nblk1 + blockIdx.x) * G.cap1 + pos] = r;
-            else fresh += table_add_or_spill(T, hash_of((uint64_t)lo, r, G.recbits), 1ull);   // slice full: direct path (no LDS image exists yet)
+            else defer_record(T, hash_of((uint64_t)lo, r, G.recbits), deferred, deferred_n, deferred_cap);   // slice full
         }
         __syncthreads();
         if (t < nb) { s_cur[t] += s_cnt[t]; s_cnt[t] = 0; }
@@ -183,7 +192,9 @@ constexpr size_t P1_LDS = (size_t)PT_TILE * 8 + (size_t)(PT_THREADS + PT_HALO) *
 // grid (nblk2, buckets): block (x, b1) reads the level-1 slices x, x+nblk2, ... of bucket b1 and appends to ITS slice
 // of each of the bucket's 2^p2 region lists, again with LDS cursors only.
 __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__restrict__ out1, const unsigned int *__restrict__ cnt1, TableDev T,
-                                                            PartGeom G, uint64_t *__restrict__ out2, unsigned int *__restrict__ cnt2) {
+                                                            PartGeom G, uint64_t *__restrict__ out2, unsigned int *__restrict__ cnt2,
+                                                            unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
+                                                            uint64_t deferred_cap) {
     __shared__ unsigned int s_cur[PT_MAXBUCKETS];
     const int t = threadIdx.x;
     const int nb2 = 1 << G.p2;
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
                 const unsigned int pos = atomicAdd(&s_cur[b2], 1u);
                 const uint64_t region = ((uint64_t)b1 << G.p2) + b2;
                 if (pos < G.cap2) out2[(region * G.nblk2 + blockIdx.x) * G.cap2 + pos] = rec;
-                else fresh += table_add_or_spill(T, hash_of(b1, rec, G.recbits), 1ull);
+                else defer_record(T, hash_of(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
             }
         }
         __syncthreads();
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
 // ---- final: region lists -> LDS image of the region -> table ------------------------------------------------------
 // lists: slices  lists[(region * nsl + x) * cap + i], i < cnt[region * nsl + x].  `parity`: regions with (region & 1) == parity.
 __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *__restrict__ lists, const unsigned int *__restrict__ cnt, uint32_t cap,
-                                                                 uint32_t nsl, TableDev T, PartGeom G, uint32_t nregions, uint32_t parity,
+                                                                 uint32_t nsl, TableDev T, PartGeom G, uint32_t nregions, uint32_t parity, int fresh_table,
                                                                  unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
                                                                  uint64_t deferred_cap) {
     extern __shared__ __align__(16) unsigned long long s_img[];    // 2 words per slot: (R + halo) slots
@@ -228,11 +239,15 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *
     for (uint32_t region = blockIdx.x * 2 + parity; region < nregions; region += gridDim.x * 2) {
         uint32_t total = 0;
         for (uint32_t x = 0; x < nsl; ++x) total += cnt[(uint64_t)region * nsl + x];
-        if (total == 0) continue;                                  // block-uniform
+        if (total == 0 && !fresh_table) continue;                  // block-uniform (a fresh table must still be zeroed here)
         const uint64_t first = (uint64_t)region << G.rbits;        // first slot of the region
-        // image in: coalesced 16-B loads (the halo wraps around the end of the table)
+        // image in: coalesced 16-B loads (the halo wraps around the end of the table).  On a lazily cleared table the slot
+        // memory is garbage except for what this pass has already written: nothing yet in the even launch; in the odd
+        // launch the even regions, i.e. this region's own first `halo` slots (its left neighbour's halo) and its own halo.
         for (uint32_t i = t; i < span; i += PT_THREADS) {
-            const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * ((first + i) & T.mask));
+            const bool have = !fresh_table || (parity == 1 && (i < halo || i >= R));
+            ulonglong2 e = make_ulonglong2(0ull, 0ull);
+            if (have) e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * ((first + i) & T.mask));
             s_img[2 * i] = e.x;
             s_img[2 * i + 1] = e.y;
         }
@@ -263,11 +278,7 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *
                         done = true;
                     }
                 }
-                if (!done) {
-                    const unsigned long long di = atomicAdd(deferred_n, 1ull);
-                    if (di < deferred_cap) { deferred[3 * di] = h.hi; deferred[3 * di + 1] = h.lo; deferred[3 * di + 2] = 1ull; }
-                    else atomicExch(&T.stats[ST_FATAL], 1ull);
-                }
+                if (!done) defer_record(T, h, deferred, deferred_n, deferred_cap);
             }
         }
         __syncthreads();
@@ -340,7 +351,7 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr1_set = true;
     }
-    hipLaunchKernelGGL(part1_kernel, dim3(G.nblk1), dim3(PT_THREADS), P1_LDS, stream, d_piece, len, ntiles, emit_from, d, G, out1, cnt1);
+    hipLaunchKernelGGL(part1_kernel, dim3(G.nblk1), dim3(PT_THREADS), P1_LDS, stream, d_piece, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, deferred_cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_stage_t[1], stream));
     const uint64_t *lists = out1;
@@ -348,12 +359,16 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     uint32_t lcap = G.cap1, nsl = G.nblk1;
     if (G.p2) {
         dim3 grid(G.nblk2, std::min<uint32_t>(nb1, 2048));
-        hipLaunchKernelGGL(part2_kernel, grid, dim3(PT_THREADS), 0, stream, out1, cnt1, d, G, out2, cnt2);
+        hipLaunchKernelGGL(part2_kernel, grid, dim3(PT_THREADS), 0, stream, out1, cnt1, d, G, out2, cnt2, defer_e, defer_n, deferred_cap);
         HIPCHK(hipGetLastError());
         lists = out2; lcnt = cnt2; lcap = G.cap2; nsl = G.nblk2;
     }
     HIPCHK(hipEventRecord(ev_stage_t[2], stream));
     const size_t lds = ((size_t)(1u << G.rbits) + RG_HALO) * 16;
+    // lazily cleared table: part1/part2 overflow fallbacks and the deferred list use the direct path on the slot array,
+    // so they need real zeros -- they are rare; when the lists show none, the LDS pass does the clearing for free
+    if (slots_dirty && nregions <= 1) { if (materialize(err)) return -1; }
+    const int fresh = slots_dirty ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_insert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -362,19 +377,20 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     for (uint32_t parity = 0; parity < 2; ++parity) {
         if (!(nregions == 1 && parity == 1)) {
             const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
-            hipLaunchKernelGGL(lds_insert_kernel, dim3(nblk), dim3(PT_THREADS), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, parity, defer_e,
+            hipLaunchKernelGGL(lds_insert_kernel, dim3(nblk), dim3(PT_THREADS), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, parity, fresh, defer_e,
                                defer_n, deferred_cap);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(ev_stage_t[3 + parity], stream));
     }
+    slots_dirty = false;   // every region has been written by the two launches above
     hipLaunchKernelGGL(import3_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, deferred_cap, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_k1, stream));
     HIPCHK(hipEventRecord(ev_stage_t[5], stream));
     part_stage_pending = true;
     if (getenv("JASPER_COUNT_DEBUG") && atoi(getenv("JASPER_COUNT_DEBUG")) >= 2) {
-        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(jk_stream_wait(stream));
         unsigned long long dn = 0;
         HIPCHK(hipMemcpy(&dn, defer_n, 8, hipMemcpyDeviceToHost));
         std::vector<unsigned int> hc(n_cnt1 + n_cnt2);

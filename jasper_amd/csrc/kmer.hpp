@@ -11,6 +11,16 @@
 
 #define JK_HD __host__ __device__ __forceinline__
 
+// Host-side wait for a stream.  hipStreamSynchronize may put the thread to sleep and wake it milliseconds after the
+// work finished (observed: 7-10 ms for an empty stream on some hosts); polling hipStreamQuery returns as soon as the GPU
+// is done.  The polling loop is bounded by the work itself -- it issues nothing.
+static inline hipError_t jk_stream_wait(hipStream_t st) {
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+    }
+}
+
 namespace jk {
 
 struct u128 {

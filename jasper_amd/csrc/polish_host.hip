@@ -40,6 +40,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     const int64_t TMIN = 4096;        // minimum distance between sync points
     hipStream_t st = T.stream;
     HIPCHK(hipSetDevice(T.device));
+    if (T.materialize(err)) return -1;
     R.seqs.assign(n_chunks, std::string());
     R.aux.assign(n_chunks, std::string());
     R.recs.clear();
@@ -115,7 +116,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     HIPCHK(hipMemcpyAsync(b_ptrB.p, hptrB.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
     uint8_t **ptrIn = b_ptrA.as<uint8_t *>(), **ptrOut = b_ptrB.as<uint8_t *>();
 
-    if (dbg) { (void)hipStreamSynchronize(st); fprintf(stderr, "[polish] setup + H2D: %.2f ms\n", now() - t_begin); }
+    if (dbg) { (void)jk_stream_wait(st); fprintf(stderr, "[polish] setup + H2D: %.2f ms\n", now() - t_begin); }
     const double t_loop = now();
     PolishParams pp;
     pp.k = k;
@@ -155,12 +156,12 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                 S.want_sync = (len[c] - k + 1) > 2 * TMIN;
             }
             HIPCHK(hipMemcpyAsync(b_scan.p, sc.data(), sizeof(ScanChunk) * n_chunks, hipMemcpyHostToDevice, st));
-            HIPCHK(hipStreamSynchronize(st));   // `sc` is a stack vector: the copy must have read it before it goes away
+            HIPCHK(jk_stream_wait(st));   // `sc` is a stack vector: the copy must have read it before it goes away
             launch_scan_batch(T.d, b_scan.as<ScanChunk>(), n_chunks, k, pp.solid, st);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ccount.data(), b_ccount.p, n_chunks * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(jk_stream_wait(st));
 
         // ---- 2. segments
         auto build_segments = [&](const std::vector<int> &chunks, bool speculate, std::vector<SegDev> &out, std::string &e2) -> int {
@@ -220,7 +221,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             launch_seg_walk(T.d, b_segs.as<SegDev>(), (int)sv.size(), pp, pass, pool, st);
             if (hipGetLastError() != hipSuccess) { e2 = "polish: kernel launch failed"; return -1; }
             if (hipMemcpyAsync(sv.data(), b_segs.p, sv.size() * sizeof(SegDev), hipMemcpyDeviceToHost, st) != hipSuccess) { e2 = "polish: D2H segs"; return -1; }
-            if (hipStreamSynchronize(st) != hipSuccess) { e2 = "polish: kernel execution failed"; return -1; }
+            if (jk_stream_wait(st) != hipSuccess) { e2 = "polish: kernel execution failed"; return -1; }
             return 0;
         };
         std::vector<int> all(n_chunks);
@@ -344,7 +345,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             HIPCHK(hipMemcpyAsync(&R.recs[r0], d_recs.p, nrec_pass * sizeof(FixRec), hipMemcpyDeviceToHost, st));
             aux_pass.back().resize(naux_pass);
             if (naux_pass) HIPCHK(hipMemcpyAsync(aux_pass.back().data(), d_aux.p, naux_pass, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(jk_stream_wait(st));
         }
         launch_seg_stitch(b_segs.as<SegDev>(), (int)ns, (uint8_t *const *)ptrOut, st);
         HIPCHK(hipGetLastError());
@@ -352,7 +353,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         std::swap(textIn, textOut);
         std::swap(ptrIn, ptrOut);
     }
-    if (dbg) { (void)hipStreamSynchronize(st); fprintf(stderr, "[polish] passes: %.2f ms\n", now() - t_loop); }
+    if (dbg) { (void)jk_stream_wait(st); fprintf(stderr, "[polish] passes: %.2f ms\n", now() - t_loop); }
     const double t_out = now();
     if (rc == 0) {
         HIPCHK(hipEventRecord(ev1, st));
@@ -361,7 +362,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             R.seqs[c].resize((size_t)len[c]);
             if (len[c]) HIPCHK(hipMemcpyAsync(&R.seqs[c][0], textIn + off_text[c], (size_t)len[c], hipMemcpyDeviceToHost, st));
         }
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(jk_stream_wait(st));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
         R.seconds = ms * 1e-3;
@@ -385,7 +386,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             return a.seqno < b.seqno;
         });
     }
-    (void)hipStreamSynchronize(st);
+    (void)jk_stream_wait(st);
     if (dbg) fprintf(stderr, "[polish] D2H + record sort: %.2f ms; total %.2f ms\n", now() - t_out, now() - t_begin);
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);

@@ -351,13 +351,13 @@ int Table::init(int k_, uint64_t min_slots, int device_, std::string &err) {
     HIPCHK(hipMalloc((void **)&d.slots, nslots * 16));
     HIPCHK(hipMalloc((void **)&d.stats, ST_WORDS * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&d.spill, d.spill_cap * 3 * sizeof(unsigned long long)));
-    if (zero_slots(d.slots, nslots, err)) return -1;
+    slots_dirty = true;   // zeroed on first use (or never, if that use is a partitioned counting piece)
     HIPCHK(hipMemsetAsync(d.stats, 0, ST_WORDS * sizeof(unsigned long long), stream));
     HIPCHK(hipHostMalloc((void **)&h_stats, ST_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     HIPCHK(hipEventCreate(&ev_k0));
     HIPCHK(hipEventCreate(&ev_k1));
     memset(h_stats, 0, ST_WORDS * sizeof(unsigned long long));
-    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(jk_stream_wait(stream));
     return 0;
 }
 
@@ -365,7 +365,7 @@ void *Table::workspace(int id, size_t bytes, std::string &err) {
     if (bytes == 0) bytes = 256;
     WsBuf &b = ws[id];
     if (b.bytes >= bytes) return b.p;
-    if (b.p) { (void)hipStreamSynchronize(stream); (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    if (b.p) { (void)jk_stream_wait(stream); (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
     const size_t want = bytes + bytes / 8;   // a little headroom so that slightly larger batches do not reallocate
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) {
@@ -380,7 +380,7 @@ void *Table::workspace(int id, size_t bytes, std::string &err) {
 
 void Table::destroy() {
     (void)hipSetDevice(device);
-    if (stream) (void)hipStreamSynchronize(stream);
+    if (stream) (void)jk_stream_wait(stream);
     for (WsBuf &b : ws) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
     for (int i = 0; i < 2; ++i) {
         if (d_stage[i]) (void)hipFree(d_stage[i]);
@@ -404,16 +404,44 @@ int Table::zero_slots(unsigned long long *slots, uint64_t n, std::string &err) {
     return 0;
 }
 
+__global__ void zero_stats_kernel(unsigned long long *stats) { if (threadIdx.x < ST_WORDS) stats[threadIdx.x] = 0ull; }
+
+int Table::clear(std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    slots_dirty = true;
+    timespec a, b, c;
+    const bool dbg = getenv("JASPER_COUNT_DEBUG") != nullptr;
+    if (dbg) clock_gettime(CLOCK_MONOTONIC, &a);
+    hipLaunchKernelGGL(zero_stats_kernel, dim3(1), dim3(64), 0, stream, d.stats);
+    HIPCHK(hipGetLastError());
+    if (dbg) {
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        (void)jk_stream_wait(stream);
+        clock_gettime(CLOCK_MONOTONIC, &c);
+        fprintf(stderr, "[count] clear: launch %.3f ms, wait %.3f ms\n", (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6,
+                (c.tv_sec - b.tv_sec) * 1e3 + (c.tv_nsec - b.tv_nsec) * 1e-6);
+    }
+    return 0;
+}
+
 int Table::read_stats(std::string &err) {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipMemcpyAsync(h_stats, d.stats, ST_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(jk_stream_wait(stream));
     return 0;
 }
 
 int Table::grow(int new_s, std::string &err) {
     if (new_s > d.B) new_s = d.B;
     if (new_s <= d.s) return 0;
+    if (slots_dirty) {   // logically empty: nothing to rehash, the new slot array stays lazily cleared as well
+        unsigned long long *ns = nullptr;
+        HIPCHK(hipMalloc((void **)&ns, (1ull << new_s) * 16));
+        HIPCHK(jk_stream_wait(stream));
+        HIPCHK(hipFree(d.slots));
+        d.slots = ns; d.s = new_s; d.mask = (1ull << new_s) - 1; nslots = 1ull << new_s;
+        return 0;
+    }
     TableDev nt = d;
     nt.s = new_s;
     nt.mask = (1ull << new_s) - 1;
@@ -423,7 +451,7 @@ int Table::grow(int new_s, std::string &err) {
     HIPCHK(hipMemsetAsync(d.stats + ST_DISTINCT, 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, stream, d, nt);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(jk_stream_wait(stream));
     HIPCHK(hipFree(d.slots));
     d = nt;
     nslots = 1ull << new_s;
@@ -455,7 +483,7 @@ int Table::after_batch(std::string &err) {
             HIPCHK(hipMemcpy(tmp, sp.data(), sp.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
             hipLaunchKernelGGL(import_kernel, dim3(grid_for(spilled, 256)), dim3(256), 0, stream, tmp, spilled, d);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(jk_stream_wait(stream));
             HIPCHK(hipFree(tmp));
         }
     }
@@ -480,6 +508,7 @@ int Table::launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from
         ++count_partitioned_launches;
         return launch_count_partitioned(d_piece, len, emit_from, geom, err);
     }
+    if (materialize(err)) return -1;
     const uint64_t ntiles = (len + CT_TILE - 1) / CT_TILE;
     HIPCHK(hipEventRecord(ev_k0, stream));
     static const int mode = getenv("JASPER_EXPERIMENT_MODE") ? atoi(getenv("JASPER_EXPERIMENT_MODE")) : 0;
@@ -562,8 +591,7 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
             // Nothing else was in the table when this call started, so start over with worst-case piece sizes.
             if (dbg) fprintf(stderr, "[count] size hint too small for this input: restarting with worst-case sizing\n");
             err.clear();
-            if (zero_slots(d.slots, nslots, err)) return -1;
-            HIPCHK(hipMemsetAsync(d.stats, 0, ST_WORDS * sizeof(unsigned long long), stream));
+            if (clear(err)) return -1;
             if (read_stats(err)) return -1;
             if (grow(std::min(d.B, d.s + 2), err)) return -1;
             have_ratio = false;
@@ -633,19 +661,21 @@ int Table::count_host(const char *bases, uint64_t n, std::string &err) {
 
 int Table::histogram(uint64_t *out, std::string &err) {
     HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
     unsigned long long *d_out = nullptr;
     HIPCHK(hipMalloc((void **)&d_out, HISTO_BINS * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(d_out, 0, HISTO_BINS * sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(histo_kernel, dim3(grid_for(nslots, 256 * 16)), dim3(256), 0, stream, d, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out, HISTO_BINS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(jk_stream_wait(stream));
     HIPCHK(hipFree(d_out));
     return 0;
 }
 
 int Table::lookup_strings(const char *chars, const int64_t *offsets, uint64_t n, uint32_t *out, std::string &err) {
     HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
     if (n == 0) return 0;
     const uint64_t nchars = (uint64_t)offsets[n];
     char *d_chars = nullptr;
@@ -659,7 +689,7 @@ int Table::lookup_strings(const char *chars, const int64_t *offsets, uint64_t n,
     hipLaunchKernelGGL(lookup_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_chars, d_offs, n, d_out, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(jk_stream_wait(stream));
     HIPCHK(hipFree(d_chars));
     HIPCHK(hipFree(d_offs));
     HIPCHK(hipFree(d_out));
@@ -668,6 +698,7 @@ int Table::lookup_strings(const char *chars, const int64_t *offsets, uint64_t n,
 
 int Table::export_entries(uint64_t *n_out, unsigned long long **d_entries_out, std::string &err) {
     HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
     if (read_stats(err)) return -1;
     const uint64_t cap = h_stats[ST_DISTINCT];
     unsigned long long *d_e = nullptr, *d_ctr = nullptr;
@@ -678,7 +709,7 @@ int Table::export_entries(uint64_t *n_out, unsigned long long **d_entries_out, s
     HIPCHK(hipGetLastError());
     unsigned long long got = 0;
     HIPCHK(hipMemcpyAsync(&got, d_ctr, sizeof got, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(jk_stream_wait(stream));
     HIPCHK(hipFree(d_ctr));
     if (got != cap) { (void)hipFree(d_e); err = "export: entry count changed under us"; return -1; }
     *n_out = got;
@@ -688,6 +719,7 @@ int Table::export_entries(uint64_t *n_out, unsigned long long **d_entries_out, s
 
 int Table::import_entries(const unsigned long long *d_entries, uint64_t n, std::string &err) {
     HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
     if (read_stats(err)) return -1;
     uint64_t pos = 0;
     while (pos < n) {
@@ -714,6 +746,7 @@ int Table::reserve(uint64_t min_slots, std::string &err) {
 
 int Table::export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t part, uint32_t nparts, std::string &err) {
     HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
     unsigned long long *d_ctr = nullptr;
     HIPCHK(hipMalloc((void **)&d_ctr, sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(d_ctr, 0, sizeof(unsigned long long), stream));
@@ -736,7 +769,7 @@ int Table::export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t pa
     HIPCHK(hipGetLastError());
     unsigned long long got = 0;
     HIPCHK(hipMemcpyAsync(&got, d_ctr, sizeof got, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(jk_stream_wait(stream));
     HIPCHK(hipFree(d_ctr));
     if (read_stats(err)) return -1;
     if (h_stats[ST_FATAL] == 2) { err = "a count does not fit the packed exchange format"; return -2; }
@@ -746,6 +779,7 @@ int Table::export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t pa
 
 int Table::import_packed(const void *d_src, uint64_t n, int mode, std::string &err) {
     HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
     if (read_stats(err)) return -1;
     uint64_t pos = 0;
     while (pos < n) {

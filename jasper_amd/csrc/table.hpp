@@ -175,6 +175,13 @@ struct Table {
     void destroy();
     int read_stats(std::string &err);                 // stream sync + copy stats to h_stats
     int zero_slots(unsigned long long *slots, uint64_t n, std::string &err);
+    // Lazy clear: a table that is known to be logically empty does not have to be zeroed in HBM if the next thing that
+    // happens to it is a partitioned counting piece -- lds_insert_kernel then starts every region image from zeros
+    // instead of reading it, and writes every region back (one write pass instead of write + read + write).
+    // Everything else calls materialize() first.
+    bool slots_dirty = false;      // slot memory holds garbage; the table is logically empty
+    int materialize(std::string &err) { if (!slots_dirty) return 0; slots_dirty = false; return zero_slots(d.slots, nslots, err); }
+    int clear(std::string &err);
     int ensure_capacity(uint64_t upcoming_kmers, std::string &err);
     int grow(int new_s, std::string &err);            // rehash into 2^new_s slots
     int after_batch(std::string &err);                // spill / fatal / growth handling
