@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--genome-mb", type=float, default=47.0, help="assembly size per GPU in Mb (47 = chr21-sized, BASELINE configs[1])")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--one-gpu", action="store_true", help="rehearsal: all ranks share GPU 0")
     a = ap.parse_args()
 
     import torch
@@ -147,11 +149,16 @@ def main():
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible; the product has no CPU path\n")
         sys.exit(2)
+    if a.one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     reads, names, seqs, asm_len, bs, nreads = build_workload(torch, dev, rank, world, a.genome_mb, a.seed)
     # size hint like jasper.sh: JF_SIZE = FASTQ bytes / 10 (src/jasper.sh:82); FASTQ ~ 2.1 bytes per base

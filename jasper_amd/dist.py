@@ -69,6 +69,12 @@ def all_gather_entries(entries, group=None):
     return torch.cat(others, dim=0).contiguous()
 
 
+def _sync(device):
+    import torch
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
 def _all_to_all_rows(send, group=None):
     """send[dst] goes to rank dst; returns recv with recv[src] = what rank src sent to this rank.
     RCCL: one all_to_all_single (point-to-point over every xGMI link at once). gloo has no all_to_all for device
@@ -113,13 +119,16 @@ def merge_tables(table, device, group=None):
     dist.all_gather(allc, counts, group=group)
     allc = torch.stack(allc).cpu()                     # allc[src][dst]
     mx = max(int(allc.max().item()), 1)
-    send = torch.zeros((world, mx, 2), dtype=torch.int64, device=device)   # zero rows (count 0) are ignored by import
+    # libjasper_hip works on its own HIP stream: torch memory must be idle (no pending fill / no pending work of a previous
+    # owner of the cached block) before it is handed over, hence empty() + synchronize, never zeros()
+    send = torch.empty((world, mx, 2), dtype=torch.int64, device=device)   # rows beyond the exact counts are never imported
+    _sync(device)
     for o in range(world):
         if o != rank and int(allc[rank][o]):
             table.export_packed(send[o].data_ptr(), mx, o, world)
-    torch.cuda.synchronize(device) if device.type == "cuda" else None
+    _sync(device)
     recv = _all_to_all_rows(send, group)
-    torch.cuda.synchronize(device) if device.type == "cuda" else None
+    _sync(device)
     del send
     received = 0
     for src in range(world):
@@ -135,9 +144,10 @@ def merge_tables(table, device, group=None):
     dist.all_gather(alln, nm, group=group)
     alln = [int(x.item()) for x in alln]
     mx2 = max(max(alln), 1)
-    mine = torch.zeros((mx2, 2), dtype=torch.int64, device=device)
+    mine = torch.empty((mx2, 2), dtype=torch.int64, device=device)
+    _sync(device)
     table.export_packed(mine.data_ptr(), mx2, rank, world)
-    torch.cuda.synchronize(device) if device.type == "cuda" else None
+    _sync(device)
     full = torch.empty((world, mx2, 2), dtype=torch.int64, device=device)
     try:
         dist.all_gather_into_tensor(full.view(world * mx2, 2), mine, group=group)
@@ -145,7 +155,7 @@ def merge_tables(table, device, group=None):
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine, group=group)
         full = torch.stack(parts)
-    torch.cuda.synchronize(device) if device.type == "cuda" else None
+    _sync(device)
     for src in range(world):
         if src != rank and alln[src]:
             table.import_packed(full[src].data_ptr(), alln[src], 1)  # set: the owner's final counts replace my partial ones

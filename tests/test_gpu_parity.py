@@ -172,17 +172,20 @@ def test_packed_partition_exchange_primitives(KT, O):
     assert sum(sizes) == tb.info()["distinct"] == tb.export_packed(0, 0)
     # "rank a" owns partition 1: it receives b's entries of partition 1 (add) -> final there
     buf = torch.zeros((max(sizes), 2), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()          # the library runs on its own stream: torch's fill must be done first
     assert tb.export_packed(buf.data_ptr(), buf.shape[0], 1, nparts) == sizes[1]
     ta.import_packed(buf.data_ptr(), sizes[1], 0)
     # then publishes its final partition 1 and b SETs it
     n1 = ta.export_packed(0, 0, 1, nparts)
     out = torch.zeros((n1, 2), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
     ta.export_packed(out.data_ptr(), n1, 1, nparts)
     tb.import_packed(out.data_ptr(), n1, 1)
     # partition 1 of b now equals partition 1 of the full table
     ref = torch.zeros((n1, 2), dtype=torch.int64, device="cuda")
-    assert full.export_packed(ref.data_ptr(), n1, 1, nparts) == n1
     got = torch.zeros((n1, 2), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    assert full.export_packed(ref.data_ptr(), n1, 1, nparts) == n1
     assert tb.export_packed(got.data_ptr(), n1, 1, nparts) == n1
     key = lambda x: sorted(map(tuple, x.cpu().tolist()))
     assert key(got) == key(ref) == key(out)
