@@ -201,6 +201,15 @@ def main():
     kernel_s = mean("kernel_ms") * 1e-3
     launches = max(int(T["launches"]), 1)
     achieved = BYTES_PER_KMER * kmers_rank / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    # HBM bytes of the counting pipeline per launch, from the PMC passes committed with the same build (rocprofv3 cannot
+    # collect FETCH_SIZE / WRITE_SIZE inside this process); null when that file is absent
+    traffic, traffic_src = None, None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "round1", "bench_hbm_counters.json")))
+        traffic = int(pj["counting_pipeline"]["hbm_bytes_per_step"] / launches)
+        traffic_src = "profiles/round1/bench_hbm_counters.json (FETCH_SIZE+WRITE_SIZE, separate rocprofv3 --pmc passes, per step / launches)"
+    except Exception:
+        pass
     out = {
         "metric": "assembly Mbp/s polished + Gk-mers/s counted, k=37",
         "value": round(asm_total / 1e6 / (dt / steps), 3),
@@ -222,7 +231,7 @@ def main():
                      "kernel": "k-mer counting = part1_kernel + part2_kernel + lds_insert_kernel (even, odd) per piece"
                                if T["part_launches"] else "count_kernel",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": int(BYTES_PER_KMER * kmers_rank / launches),
                      "launches_per_step": launches, "partitioned_launches": T["part_launches"],
                      "avg_launch_ms": round(mean("kernel_ms") / launches, 3),

@@ -58,6 +58,9 @@ int jasper_device_count(int *n);
 /* k in [1,64]; min_slots is a size hint like `jellyfish count -s` (rounded up to a power of two; the table
  * doubles by itself when half full).  k > 26 needs at least 2^(2k-53) slots (k=37: 2^21 = 32 MiB). */
 int jasper_table_create(int k, uint64_t min_slots, int device, jasper_table **out);
+/* open a Jellyfish "binary/sorted" database (jasper.sh -j, or an existing mer_counts$K.jf) into a new HBM table; k comes from
+ * the file header like jf.QueryMerFile(path) does (JF::swig/mer_file.i:18-36); errors use Jellyfish's wording */
+int jasper_table_load_jf(const char *path, int device, jasper_table **out);
 void jasper_table_destroy(jasper_table *t);
 int jasper_table_info(jasper_table *t, int *k, uint64_t *slots, uint64_t *distinct, uint64_t *occurrences);
 int jasper_table_sync(jasper_table *t);

@@ -7,7 +7,7 @@ polisher.  Lines are cited as src/jasper.sh:N.
 Differences that are deliberate and documented in DESIGN.md:
   * contigs are written to <asm>.polished.fasta in input order (the reference's order is perl-hash random, :220)
   * column sums for the QV are exact integers (gawk behaviour)
-  * `mer_counts$K.jf` is not written (the table lives in HBM); an existing one, or -j, is not read yet
+  * `mer_counts$K.jf` is not written (the table lives in HBM); an existing one, or -j, is read into HBM
 """
 import datetime
 import glob
@@ -302,19 +302,41 @@ def run(argv):
         for fn in reads:
             if not (os.path.isfile(fn) and os.path.getsize(fn) > 0):
                 error_exit("The reads file  %s does not exist. Please supply a series of valid reads files separated by space and wrapped in one pair of quotation marks." % fn)
-        log("Creating jellyfish database mer_counts%d.jf" % kmer)
-        table = KmerTable(kmer, min_slots=max(1 << 20, 2 * o.jf_size), device=o.device)
-        table.count_files(reads)
+        jf_file = "mer_counts%d.jf" % kmer
+        if os.path.isfile(jf_file) and os.path.getsize(jf_file) > 0:     # :171-173
+            log("Using existing jellyfish database %s" % jf_file)
+            if os.path.exists("jasper.no_cat.success"):
+                os.remove("jasper.no_cat.success")
+            table = KmerTable.from_jf(jf_file, device=o.device)
+        else:
+            log("Creating jellyfish database mer_counts%d.jf" % kmer)
+            table = KmerTable(kmer, min_slots=max(1 << 20, 2 * o.jf_size), device=o.device)
+            table.count_files(reads)
+            with open(histo_file + ".tmp", "w") as f:
+                for m, n in table.histo_rows():
+                    f.write("%d %d\n" % (m, n))
+            os.replace(histo_file + ".tmp", histo_file)
+            open("jasper.no_cat.success", "w").close()
+            open("jasper.histo.success", "w").close()
+            if os.path.exists("jasper.correct.success"):
+                os.remove("jasper.correct.success")
+    else:
+        # -j: an existing Jellyfish database; its header decides k (JF::swig/mer_file.i:23 -- the DB wins over -k)
+        try:
+            table = KmerTable.from_jf(o.jf_db, device=o.device)
+        except Exception as e:
+            error_exit("Computing mer counts histogram from %s failed, please make sure that %s is a valid Jellyfish mer counts file (%s)"
+                       % (o.jf_db, o.jf_db, e))
+
+    if not os.path.exists("jasper.histo.success") or not (os.path.isfile(histo_file) and os.path.getsize(histo_file) > 0):   # :187-193
+        log("Computing K-mer histogram")
         with open(histo_file + ".tmp", "w") as f:
             for m, n in table.histo_rows():
                 f.write("%d %d\n" % (m, n))
         os.replace(histo_file + ".tmp", histo_file)
-        open("jasper.no_cat.success", "w").close()
-        open("jasper.histo.success", "w").close()
         if os.path.exists("jasper.correct.success"):
             os.remove("jasper.correct.success")
-    else:
-        error_exit("Reading an existing Jellyfish database (-j) is not implemented in this build; pass the reads with -r")
+        open("jasper.histo.success", "w").close()
 
     if not os.path.exists("jasper.correct.success"):                    # :195-216
         log("Polishing")

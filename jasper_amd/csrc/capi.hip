@@ -56,6 +56,21 @@ int jasper_table_create(int k, uint64_t min_slots, int device, jasper_table **ou
     return JASPER_OK;
 }
 
+int jasper_table_load_jf(const char *path, int device, jasper_table **out) {
+    if (!out || !path) { g_err = "null argument"; return JASPER_ERR; }
+    JfHeader h;
+    int rc = jf_read_header(path, h, g_err);
+    if (rc) return rc == -3 ? JASPER_ERR_FORMAT : JASPER_ERR;
+    jasper_table *t = nullptr;
+    rc = jasper_table_create(h.key_len / 2, std::max<uint64_t>(1u << 16, 2 * h.n_records), device, &t);
+    if (rc) return rc;
+    Table *T = &t->t;
+    rc = jf_read_records(path, h, [T](const unsigned long long *e, size_t n) { return T->add_kmers(e, n, g_err); }, g_err);
+    if (rc) { jasper_table_destroy(t); return rc < -1 ? rc : JASPER_ERR; }
+    *out = t;
+    return JASPER_OK;
+}
+
 void jasper_table_destroy(jasper_table *t) {
     if (!t) return;
     t->t.destroy();

@@ -1,5 +1,8 @@
 // ingest.cpp -- see ingest.hpp
 #include "ingest.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <zlib.h>
@@ -113,6 +116,74 @@ int parse_files(const char *const *paths, int n_paths, FastxParser &parser, std:
     int rc = parser.finish();
     if (rc) err = parser.error();
     return rc;
+}
+
+static bool json_int(const std::string &j, const char *key, long &out) {
+    const std::string pat = std::string("\"") + key + "\"";
+    size_t p = j.find(pat);
+    if (p == std::string::npos) return false;
+    p = j.find(':', p + pat.size());
+    if (p == std::string::npos) return false;
+    ++p;
+    while (p < j.size() && (j[p] == ' ' || j[p] == '\t' || j[p] == '\n')) ++p;
+    char *end = nullptr;
+    out = strtol(j.c_str() + p, &end, 10);
+    return end != j.c_str() + p;
+}
+
+int jf_read_header(const char *path, JfHeader &h, std::string &err) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { err = std::string("Can't open file '") + path + "'"; return -1; }     // JF::swig/mer_file.i:21
+    char digits[10] = {0};
+    if (fread(digits, 1, 9, f) != 9) { fclose(f); err = "Unsupported format"; return -3; }
+    for (int i = 0; i < 9; ++i) if (digits[i] < '0' || digits[i] > '9') { fclose(f); err = "Unsupported format"; return -3; }
+    const long hlen = strtol(digits, nullptr, 10);
+    std::string j((size_t)hlen, '\0');
+    if (hlen <= 0 || fread(&j[0], 1, (size_t)hlen, f) != (size_t)hlen) { fclose(f); err = "Unsupported format"; return -3; }
+    fseek(f, 0, SEEK_END);
+    const long fsize = ftell(f);
+    fclose(f);
+    if (j.find("\"binary/sorted\"") == std::string::npos) { err = "Unsupported format"; return -3; }           // JF::swig/mer_file.i:34
+    long kl = 0, cl = 0;
+    if (!json_int(j, "key_len", kl) || !json_int(j, "counter_len", cl) || kl <= 0 || kl > 128 || (kl & 1) || cl <= 0 || cl > 8) {
+        err = "Unsupported format"; return -3;
+    }
+    h.key_len = (int)kl;
+    h.counter_len = (int)cl;
+    h.canonical = j.find("\"canonical\":true") != std::string::npos || j.find("\"canonical\" : true") != std::string::npos ||
+                  j.find("\"canonical\": true") != std::string::npos;
+    h.data_offset = 9 + (uint64_t)hlen;
+    const uint64_t rec = (uint64_t)((kl + 7) / 8) + (uint64_t)cl;
+    h.n_records = ((uint64_t)fsize - h.data_offset) / rec;
+    return 0;
+}
+
+int jf_read_records(const char *path, const JfHeader &h, std::function<int(const unsigned long long *, size_t)> sink, std::string &err) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { err = std::string("Can't open file '") + path + "'"; return -1; }
+    fseek(f, (long)h.data_offset, SEEK_SET);
+    const size_t kb = (size_t)((h.key_len + 7) / 8), cl = (size_t)h.counter_len, rec = kb + cl;
+    const size_t block = 1u << 20;
+    std::vector<unsigned char> raw(block * rec);
+    std::vector<unsigned long long> ent(block * 3);
+    uint64_t left = h.n_records;
+    while (left) {
+        const size_t n = (size_t)std::min<uint64_t>(left, block);
+        if (fread(raw.data(), rec, n, f) != n) { fclose(f); err = "truncated Jellyfish database"; return -1; }
+        for (size_t i = 0; i < n; ++i) {
+            const unsigned char *p = raw.data() + i * rec;
+            unsigned long long lo = 0, hi = 0, c = 0;
+            for (size_t b = 0; b < kb && b < 8; ++b) lo |= (unsigned long long)p[b] << (8 * b);
+            for (size_t b = 8; b < kb; ++b) hi |= (unsigned long long)p[b] << (8 * (b - 8));
+            for (size_t b = 0; b < cl; ++b) c |= (unsigned long long)p[kb + b] << (8 * b);
+            ent[3 * i] = hi; ent[3 * i + 1] = lo; ent[3 * i + 2] = c;
+        }
+        const int rc = sink(ent.data(), n);
+        if (rc) { fclose(f); return rc; }
+        left -= n;
+    }
+    fclose(f);
+    return 0;
 }
 
 }  // namespace jk

@@ -299,6 +299,20 @@ __global__ __launch_bounds__(256) void zero_kernel(ulonglong2 *__restrict__ p, u
         p[i] = make_ulonglong2(0ull, 0ull);
 }
 
+// raw k-mers (hi, lo, count) as stored in a Jellyfish DB: keys are inserted AS STORED (no canonicalisation), so that a
+// lookup of canonical(query) hits exactly when the reference's binary search would (JF::include/jellyfish/binary_dumper.hpp:148-199)
+__global__ __launch_bounds__(256) void add_kmers_kernel(const unsigned long long *__restrict__ entries, uint64_t n, TableDev T) {
+    unsigned long long fresh = 0;
+    const u128 kmask = maskbits(T.B);
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const u128 m = band(mk(entries[3 * i + 0], entries[3 * i + 1]), kmask);
+        const unsigned long long c = entries[3 * i + 2];
+        if (c) fresh += table_add_or_spill(T, mix(m, T.B), c);
+    }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+}
+
 // rehash straight from an old slot array into a (larger) table
 __global__ __launch_bounds__(256) void rehash_kernel(TableDev oldT, TableDev newT) {
     unsigned long long fresh = 0;
@@ -504,7 +518,9 @@ int Table::launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from
     alignas(16) char geom[64];
     // the partitioned path streams the whole table once per piece: worth it only for pieces that are large relative
     // to the table (host-staged 64 MiB pieces stay on the direct kernel and are PCIe-bound anyway)
-    if (len >= nslots / 2 && partition_geometry(len, geom)) {
+    // break-even measured on MI355X: direct ~18 Gk-mers/s; partitioned ~55 Gk-mers/s for the two list passes plus one
+    // streaming pass over the table (32 B/slot, 16 B/slot when the table is still lazily cleared)
+    if (len >= (slots_dirty ? nslots / 6 : nslots / 4) && partition_geometry(len, geom)) {
         ++count_partitioned_launches;
         return launch_count_partitioned(d_piece, len, emit_from, geom, err);
     }
@@ -737,6 +753,22 @@ int Table::import_entries(const unsigned long long *d_entries, uint64_t n, std::
         if (rc) return rc;
     }
     return 0;
+}
+
+int Table::add_kmers(const unsigned long long *h_entries, uint64_t n, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
+    if (!n) return 0;
+    if (read_stats(err)) return -1;
+    if (ensure_capacity(n, err)) return -1;
+    unsigned long long *d_e = nullptr;
+    HIPCHK(hipMalloc((void **)&d_e, n * 24));
+    HIPCHK(hipMemcpyAsync(d_e, h_entries, n * 24, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(add_kmers_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_e, n, d);
+    HIPCHK(hipGetLastError());
+    int rc = after_batch(err);
+    HIPCHK(hipFree(d_e));
+    return rc;
 }
 
 int Table::reserve(uint64_t min_slots, std::string &err) {

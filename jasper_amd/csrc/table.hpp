@@ -196,6 +196,7 @@ struct Table {
     int export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t part, uint32_t nparts, std::string &err);
     int import_packed(const void *d_src, uint64_t n, int mode, std::string &err);
     int reserve(uint64_t min_slots, std::string &err);
+    int add_kmers(const unsigned long long *h_entries, uint64_t n, std::string &err);   // (kmer hi, lo, count) as stored in a .jf
 };
 
 }  // namespace jk

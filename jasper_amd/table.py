@@ -99,6 +99,17 @@ class KmerTable:
         self.device = int(device)
         check(self._L.jasper_table_create(self.k, int(min_slots), self.device, C.byref(self._h)))
 
+    @classmethod
+    def from_jf(cls, path, device=0):
+        """jf.QueryMerFile(path): open a Jellyfish binary/sorted DB into HBM; k comes from the file (JF::swig/mer_file.i:18-36)"""
+        self = cls.__new__(cls)
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        self.device = int(device)
+        check(self._L.jasper_table_load_jf(path.encode(), self.device, C.byref(self._h)))
+        self.k = self.info()["k"]
+        return self
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._L.jasper_table_destroy(self._h)

@@ -302,6 +302,8 @@ def build_case(name, spec, outdir, seed):
     with gzip.GzipFile(os.path.join(cdir, "dump.txt.gz"), "wb", mtime=0) as f:
         f.write(dump)
     open(os.path.join(cdir, "histo.csv"), "wb").write(histo)
+    if name in ("simple_k25", "simple_k37"):      # the reference's own DB file, for the .jf reader (jasper.sh -j)
+        shutil.copy(db, os.path.join(cdir, "db.jf"))
     meta = dict(k=k, passes=P, thre=spec["thre"], reads_format=spec["fmt"], seed=seed,
                 jellyfish_py_exit=thr.returncode, jellyfish_py_stdout=thr.stdout.decode(),
                 jasper_py_exit=p.returncode)
