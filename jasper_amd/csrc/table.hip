@@ -651,14 +651,19 @@ int Table::count_host(const char *bases, uint64_t n, std::string &err) {
     const uint64_t halo = (uint64_t)(k - 1);
     uint64_t pos = 0;
     int buf = 0;
+    uint64_t pending = 0;   // bases launched since the table's load was last checked (worst case: all of them new keys)
     while (pos < n) {
-        const uint64_t room = (uint64_t)(0.75 * (double)nslots) > h_stats[ST_DISTINCT] ? (uint64_t)(0.75 * (double)nslots) - h_stats[ST_DISTINCT] : 0;
-        const uint64_t piece = std::min<uint64_t>(stage_bytes - halo, std::max<uint64_t>(room, 1u << 20));
-        if (piece > room) {
-            if (ensure_capacity(std::min<uint64_t>(piece, n - pos), err)) return -1;
+        const uint64_t piece = std::min<uint64_t>(stage_bytes - halo, n - pos);
+        // the load factor is only re-checked (a stream sync) when the worst case could pass 3/4: between checks the
+        // host copy of piece i+1 into pinned memory overlaps the PCIe copy and the kernel of piece i
+        if ((double)(h_stats[ST_DISTINCT] + pending + piece) > 0.75 * (double)nslots) {
+            int rc = after_batch(err);
+            if (rc) return rc;
+            pending = 0;
+            if (ensure_capacity(piece, err)) return -1;
         }
         const uint64_t start = pos >= halo ? pos - halo : 0;
-        const uint64_t end = std::min<uint64_t>(n, pos + piece);
+        const uint64_t end = pos + piece;
         const uint64_t len = end - start;
         HIPCHK(hipEventSynchronize(ev_stage[buf]));  // staging buffer free again?
         memcpy(h_stage[buf], bases + start, len);
@@ -666,13 +671,15 @@ int Table::count_host(const char *bases, uint64_t n, std::string &err) {
         if (launch_count(d_stage[buf], len, pos - start, err)) return -1;
         HIPCHK(hipEventRecord(ev_stage[buf], stream));
         pos = end;
+        pending += piece;
         buf ^= 1;
-        int rc = after_batch(err);
-        if (rc) return rc;
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, ev_k0, ev_k1));
-        count_kernel_ms += ms;
         count_launches += 1;
+    }
+    const int rc = after_batch(err);   // spill / growth handling and fresh statistics before returning
+    if (rc) return rc;
+    {   // kernel time of this call is not tracked per launch on the streaming path (events are reused): report the last one
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev_k0, ev_k1) == hipSuccess) count_kernel_ms += ms;
     }
     return 0;
 }
