@@ -76,6 +76,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     DevBuf b_textA, b_textB, b_cnt, b_valid, b_cls, b_cand, b_ccount, b_ptrA, b_ptrB, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks, b_scan;
     int ws_next = 0;
     auto dmalloc = [&](DevBuf &b, size_t bytes) -> bool {      // persistent: slot of the table's workspace
+        if (ws_next >= 24) { err = "polish: workspace slots exhausted"; return false; }
         b.p = T.workspace(ws_next++, bytes, err);
         b.owned = false;
         return b.p != nullptr;
@@ -131,6 +132,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     HIPCHK(hipEventRecord(ev0, st));
 
     std::vector<SegDev> segs;
+    std::vector<ScanChunk> sc(n_chunks);            // lives across passes: the async H2D copy reads it after the call returns
+    std::vector<int64_t> all_cands(cand_items);     // every chunk's sync-point candidates, fetched with one copy per pass
     std::vector<unsigned int> ccount(n_chunks);
     std::vector<int64_t> cands;
     std::vector<uint32_t> aux_total(n_chunks, 0);   // aux bytes gathered so far per chunk (all passes)
@@ -142,7 +145,6 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         // ---- 1. dense scan, classes, sync-point candidates
         HIPCHK(hipMemsetAsync(b_ccount.p, 0, n_chunks * 4, st));
         {
-            std::vector<ScanChunk> sc(n_chunks);
             for (int c = 0; c < n_chunks; ++c) {
                 ScanChunk &S = sc[c];
                 S.text = textIn + off_text[c];
@@ -156,11 +158,11 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                 S.want_sync = (len[c] - k + 1) > 2 * TMIN;
             }
             HIPCHK(hipMemcpyAsync(b_scan.p, sc.data(), sizeof(ScanChunk) * n_chunks, hipMemcpyHostToDevice, st));
-            HIPCHK(jk_stream_wait(st));   // `sc` is a stack vector: the copy must have read it before it goes away
             launch_scan_batch(T.d, b_scan.as<ScanChunk>(), n_chunks, k, pp.solid, st);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ccount.data(), b_ccount.p, n_chunks * 4, hipMemcpyDeviceToHost, st));
+        if (cand_items) HIPCHK(hipMemcpyAsync(all_cands.data(), b_cand.p, cand_items * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(jk_stream_wait(st));
 
         // ---- 2. segments
@@ -171,10 +173,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                 std::vector<int64_t> sync;
                 if (speculate && ccount[c] > 0) {
                     const unsigned int nc = std::min(ccount[c], cand_cap[c]);
-                    cands.resize(nc);
-                    if (hipMemcpy(cands.data(), b_cand.as<int64_t>() + off_cand[c], nc * 8, hipMemcpyDeviceToHost) != hipSuccess) {
-                        e2 = "polish: reading sync candidates failed"; return -1;
-                    }
+                    cands.assign(all_cands.begin() + off_cand[c], all_cands.begin() + off_cand[c] + nc);
                     std::sort(cands.begin(), cands.end());
                     int64_t last = 0;
                     for (int64_t p : cands)
@@ -331,8 +330,10 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         aux_pass.emplace_back();
         if (nrec_pass) {
             DevBuf d_idx, d_seq, d_ro, d_ao, d_recs, d_aux;
-            if (!tmalloc(d_idx, ns * 8) || !tmalloc(d_seq, ns * 4) || !tmalloc(d_ro, ns * 4) || !tmalloc(d_ao, ns * 4) ||
-                !tmalloc(d_recs, nrec_pass * sizeof(FixRec)) || !tmalloc(d_aux, naux_pass)) { rc = -2; break; }
+            int ws_save = ws_next;          // the same six workspace slots every pass
+            if (!dmalloc(d_idx, ns * 8) || !dmalloc(d_seq, ns * 4) || !dmalloc(d_ro, ns * 4) || !dmalloc(d_ao, ns * 4) ||
+                !dmalloc(d_recs, nrec_pass * sizeof(FixRec)) || !dmalloc(d_aux, naux_pass)) { rc = -2; break; }
+            ws_next = ws_save;
             HIPCHK(hipMemcpyAsync(d_idx.p, idx_base.data(), ns * 8, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(d_seq.p, seq_base.data(), ns * 4, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(d_ro.p, rec_off.data(), ns * 4, hipMemcpyHostToDevice, st));
