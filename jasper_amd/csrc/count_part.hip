@@ -368,10 +368,10 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     const uint32_t nb1 = 1u << G.p1, nregions = 1u << (G.p1 + G.p2);
     const uint64_t deferred_cap = std::max<uint64_t>(1u << 16, len / 16);
     const size_t n_cnt1 = (size_t)nb1 * G.nblk1, n_cnt2 = G.p2 ? (size_t)nregions * G.nblk2 : 0;
-    uint64_t *out1 = (uint64_t *)workspace(26, n_cnt1 * G.cap1 * 8, err);
-    uint64_t *out2 = G.p2 ? (uint64_t *)workspace(27, n_cnt2 * G.cap2 * 8, err) : nullptr;
-    unsigned int *cur = (unsigned int *)workspace(28, (n_cnt1 + n_cnt2 + 4) * 4, err);
-    unsigned long long *defer = (unsigned long long *)workspace(29, deferred_cap * 24 + 64, err);
+    uint64_t *out1 = (uint64_t *)workspace(WS_COUNT + 0, n_cnt1 * G.cap1 * 8, err);
+    uint64_t *out2 = G.p2 ? (uint64_t *)workspace(WS_COUNT + 1, n_cnt2 * G.cap2 * 8, err) : nullptr;
+    unsigned int *cur = (unsigned int *)workspace(WS_COUNT + 2, (n_cnt1 + n_cnt2 + 4) * 4, err);
+    unsigned long long *defer = (unsigned long long *)workspace(WS_COUNT + 3, deferred_cap * 24 + 64, err);
     if (!out1 || (G.p2 && !out2) || !cur || !defer) return -2;
     unsigned int *cnt1 = cur, *cnt2 = cur + n_cnt1;
     unsigned long long *defer_n = defer;                    // first 8 bytes: counter; entries start 64 bytes in

@@ -40,7 +40,6 @@ class FastxParser {
     FqState fq_ = FQ_HEADER;
     uint64_t seq_len_ = 0, qual_len_ = 0;
     uint64_t records_ = 0;
-    bool at_record_boundary_ = true;
 };
 
 // reads plain or gzip files (zlib gzread passes plain data through, like `zcat -f`) as one stream

@@ -55,7 +55,7 @@ struct Walker {
     int64_t len, gs, glen, cap;
     SegDev *C;
     uint32_t chunk_id;
-    uint32_t nrec, naux, seqno;
+    uint32_t nrec, naux, seqno, nedit;
     int pass;
     int status;
     uint64_t nlook;
@@ -148,6 +148,13 @@ struct Walker {
         move_gap(a);
         glen += (b - a);
         if (glen < plen) { status = PS_GAP_EXHAUSTED; return; }
+        if (nedit >= C->edit_cap) { status = PS_REC_OVERFLOW; return; }
+        if (lane == 0) {
+            EditRec e;
+            e.a = a; e.plen = (int32_t)plen; e.oldlen = (int32_t)(b - a);
+            C->edits[nedit] = e;
+        }
+        nedit++;
         for (int64_t q = lane; q < plen; q += 64) buf[gs + q] = patch[q];
         gs += plen;
         glen -= plen;
@@ -828,7 +835,7 @@ __global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, 
     Walker w;
     w.T = T; w.k = P.k; w.step = P.step; w.lane = threadIdx.x; w.solid = P.solid;
     w.buf = C->buf; w.len = C->len; w.gs = C->gs; w.glen = C->glen; w.cap = C->cap;
-    w.C = C; w.chunk_id = C->chunk; w.nrec = 0; w.naux = 0; w.seqno = 0; w.pass = pass;
+    w.C = C; w.chunk_id = C->chunk; w.nrec = 0; w.naux = 0; w.seqno = 0; w.nedit = 0; w.pass = pass;
     w.status = PS_OK; w.nlook = 0;
     w.s_tbf = s_tbf; w.s_t1 = s_t1; w.s_t2 = s_t2; w.s_gkb = s_gkb; w.s_gka = s_gka;
     w.delta = 0; w.dirty_end = INT64_MIN / 2; w.glo = P.k;
@@ -843,7 +850,7 @@ __global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, 
     if (threadIdx.x == 0) {
         C->ticks = wall_clock64() - t0;
         C->len = w.len; C->gs = w.gs; C->glen = w.glen;
-        C->nrec = w.nrec; C->naux = w.naux; C->status = w.status; C->spec_fail = w.spec_fail;
+        C->nrec = w.nrec; C->naux = w.naux; C->nedit = w.nedit; C->status = w.status; C->spec_fail = w.spec_fail;
         C->wrong = wrong;
         C->lookups = w.nlook;
     }
@@ -957,15 +964,38 @@ __global__ __launch_bounds__(256) void seg_init_kernel(SegDev *segs, int n_segs,
     }
 }
 
-// write each segment's owned part of the polished text into the chunk's new text
-__global__ __launch_bounds__(256) void seg_stitch_kernel(const SegDev *segs, int n_segs, uint8_t *const *chunk_out) {
+// write each segment's owned part of the polished text into the chunk's new text.  With cls_out it also carries the
+// position classes over: a new position is traced back through the segment's edits (newest first); if it lands in or
+// next to replaced text its 64-position tile is flagged for the rescan, otherwise its old class is copied.
+constexpr uint32_t STITCH_MAX_EDITS = 32;   // beyond this the whole segment is flagged (always safe: flagged = recomputed)
+__global__ __launch_bounds__(256) void seg_stitch_kernel(const SegDev *segs, int n_segs, uint8_t *const *chunk_out, uint8_t *const *cls_out,
+                                                         uint8_t *const *flags) {
     for (int s = blockIdx.y; s < n_segs; s += gridDim.y) {
         const SegDev S = segs[s];
         uint8_t *dst = chunk_out[S.chunk] + S.out_off;
+        uint8_t *cdst = cls_out ? cls_out[S.chunk] + S.out_off : nullptr;
+        uint8_t *fl = cls_out ? flags[S.chunk] : nullptr;
         const int64_t n = S.own_hi - S.own_lo;
+        const bool all_dirty = S.nedit > STITCH_MAX_EDITS;
         for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
             const int64_t p = S.own_lo + q;
             dst[q] = S.buf[p < S.gs ? p : p + S.glen];
+            if (!cdst) continue;
+            int64_t l = p;
+            bool dirty = all_dirty;
+            if (!dirty)
+                for (int e = (int)S.nedit - 1; e >= 0; --e) {
+                    const EditRec E = S.edits[e];
+                    if (l > E.a + E.plen) l -= (int64_t)E.plen - E.oldlen;
+                    else if (l >= E.a - 1) { dirty = true; break; }
+                }
+            if (dirty) {
+                fl[(S.out_off + q) >> 6] = 1;
+                cdst[q] = PC_OTHER;
+            } else {
+                const int64_t old = S.seg_lo + l;
+                cdst[q] = old < S.cls_n ? S.cls[old] : (uint8_t)PC_OTHER;
+            }
         }
     }
 }
@@ -1097,6 +1127,72 @@ __global__ __launch_bounds__(256) void find_sync_batch_kernel(const ScanChunk *_
     }
 }
 
+// Classes next to changed text: one wave per 64-window tile; a tile is recomputed when it or a neighbouring tile holds
+// changed text (k <= 64, so a changed base at P affects the windows P-k+1..P and, through the count k back, up to P+k).
+__global__ __launch_bounds__(256) void rescan_batch_kernel(const ScanChunk *__restrict__ chunks, int n_chunks, TableDev T, uint32_t solid) {
+    __shared__ uint32_t s_cnt[4][128];
+    __shared__ uint8_t s_valid[4][128];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = T.k;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const ScanChunk C = chunks[ci];
+        const int64_t nwin = C.len - k + 1;
+        if (nwin <= 0) continue;
+        const int64_t ntile = (nwin + 63) >> 6, nflag = (C.len >> 6) + 1;
+        for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+            uint8_t f = C.flags[tile];
+            if (tile > 0) f |= C.flags[tile - 1];
+            if (tile + 1 < nflag) f |= C.flags[tile + 1];
+            if (!f) continue;
+            const int64_t base = tile * 64 - 64;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int64_t p = base + r * 64 + lane;
+                uint32_t cnt = 0;
+                uint8_t valid = 0;
+                if (p >= 0 && p < nwin) {
+                    u128 fwd = mk(0, 0);
+                    bool ok = true;
+                    for (int j = 0; j < k; ++j) {
+                        const int c = code(C.text[p + j]);
+                        ok = ok && c >= 0;
+                        fwd = bor(shl(fwd, 2), mk(0, (uint64_t)(c & 3)));
+                    }
+                    if (ok) {
+                        cnt = clamp32(table_get(T, mix(canonical(fwd, k), T.B)));
+                        valid = 1;
+                    }
+                }
+                s_cnt[wave][r * 64 + lane] = cnt;
+                s_valid[wave][r * 64 + lane] = valid;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int64_t p = tile * 64 + lane;
+            if (p < nwin) {
+                const int me = 64 + lane;
+                uint8_t c;
+                if (!s_valid[wave][me]) c = PC_OTHER;
+                else if (s_cnt[wave][me] < solid) c = PC_BAD;
+                else if (p > 0) {
+                    const int qi = p - k > 0 ? me - k : 64;       // window k back, or window 0 (only reachable in tile 0)
+                    c = (!s_valid[wave][qi] || 50ull * s_cnt[wave][me] < (unsigned long long)s_cnt[wave][qi]) ? PC_OTHER : PC_CLEAN;
+                } else c = PC_CLEAN;
+                C.cls[p] = c;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+void launch_rescan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunks, int k, uint32_t solid, hipStream_t stream) {
+    if (n_chunks <= 0) return;
+    const int gy = n_chunks < 1024 ? n_chunks : 1024;
+    const int gx = std::max(1, 4096 / gy);
+    hipLaunchKernelGGL(rescan_batch_kernel, dim3(gx, gy), dim3(256), 0, stream, d_chunks, n_chunks, T, solid);
+    hipLaunchKernelGGL(find_sync_batch_kernel, dim3(gx, gy), dim3(256), 0, stream, d_chunks, n_chunks, k);
+}
+
 void launch_scan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunks, int k, uint32_t solid, hipStream_t stream) {
     if (n_chunks <= 0) return;
     const int gy = n_chunks < 1024 ? n_chunks : 1024;
@@ -1141,10 +1237,11 @@ void launch_seg_gather(const SegDev *d_segs, int n_segs, const int64_t *idx_base
     if (n_segs <= 0) return;
     hipLaunchKernelGGL(seg_gather_kernel, dim3(n_segs), dim3(64), 0, stream, d_segs, n_segs, idx_base, seq_base, rec_off, aux_off, out_recs, out_aux);
 }
-void launch_seg_stitch(const SegDev *d_segs, int n_segs, uint8_t *const *d_chunk_out, hipStream_t stream) {
+void launch_seg_stitch(const SegDev *d_segs, int n_segs, uint8_t *const *d_chunk_out, uint8_t *const *d_cls_out, uint8_t *const *d_flags,
+                       hipStream_t stream) {
     if (n_segs <= 0) return;
     dim3 grid(n_segs >= 512 ? 4 : 64, n_segs < 4096 ? n_segs : 4096);
-    hipLaunchKernelGGL(seg_stitch_kernel, grid, dim3(256), 0, stream, d_segs, n_segs, d_chunk_out);
+    hipLaunchKernelGGL(seg_stitch_kernel, grid, dim3(256), 0, stream, d_segs, n_segs, d_chunk_out, d_cls_out, d_flags);
 }
 
 }  // namespace jk

@@ -53,6 +53,14 @@ struct ScratchPool {
 // that are preceded by >= 4k clean positions.  Whatever stride phase the reference's walk arrives with, it lands inside
 // such a run and handle_bad_kmers() then does the same thing -- so the walk to the right of a sync point does not
 // depend on anything to its left except a coordinate shift, and segments can be walked concurrently.
+// one text replacement of a segment walk, in the segment's local coordinates AT THE TIME of the edit: local
+// [a, a+oldlen) became plen new bytes.  The stitch step replays the list backwards to carry the position classes of
+// untouched windows over to the next pass instead of recomputing them.
+struct EditRec {
+    int64_t a;
+    int32_t plen, oldlen;
+};
+
 struct SegDev {
     uint8_t *buf;        // gap buffer holding a private copy of the segment's text (local coordinates)
     int64_t cap;
@@ -69,6 +77,8 @@ struct SegDev {
     uint32_t rec_cap, nrec;
     uint8_t *aux;
     uint32_t aux_cap, naux;
+    EditRec *edits;
+    uint32_t edit_cap, nedit;
     uint32_t chunk;
     int32_t status;
     int32_t spec_fail;   // the walk touched text outside what the segment may assume -> redo the chunk unsegmented
@@ -99,8 +109,12 @@ struct ScanChunk {
     unsigned int *cand_count;
     unsigned int cand_cap;
     int32_t want_sync;
+    const uint8_t *flags;   // one byte per 64 text positions: the previous pass changed text there (rescan only)
 };
+// pass 0: dense scan + classes + sync-point candidates of every chunk
 void launch_scan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunks, int k, uint32_t solid, hipStream_t stream);
+// later passes: classes were carried over by the stitch; recompute the 64-window tiles next to changed text, then candidates
+void launch_rescan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunks, int k, uint32_t solid, hipStream_t stream);
 
 // dense scan of one contiguous text: count of every window (0xFFFFFFFF clamp as in lookups) + validity
 void launch_scan(const TableDev &T, const uint8_t *d_text, int64_t len, uint32_t *d_cnt, uint8_t *d_valid, hipStream_t stream);
@@ -110,7 +124,9 @@ void launch_find_sync(const uint8_t *d_cls, int64_t nwin, int k, int64_t *d_out,
                       hipStream_t stream);
 void launch_seg_init(SegDev *d_segs, int n_segs, const uint8_t *const *d_chunk_text, hipStream_t stream);
 void launch_seg_walk(const TableDev &T, SegDev *d_segs, int n_segs, PolishParams pp, int pass, ScratchPool pool, hipStream_t stream);
-void launch_seg_stitch(const SegDev *d_segs, int n_segs, uint8_t *const *d_chunk_out, hipStream_t stream);
+// d_cls_out / d_flags may be null (last pass): then only the text is stitched
+void launch_seg_stitch(const SegDev *d_segs, int n_segs, uint8_t *const *d_chunk_out, uint8_t *const *d_cls_out, uint8_t *const *d_flags,
+                       hipStream_t stream);
 void launch_seg_gather(const SegDev *d_segs, int n_segs, const int64_t *idx_base, const uint32_t *seq_base, const uint32_t *rec_off,
                        const uint32_t *aux_off, FixRec *out_recs, uint8_t *out_aux, hipStream_t stream);
 

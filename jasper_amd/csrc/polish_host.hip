@@ -56,9 +56,9 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     const double t_begin = now();
     // ---------------- layout ----------------
     std::vector<int64_t> len(lens, lens + n_chunks), cap(n_chunks);
-    std::vector<size_t> off_text(n_chunks), off_pos(n_chunks), off_cand(n_chunks);
+    std::vector<size_t> off_text(n_chunks), off_pos(n_chunks), off_cand(n_chunks), off_flag(n_chunks);
     std::vector<uint32_t> cand_cap(n_chunks);
-    size_t text_bytes = 0, pos_items = 0, cand_items = 0, seg_text_bound = 0, seg_rec_bound = 0, seg_aux_bound = 0;
+    size_t text_bytes = 0, pos_items = 0, cand_items = 0, flag_items = 0, seg_text_bound = 0, seg_rec_bound = 0, seg_aux_bound = 0;
     int64_t max_segs = 0;
     for (int c = 0; c < n_chunks; ++c) {
         cap[c] = len[c] + std::max<int64_t>(4096, len[c] / 8) + 64;
@@ -66,6 +66,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         off_pos[c] = pos_items;    pos_items += al256((size_t)cap[c]);
         cand_cap[c] = (uint32_t)std::min<int64_t>(1 << 28, cap[c] / (4 * k) + 16);
         off_cand[c] = cand_items;  cand_items += cand_cap[c];
+        off_flag[c] = flag_items;  flag_items += al256((size_t)(cap[c] >> 6) + 2);
         const int64_t ms = cap[c] / TMIN + 2;
         max_segs += ms;
         const int64_t tb = cap[c] + ms * (W + M + 64);
@@ -73,22 +74,18 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         seg_rec_bound += (size_t)(2 * tb / k + 16 * ms);
         seg_aux_bound += (size_t)(2 * tb + 1024 * ms);
     }
-    DevBuf b_textA, b_textB, b_cnt, b_valid, b_cls, b_cand, b_ccount, b_ptrA, b_ptrB, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks, b_scan;
+    DevBuf b_textA, b_textB, b_cnt, b_valid, b_cls, b_clsB, b_flags, b_ptrCA, b_ptrCB, b_ptrF, b_segedit, b_cand, b_ccount, b_ptrA, b_ptrB, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks, b_scan;
     int ws_next = 0;
     auto dmalloc = [&](DevBuf &b, size_t bytes) -> bool {      // persistent: slot of the table's workspace
-        if (ws_next >= 24) { err = "polish: workspace slots exhausted"; return false; }
+        if (ws_next >= Table::WS_POLISH_MAX) { err = "polish: workspace slots exhausted"; return false; }
         b.p = T.workspace(ws_next++, bytes, err);
         b.owned = false;
         return b.p != nullptr;
     };
-    auto tmalloc = [&](DevBuf &b, size_t bytes) -> bool {      // per-pass temporary
-        hipError_t e = hipMalloc(&b.p, bytes ? bytes : 256);
-        b.owned = true;
-        if (e != hipSuccess) { b.p = nullptr; err = std::string("polish: device allocation failed: ") + hipGetErrorString(e); return false; }
-        return true;
-    };
     if (!dmalloc(b_textA, text_bytes) || !dmalloc(b_textB, text_bytes) || !dmalloc(b_cnt, pos_items * 4) || !dmalloc(b_valid, pos_items) ||
-        !dmalloc(b_cls, pos_items) || !dmalloc(b_cand, cand_items * 8) || !dmalloc(b_ccount, n_chunks * 4) ||
+        !dmalloc(b_cls, pos_items) || !dmalloc(b_clsB, pos_items) || !dmalloc(b_flags, flag_items) ||
+        !dmalloc(b_ptrCA, n_chunks * sizeof(void *)) || !dmalloc(b_ptrCB, n_chunks * sizeof(void *)) || !dmalloc(b_ptrF, n_chunks * sizeof(void *)) ||
+        !dmalloc(b_segedit, seg_rec_bound * sizeof(EditRec)) || !dmalloc(b_cand, cand_items * 8) || !dmalloc(b_ccount, n_chunks * 4) ||
         !dmalloc(b_ptrA, n_chunks * sizeof(void *)) || !dmalloc(b_ptrB, n_chunks * sizeof(void *)) ||
         !dmalloc(b_segs, (size_t)max_segs * sizeof(SegDev)) || !dmalloc(b_segtext, seg_text_bound) ||
         !dmalloc(b_segrec, seg_rec_bound * sizeof(FixRec)) || !dmalloc(b_segaux, seg_aux_bound))
@@ -107,15 +104,23 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     HIPCHK(hipMemsetAsync(pool.locks, 0, pool.nslots * 4, st));
 
     uint8_t *textIn = b_textA.as<uint8_t>(), *textOut = b_textB.as<uint8_t>();
-    std::vector<uint8_t *> hptrA(n_chunks), hptrB(n_chunks);
+    uint8_t *clsIn = b_cls.as<uint8_t>(), *clsOut = b_clsB.as<uint8_t>();
+    std::vector<uint8_t *> hptrA(n_chunks), hptrB(n_chunks), hptrCA(n_chunks), hptrCB(n_chunks), hptrF(n_chunks);
     for (int c = 0; c < n_chunks; ++c) {
         hptrA[c] = b_textA.as<uint8_t>() + off_text[c];
         hptrB[c] = b_textB.as<uint8_t>() + off_text[c];
+        hptrCA[c] = b_cls.as<uint8_t>() + off_pos[c];
+        hptrCB[c] = b_clsB.as<uint8_t>() + off_pos[c];
+        hptrF[c] = b_flags.as<uint8_t>() + off_flag[c];
         if (len[c]) HIPCHK(hipMemcpyAsync(hptrA[c], seqs[c], (size_t)len[c], hipMemcpyHostToDevice, st));
     }
     HIPCHK(hipMemcpyAsync(b_ptrA.p, hptrA.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b_ptrB.p, hptrB.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b_ptrCA.p, hptrCA.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b_ptrCB.p, hptrCB.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b_ptrF.p, hptrF.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
     uint8_t **ptrIn = b_ptrA.as<uint8_t *>(), **ptrOut = b_ptrB.as<uint8_t *>();
+    uint8_t **ptrClsIn = b_ptrCA.as<uint8_t *>(), **ptrClsOut = b_ptrCB.as<uint8_t *>();
 
     if (dbg) { (void)jk_stream_wait(st); fprintf(stderr, "[polish] setup + H2D: %.2f ms\n", now() - t_begin); }
     const double t_loop = now();
@@ -142,7 +147,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     int rc = 0;
 
     for (int pass = 0; pass <= passes && rc == 0; ++pass) {                                   // src/jasper.py:25
-        // ---- 1. dense scan, classes, sync-point candidates
+        // ---- 1. position classes + sync-point candidates: a dense scan in pass 0; afterwards the stitch has carried the
+        //         classes of untouched windows over and only the tiles next to changed text are recomputed
         HIPCHK(hipMemsetAsync(b_ccount.p, 0, n_chunks * 4, st));
         {
             for (int c = 0; c < n_chunks; ++c) {
@@ -151,14 +157,16 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                 S.len = len[c];
                 S.cnt = b_cnt.as<uint32_t>() + off_pos[c];
                 S.valid = b_valid.as<uint8_t>() + off_pos[c];
-                S.cls = b_cls.as<uint8_t>() + off_pos[c];
+                S.cls = clsIn + off_pos[c];
+                S.flags = b_flags.as<uint8_t>() + off_flag[c];
                 S.cand = b_cand.as<int64_t>() + off_cand[c];
                 S.cand_count = b_ccount.as<unsigned int>() + c;
                 S.cand_cap = cand_cap[c];
                 S.want_sync = (len[c] - k + 1) > 2 * TMIN;
             }
             HIPCHK(hipMemcpyAsync(b_scan.p, sc.data(), sizeof(ScanChunk) * n_chunks, hipMemcpyHostToDevice, st));
-            launch_scan_batch(T.d, b_scan.as<ScanChunk>(), n_chunks, k, pp.solid, st);
+            if (pass == 0) launch_scan_batch(T.d, b_scan.as<ScanChunk>(), n_chunks, k, pp.solid, st);
+            else launch_rescan_batch(T.d, b_scan.as<ScanChunk>(), n_chunks, k, pp.solid, st);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ccount.data(), b_ccount.p, n_chunks * 4, hipMemcpyDeviceToHost, st));
@@ -195,12 +203,14 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                     S.cap = S.len0 + std::max<int64_t>(1024, S.len0 / 8);
                     S.gs = 0;
                     S.glen = S.cap - S.len0;
-                    S.cls = (len[c] - k + 1 > 0) ? b_cls.as<uint8_t>() + off_pos[c] : nullptr;
+                    S.cls = (len[c] - k + 1 > 0) ? clsIn + off_pos[c] : nullptr;
                     S.cls_n = std::max<int64_t>(0, len[c] - k + 1);
                     S.rec_cap = (uint32_t)std::min<int64_t>(0x7fffffff, 2 * S.len0 / k + 16);
                     S.aux_cap = (uint32_t)std::min<int64_t>(0x7fffffff, 2 * S.len0 + 1024);
                     S.buf = b_segtext.as<uint8_t>() + tpos;            tpos += al256((size_t)S.cap);
-                    S.recs = b_segrec.as<FixRec>() + rpos;             rpos += S.rec_cap;
+                    S.recs = b_segrec.as<FixRec>() + rpos;
+                    S.edits = b_segedit.as<EditRec>() + rpos;          // one edit list entry per possible record
+                    S.edit_cap = S.rec_cap;                            rpos += S.rec_cap;
                     S.aux = b_segaux.as<uint8_t>() + apos;             apos += al256(S.aux_cap);
                     // owned part of the text: chunk coordinates [B_j, B_{j+1}), B = sync - 2k
                     S.own_lo = j == 0 ? 0 : 2ll * k;                   // local (no edit can precede it)
@@ -250,7 +260,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             size_t t2 = tpos, r2 = rpos, a2 = apos;
             for (SegDev &S : redo_segs) {
                 S.buf = b_segtext.as<uint8_t>() + t2;  t2 += al256((size_t)S.cap);
-                S.recs = b_segrec.as<FixRec>() + r2;   r2 += S.rec_cap;
+                S.recs = b_segrec.as<FixRec>() + r2;
+                S.edits = b_segedit.as<EditRec>() + r2; r2 += S.rec_cap;
                 S.aux = b_segaux.as<uint8_t>() + a2;   a2 += al256(S.aux_cap);
             }
             if (t2 > seg_text_bound || r2 > seg_rec_bound || a2 > seg_aux_bound) {
@@ -348,11 +359,16 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             if (naux_pass) HIPCHK(hipMemcpyAsync(aux_pass.back().data(), d_aux.p, naux_pass, hipMemcpyDeviceToHost, st));
             HIPCHK(jk_stream_wait(st));
         }
-        launch_seg_stitch(b_segs.as<SegDev>(), (int)ns, (uint8_t *const *)ptrOut, st);
+        const bool carry = pass < passes;           // another pass follows: carry the classes over, flag changed text
+        if (carry) HIPCHK(hipMemsetAsync(b_flags.p, 0, flag_items, st));
+        launch_seg_stitch(b_segs.as<SegDev>(), (int)ns, (uint8_t *const *)ptrOut, carry ? (uint8_t *const *)ptrClsOut : nullptr,
+                          carry ? (uint8_t *const *)b_ptrF.as<uint8_t *>() : nullptr, st);
         HIPCHK(hipGetLastError());
         for (int c = 0; c < n_chunks; ++c) len[c] = newlen[c];
         std::swap(textIn, textOut);
         std::swap(ptrIn, ptrOut);
+        std::swap(clsIn, clsOut);
+        std::swap(ptrClsIn, ptrClsOut);
     }
     if (dbg) { (void)jk_stream_wait(st); fprintf(stderr, "[polish] passes: %.2f ms\n", now() - t_loop); }
     const double t_out = now();

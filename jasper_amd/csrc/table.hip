@@ -560,7 +560,7 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             mem_have = free_b;
-            for (int w = 26; w <= 29; ++w) mem_have += ws[w].bytes;
+            for (int w = WS_COUNT; w < WS_COUNT + 4; ++w) mem_have += ws[w].bytes;
         }
     }
     const bool dbg = getenv("JASPER_COUNT_DEBUG") != nullptr;
