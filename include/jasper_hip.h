@@ -98,8 +98,17 @@ int jasper_table_reserve(jasper_table *t, uint64_t min_slots);
 /* one batch of chunk records through `passes` fixing passes + the final QV pass (src/jasper.py:25-26) */
 int jasper_polish_batch(jasper_table *t, int n_chunks, const char *const *seqs, const int64_t *lens,
                         int solid_thre, int passes, int fix, jasper_result **out);
+/* the same with the chunk records already in HBM on the table's device (chunk c = d_text[offsets[c] .. offsets[c+1]),
+ * offsets is a host array of n_chunks+1 entries).  The polished text is left in HBM: jasper_result_seq_device points at
+ * it, jasper_result_seq copies it to the host on first use.  It lies in the table's workspace, so the library copies it
+ * to the host by itself before the next polish call on the same table (or jasper_table_destroy) would overwrite it;
+ * after that jasper_result_seq_device fails and jasper_result_seq still works. */
+int jasper_polish_batch_device(jasper_table *t, int n_chunks, const void *d_text, const int64_t *offsets,
+                               int solid_thre, int passes, int fix, jasper_result **out);
 int jasper_result_num_chunks(const jasper_result *r);
 int jasper_result_seq(const jasper_result *r, int chunk, const char **seq, int64_t *len);
+int jasper_result_seq_len(const jasper_result *r, int chunk, int64_t *len);
+int jasper_result_seq_device(const jasper_result *r, int chunk, const void **d_seq, int64_t *len);
 int jasper_result_records(const jasper_result *r, const jasper_fixrec **recs, uint64_t *n);
 int jasper_result_aux(const jasper_result *r, int chunk, const char **aux, uint64_t *n);
 int jasper_result_qv(const jasper_result *r, int64_t out4[4]); /* bad0,total0,badP,totalP  (src/jasper.py:107-111) */

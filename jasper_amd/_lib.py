@@ -51,7 +51,10 @@ SYMBOLS = {
     "jasper_table_reserve": (C.c_int, [_P, C.c_uint64]),
     "jasper_polish_batch": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "jasper_result_num_chunks": (C.c_int, [_P]),
+    "jasper_polish_batch_device": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "jasper_result_seq": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "jasper_result_seq_len": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
+    "jasper_result_seq_device": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "jasper_result_records": (C.c_int, [_P, C.POINTER(C.POINTER(FixRec)), C.POINTER(C.c_uint64)]),
     "jasper_result_aux": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "jasper_result_qv": (C.c_int, [_P, C.POINTER(C.c_int64)]),

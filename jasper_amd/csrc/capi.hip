@@ -13,11 +13,16 @@ using namespace jk;
 
 static thread_local std::string g_err;
 
+struct jasper_result;
 struct jasper_table {
     Table t;
+    jasper_result *pending = nullptr;   // result whose polished text still lies in this table's workspace
 };
 
 struct jasper_result {
+    jasper_table *owner = nullptr;       // non-null while the text is on the device
+    std::vector<const uint8_t *> d_seqs;
+    std::vector<int64_t> d_lens;
     std::vector<std::string> seqs;
     std::vector<jasper_fixrec> recs;
     std::vector<std::string> aux;
@@ -28,6 +33,23 @@ struct jasper_result {
 };
 
 static_assert(sizeof(jasper_fixrec) == sizeof(FixRec), "public and device record layouts must match");
+
+// copy a device-resident result's text to the host (before its workspace is reused, or when the caller asks for it)
+static int result_fetch(jasper_result *r) {
+    if (!r->owner) return JASPER_OK;
+    jasper_table *t = r->owner;
+    Table &T = t->t;
+    hipError_t e = hipSetDevice(T.device);
+    for (size_t c = 0; c < r->d_seqs.size() && e == hipSuccess; ++c) {
+        r->seqs[c].resize((size_t)r->d_lens[c]);
+        if (r->d_lens[c]) e = hipMemcpyAsync(&r->seqs[c][0], r->d_seqs[c], (size_t)r->d_lens[c], hipMemcpyDeviceToHost, T.stream);
+    }
+    if (e == hipSuccess) e = jk_stream_wait(T.stream);
+    if (t->pending == r) t->pending = nullptr;
+    r->owner = nullptr;
+    if (e != hipSuccess) { g_err = std::string("fetching polished text: ") + hipGetErrorString(e); return JASPER_ERR; }
+    return JASPER_OK;
+}
 
 #define CHK(x)                                                        \
     do {                                                              \
@@ -73,6 +95,7 @@ int jasper_table_load_jf(const char *path, int device, jasper_table **out) {
 
 void jasper_table_destroy(jasper_table *t) {
     if (!t) return;
+    if (t->pending) (void)result_fetch(t->pending);   // a live result must not lose its text with the table
     t->t.destroy();
     delete t;
 }
@@ -212,17 +235,18 @@ int jasper_table_import(jasper_table *t, const uint64_t *host_entries, uint64_t 
 // ---------------------------------------------------------------------------------------------------
 // polishing (host orchestration in polish_host.hip)
 // ---------------------------------------------------------------------------------------------------
-int jasper_polish_batch(jasper_table *t, int n_chunks, const char *const *seqs, const int64_t *lens, int solid_thre,
-                        int passes, int fix, jasper_result **out) {
+static int polish_common(jasper_table *t, int n_chunks, const char *const *seqs, const int64_t *lens, int solid_thre, int passes, int fix,
+                         bool device_io, jasper_result **out) {
     Table &T = t->t;
     if (T.k < 6) { g_err = "polishing needs k >= 6"; return JASPER_ERR; }
     if (passes < 0 || passes > 200) { g_err = "bad number of passes"; return JASPER_ERR; }
     if (solid_thre < 0) { g_err = "bad threshold"; return JASPER_ERR; }
     if (n_chunks < 0 || !out) { g_err = "bad arguments"; return JASPER_ERR; }
+    if (t->pending && result_fetch(t->pending)) return JASPER_ERR;     // its text is about to be overwritten
     jasper_result *R = new jasper_result();
     *out = R;
     PolishOut po;
-    const int rc = run_polish(T, n_chunks, seqs, lens, solid_thre, passes, fix, po, g_err);
+    const int rc = run_polish(T, n_chunks, seqs, lens, solid_thre, passes, fix, po, g_err, device_io, device_io);
     R->seqs.swap(po.seqs);
     R->aux.swap(po.aux);
     R->recs.resize(po.recs.size());
@@ -232,16 +256,53 @@ int jasper_polish_batch(jasper_table *t, int n_chunks, const char *const *seqs, 
     R->seconds = po.seconds;
     R->n_segments = po.n_segments;
     R->n_respeculated = po.n_respeculated;
+    if (rc == 0 && device_io) {
+        R->d_seqs.swap(po.d_seqs);
+        R->d_lens.swap(po.d_lens);
+        R->owner = t;
+        t->pending = R;
+    }
     if (rc == -4) return JASPER_ERR_REFERENCE_EXIT;
     if (rc == -2) return JASPER_ERR_CAPACITY;
     return rc ? JASPER_ERR : JASPER_OK;
 }
 
+int jasper_polish_batch(jasper_table *t, int n_chunks, const char *const *seqs, const int64_t *lens, int solid_thre,
+                        int passes, int fix, jasper_result **out) {
+    return polish_common(t, n_chunks, seqs, lens, solid_thre, passes, fix, false, out);
+}
+
+int jasper_polish_batch_device(jasper_table *t, int n_chunks, const void *d_text, const int64_t *offsets, int solid_thre,
+                               int passes, int fix, jasper_result **out) {
+    if (n_chunks < 0 || (n_chunks && (!d_text || !offsets))) { g_err = "bad arguments"; return JASPER_ERR; }
+    std::vector<const char *> ptrs((size_t)n_chunks);
+    std::vector<int64_t> lens((size_t)n_chunks);
+    for (int c = 0; c < n_chunks; ++c) {
+        if (offsets[c + 1] < offsets[c]) { g_err = "offsets must not decrease"; return JASPER_ERR; }
+        ptrs[c] = (const char *)d_text + offsets[c];
+        lens[c] = offsets[c + 1] - offsets[c];
+    }
+    return polish_common(t, n_chunks, ptrs.data(), lens.data(), solid_thre, passes, fix, true, out);
+}
+
 int jasper_result_num_chunks(const jasper_result *r) { return (int)r->seqs.size(); }
 int jasper_result_seq(const jasper_result *r, int chunk, const char **seq, int64_t *len) {
     if (chunk < 0 || chunk >= (int)r->seqs.size()) { g_err = "chunk out of range"; return JASPER_ERR; }
+    if (r->owner && result_fetch(const_cast<jasper_result *>(r))) return JASPER_ERR;
     *seq = r->seqs[chunk].data();
     *len = (int64_t)r->seqs[chunk].size();
+    return JASPER_OK;
+}
+int jasper_result_seq_len(const jasper_result *r, int chunk, int64_t *len) {
+    if (chunk < 0 || chunk >= (int)r->seqs.size()) { g_err = "chunk out of range"; return JASPER_ERR; }
+    *len = r->owner ? r->d_lens[chunk] : (int64_t)r->seqs[chunk].size();
+    return JASPER_OK;
+}
+int jasper_result_seq_device(const jasper_result *r, int chunk, const void **d_seq, int64_t *len) {
+    if (chunk < 0 || chunk >= (int)r->seqs.size()) { g_err = "chunk out of range"; return JASPER_ERR; }
+    if (!r->owner) { g_err = "the polished text of this result is no longer on the device"; return JASPER_ERR; }
+    *d_seq = r->d_seqs[chunk];
+    *len = r->d_lens[chunk];
     return JASPER_OK;
 }
 int jasper_result_records(const jasper_result *r, const jasper_fixrec **recs, uint64_t *n) {
@@ -266,6 +327,9 @@ int jasper_result_segments(const jasper_result *r, uint64_t *n_segments, uint64_
     if (n_respeculated) *n_respeculated = r->n_respeculated;
     return JASPER_OK;
 }
-void jasper_result_free(jasper_result *r) { delete r; }
+void jasper_result_free(jasper_result *r) {
+    if (r && r->owner && r->owner->pending == r) r->owner->pending = nullptr;
+    delete r;
+}
 
 }  // extern "C"

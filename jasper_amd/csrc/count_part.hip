@@ -164,15 +164,20 @@ __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__rest
         for (int j = 0; j < PT_GROUP; ++j)
             if (br[j] != 0xFFFFFFFFu) s_stage[s_off[br[j] >> 16] + (br[j] & 0xFFFFu)] = rec[j];
         __syncthreads();
-        // D. copy out: element e belongs to the bucket b with s_off[b] <= e < s_off[b+1]
-        const unsigned int total = s_off[nb];
-        for (unsigned int e = t; e < total; e += PT_THREADS) {
-            int lo = 0, hi = nb - 1;                                         // largest b with s_off[b] <= e
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= e) lo = mid; else hi = mid - 1; }
-            const unsigned int pos = s_cur[lo] + (e - s_off[lo]);
-            const uint64_t r = s_stage[e];
-            if (pos < G.cap1) out1[((uint64_t)lo * G.nblk1 + blockIdx.x) * G.cap1 + pos] = r;
-            else defer_record(T, hash_of((uint64_t)lo, r, G.recbits), deferred, deferred_n, deferred_cap);   // slice full
+        // D. copy out, one bucket per 16 lanes: a tile holds ~16 records per bucket, so a 16-lane group writes one
+        //    128-B run of its bucket's slice per round (three LDS reads per bucket instead of a binary search per record)
+        {
+            const int g16 = t >> 4, r16 = t & 15;
+            for (int b = g16; b < nb; b += PT_THREADS / 16) {
+                const unsigned int off = s_off[b], cnt = s_cnt[b], cur = s_cur[b];
+                uint64_t *dst = out1 + ((uint64_t)b * G.nblk1 + blockIdx.x) * G.cap1;
+                for (unsigned int q = r16; q < cnt; q += 16) {
+                    const unsigned int pos = cur + q;
+                    const uint64_t r = s_stage[off + q];
+                    if (pos < G.cap1) dst[pos] = r;
+                    else defer_record(T, hash_of((uint64_t)b, r, G.recbits), deferred, deferred_n, deferred_cap);   // slice full
+                }
+            }
         }
         __syncthreads();
         if (t < nb) { s_cur[t] += s_cnt[t]; s_cnt[t] = 0; }

@@ -103,22 +103,43 @@ JK_HD u128 canonical(u128 m, int k) {
 }
 
 // ---- bijective mixing of a B-bit key (B = 2k, even, <= 128) -------------------------------------
-// Two rounds of (odd multiply mod 2^B, xor-shift by B/2). Both steps are bijections on B-bit values, so
-// the table stores only the part of the hash that the slot index does not imply.
-// (Same idea as Jellyfish's invertible GF(2) matrix, JF::include/jellyfish/rectangular_binary_matrix.hpp,
-// but a different function: integer multiply-shift suits the GPU's ALUs, a 2k x 2k bit matrix does not.)
-#define JK_C1_HI 0x9E3779B97F4A7C15ull
-#define JK_C1_LO 0xF39CC0605CEDC835ull
-#define JK_C2_HI 0xC2B2AE3D27D4EB4Full
-#define JK_C2_LO 0x165667B19E3779F9ull
+// The table stores only the part of the hash that the slot index does not imply, so the mix must be a bijection on
+// B-bit values.  (Same idea as Jellyfish's invertible GF(2) matrix, JF::include/jellyfish/rectangular_binary_matrix.hpp,
+// but a different function: 64-bit multiply-shift suits the GPU's ALUs, a 2k x 2k bit matrix does not.)
+//   B <= 64: two rounds of (odd multiply mod 2^B, xor-shift by B/2) -- each step is invertible on B bits.
+//   B >  64: one Feistel step over (hi: B-64 bits, lo: 64 bits): lo' = mix64(lo), hi' = hi ^ top_bits(lo' * C3).
+//            lo -> lo' is a bijection and hi' is recoverable from (hi', lo'), so the pair is a bijection; keys that
+//            differ only in hi get different TOP hash bits (far-apart home slots), keys that differ in lo get
+//            independent lo'.  Three 64-bit multiplies instead of two 128-bit ones: hashing is ALU-bound in part1.
+#define JK_C1 0x9E3779B97F4A7C15ull
+#define JK_C2 0xBF58476D1CE4E5B9ull
+#define JK_C3 0x94D049BB133111EBull
+
+JK_HD uint64_t mix64(uint64_t x) {
+    x ^= x >> 32;
+    x *= JK_C1;
+    x ^= x >> 29;
+    x *= JK_C2;
+    x ^= x >> 32;
+    return x;
+}
 
 JK_HD u128 mix(u128 x, int B) {
-    const u128 m = maskbits(B);
-    x = band(mul(x, mk(JK_C1_HI, JK_C1_LO)), m);
-    x = bxor(x, shr(x, B / 2));
-    x = band(mul(x, mk(JK_C2_HI, JK_C2_LO)), m);
-    x = bxor(x, shr(x, B / 2));
-    return x;
+    if (B <= 64) {
+        const uint64_t m = B == 64 ? ~0ull : ((1ull << B) - 1);
+        const int h = B / 2;
+        uint64_t v = x.lo & m;
+        v = (v * JK_C1) & m;
+        v ^= v >> h;
+        v = (v * JK_C2) & m;
+        v ^= v >> h;
+        return mk(0, v);
+    }
+    const int hb = B - 64;                                   // 2..64
+    const uint64_t lo = mix64(x.lo);
+    const uint64_t f = (lo * JK_C3) >> (64 - hb);
+    const uint64_t hm = hb == 64 ? ~0ull : ((1ull << hb) - 1);
+    return mk((x.hi ^ f) & hm, lo);
 }
 
 // ---- slot word ------------------------------------------------------------------------------------

@@ -33,7 +33,7 @@ struct DevBuf {  // a slot of the table's grow-only workspace (not owned) or a t
 }  // namespace
 
 int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *lens, int solid_thre, int passes, int fix,
-               PolishOut &R, std::string &err) {
+               PolishOut &R, std::string &err, bool device_in, bool keep_on_device) {
     const int k = T.k;
     const int64_t W = 4ll * k;        // clean window required left of a sync point
     const int64_t M = 3ll * k;        // text kept right of the next sync point
@@ -42,6 +42,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     HIPCHK(hipSetDevice(T.device));
     if (T.materialize(err)) return -1;
     R.seqs.assign(n_chunks, std::string());
+    R.d_seqs.clear();
+    R.d_lens.clear();
     R.aux.assign(n_chunks, std::string());
     R.recs.clear();
     R.qv[0] = R.qv[1] = R.qv[2] = R.qv[3] = 0;
@@ -112,7 +114,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         hptrCA[c] = b_cls.as<uint8_t>() + off_pos[c];
         hptrCB[c] = b_clsB.as<uint8_t>() + off_pos[c];
         hptrF[c] = b_flags.as<uint8_t>() + off_flag[c];
-        if (len[c]) HIPCHK(hipMemcpyAsync(hptrA[c], seqs[c], (size_t)len[c], hipMemcpyHostToDevice, st));
+        if (len[c]) HIPCHK(hipMemcpyAsync(hptrA[c], seqs[c], (size_t)len[c], device_in ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     }
     HIPCHK(hipMemcpyAsync(b_ptrA.p, hptrA.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b_ptrB.p, hptrB.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
@@ -374,8 +376,13 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     const double t_out = now();
     if (rc == 0) {
         HIPCHK(hipEventRecord(ev1, st));
-        // ---- results to the host
-        for (int c = 0; c < n_chunks; ++c) {
+        // ---- results to the host (or left where they are)
+        if (keep_on_device) {
+            R.d_seqs.resize(n_chunks);
+            R.d_lens.assign(len.begin(), len.end());
+            for (int c = 0; c < n_chunks; ++c) R.d_seqs[c] = textIn + off_text[c];
+        }
+        for (int c = 0; c < n_chunks && !keep_on_device; ++c) {
             R.seqs[c].resize((size_t)len[c]);
             if (len[c]) HIPCHK(hipMemcpyAsync(&R.seqs[c][0], textIn + off_text[c], (size_t)len[c], hipMemcpyDeviceToHost, st));
         }

@@ -7,7 +7,9 @@
 namespace jk {
 
 struct PolishOut {
-    std::vector<std::string> seqs;   // polished chunk texts, batch order
+    std::vector<std::string> seqs;   // polished chunk texts, batch order (empty strings while the text is kept in HBM)
+    std::vector<const uint8_t *> d_seqs;   // keep_on_device: where each polished chunk lies in the table's workspace
+    std::vector<int64_t> d_lens;
     std::vector<FixRec> recs;        // ordered by chunk, pass, emission; index in chunk coordinates
     std::vector<std::string> aux;    // per chunk: bytes referenced by its 'x' records
     int64_t qv[4];                   // bad0, total0, badP, totalP   (src/jasper.py:107-111)
@@ -18,7 +20,9 @@ struct PolishOut {
 };
 
 // returns 0, -1 (HIP error), -2 (capacity), -4 (the reference itself would exit 1)
+// seqs[c] are host pointers, or device pointers when `device_in`.  With `keep_on_device` the polished text is not copied
+// to the host: R.d_seqs/d_lens point into the table's workspace, valid until the next run_polish on the same table.
 int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *lens, int solid_thre, int passes, int fix,
-               PolishOut &R, std::string &err);
+               PolishOut &R, std::string &err, bool device_in = false, bool keep_on_device = false);
 
 }  // namespace jk

@@ -48,10 +48,17 @@ class PolishResult:
         return memoryview((C.c_char * ln.value).from_address(p.value)).cast("B")
 
     def seq_len(self, i):
+        ln = C.c_int64(0)
+        check(self._L.jasper_result_seq_len(self._h, i, C.byref(ln)))
+        return ln.value
+
+    def seq_device(self, i):
+        """(device pointer, length) of polished chunk i while the text is still in HBM (polish_batch_device results, until
+        the next polish call on the same table or the first host access)"""
         p = C.c_void_p()
         ln = C.c_int64(0)
-        check(self._L.jasper_result_seq(self._h, i, C.byref(p), C.byref(ln)))
-        return ln.value
+        check(self._L.jasper_result_seq_device(self._h, i, C.byref(p), C.byref(ln)))
+        return (p.value or 0), ln.value
 
     @property
     def seqs(self):
@@ -249,6 +256,20 @@ class KmerTable:
         lens = (C.c_int64 * max(n, 1))(*[len(b) for b in bs])
         res = C.c_void_p()
         rc = self._L.jasper_polish_batch(self._h, n, cs, lens, int(solid_thre), int(passes), 1 if fix else 0, C.byref(res))
+        return self._wrap_result(rc, res, n, want_str)
+
+    def polish_batch_device(self, d_text, offsets, solid_thre, passes, fix=True):
+        """chunk records already in HBM: d_text is a device pointer (int) or an object with .data_ptr() holding the chunk
+        texts back to back, offsets the n+1 chunk boundaries.  The polished text stays in HBM (PolishResult.seq_device)
+        and is copied to the host on first use of seq_view / seqs."""
+        n = len(offsets) - 1
+        ptr = d_text.data_ptr() if hasattr(d_text, "data_ptr") else int(d_text)
+        offs = (C.c_int64 * (n + 1))(*[int(o) for o in offsets])
+        res = C.c_void_p()
+        rc = self._L.jasper_polish_batch_device(self._h, n, C.c_void_p(ptr), offs, int(solid_thre), int(passes), 1 if fix else 0, C.byref(res))
+        return self._wrap_result(rc, res, n, False)
+
+    def _wrap_result(self, rc, res, n, want_str):
         try:
             check(rc)
             import numpy as np

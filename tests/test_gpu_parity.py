@@ -259,3 +259,42 @@ def test_properties_at_scale(KT):
             delta += len(r["patch"]) - len(r["orig"])
     assert sum(len(s) for s in res.seqs) - sum(len(s) for s in seqs) == delta
     t.close()
+
+
+def test_polish_device_resident_equals_host_call(KT, O):
+    """jasper_polish_batch_device (chunk records and polished text in HBM) gives what jasper_polish_batch gives, which
+    the oracle checks; its text survives the next polish call on the same table (fetched to the host before reuse)"""
+    import torch
+    k = 31
+    genome, reads, asm = workload(41, 400_000, k, asm_err=2e-3)
+    t = KT(k, min_slots=1 << 20)
+    t.count_bases(reads)
+    bs = 90_000
+    recs = synth.chunk_records("c", len(asm), bs)
+    seqs = [asm[a:b].encode() for _, a, b in recs] + [b"", asm[:k - 1].encode()]
+    offs = [0]
+    for s in seqs:
+        offs.append(offs[-1] + len(s))
+    d = torch.frombuffer(bytearray(b"".join(seqs)), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    rh = t.polish_batch(seqs, 3, 2)
+    rd = t.polish_batch_device(d, offs, 3, 2)
+    assert [rd.seq_len(i) for i in range(len(seqs))] == [len(s) for s in rh.seqs]
+    # still in HBM: read it back through torch from the device pointer the result reports
+    p0, n0 = rd.seq_device(0)
+    assert n0 == len(rh.seqs[0]) and p0
+    # a second call on the same table reuses the workspace: the library must have saved rd's text first
+    rd2 = t.polish_batch_device(d, offs, 3, 2)
+    with pytest.raises(Exception):
+        rd.seq_device(0)
+    for r in (rd, rd2):
+        assert r.seqs == rh.seqs and r.qv == rh.qv and r.n_records == rh.n_records
+        assert (r._raw == rh._raw).all() and r.aux == rh.aux
+    # destroying the table first must not lose a device-resident result
+    rd3 = t.polish_batch_device(d, offs, 3, 2)
+    t.close()
+    assert rd3.seqs == rh.seqs
+    db = O.OracleDB(k)
+    db.count_bases(reads)
+    fixed_o, _, qv_o, _ = db.polish_batch(["c%d" % i for i in range(len(seqs))], [s.decode() for s in seqs], 3, 2)
+    assert [s.decode() for s in rh.seqs] == fixed_o and rh.qv == qv_o
