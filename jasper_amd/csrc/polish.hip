@@ -59,6 +59,7 @@ struct Walker {
     int pass;
     int status;
     uint64_t nlook;
+    uint64_t tk[4];
     uint8_t *s_tbf, *s_t1, *s_t2, *s_gkb, *s_gka;
     // segment context
     int64_t delta;        // len - len0: how far text right of the last edit has shifted
@@ -82,12 +83,69 @@ struct Walker {
     // ---------------- text access ----------------
     __device__ __forceinline__ uint8_t at(int64_t p) const { return buf[p < gs ? p : p + glen]; }
 
+    // 16 bytes at an arbitrary byte address (gfx950 runs with unaligned global access enabled)
+    struct __attribute__((packed, aligned(1))) U16 { uint32_t w[4]; };
+
+    // the (up to 64) text bytes [lo, lo+n) into registers with at most four 16-B loads that are all in flight together.
+    // (Reading the window byte by byte in a loop that stops at the first non-ACGT base serialises k load latencies --
+    // that was most of the time of every fix.)
+    __device__ __forceinline__ void load_window(int64_t lo, int n, uint32_t w[16]) const {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t s = lo + 16 * c;
+            U16 v;
+            v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0;
+            if (16 * c < n) {
+                if (s + 16 <= gs) v = *reinterpret_cast<const U16 *>(buf + s);
+                else if (s >= gs && s + glen + 16 <= cap) v = *reinterpret_cast<const U16 *>(buf + s + glen);
+                else {                                   // straddles the gap or the end of the buffer
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int64_t p = s + j;
+                        const uint32_t b = p < len ? at(p) : 0u;
+                        v.w[j >> 2] |= b << (8 * (j & 3));
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[4 * c + j] = v.w[j];
+        }
+    }
+    // MerDNA(str) of the first `lim` (<= k) bytes held in w: 2-bit codes up to the first non-ACGT byte, 'A'-padded to k.
+    // Four bases per step: code = x ^ (x >> 1) with x = bits 1..2 of the letter (A,C,G,T -> 0,1,2,3); a byte is a base
+    // iff the letter that code stands for equals the byte with its case bit cleared (v_perm_b32 as a 4-entry table).
+    __device__ __forceinline__ u128 encode_words(const uint32_t w[16], int lim, int &nvalid) const {
+        uint64_t hi = 0, lo = 0, inv = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t x0 = (w[i] >> 1) & 0x03030303u;
+            const uint32_t x = x0 ^ ((x0 >> 1) & 0x01010101u);
+            const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u, x);
+            const uint32_t d = expect ^ (w[i] & 0xDFDFDFDFu);
+            const uint32_t nz = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;     // 0x80 per byte that differs
+            const uint32_t c8 = (x * 0x40100401u) >> 24;                                      // b0<<6 | b1<<4 | b2<<2 | b3
+            const uint32_t n4 = (((nz >> 7) * 0x01020408u) >> 24) & 0xFu;                     // bit j = byte j is no base
+            if (i < 8) hi |= (uint64_t)c8 << (56 - 8 * i);
+            else lo |= (uint64_t)c8 << (56 - 8 * (i - 8));
+            inv |= (uint64_t)n4 << (4 * i);
+        }
+        if (lim < 64) inv |= ~0ull << lim;
+        const int t = inv ? (int)__builtin_ctzll(inv) : 64;
+        nvalid = t;
+        if (t == 0) return mk(0, 0);
+        return shl(shr(mk(hi, lo), 128 - 2 * t), 2 * (k - t));
+    }
+
     // qf[jf.MerDNA(seq[a:b]).get_canonical()] -- python slice semantics, per lane
     __device__ __forceinline__ uint32_t cnt_seq(int64_t a, int64_t b) {
         int64_t lo, hi;
         guard(a, b);
         pyslice(len, a, b, lo, hi);
-        const u128 m = encode_padded(k, (long)(hi - lo), [&](int q) { return at(lo + q); });
+        const int n = (int)(hi - lo < k ? hi - lo : k);
+        uint32_t w[16];
+        load_window(lo, n, w);
+        int nv;
+        const u128 m = encode_words(w, n, nv);
         return clamp32(table_get(T, mix(canonical(m, k), T.B)));
     }
     // same for a string in LDS / global scratch
@@ -97,8 +155,6 @@ struct Walker {
     }
 
     // ---------------- gap buffer ----------------
-    // 16 bytes at an arbitrary byte address (gfx950 runs with unaligned global access enabled)
-    struct __attribute__((packed, aligned(1))) U16 { uint32_t w[4]; };
     __device__ void move_gap(int64_t to) {
         if (to == gs) return;
         if (to > gs) {  // bytes [gs+glen, to+glen) slide down to [gs, to): ascending, loads of a step before its stores
@@ -145,6 +201,11 @@ struct Walker {
     }
     // seq = seq[:a] + patch + seq[b:]   (0 <= a <= b <= len), patch readable by every lane
     __device__ void replace(int64_t a, int64_t b, const uint8_t *patch, int64_t plen) {
+        const uint64_t tr0 = wall_clock64();
+        replace_(a, b, patch, plen);
+        tk[3] += wall_clock64() - tr0;
+    }
+    __device__ void replace_(int64_t a, int64_t b, const uint8_t *patch, int64_t plen) {
         move_gap(a);
         glen += (b - a);
         if (glen < plen) { status = PS_GAP_EXHAUSTED; return; }
@@ -624,6 +685,7 @@ struct Walker {
     // ---------------- src/jasper.py:150-223 handle_bad_kmers ----------------
     __device__ int64_t handle_bad_kmers(int64_t i, int64_t &wrong, bool fix, int64_t rolling_thre, bool &brk) {
         brk = false;
+        const uint64_t th0 = wall_clock64();
         uint32_t thre = solid;
         if (rolling_thre > 0) thre = (uint32_t)rolling_thre;                   // :151-153
         // backward: j = i-1; while cnt(seq[j:j+k]) < thre and j >= 0: j -= 1      (:155-159), 64 candidates per round
@@ -698,6 +760,9 @@ struct Walker {
         pyslice(len, s0, ga + k - 1, tlo, thi);                                // :206
         int64_t n = ga - s0; if (n < 0) n = 0;                                 // :207
         wrong += n;
+        const uint64_t tf0 = wall_clock64();
+        tk[1] += tf0 - th0;
+        struct FixTimer { uint64_t &acc; uint64_t t0; __device__ ~FixTimer() { acc += wall_clock64() - t0; } } fix_timer{tk[2], tf0};
         if (fix) {
             if (gb < 0) return i;                                              // :211-212
             const int64_t L = thi - tlo;
@@ -726,13 +791,11 @@ struct Walker {
             }
             if (p < end && !known) {
                 // one pass over the window: 2-bit encode + validity
-                u128 m = mk(0, 0);
-                bool valid = true;
-                for (int q = 0; q < k; ++q) {
-                    const int c = code(at(p + q));
-                    valid = valid && (c >= 0);
-                    m = bor(shl(m, 2), mk(0, (uint64_t)(c & 3)));
-                }
+                uint32_t w[16];
+                load_window(p, k, w);
+                int nv;
+                const u128 m = encode_words(w, k, nv);
+                const bool valid = nv == k;
                 if (valid) {
                     const uint32_t occ = clamp32(table_get(T, mix(canonical(m, k), T.B)));
                     ev = occ < solid;
@@ -756,7 +819,9 @@ struct Walker {
         bool handed_over = false;
         while (i < len - k + 1 && status == PS_OK) {                           // :55
             if (__ballot(spec_fail != 0)) { spec_fail = 1; break; }
+            const uint64_t ts0 = wall_clock64();
             i = skip_good(i);
+            tk[0] += wall_clock64() - ts0;
             if (i >= len - k + 1) { if (!is_last) spec_fail = 1; break; }
             // arriving at the next sync point: the next segment takes over from here
             if (!is_last && (i - delta + seg_lo) >= stop_orig) { handed_over = true; break; }
@@ -836,7 +901,7 @@ __global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, 
     w.T = T; w.k = P.k; w.step = P.step; w.lane = threadIdx.x; w.solid = P.solid;
     w.buf = C->buf; w.len = C->len; w.gs = C->gs; w.glen = C->glen; w.cap = C->cap;
     w.C = C; w.chunk_id = C->chunk; w.nrec = 0; w.naux = 0; w.seqno = 0; w.nedit = 0; w.pass = pass;
-    w.status = PS_OK; w.nlook = 0;
+    w.status = PS_OK; w.nlook = 0; w.tk[0] = w.tk[1] = w.tk[2] = w.tk[3] = 0;
     w.s_tbf = s_tbf; w.s_t1 = s_t1; w.s_t2 = s_t2; w.s_gkb = s_gkb; w.s_gka = s_gka;
     w.delta = 0; w.dirty_end = INT64_MIN / 2; w.glo = P.k;
     w.is_first = C->first != 0; w.is_last = C->last != 0; w.spec_fail = 0;
@@ -849,6 +914,7 @@ __global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, 
     w.release_scratch();
     if (threadIdx.x == 0) {
         C->ticks = wall_clock64() - t0;
+        for (int q = 0; q < 4; ++q) C->tk[q] = w.tk[q];
         C->len = w.len; C->gs = w.gs; C->glen = w.glen;
         C->nrec = w.nrec; C->naux = w.naux; C->nedit = w.nedit; C->status = w.status; C->spec_fail = w.spec_fail;
         C->wrong = wrong;

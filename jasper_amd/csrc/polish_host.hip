@@ -37,7 +37,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     const int k = T.k;
     const int64_t W = 4ll * k;        // clean window required left of a sync point
     const int64_t M = 3ll * k;        // text kept right of the next sync point
-    const int64_t TMIN = 4096;        // minimum distance between sync points
+    const int64_t TMIN = 1024;        // minimum distance between sync points
     hipStream_t st = T.stream;
     HIPCHK(hipSetDevice(T.device));
     if (T.materialize(err)) return -1;
@@ -282,13 +282,17 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
 
         if (getenv("JASPER_POLISH_DEBUG")) {
             uint64_t mx = 0, sum = 0, mxl = 0; int64_t mxlen = 0; size_t nrecs = 0, mxrec = 0;
+            uint64_t tks[4] = {0, 0, 0, 0};
             for (const SegDev &S : segs) {
                 sum += S.ticks; nrecs += S.nrec;
+                for (int q = 0; q < 4; ++q) tks[q] += S.tk[q];
                 if (S.ticks > mx) { mx = S.ticks; mxl = S.lookups; mxlen = S.len0; mxrec = S.nrec; }
             }
             fprintf(stderr, "[polish] pass %d: %zu segments, %zu records, walk ticks(10ns): mean %.0f max %llu (that segment: len %lld, %llu lookups, %zu records)\n",
                     pass, segs.size(), nrecs, segs.empty() ? 0.0 : (double)sum / segs.size(), (unsigned long long)mx, (long long)mxlen,
                     (unsigned long long)mxl, mxrec);
+            fprintf(stderr, "[polish]   of all walk ticks: skip_good %.1f%%, find run %.1f%%, choose fix %.1f%% (of which splice %.1f%%)\n",
+                    100.0 * tks[0] / (sum + 1), 100.0 * tks[1] / (sum + 1), 100.0 * tks[2] / (sum + 1), 100.0 * tks[3] / (sum + 1));
             // histogram of segment times in ms buckets
             int hb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (const SegDev &S : segs) { double ms = S.ticks * 1e-5; int b = ms < 0.1 ? 0 : ms < 0.3 ? 1 : ms < 1 ? 2 : ms < 2 ? 3 : ms < 4 ? 4 : ms < 8 ? 5 : ms < 16 ? 6 : 7; hb[b]++; }
