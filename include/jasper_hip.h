@@ -75,6 +75,9 @@ int jasper_count_reads_text(jasper_table *t, const char *text, uint64_t n);
 int jasper_count_reads_files(jasper_table *t, const char *const *paths, int n_paths);
 
 int jasper_histogram(jasper_table *t, uint64_t *out10002);
+/* 1 if the histogram is already known because the last counting call binned the final counts while it wrote them
+ * (one partitioned pass over the whole input into an empty table); jasper_histogram then costs one small copy */
+int jasper_histogram_is_fused(jasper_table *t);
 /* string i is chars[offsets[i] .. offsets[i+1]); out[i] = count of canonical(pad(string i)) clamped to 2^32-1 */
 int jasper_lookup(jasper_table *t, const char *chars, const int64_t *offsets, uint64_t n, uint32_t *out);
 

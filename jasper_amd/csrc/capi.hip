@@ -159,6 +159,8 @@ int jasper_last_count_stages(jasper_table *t, double stage_ms[5], uint64_t *part
     return JASPER_OK;
 }
 
+int jasper_histogram_is_fused(jasper_table *t) { return t && t->t.histo_cached ? 1 : 0; }
+
 int jasper_histogram(jasper_table *t, uint64_t *out10002) { return t->t.histogram(out10002, g_err); }
 
 int jasper_lookup(jasper_table *t, const char *chars, const int64_t *offsets, uint64_t n, uint32_t *out) {

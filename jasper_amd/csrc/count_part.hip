@@ -259,20 +259,29 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
 
 // ---- final: region lists -> LDS image of the region -> table ------------------------------------------------------
 // lists: slices  lists[(region * nsl + x) * cap + i], i < cnt[region * nsl + x].  `parity`: regions with (region & 1) == parity.
+constexpr int LDS_HBINS = 1024;        // histogram bins kept in LDS by lds_insert_kernel (higher multiplicities are rare: global atomics)
 __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *__restrict__ lists, const unsigned int *__restrict__ cnt, uint32_t cap,
                                                                  uint32_t nsl, TableDev T, PartGeom G, uint32_t nregions, uint32_t parity, int fresh_table,
                                                                  unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
-                                                                 uint64_t deferred_cap) {
+                                                                 uint64_t deferred_cap, unsigned long long *__restrict__ histo) {
     extern __shared__ __align__(16) unsigned long long s_img[];    // 2 words per slot: (R + halo) slots
     const int t = threadIdx.x;
     const uint32_t R = 1u << G.rbits;
     const uint32_t halo = nregions > 1 ? (uint32_t)RG_HALO : 0u;     // a single region is the whole table: probes wrap inside it
     const uint32_t span = R + halo;
     unsigned long long fresh = 0;
+    // fused multiplicity histogram (histo != null: this pass writes the FINAL counts of the whole table): every slot is
+    // binned exactly once, by the block that writes its final value -- an even region's body in the even launch; in the
+    // odd launch the odd region's head and body plus its halo, which is the head of the even region to its right.
+    unsigned int *s_bins = reinterpret_cast<unsigned int *>(s_img + 2 * (size_t)span);     // LDS_HBINS words, only with histo
+    if (histo) {
+        for (int i = t; i < LDS_HBINS; i += PT_THREADS) s_bins[i] = 0;
+        __syncthreads();
+    }
     for (uint32_t region = blockIdx.x * 2 + parity; region < nregions; region += gridDim.x * 2) {
         uint32_t total = 0;
         for (uint32_t x = 0; x < nsl; ++x) total += cnt[(uint64_t)region * nsl + x];
-        if (total == 0 && !fresh_table) continue;                  // block-uniform (a fresh table must still be zeroed here)
+        if (total == 0 && !fresh_table && !histo) continue;                  // block-uniform (a fresh table must still be zeroed here)
         const uint64_t first = (uint64_t)region << G.rbits;        // first slot of the region
         // image in: coalesced 16-B loads (the halo wraps around the end of the table).  On a lazily cleared table the slot
         // memory is garbage except for what this pass has already written: nothing yet in the even launch; in the odd
@@ -322,17 +331,30 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *
             }
         }
         __syncthreads();
-        for (uint32_t i = t; i < span; i += PT_THREADS)
-            *reinterpret_cast<ulonglong2 *>(T.slots + 2 * ((first + i) & T.mask)) = make_ulonglong2(s_img[2 * i], s_img[2 * i + 1]);
+        for (uint32_t i = t; i < span; i += PT_THREADS) {
+            const unsigned long long tag = s_img[2 * i], c64 = s_img[2 * i + 1];
+            *reinterpret_cast<ulonglong2 *>(T.slots + 2 * ((first + i) & T.mask)) = make_ulonglong2(tag, c64);
+            if (histo && tag != 0ull && c64 != 0ull && (parity == 1 || (i >= halo && i < R))) {
+                const uint32_t c = clamp32(c64);
+                const uint32_t b = c > 10001u ? 10001u : c;
+                if (b < (uint32_t)LDS_HBINS) atomicAdd(&s_bins[b], 1u);
+                else atomicAdd(&histo[b], 1ull);
+            }
+        }
         __syncthreads();
+    }
+    if (histo) {
+        for (int i = t; i < LDS_HBINS; i += PT_THREADS)
+            if (s_bins[i]) atomicAdd(&histo[i], (unsigned long long)s_bins[i]);
     }
     for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
 }
 
 __global__ __launch_bounds__(256) void import3_kernel(const unsigned long long *__restrict__ entries, const unsigned long long *__restrict__ n_ptr,
-                                                      uint64_t cap, TableDev T) {
+                                                      uint64_t cap, TableDev T, unsigned long long *__restrict__ histo_incomplete) {
     const uint64_t n = *n_ptr < cap ? *n_ptr : cap;
+    if (histo_incomplete && *n_ptr != 0ull && blockIdx.x == 0 && threadIdx.x == 0) *histo_incomplete = 1ull;   // counts change after the fused histogram
     unsigned long long fresh = 0;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         fresh += table_add_or_spill(T, mk(entries[3 * i], entries[3 * i + 1]), entries[3 * i + 2]);
@@ -404,7 +426,10 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
         lists = out2; lcnt = cnt2; lcap = G.cap2; nsl = G.nblk2;
     }
     HIPCHK(hipEventRecord(ev_stage_t[2], stream));
-    const size_t lds = ((size_t)(1u << G.rbits) + RG_HALO) * 16;
+    // fused histogram: asked for by count_device when this piece is the whole input going into an empty table
+    unsigned long long *histo = histo_request ? d_histo : nullptr;
+    if (histo) HIPCHK(hipMemsetAsync(histo, 0, HISTO_WORDS * sizeof(unsigned long long), stream));
+    const size_t lds = ((size_t)(1u << G.rbits) + RG_HALO) * 16 + (histo ? LDS_HBINS * 4 : 0);
     // lazily cleared table: part1/part2 overflow fallbacks and the deferred list use the direct path on the slot array,
     // so they need real zeros -- they are rare; when the lists show none, the LDS pass does the clearing for free
     if (slots_dirty && nregions <= 1) { if (materialize(err)) return -1; }
@@ -418,13 +443,13 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
         if (!(nregions == 1 && parity == 1)) {
             const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
             hipLaunchKernelGGL(lds_insert_kernel, dim3(nblk), dim3(PT_THREADS), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, parity, fresh, defer_e,
-                               defer_n, deferred_cap);
+                               defer_n, deferred_cap, histo);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(ev_stage_t[3 + parity], stream));
     }
     slots_dirty = false;   // every region has been written by the two launches above
-    hipLaunchKernelGGL(import3_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, deferred_cap, d);
+    hipLaunchKernelGGL(import3_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, deferred_cap, d, histo ? histo + 10002 : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_k1, stream));
     HIPCHK(hipEventRecord(ev_stage_t[5], stream));

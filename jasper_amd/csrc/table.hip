@@ -365,6 +365,8 @@ int Table::init(int k_, uint64_t min_slots, int device_, std::string &err) {
     HIPCHK(hipMalloc((void **)&d.slots, nslots * 16));
     HIPCHK(hipMalloc((void **)&d.stats, ST_WORDS * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&d.spill, d.spill_cap * 3 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&d_histo, 2 * HISTO_WORDS * sizeof(unsigned long long)));
+    histo_cached = histo_request = false;
     slots_dirty = true;   // zeroed on first use (or never, if that use is a partitioned counting piece)
     HIPCHK(hipMemsetAsync(d.stats, 0, ST_WORDS * sizeof(unsigned long long), stream));
     HIPCHK(hipHostMalloc((void **)&h_stats, ST_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
@@ -404,6 +406,8 @@ void Table::destroy() {
     if (d.slots) (void)hipFree(d.slots);
     if (d.stats) (void)hipFree(d.stats);
     if (d.spill) (void)hipFree(d.spill);
+    if (d_histo) (void)hipFree(d_histo);
+    d_histo = nullptr;
     if (h_stats) (void)hipHostFree(h_stats);
     if (ev_k0) (void)hipEventDestroy(ev_k0);
     if (ev_k1) (void)hipEventDestroy(ev_k1);
@@ -423,6 +427,7 @@ __global__ void zero_stats_kernel(unsigned long long *stats) { if (threadIdx.x <
 int Table::clear(std::string &err) {
     HIPCHK(hipSetDevice(device));
     slots_dirty = true;
+    histo_cached = false;
     timespec a, b, c;
     const bool dbg = getenv("JASPER_COUNT_DEBUG") != nullptr;
     if (dbg) clock_gettime(CLOCK_MONOTONIC, &a);
@@ -524,6 +529,7 @@ int Table::launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from
         ++count_partitioned_launches;
         return launch_count_partitioned(d_piece, len, emit_from, geom, err);
     }
+    histo_request = false;
     if (materialize(err)) return -1;
     const uint64_t ntiles = (len + CT_TILE - 1) / CT_TILE;
     HIPCHK(hipEventRecord(ev_k0, stream));
@@ -542,6 +548,7 @@ int Table::launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from
 int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
     HIPCHK(hipSetDevice(device));
     if (read_stats(err)) return -1;
+    histo_cached = false;
     const uint64_t halo = (uint64_t)(k - 1);
     const uint64_t misalign = reinterpret_cast<uintptr_t>(d_bases) & 15;
     uint64_t pos = 0;
@@ -599,10 +606,16 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
         const uint64_t distinct_before = h_stats[ST_DISTINCT], occ_before = h_stats[ST_OCCURRENCES];
         const double t_l0 = dbg ? now_ms() : 0;
         if (dbg) fprintf(stderr, "[count] host: %.2f ms since call start (sizing, capacity)\n", t_l0 - t_call);
-        if (launch_count(d_bases + start, end - start, pos - start, err)) return -1;
+        histo_request = started_empty && pos == 0 && end == n && h_stats[ST_DISTINCT] == 0;   // one piece, whole input, empty table
+        histo_cached = false;
+        const int lrc = launch_count(d_bases + start, end - start, pos - start, err);
+        const bool fused_histo = histo_request;      // still set only if the partitioned path took the request
+        histo_request = false;
+        if (lrc) return -1;
         const double t_l1 = dbg ? now_ms() : 0;
         pos = end;
         int rc = after_batch(err);
+        histo_cached = rc == 0 && fused_histo;
         if (dbg) fprintf(stderr, "[count] host: launch calls %.2f ms, wait + after_batch %.2f ms\n", t_l1 - t_l0, now_ms() - t_l1);
         if (rc == -2 && have_ratio && started_empty) {
             // The size hint promised a more repetitive input than this one: the piece sized from it overflowed the table.
@@ -640,6 +653,7 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
 int Table::count_host(const char *bases, uint64_t n, std::string &err) {
     HIPCHK(hipSetDevice(device));
     if (read_stats(err)) return -1;
+    histo_cached = histo_request = false;
     if (!stage_bytes) {
         stage_bytes = 64u << 20;
         for (int i = 0; i < 2; ++i) {
@@ -687,14 +701,23 @@ int Table::count_host(const char *bases, uint64_t n, std::string &err) {
 int Table::histogram(uint64_t *out, std::string &err) {
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
-    unsigned long long *d_out = nullptr;
-    HIPCHK(hipMalloc((void **)&d_out, HISTO_BINS * sizeof(unsigned long long)));
+    if (histo_cached) {   // taken while the counting pass wrote the table (count_part.hip); word HISTO_BINS = "not complete"
+        static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "histogram words");
+        std::vector<unsigned long long> h(HISTO_BINS + 1);
+        HIPCHK(hipMemcpyAsync(h.data(), d_histo, (HISTO_BINS + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIPCHK(jk_stream_wait(stream));
+        if (h[HISTO_BINS] == 0) {
+            memcpy(out, h.data(), HISTO_BINS * sizeof(unsigned long long));
+            return 0;
+        }
+        histo_cached = false;
+    }
+    unsigned long long *d_out = d_histo + HISTO_WORDS;
     HIPCHK(hipMemsetAsync(d_out, 0, HISTO_BINS * sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(histo_kernel, dim3(grid_for(nslots, 256 * 16)), dim3(256), 0, stream, d, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out, HISTO_BINS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     HIPCHK(jk_stream_wait(stream));
-    HIPCHK(hipFree(d_out));
     return 0;
 }
 
@@ -743,6 +766,7 @@ int Table::export_entries(uint64_t *n_out, unsigned long long **d_entries_out, s
 }
 
 int Table::import_entries(const unsigned long long *d_entries, uint64_t n, std::string &err) {
+    histo_cached = false;
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
     if (read_stats(err)) return -1;
@@ -763,6 +787,7 @@ int Table::import_entries(const unsigned long long *d_entries, uint64_t n, std::
 }
 
 int Table::add_kmers(const unsigned long long *h_entries, uint64_t n, std::string &err) {
+    histo_cached = false;
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
     if (!n) return 0;
@@ -819,6 +844,7 @@ int Table::export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t pa
 }
 
 int Table::import_packed(const void *d_src, uint64_t n, int mode, std::string &err) {
+    histo_cached = false;
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
     if (read_stats(err)) return -1;

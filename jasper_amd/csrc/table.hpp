@@ -163,6 +163,13 @@ struct Table {
     hipEvent_t ev_stage_t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries of the partitioned path
     double part_stage_ms[5] = {0, 0, 0, 0, 0};                                          // part1, part2, lds even, lds odd, deferred
     bool part_stage_pending = false;
+    // Multiplicity histogram taken for free while lds_insert_kernel writes the final region images back: valid when one
+    // partitioned piece counted the whole input into an empty table and nothing had to take the deferred (direct) path.
+    // d_histo: [0, HISTO_WORDS) fused histogram + "deferred records existed" flag, [HISTO_WORDS, 2*HISTO_WORDS) scratch of
+    // histo_kernel.  Every other mutation of the table drops the cached histogram.
+    static constexpr int HISTO_WORDS = 10002 + 6;
+    unsigned long long *d_histo = nullptr;
+    bool histo_cached = false, histo_request = false;
     double dup_ratio = 1.0;   // new distinct keys per k-mer of the last piece (sizes the next piece)
     uint64_t size_hint = 0;   // caller's expected number of distinct k-mers (`jellyfish count -s`); 0 = none given
     // grow-only device workspace reused by the polisher across calls (hipMalloc of GBs costs far more than the kernels)

@@ -174,6 +174,10 @@ class KmerTable:
         return dict(k=k.value, slots=slots.value, distinct=distinct.value, occurrences=occ.value)
 
     # ---- jellyfish histo ---------------------------------------------------------------------------
+    def histogram_is_fused(self):
+        """True if the last counting call already produced the histogram (binned while the final counts were written)"""
+        return bool(self._L.jasper_histogram_is_fused(self._h))
+
     def histogram(self):
         out = (C.c_uint64 * 10002)()
         check(self._L.jasper_histogram(self._h, out))

@@ -298,3 +298,34 @@ def test_polish_device_resident_equals_host_call(KT, O):
     db.count_bases(reads)
     fixed_o, _, qv_o, _ = db.polish_batch(["c%d" % i for i in range(len(seqs))], [s.decode() for s in seqs], 3, 2)
     assert [s.decode() for s in rh.seqs] == fixed_o and rh.qv == qv_o
+
+
+def test_histogram_fused_into_counting_pass_equals_table_scan(KT):
+    """one partitioned counting pass over the whole input into an empty table bins the final counts while it writes
+    them (lds_insert_kernel); that histogram must equal the one histo_kernel reads back from the table"""
+    import torch
+    k = 37
+    G = 12_000_000
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(17)
+    genome = synth.torch_genome(gen, G, dev)
+    nreads = G * 30 // 150
+    reads = synth.torch_reads_stream(gen, genome, nreads, 150, 0.003)
+    torch.cuda.synchronize()
+    t = KT(k, min_slots=int(1.25 * nreads * 150 * 2.1 / 10))
+    for rep in range(2):                      # second round: lazily cleared table (region images start from zeros)
+        t.clear()
+        t.count_bases_device(reads.data_ptr(), reads.numel())
+        assert t.count_stages()[1] == 1, "expected one partitioned launch"
+        assert t.histogram_is_fused()
+        h_fused = t.histogram()
+        t.count_bases_device(reads.data_ptr(), 0)        # any counting call drops the cached histogram
+        assert not t.histogram_is_fused()
+        h_scan = t.histogram()
+        assert h_fused == h_scan and sum(h_fused) == t.info()["distinct"]
+    # a second pass over the same reads is not "the whole input into an empty table": no fused histogram
+    t.count_bases_device(reads.data_ptr(), reads.numel())
+    assert not t.histogram_is_fused()
+    h2 = t.histogram()
+    assert all(h2[2 * m] == h_scan[m] for m in range(1, 5000))
+    t.close()
