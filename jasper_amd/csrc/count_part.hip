@@ -66,17 +66,8 @@ __device__ __forceinline__ void defer_record(const TableDev &T, u128 h, unsigned
     else atomicExch(&T.stats[ST_FATAL], 1ull);
 }
 
-__device__ __forceinline__ void pt_stage(const uint8_t *__restrict__ bases, int64_t pos, uint64_t n, bool aligned, uint32_t &codes, uint32_t &inv) {
-    uint8_t b[16];
-    if (pos >= 0 && (uint64_t)pos + 16 <= n && aligned) {
-        *reinterpret_cast<uint4 *>(b) = *reinterpret_cast<const uint4 *>(bases + pos);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const int64_t p = pos + j; b[j] = (p >= 0 && (uint64_t)p < n) ? bases[p] : (uint8_t)'N'; }
-    }
-    codes = 0; inv = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { const int c = code(b[j]); codes = (codes << 2) | (uint32_t)(c & 3); inv = (inv << 1) | (uint32_t)(c < 0); }
+__device__ __forceinline__ void pt_stage(const uint8_t *__restrict__ bases, int64_t pos, uint64_t n, bool /*aligned*/, uint32_t &codes, uint32_t &inv) {
+    stage16(bases, pos, (int64_t)n, codes, inv);
 }
 
 // ---- level 1: bases -> records in 2^p1 bucket lists --------------------------------------------------------

@@ -1098,29 +1098,13 @@ __global__ __launch_bounds__(SC_THREADS) void scan_batch_kernel(const ScanChunk 
         const int64_t ntiles = (n + SC_TILE - 1) / SC_TILE;
         for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             const int64_t base0 = tile * SC_TILE;
-            uint32_t c = 0, iv = 0;
-            {
-                const int64_t pos = base0 + (int64_t)t * SC_GROUP;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int64_t p = pos + j;
-                    const int cc = (p < n) ? code(text[p]) : -1;
-                    c = (c << 2) | (uint32_t)(cc & 3);
-                    iv = (iv << 1) | (uint32_t)(cc < 0);
-                }
-            }
+            uint32_t c, iv;
+            stage16(text, base0 + (int64_t)t * SC_GROUP, n, c, iv);
             s_code[t + SC_HALO] = c;
             s_inv[t + SC_HALO] = iv;
             if (t < SC_HALO) {
-                uint32_t hc = 0, hiv = 0;
-                const int64_t pos = base0 - (int64_t)(SC_HALO - t) * SC_GROUP;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int64_t p = pos + j;
-                    const int cc = (p >= 0 && p < n) ? code(text[p]) : -1;
-                    hc = (hc << 2) | (uint32_t)(cc & 3);
-                    hiv = (hiv << 1) | (uint32_t)(cc < 0);
-                }
+                uint32_t hc, hiv;
+                stage16(text, base0 - (int64_t)(SC_HALO - t) * SC_GROUP, n, hc, hiv);
                 s_code[t] = hc;
                 s_inv[t] = hiv;
             }
@@ -1132,24 +1116,54 @@ __global__ __launch_bounds__(SC_THREADS) void scan_batch_kernel(const ScanChunk 
             u128 fwd = band(mk(((uint64_t)w4 << 32) | w3, ((uint64_t)w2 << 32) | w1), kmask);
             u128 rc = revcomp(fwd, k);
             int run = ivprev ? (int)__builtin_ctzll(ivprev) : 64;
-#pragma unroll 4
-            for (int j = 0; j < SC_GROUP; ++j) {
-                const uint32_t cj = (c >> (30 - 2 * j)) & 3u;
-                const bool bad = (iv >> (15 - j)) & 1u;
-                fwd = band(bor(shl(fwd, 2), mk(0, cj)), kmask);
-                rc = bor(shr(rc, 2), shl(mk(0, 3u - cj), 2 * (k - 1)));
-                run = bad ? 0 : run + 1;
-                const int64_t e = base0 + (int64_t)t * SC_GROUP + j;
-                const int64_t p = e - k + 1;
-                if (p >= 0 && e < n) {
-                    if (run >= k) {
-                        const u128 canon = lt(rc, fwd) ? rc : fwd;
-                        C.cnt[p] = clamp32(table_get(T, mix(canon, T.B)));
-                        C.valid[p] = 1;
-                    } else {
-                        C.cnt[p] = 0;
-                        C.valid[p] = 0;
-                    }
+            // my 16 windows, four at a time: hash four, put their four home-slot loads in flight together, resolve;
+            // results stay in registers and leave as whole 16-B stores (one 4-B store per window cost 10x the bytes)
+            uint32_t cntv[SC_GROUP];
+            uint32_t valw[SC_GROUP / 4] = {0, 0, 0, 0};
+            const int64_t e0 = base0 + (int64_t)t * SC_GROUP;
+#pragma unroll
+            for (int j0 = 0; j0 < SC_GROUP; j0 += 4) {
+                u128 hs[4];
+                bool ok[4];
+                ulonglong2 ent[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u;
+                    const uint32_t cj = (c >> (30 - 2 * j)) & 3u;
+                    const bool bad = (iv >> (15 - j)) & 1u;
+                    fwd = band(bor(shl(fwd, 2), mk(0, cj)), kmask);
+                    rc = bor(shr(rc, 2), shl(mk(0, 3u - cj), 2 * (k - 1)));
+                    run = bad ? 0 : run + 1;
+                    const int64_t e = e0 + j;
+                    ok[u] = run >= k && e - k + 1 >= 0 && e < n;
+                    hs[u] = mix(lt(rc, fwd) ? rc : fwd, T.B);
+                    ent[u] = make_ulonglong2(0ull, 0ull);
+                    if (ok[u]) ent[u] = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * home_of(hs[u], T.B, T.s));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u;
+                    cntv[j] = ok[u] ? clamp32(table_get_prefetched(T, hs[u], ent[u])) : 0u;
+                    valw[j >> 2] |= (ok[u] ? 1u : 0u) << (8 * (j & 3));
+                }
+            }
+            const int64_t p0 = e0 - k + 1;
+            if (p0 >= 0 && e0 + SC_GROUP <= n) {
+                struct __attribute__((packed, aligned(1))) V16 { uint32_t w[4]; };
+#pragma unroll
+                for (int q = 0; q < SC_GROUP / 4; ++q) {
+                    V16 v;
+                    v.w[0] = cntv[4 * q]; v.w[1] = cntv[4 * q + 1]; v.w[2] = cntv[4 * q + 2]; v.w[3] = cntv[4 * q + 3];
+                    *reinterpret_cast<V16 *>(C.cnt + p0 + 4 * q) = v;
+                }
+                V16 vv;
+                vv.w[0] = valw[0]; vv.w[1] = valw[1]; vv.w[2] = valw[2]; vv.w[3] = valw[3];
+                *reinterpret_cast<V16 *>(C.valid + p0) = vv;
+            } else {
+#pragma unroll
+                for (int j = 0; j < SC_GROUP; ++j) {
+                    const int64_t e = e0 + j, p = e - k + 1;
+                    if (p >= 0 && e < n) { C.cnt[p] = cntv[j]; C.valid[p] = (uint8_t)((valw[j >> 2] >> (8 * (j & 3))) & 1u); }
                 }
             }
         }

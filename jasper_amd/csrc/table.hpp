@@ -117,8 +117,58 @@ __device__ __forceinline__ unsigned long long table_get(const TableDev &T, u128 
     return 0ull;
 }
 
+// the same with the home slot already loaded (callers put several home-slot loads in flight before resolving them)
+__device__ __forceinline__ unsigned long long table_get_prefetched(const TableDev &T, u128 h, ulonglong2 e0) {
+    const uint64_t home = home_of(h, T.B, T.s);
+    const uint64_t rem = rem_of(h, T.B, T.s);
+    if (e0.x == tag_of(rem, 0)) return e0.y;
+    if (e0.x == 0ull) return 0ull;
+    for (uint32_t off = 1; off < MAXPROBE; ++off) {
+        const uint64_t slot = (home + off) & T.mask;
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * slot);
+        if (e.x == tag_of(rem, off)) return e.y;
+        if (e.x == 0ull) return 0ull;
+    }
+    return 0ull;
+}
+
 // count as the reference's DB file reports it: min(count, 2^32-1)  (JF::include/jellyfish/binary_dumper.hpp:36-40)
 __device__ __forceinline__ uint32_t clamp32(unsigned long long c) { return c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c; }
+
+// 16 text bytes (4 little-endian words, first base in the low byte of w[0]) -> 2-bit codes (first base in the top bit
+// pair) and an "is no base" bit per byte (first base in bit 15).  Four bases per step: code = x ^ (x >> 1) with x = bits
+// 1..2 of the letter (A,C,G,T -> 0,1,2,3; case-insensitive); a byte is a base iff the letter that code stands for equals
+// the byte with its case bit cleared (v_perm_b32 used as a 4-entry table).  ~4 VALU ops per base instead of ~14.
+__device__ __forceinline__ void encode16(const uint32_t w[4], uint32_t &codes, uint32_t &inv) {
+    codes = 0;
+    inv = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t x0 = (w[i] >> 1) & 0x03030303u;
+        const uint32_t x = x0 ^ ((x0 >> 1) & 0x01010101u);
+        const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u, x);
+        const uint32_t d = expect ^ (w[i] & 0xDFDFDFDFu);
+        const uint32_t nz = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
+        codes = (codes << 8) | ((x * 0x40100401u) >> 24);
+        inv = (inv << 4) | ((((nz >> 7) * 0x08040201u) >> 24) & 0xFu);
+    }
+}
+// the 16 bytes text[pos .. pos+16) of a text of n bytes (positions outside it read as 'N') through encode16
+__device__ __forceinline__ void stage16(const uint8_t *__restrict__ text, int64_t pos, int64_t n, uint32_t &codes, uint32_t &inv) {
+    struct __attribute__((packed, aligned(1))) V16 { uint32_t w[4]; };
+    V16 v;
+    if (pos >= 0 && pos + 16 <= n) {
+        v = *reinterpret_cast<const V16 *>(text + pos);
+    } else {
+        v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0x4E4E4E4Eu;   // "NNNN"
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t p = pos + j;
+            if (p >= 0 && p < n) v.w[j >> 2] = (v.w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | ((uint32_t)text[p] << (8 * (j & 3)));
+        }
+    }
+    encode16(v.w, codes, inv);
+}
 
 // H2 / Appendix A.3: k-mer of a string cut at the first non-ACGTacgt byte (or at k) and right-filled with 'A'
 // (JF::include/jellyfish/mer_dna.hpp:525-542).  `get(i)` returns byte i of the string, n = its length.
