@@ -185,68 +185,117 @@ __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__rest
 constexpr size_t P1_LDS = (size_t)PT_TILE * 8 + (size_t)(PT_THREADS + PT_HALO) * 8 + (size_t)(3 * P1_MAXB + 1 + 16) * 4;
 
 // ---- level 2: every bucket list -> 2^p2 region lists ---------------------------------------------------------
-// grid (nblk2, buckets): block (x, b1) reads the level-1 slices x, x+nblk2, ... of bucket b1 and appends to ITS slice
-// of each of the bucket's 2^p2 region lists, again with LDS cursors only.
+// grid (nblk2, buckets): block (x, b1) reads the level-1 slices x, x+nblk2, ... of bucket b1 (as one concatenated
+// list) and appends to ITS slice of each of the bucket's 2^p2 region lists.  Same shape as part1: a tile of 16 K records
+// is sorted by region inside LDS (rank from a returning LDS atomic, offsets from a block scan) and leaves in region
+// order, so a wave writes whole runs of one list.  (The first version appended each record straight from the lane that
+// loaded it, with wave-level "match any" ballots to share the cursor atomics: ~100 instructions per record, and every
+// store instruction touched ~64 different lines -- the kernel was instruction-bound at 2.3 TB/s.)
+constexpr int P2_MAXSL = 256;          // level-1 slices per bucket (= nblk1 <= 256)
 __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__restrict__ out1, const unsigned int *__restrict__ cnt1, TableDev T,
                                                             PartGeom G, uint64_t *__restrict__ out2, unsigned int *__restrict__ cnt2,
                                                             unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
                                                             uint64_t deferred_cap) {
-    __shared__ unsigned int s_cur[PT_MAXBUCKETS];
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_raw);                               // PT_TILE records
+    unsigned int *s_cur = reinterpret_cast<unsigned int *>(s_raw + (size_t)PT_TILE * 8);   // PT_MAXBUCKETS slice cursors (per b1)
+    unsigned int *s_cnt = s_cur + PT_MAXBUCKETS;                                           // PT_MAXBUCKETS records of this tile per region
+    unsigned int *s_off = s_cnt + PT_MAXBUCKETS;                                           // PT_MAXBUCKETS+1 exclusive prefix of s_cnt
+    unsigned int *s_wsum = s_off + PT_MAXBUCKETS + 1;                                      // 16 wave totals
+    unsigned int *s_pref = s_wsum + 16;                                                    // P2_MAXSL+1 prefix of my slices' lengths
     const int t = threadIdx.x;
     const int nb2 = 1 << G.p2;
     const int shift2 = G.recbits - G.p2;               // the p2 bits right below the level-1 bucket bits
-    unsigned long long fresh = 0;
+    const uint32_t nmine = (G.nblk1 - blockIdx.x + G.nblk2 - 1) / G.nblk2;                 // slices x, x+nblk2, ... < nblk1
     for (uint32_t b1 = blockIdx.y; b1 < (1u << G.p1); b1 += gridDim.y) {
-        for (int i = t; i < nb2; i += PT_THREADS) s_cur[i] = 0;
+        for (int i = t; i < nb2; i += PT_THREADS) { s_cur[i] = 0; s_cnt[i] = 0; }
+        if (t < 64) {                                  // exclusive prefix of my slices' lengths (wave 0)
+            unsigned int carry = 0;
+            for (uint32_t x0 = 0; x0 < nmine; x0 += 64) {
+                const uint32_t x = x0 + t;
+                const unsigned int v = x < nmine ? cnt1[(uint64_t)b1 * G.nblk1 + blockIdx.x + (uint64_t)x * G.nblk2] : 0u;
+                unsigned int inc = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if (t >= o) inc += u; }
+                if (x < nmine) s_pref[x] = carry + inc - v;
+                carry += __shfl(inc, 63);
+            }
+            if (t == 0) s_pref[nmine] = carry;
+        }
         __syncthreads();
-        for (uint32_t sl = blockIdx.x; sl < G.nblk1; sl += G.nblk2) {
-            const uint32_t n1 = cnt1[(uint64_t)b1 * G.nblk1 + sl];
-            const uint64_t *src = out1 + ((uint64_t)b1 * G.nblk1 + sl) * G.cap1;
-            // four coalesced 8-B loads in flight per lane: with one, a CU keeps only ~16 KB outstanding and the pass
-            // runs at a quarter of the HBM rate (Little's law)
-            for (uint32_t base = 0; base < n1; base += 4 * PT_THREADS) {   // wave-uniform trip count (ballots below)
-                uint64_t recs[4];
-                bool haves[4];
+        const uint32_t total = s_pref[nmine];
+        const uint64_t *src0 = out1 + ((uint64_t)b1 * G.nblk1 + blockIdx.x) * G.cap1;      // slice x; slice x + j*nblk2 is j*nblk2*cap1 further
+        for (uint32_t tile0 = 0; tile0 < total; tile0 += PT_TILE) {
+            // A. my 16 records (all loads in flight), their region, a rank in the tile's region histogram
+            uint64_t rec[PT_GROUP];
+            uint32_t br[PT_GROUP];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t idx = base + u * PT_THREADS + t;
-                    haves[u] = idx < n1;
-                    recs[u] = haves[u] ? src[idx] : 0ull;
+            for (int j = 0; j < PT_GROUP; ++j) {
+                const uint32_t i = tile0 + (uint32_t)j * PT_THREADS + t;
+                rec[j] = 0ull;
+                br[j] = 0xFFFFFFFFu;
+                if (i < total) {
+                    uint32_t lo = 0, hi = nmine - 1;                          // slice: largest x with s_pref[x] <= i
+                    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= i) lo = mid; else hi = mid - 1; }
+                    rec[j] = src0[(uint64_t)lo * G.nblk2 * G.cap1 + (i - s_pref[lo])];
+                    br[j] = lo;                                               // (reused below)
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool have = haves[u];
-                    const uint64_t rec = recs[u];
-                    const uint32_t b2 = have ? ((uint32_t)(rec >> shift2) & (uint32_t)(nb2 - 1)) : 0xFFFFFFFFu;
-                    // lanes of this wave that hold the same bucket ("match any" from p2 ballots): one LDS atomic per
-                    // (wave, bucket) instead of one per record on only 2^p2 <= 64 hot counters
-                    uint64_t peers = __ballot(have);
-                    for (int bit = 0; bit < G.p2; ++bit) {
-                        const uint64_t m = __ballot((b2 >> bit) & 1u);
-                        peers &= ((b2 >> bit) & 1u) ? m : ~m;
-                    }
-                    if (have) {
-                        const int leader = (int)__builtin_ctzll(peers);
-                        const int lane = t & 63;
-                        unsigned int basepos = 0;
-                        if (lane == leader) basepos = atomicAdd(&s_cur[b2], (unsigned int)__popcll(peers));
-                        basepos = __shfl(basepos, leader);
-                        const unsigned int pos = basepos + (unsigned int)__popcll(peers & ((1ull << lane) - 1ull));
-                        const uint64_t region = ((uint64_t)b1 << G.p2) + b2;
-                        if (pos < G.cap2) out2[(region * G.nblk2 + blockIdx.x) * G.cap2 + pos] = rec;
-                        else defer_record(T, hash_of(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
+            for (int j = 0; j < PT_GROUP; ++j) {
+                if (br[j] == 0xFFFFFFFFu) continue;
+                const uint32_t b2 = (uint32_t)(rec[j] >> shift2) & (uint32_t)(nb2 - 1);
+                br[j] = (b2 << 16) | (atomicAdd(&s_cnt[b2], 1u) & 0xFFFFu);   // a tile holds 2^14 records
+            }
+            __syncthreads();
+            // B. exclusive prefix of the region counts: thread t owns regions 2t and 2t+1 (nb2 <= 2048)
+            {
+                const unsigned int v0 = 2 * t < nb2 ? s_cnt[2 * t] : 0u, v1 = 2 * t + 1 < nb2 ? s_cnt[2 * t + 1] : 0u;
+                const unsigned int v = v0 + v1;
+                unsigned int inc = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
+                if ((t & 63) == 63) s_wsum[t >> 6] = inc;
+                __syncthreads();
+                unsigned int wbase = 0;
+                for (int w = 0; w < (t >> 6); ++w) wbase += s_wsum[w];
+                const unsigned int ex = wbase + inc - v;
+                if (2 * t < nb2) s_off[2 * t] = ex;
+                if (2 * t + 1 < nb2) s_off[2 * t + 1] = ex + v0;
+                if (t == PT_THREADS - 1) s_off[nb2] = wbase + inc;
+            }
+            __syncthreads();
+            // C. records into LDS in region order
+#pragma unroll
+            for (int j = 0; j < PT_GROUP; ++j)
+                if (br[j] != 0xFFFFFFFFu) s_stage[s_off[br[j] >> 16] + (br[j] & 0xFFFFu)] = rec[j];
+            __syncthreads();
+            // D. copy out: `lpb` lanes per region (a tile holds PT_TILE / nb2 records per region on average)
+            {
+                const int lpb = nb2 <= 256 ? 64 : 16;
+                const int g = t / lpb, r = t % lpb;
+                for (int b2 = g; b2 < nb2; b2 += PT_THREADS / lpb) {
+                    const unsigned int off = s_off[b2], cnt = s_cnt[b2], cur = s_cur[b2];
+                    const uint64_t region = ((uint64_t)b1 << G.p2) + (uint64_t)b2;
+                    uint64_t *dst = out2 + (region * G.nblk2 + blockIdx.x) * G.cap2;
+                    for (unsigned int q = r; q < cnt; q += lpb) {
+                        const unsigned int pos = cur + q;
+                        const uint64_t rr = s_stage[off + q];
+                        if (pos < G.cap2) dst[pos] = rr;
+                        else defer_record(T, hash_of(b1, rr, G.recbits), deferred, deferred_n, deferred_cap);
                     }
                 }
             }
+            __syncthreads();
+            for (int i = t; i < nb2; i += PT_THREADS) { s_cur[i] += s_cnt[i]; s_cnt[i] = 0; }
+            __syncthreads();
         }
-        __syncthreads();
         for (int i = t; i < nb2; i += PT_THREADS)
             cnt2[(((uint64_t)b1 << G.p2) + i) * G.nblk2 + blockIdx.x] = s_cur[i] < G.cap2 ? s_cur[i] : G.cap2;
         __syncthreads();
     }
-    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
-    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
 }
+constexpr size_t P2_LDS = (size_t)PT_TILE * 8 + (size_t)(3 * PT_MAXBUCKETS + 1 + 16 + P2_MAXSL + 1) * 4;
 
 // ---- final: region lists -> LDS image of the region -> table ------------------------------------------------------
 // lists: slices  lists[(region * nsl + x) * cap + i], i < cnt[region * nsl + x].  `parity`: regions with (region & 1) == parity.
@@ -412,7 +461,12 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     uint32_t lcap = G.cap1, nsl = G.nblk1;
     if (G.p2) {
         dim3 grid(G.nblk2, std::min<uint32_t>(nb1, 2048));
-        hipLaunchKernelGGL(part2_kernel, grid, dim3(PT_THREADS), 0, stream, out1, cnt1, d, G, out2, cnt2, defer_e, defer_n, deferred_cap);
+        static bool attr2_set = false;
+        if (!attr2_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr2_set = true;
+        }
+        hipLaunchKernelGGL(part2_kernel, grid, dim3(PT_THREADS), P2_LDS, stream, out1, cnt1, d, G, out2, cnt2, defer_e, defer_n, deferred_cap);
         HIPCHK(hipGetLastError());
         lists = out2; lcnt = cnt2; lcap = G.cap2; nsl = G.nblk2;
     }
