@@ -77,6 +77,10 @@ __device__ __forceinline__ void pt_stage(const uint8_t *__restrict__ bases, int6
 // 128-B runs.  (Writing each 8-B record straight from the thread that produced it cost 3.9x the bytes in WRITE_SIZE:
 // 1024 open lines per block x 2 blocks per CU do not stay in the 4 MiB L2 until they are full.)
 constexpr int P1_MAXB = 1024;          // part1 handles p1 <= 10; larger p1 falls back to the direct kernel
+// WIDE = (k > 32): the k-mer needs two 64-bit words; its inner loop is written out on word pairs with the shift amounts
+// fixed by WIDE (the generic u128 helpers shift by run-time amounts: a scalar branch per helper call, ~8 per k-mer, and
+// twice the ALU work where one word would do).  Hashing is ALU-bound here, so instruction count is what matters.
+template <bool WIDE>
 __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t ntiles, uint64_t emit_from,
                                                             TableDev T, PartGeom G, uint64_t *__restrict__ out1, unsigned int *__restrict__ cnt1,
                                                             unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
@@ -94,6 +98,15 @@ __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__rest
     const int nb = 1 << G.p1;
     const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
     const u128 kmask = maskbits(2 * k);
+    // word-level constants of the inner loop (see WIDE above)
+    const int hb = WIDE ? 2 * k - 64 : 0;                                       // k-mer / hash bits in the high word
+    const uint64_t himask = WIDE ? (hb == 64 ? ~0ull : ((1ull << hb) - 1ull)) : 0ull;
+    const uint64_t lomask = WIDE ? ~0ull : (2 * k == 64 ? ~0ull : ((1ull << (2 * k)) - 1ull));
+    const int rcins = WIDE ? 2 * (k - 1) - 64 : 2 * (k - 1);
+    const int hshift = WIDE ? 64 - hb : 0;
+    const bool rec64 = G.recbits >= 64;                                         // WIDE with p1 == hb: record = the whole low word
+    const uint64_t recmask = G.recbits >= 64 ? ~0ull : ((1ull << G.recbits) - 1ull);
+    const int bsh = WIDE && !rec64 ? 64 - G.recbits : 0;                        // hi word's place in the bucket number
     unsigned long long added = 0, fresh = 0;
     for (int i = t; i < nb; i += PT_THREADS) { s_cur[i] = 0; s_cnt[i] = 0; }
     __syncthreads();
@@ -113,24 +126,44 @@ __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__rest
         // A. hash my 16 windows, take a rank in the tile's bucket histogram
         const uint32_t w4 = s_code[t], w3 = s_code[t + 1], w2 = s_code[t + 2], w1 = s_code[t + 3];
         const uint64_t ivprev = ((uint64_t)s_inv[t] << 48) | ((uint64_t)s_inv[t + 1] << 32) | ((uint64_t)s_inv[t + 2] << 16) | (uint64_t)s_inv[t + 3];
-        u128 fwd = band(mk(((uint64_t)w4 << 32) | w3, ((uint64_t)w2 << 32) | w1), kmask);
-        u128 rc = revcomp(fwd, k);
+        const u128 fwd0 = band(mk(((uint64_t)w4 << 32) | w3, ((uint64_t)w2 << 32) | w1), kmask);
+        const u128 rc0 = revcomp(fwd0, k);
+        uint64_t fl = fwd0.lo, fh = fwd0.hi, rl = rc0.lo, rh = rc0.hi;     // forward / reverse-complement k-mer, (hi, lo) words
         int run = ivprev ? (int)__builtin_ctzll(ivprev) : 64;
         uint64_t rec[PT_GROUP];
         uint32_t br[PT_GROUP];     // bucket << 16 | rank in tile ; 0xFFFFFFFF = no record
 #pragma unroll
         for (int j = 0; j < PT_GROUP; ++j) {
-            const uint32_t cj = (c >> (30 - 2 * j)) & 3u;
+            const uint64_t cj = (c >> (30 - 2 * j)) & 3u;
             const bool bad = (iv >> (15 - j)) & 1u;
-            fwd = band(bor(shl(fwd, 2), mk(0, cj)), kmask);
-            rc = bor(shr(rc, 2), shl(mk(0, 3u - cj), 2 * (k - 1)));
+            if (WIDE) {               // 2k in 66..128: the new base enters rc in the high word at bit 2(k-1)-64
+                fh = ((fh << 2) | (fl >> 62)) & himask;
+                fl = (fl << 2) | cj;
+                rl = (rl >> 2) | (rh << 62);
+                rh = (rh >> 2) | ((3ull - cj) << rcins);
+            } else {                  // 2k <= 64: one word
+                fl = ((fl << 2) | cj) & lomask;
+                rl = (rl >> 2) | ((3ull - cj) << rcins);
+            }
             run = bad ? 0 : run + 1;
             br[j] = 0xFFFFFFFFu;
             rec[j] = 0;
             if (run >= k && (uint64_t)(base0 + t * PT_GROUP + j) >= emit_from) {
-                const u128 h = mix(lt(rc, fwd) ? rc : fwd, T.B);
-                const uint32_t b = (uint32_t)shr(h, G.recbits).lo;
-                rec[j] = rec_of(h, G.recbits);
+                uint32_t b;
+                if (WIDE) {
+                    const bool take_rc = rh < fh || (rh == fh && rl < fl);            // canonical = numeric min
+                    const uint64_t mh = take_rc ? rh : fh, ml = take_rc ? rl : fl;
+                    const uint64_t lo = mix64(ml);                                     // = mix() for 2k > 64 (kmer.hpp)
+                    const uint64_t hi = (mh ^ ((lo * JK_C3) >> hshift)) & himask;
+                    // bucket = top p1 bits of the 2k-bit hash (hi:hb bits, lo:64 bits), p1 >= hb here; record = the rest
+                    b = rec64 ? (uint32_t)hi : (uint32_t)((hi << bsh) | (lo >> G.recbits));
+                    rec[j] = rec64 ? lo : (lo & recmask);
+                } else {
+                    const uint64_t m = rl < fl ? rl : fl;
+                    const uint64_t h = mix(mk(0, m), T.B).lo;
+                    b = (uint32_t)(h >> G.recbits);
+                    rec[j] = h & recmask;
+                }
                 br[j] = (b << 16) | (atomicAdd(&s_cnt[b], 1u) & 0xFFFFu);    // LDS returning atomic; a tile holds < 2^15 records
                 ++added;
             }
@@ -309,6 +342,8 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *
     const uint32_t R = 1u << G.rbits;
     const uint32_t halo = nregions > 1 ? (uint32_t)RG_HALO : 0u;     // a single region is the whole table: probes wrap inside it
     const uint32_t span = R + halo;
+    const int rs = T.B - T.s;                                        // remainder bits (<= 53 by the tag format)
+    const uint64_t rmask = (1ull << rs) - 1ull;
     unsigned long long fresh = 0;
     // fused multiplicity histogram (histo != null: this pass writes the FINAL counts of the whole table): every slot is
     // binned exactly once, by the block that writes its final value -- an even region's body in the even launch; in the
@@ -346,10 +381,10 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *
               for (int u = 0; u < 4; ++u) {
                 if (i0 + u * PT_THREADS + t >= nrec) continue;
                 const uint64_t rec = recs[u];
-                const u128 h = hash_of(b1, rec, G.recbits);
-                const uint64_t home = home_of(h, T.B, T.s);
-                const uint64_t rem = rem_of(h, T.B, T.s);
-                const uint32_t local = (uint32_t)(home - first);   // < R
+                // the record holds the low recbits hash bits; the bits above the slot index of this region are implied
+                // by the list it is in, so slot and remainder come from the record alone (no 128-bit arithmetic here)
+                const uint64_t rem = rec & rmask;
+                const uint32_t local = (uint32_t)(rec >> rs) & (R - 1);
                 bool done = false;
                 for (uint32_t off = 0; off < MAXPROBE && !done; ++off) {
                     uint32_t idx = local + off;
@@ -366,7 +401,7 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *
                         done = true;
                     }
                 }
-                if (!done) defer_record(T, h, deferred, deferred_n, deferred_cap);
+                if (!done) defer_record(T, hash_of(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
               }
             }
         }
@@ -450,10 +485,12 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     HIPCHK(hipEventRecord(ev_stage_t[0], stream));
     static bool attr1_set = false;
     if (!attr1_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr1_set = true;
     }
-    hipLaunchKernelGGL(part1_kernel, dim3(G.nblk1), dim3(PT_THREADS), P1_LDS, stream, d_piece, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, deferred_cap);
+    if (k > 32) hipLaunchKernelGGL(part1_kernel<true>, dim3(G.nblk1), dim3(PT_THREADS), P1_LDS, stream, d_piece, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, deferred_cap);
+    else hipLaunchKernelGGL(part1_kernel<false>, dim3(G.nblk1), dim3(PT_THREADS), P1_LDS, stream, d_piece, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, deferred_cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_stage_t[1], stream));
     const uint64_t *lists = out1;

@@ -329,3 +329,36 @@ def test_histogram_fused_into_counting_pass_equals_table_scan(KT):
     h2 = t.histogram()
     assert all(h2[2 * m] == h_scan[m] for m in range(1, 5000))
     t.close()
+
+
+@pytest.mark.parametrize("k", [21, 27, 31, 32, 33, 35, 37])
+def test_partitioned_counting_equals_direct_counting(KT, k):
+    """the atomic-free partitioned path (part1 -> part2 -> lds_insert, count_part.hip) and the direct insert kernel
+    must build the same table for every k the partitioned path accepts (one- and two-word k-mers)"""
+    import torch
+    G = 1_500_000
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(100 + k)
+    genome = synth.torch_genome(gen, G, dev)
+    nreads = G * 30 // 150
+    reads = synth.torch_reads_stream(gen, genome, nreads, 150, 0.004)
+    torch.cuda.synchronize()
+    slots = int(1.25 * nreads * 150 * 2.1 / 10)
+    tp = KT(k, min_slots=slots)
+    tp.count_bases_device(reads.data_ptr(), reads.numel())
+    assert tp.count_stages()[1] >= 1, "partitioned path not taken"
+    os.environ["JASPER_COUNT_DIRECT"] = "1"
+    try:
+        td = KT(k, min_slots=slots)
+        td.count_bases_device(reads.data_ptr(), reads.numel())
+        assert td.count_stages()[1] == 0
+    finally:
+        del os.environ["JASPER_COUNT_DIRECT"]
+    ip, idr = tp.info(), td.info()
+    assert ip["occurrences"] == idr["occurrences"] == nreads * (150 - k + 1) and ip["distinct"] == idr["distinct"]
+    assert tp.histogram() == td.histogram()
+    g = genome[:200_000].cpu().numpy().tobytes().decode()
+    qs = [g[i:i + k] for i in range(0, len(g) - k, 997)] + ["A" * k, "ACGT" * 16]
+    assert tp.lookup(qs) == td.lookup(qs)
+    tp.close()
+    td.close()
