@@ -110,10 +110,14 @@ __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__rest
     unsigned long long added = 0, fresh = 0;
     for (int i = t; i < nb; i += PT_THREADS) { s_cur[i] = 0; s_cnt[i] = 0; }
     __syncthreads();
+    // my 16 bases of the NEXT tile are requested while the current one is processed (one block per CU: nothing else
+    // would hide that latency)
+    Raw16 raw = load16(bases, (int64_t)(blockIdx.x * (uint64_t)PT_TILE) + (int64_t)t * PT_GROUP, (int64_t)n);
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base0 = (int64_t)(tile * PT_TILE);
         uint32_t c, iv;
-        pt_stage(bases, base0 + (int64_t)t * PT_GROUP, n, aligned, c, iv);
+        encode16(raw.w, c, iv);
+        if (tile + gridDim.x < ntiles) raw = load16(bases, (int64_t)((tile + gridDim.x) * PT_TILE) + (int64_t)t * PT_GROUP, (int64_t)n);
         s_code[t + PT_HALO] = c;
         s_inv[t + PT_HALO] = iv;
         if (t < PT_HALO) {
@@ -153,8 +157,9 @@ __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__rest
                 if (WIDE) {
                     const bool take_rc = rh < fh || (rh == fh && rl < fl);            // canonical = numeric min
                     const uint64_t mh = take_rc ? rh : fh, ml = take_rc ? rl : fl;
-                    const uint64_t lo = mix64(ml);                                     // = mix() for 2k > 64 (kmer.hpp)
-                    const uint64_t hi = (mh ^ ((lo * JK_C3) >> hshift)) & himask;
+                    uint64_t mid;
+                    const uint64_t lo = mix64_mid(ml, mid);                            // = mix() for 2k > 64 (kmer.hpp)
+                    const uint64_t hi = (mh ^ (mid >> hshift)) & himask;
                     // bucket = top p1 bits of the 2k-bit hash (hi:hb bits, lo:64 bits), p1 >= hb here; record = the rest
                     b = rec64 ? (uint32_t)hi : (uint32_t)((hi << bsh) | (lo >> G.recbits));
                     rec[j] = rec64 ? lo : (lo & recmask);
@@ -192,6 +197,7 @@ __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__rest
         //    128-B run of its bucket's slice per round (three LDS reads per bucket instead of a binary search per record)
         {
             const int g16 = t >> 4, r16 = t & 15;
+#pragma unroll 4
             for (int b = g16; b < nb; b += PT_THREADS / 16) {
                 const unsigned int off = s_off[b], cnt = s_cnt[b], cur = s_cur[b];
                 uint64_t *dst = out1 + ((uint64_t)b * G.nblk1 + blockIdx.x) * G.cap1;

@@ -107,22 +107,25 @@ JK_HD u128 canonical(u128 m, int k) {
 // B-bit values.  (Same idea as Jellyfish's invertible GF(2) matrix, JF::include/jellyfish/rectangular_binary_matrix.hpp,
 // but a different function: 64-bit multiply-shift suits the GPU's ALUs, a 2k x 2k bit matrix does not.)
 //   B <= 64: two rounds of (odd multiply mod 2^B, xor-shift by B/2) -- each step is invertible on B bits.
-//   B >  64: one Feistel step over (hi: B-64 bits, lo: 64 bits): lo' = mix64(lo), hi' = hi ^ top_bits(lo' * C3).
-//            lo -> lo' is a bijection and hi' is recoverable from (hi', lo'), so the pair is a bijection; keys that
-//            differ only in hi get different TOP hash bits (far-apart home slots), keys that differ in lo get
-//            independent lo'.  Three 64-bit multiplies instead of two 128-bit ones: hashing is ALU-bound in part1.
+//   B >  64: one Feistel step over (hi: B-64 bits, lo: 64 bits): lo' = mix64(lo), hi' = hi ^ F(lo) where F = the top
+//            bits of mix64's first product.  lo -> lo' is a bijection and F depends on lo only, so (hi', lo') is a
+//            bijection; keys that differ only in hi get different TOP hash bits (far-apart home slots), keys that differ
+//            in lo get independent lo' (F and lo' are a multiply and a xor-shift apart).  Two 64-bit multiplies instead
+//            of two 128-bit ones: hashing is ALU-bound in part1.
 #define JK_C1 0x9E3779B97F4A7C15ull
 #define JK_C2 0xBF58476D1CE4E5B9ull
-#define JK_C3 0x94D049BB133111EBull
 
-JK_HD uint64_t mix64(uint64_t x) {
+// mix64 with its intermediate product exposed (mid = state after the first multiply)
+JK_HD uint64_t mix64_mid(uint64_t x, uint64_t &mid) {
     x ^= x >> 32;
     x *= JK_C1;
+    mid = x;
     x ^= x >> 29;
     x *= JK_C2;
     x ^= x >> 32;
     return x;
 }
+JK_HD uint64_t mix64(uint64_t x) { uint64_t mid; return mix64_mid(x, mid); }
 
 JK_HD u128 mix(u128 x, int B) {
     if (B <= 64) {
@@ -136,8 +139,9 @@ JK_HD u128 mix(u128 x, int B) {
         return mk(0, v);
     }
     const int hb = B - 64;                                   // 2..64
-    const uint64_t lo = mix64(x.lo);
-    const uint64_t f = (lo * JK_C3) >> (64 - hb);
+    uint64_t mid;
+    const uint64_t lo = mix64_mid(x.lo, mid);
+    const uint64_t f = mid >> (64 - hb);
     const uint64_t hm = hb == 64 ? ~0ull : ((1ull << hb) - 1);
     return mk((x.hi ^ f) & hm, lo);
 }

@@ -153,21 +153,27 @@ __device__ __forceinline__ void encode16(const uint32_t w[4], uint32_t &codes, u
         inv = (inv << 4) | ((((nz >> 7) * 0x08040201u) >> 24) & 0xFu);
     }
 }
-// the 16 bytes text[pos .. pos+16) of a text of n bytes (positions outside it read as 'N') through encode16
-__device__ __forceinline__ void stage16(const uint8_t *__restrict__ text, int64_t pos, int64_t n, uint32_t &codes, uint32_t &inv) {
+// the 16 bytes text[pos .. pos+16) of a text of n bytes (positions outside it read as 'N')
+struct Raw16 { uint32_t w[4]; };
+__device__ __forceinline__ Raw16 load16(const uint8_t *__restrict__ text, int64_t pos, int64_t n) {
     struct __attribute__((packed, aligned(1))) V16 { uint32_t w[4]; };
-    V16 v;
+    Raw16 r;
     if (pos >= 0 && pos + 16 <= n) {
-        v = *reinterpret_cast<const V16 *>(text + pos);
+        const V16 v = *reinterpret_cast<const V16 *>(text + pos);
+        r.w[0] = v.w[0]; r.w[1] = v.w[1]; r.w[2] = v.w[2]; r.w[3] = v.w[3];
     } else {
-        v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0x4E4E4E4Eu;   // "NNNN"
+        r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0x4E4E4E4Eu;   // "NNNN"
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int64_t p = pos + j;
-            if (p >= 0 && p < n) v.w[j >> 2] = (v.w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | ((uint32_t)text[p] << (8 * (j & 3)));
+            if (p >= 0 && p < n) r.w[j >> 2] = (r.w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | ((uint32_t)text[p] << (8 * (j & 3)));
         }
     }
-    encode16(v.w, codes, inv);
+    return r;
+}
+__device__ __forceinline__ void stage16(const uint8_t *__restrict__ text, int64_t pos, int64_t n, uint32_t &codes, uint32_t &inv) {
+    const Raw16 r = load16(text, pos, n);
+    encode16(r.w, codes, inv);
 }
 
 // H2 / Appendix A.3: k-mer of a string cut at the first non-ACGTacgt byte (or at k) and right-filled with 'A'
