@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 output of tools/prof_bench.sh (gpurun_out/prof) into the summaries kept under profiles/:
+
+    python tools/summarize_prof.py gpurun_out/prof profiles/round1 [steps_profiled]
+
+  bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, jk:: kernels only
+  bench_hbm_counters.json  FETCH_SIZE / WRITE_SIZE per jk:: kernel (KB as reported; two separate --pmc passes) and the
+                           counting pipeline's HBM bytes per step (bench.py reads roofline.traffic from here)
+"""
+import csv, glob, json, os, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3      # --steps 2 --warmup 1
+csv.field_size_limit(1 << 30)
+
+
+def newest(pattern):
+    files = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
+    if not files:
+        sys.exit("missing " + pattern)
+    return files[-1]
+
+
+os.makedirs(dst, exist_ok=True)
+def short(n):
+    n = n[5:] if n.startswith("void ") else n
+    return n.split("(")[0]
+
+
+rows = [r for r in csv.DictReader(open(newest("trace/*/*kernel_stats.csv"))) if short(r["Name"]).startswith("jk::")]
+with open(os.path.join(dst, "bench_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
+    for r in rows:
+        w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"]])
+
+out = {}
+for ctr, pat in (("FETCH_SIZE", "pmc_fetch/*/*counter_collection.csv"), ("WRITE_SIZE", "pmc_write/*/*counter_collection.csv")):
+    acc = {}
+    for r in csv.DictReader(open(newest(pat))):
+        name = short(r["Kernel_Name"])
+        if r["Counter_Name"] != ctr or not name.startswith("jk::"):
+            continue
+        a = acc.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    out[ctr] = {k: {"dispatches": v[0], "sum_KB": v[1], "KB_per_dispatch": v[1] / v[0]} for k, v in acc.items()}
+pipe = ("jk::part1_kernel", "jk::part2_kernel", "jk::lds_insert_kernel", "jk::import3_kernel", "jk::count_kernel")
+tot_kb = sum(v["sum_KB"] for c in ("FETCH_SIZE", "WRITE_SIZE") for k, v in out[c].items() if k.startswith(pipe))
+launches = max(1, out["FETCH_SIZE"].get("jk::part1_kernel<true>", out["FETCH_SIZE"].get("jk::part1_kernel", {"dispatches": steps}))["dispatches"] // steps)
+out["counting_pipeline"] = {"steps_profiled": steps, "hbm_bytes_per_step": tot_kb * 1024.0 / steps, "launches_per_step": launches,
+                            "hbm_bytes_per_launch": tot_kb * 1024.0 / steps / launches,
+                            "note": "FETCH_SIZE + WRITE_SIZE of part1 + part2 + lds_insert (+ deferred import); KB as reported by rocprofv3"}
+json.dump(out, open(os.path.join(dst, "bench_hbm_counters.json"), "w"), indent=1)
+for r in rows[:14]:
+    print("%-34s calls %4s avg %10.1f us" % (short(r["Name"])[:34], r["Calls"], float(r["AverageNs"]) / 1e3))
+print("counting pipeline: %.2f GB HBM traffic per step" % (out["counting_pipeline"]["hbm_bytes_per_step"] / 1e9))
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for k, v in out[c].items():
+        print("  %-11s %-34s %8.3f GB per dispatch x %d" % (c, k[:34], v["KB_per_dispatch"] * 1024 / 1e9, v["dispatches"]))
