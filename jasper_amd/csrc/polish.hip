@@ -787,7 +787,8 @@ struct Walker {
             bool known = false;
             if (p < end && cls != nullptr && p >= dirty_end + k) {
                 const int64_t o = p - delta + seg_lo;              // pass-start chunk coordinate
-                if (o >= 0 && o < cls_n) { known = true; ev = cls[o] != PC_CLEAN; }
+                if (!is_last && o >= stop_orig) known = true;      // (ev stays true) the next segment's: hand over here
+                else if (o >= 0 && o < cls_n) { known = true; ev = cls[o] != PC_CLEAN; }
             }
             if (p < end && !known) {
                 // one pass over the window: 2-bit encode + validity
@@ -814,9 +815,10 @@ struct Walker {
     }
 
     // ---------------- src/jasper.py:50-104, one chunk, one pass ----------------
-    __device__ void walk(bool fix, int64_t &wrong_out) {
-        int64_t i = C->start_i, wrong = 0;
+    __device__ void walk(bool fix, int64_t start_i, int64_t &wrong_out, long long &arrive_out) {
+        int64_t i = start_i, wrong = 0;
         bool handed_over = false;
+        arrive_out = ARRIVE_FAIL;
         while (i < len - k + 1 && status == PS_OK) {                           // :55
             if (__ballot(spec_fail != 0)) { spec_fail = 1; break; }
             const uint64_t ts0 = wall_clock64();
@@ -824,7 +826,11 @@ struct Walker {
             tk[0] += wall_clock64() - ts0;
             if (i >= len - k + 1) { if (!is_last) spec_fail = 1; break; }
             // arriving at the next sync point: the next segment takes over from here
-            if (!is_last && (i - delta + seg_lo) >= stop_orig) { handed_over = true; break; }
+            if (!is_last && (i - delta + seg_lo) >= stop_orig) {
+                if (i < dirty_end + k) spec_fail = 1;          // (never seen: boundaries lie >= 4k right of any event)
+                else { handed_over = true; arrive_out = i - delta + seg_lo; }
+                break;
+            }
             // the reference's own loop body at position i
             uint8_t ch = 'A';
             if (lane < k) ch = at(i + lane);
@@ -887,16 +893,81 @@ struct Walker {
         }
         if (!is_last && !handed_over && status == PS_OK) spec_fail = 1;   // ran off the segment instead of reaching the sync point
         if (__ballot(spec_fail != 0)) spec_fail = 1;
+        if (is_last && status == PS_OK && !spec_fail) arrive_out = ARRIVE_END;
+        if (spec_fail || status != PS_OK) arrive_out = ARRIVE_FAIL;
         wrong_out = wrong;
     }
 };
 
-__global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, int n_segs, PolishParams P, int pass, ScratchPool pool) {
+// The arrival slot is the ONLY thing a successor reads from its predecessor, so relaxed agent-scope atomics are enough
+// (they go past the per-XCD L2).  Release/acquire here would write back / invalidate a whole L2 per hop: ~50 us each.
+__device__ __forceinline__ void publish_arrival(long long *slot, long long v) {
+    if (threadIdx.x == 0) __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, int n_segs, PolishParams P, int pass, ScratchPool pool,
+                                                      unsigned int *ticket) {
     __shared__ uint8_t s_tbf[SMAX], s_t1[SMAX], s_t2[SMAX], s_gkb[64], s_gka[64];
-    const int c = blockIdx.x;
+    // segments are taken in the order the waves START (a ticket, not blockIdx): a chained segment spins on its
+    // predecessor's arrival, and a ticket guarantees that predecessor is already running or done
+    unsigned int tk = 0;
+    if (threadIdx.x == 0) tk = atomicAdd(ticket, 1u);
+    const int c = (int)__shfl(tk, 0);
     if (c >= n_segs) return;
     SegDev *C = &segs[c];
-    if (C->status != PS_OK) return;
+    if (C->status != PS_OK) { publish_arrival(C->arrive, ARRIVE_FAIL); return; }
+    const int k = P.k;
+    const int lane = threadIdx.x;
+    const uint64_t t0 = wall_clock64();
+    int64_t start_i = C->start_i;
+    if (C->chain_in) {
+        // (1) while the predecessor is still walking: can anything at all happen in my range?  Every window start the walk
+        //     can visit here, [my boundary, the next boundary + k) or up to the chunk end, all CLEAN -> it only steps.
+        const int64_t lo = C->seg_lo + 4ll * k;
+        int64_t hi = C->last ? C->cls_n : C->stop_orig + k;
+        if (hi > C->cls_n) hi = C->cls_n;
+        bool dirty = C->cls == nullptr;
+        static_assert(PC_CLEAN == 0, "the clean test below ORs class bytes");
+        for (int64_t p0 = lo; p0 < hi && !dirty; p0 += 64 * 16) {
+            bool nc = false;
+            const int64_t p = p0 + (int64_t)lane * 16;
+            if (p + 16 <= hi) {
+                struct __attribute__((packed, aligned(1))) V16 { uint32_t w[4]; };
+                const V16 v = *reinterpret_cast<const V16 *>(C->cls + p);
+                nc = (v.w[0] | v.w[1] | v.w[2] | v.w[3]) != 0u;
+            } else {
+                for (int q = 0; q < 16; ++q) nc = nc || (p + q < hi && C->cls[p + q] != PC_CLEAN);
+            }
+            dirty = __ballot(nc) != 0ull;
+        }
+        // (2) where does the walk arrive?  Blocks are dispatched in index order, so the predecessor is resident or done.
+        long long a = 0;
+        if (lane == 0) {
+            for (;;) {
+                a = __hip_atomic_load(C->arrive - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a != ARRIVE_PENDING) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        a = __shfl(a, 0);
+        if (a < 0 || a < lo || a - C->seg_lo >= C->len0) {       // the predecessor gave up, or an arrival I cannot take over
+            if (lane == 0) { C->spec_fail = 1; C->ticks = wall_clock64() - t0; }
+            publish_arrival(C->arrive, ARRIVE_FAIL);
+            return;
+        }
+        if (!dirty) {
+            const int64_t stop = C->last ? C->cls_n : C->stop_orig;
+            const int64_t steps = a >= stop ? 0 : (stop - a + (k - 2)) / (k - 1);
+            if (lane == 0) {
+                C->took_shortcut = 1;
+                C->lookups = 2ull * (uint64_t)steps;
+                C->ticks = wall_clock64() - t0;
+            }
+            publish_arrival(C->arrive, C->last ? ARRIVE_END : a + steps * (k - 1));
+            return;
+        }
+        start_i = a - C->seg_lo;
+    }
     Walker w;
     w.T = T; w.k = P.k; w.step = P.step; w.lane = threadIdx.x; w.solid = P.solid;
     w.buf = C->buf; w.len = C->len; w.gs = C->gs; w.glen = C->glen; w.cap = C->cap;
@@ -909,8 +980,8 @@ __global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, 
     w.pool = pool; w.bfs_slot = -1; w.bfs_nodes = nullptr; w.bfs_front = nullptr; w.bfs_patch = nullptr;
     const bool fix = P.fix && pass < P.passes;                                 // src/jasper.py:37-38
     int64_t wrong = 0;
-    const uint64_t t0 = wall_clock64();
-    w.walk(fix, wrong);
+    long long arrive = ARRIVE_FAIL;
+    w.walk(fix, start_i, wrong, arrive);
     w.release_scratch();
     if (threadIdx.x == 0) {
         C->ticks = wall_clock64() - t0;
@@ -920,6 +991,7 @@ __global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, 
         C->wrong = wrong;
         C->lookups = w.nlook;
     }
+    publish_arrival(C->arrive, arrive);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1265,12 +1337,48 @@ __global__ __launch_bounds__(256) void rescan_batch_kernel(const ScanChunk *__re
     }
 }
 
+// clean-zone boundaries: per CLEAN_CELL positions of a chunk, a position p (searched from the middle of the cell) whose
+// window starts [p-4k, p+k) are all CLEAN.  No event can happen there whatever stride phase the walk arrives with, so
+// a chunk may be cut at p if the segment to the right takes its start position from the one to the left (SegDev::chain_in).
+__global__ __launch_bounds__(64) void find_clean_batch_kernel(const ScanChunk *__restrict__ chunks, int n_chunks, int k) {
+    const int lane = threadIdx.x;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const ScanChunk C = chunks[ci];
+        const int64_t nwin = C.len - k + 1;
+        for (uint32_t g = blockIdx.x; g < C.n_cells; g += gridDim.x) {
+            int64_t p0 = (int64_t)g * CLEAN_CELL + CLEAN_CELL / 2;
+            const int64_t cell_end = (int64_t)(g + 1) * CLEAN_CELL;
+            int64_t cand = -1;
+            for (int attempt = 0; attempt < 8; ++attempt) {
+                if (p0 - 4ll * k < 0 || p0 + k > nwin || p0 + k > cell_end) break;
+                int64_t last_bad = -1;
+                for (int64_t q0 = p0 - 4ll * k; q0 < p0 + k; q0 += 64) {
+                    const int64_t q = q0 + lane;
+                    const bool nc = q < p0 + k && C.cls[q] != PC_CLEAN;
+                    const uint64_t m = __ballot(nc);
+                    if (m) last_bad = q0 + 63 - (int64_t)__builtin_clzll(m);
+                }
+                if (last_bad < 0) { cand = p0; break; }
+                p0 = last_bad + 4ll * k + 1;
+            }
+            if (lane == 0) C.clean_cand[g] = cand;
+        }
+    }
+}
+
+static void launch_find_clean(const ScanChunk *d_chunks, int n_chunks, int k, hipStream_t stream) {
+    const int gy = n_chunks < 1024 ? n_chunks : 1024;
+    const int gx = std::max(1, 8192 / gy);
+    hipLaunchKernelGGL(find_clean_batch_kernel, dim3(gx, gy), dim3(64), 0, stream, d_chunks, n_chunks, k);
+}
+
 void launch_rescan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunks, int k, uint32_t solid, hipStream_t stream) {
     if (n_chunks <= 0) return;
     const int gy = n_chunks < 1024 ? n_chunks : 1024;
     const int gx = std::max(1, 4096 / gy);
     hipLaunchKernelGGL(rescan_batch_kernel, dim3(gx, gy), dim3(256), 0, stream, d_chunks, n_chunks, T, solid);
     hipLaunchKernelGGL(find_sync_batch_kernel, dim3(gx, gy), dim3(256), 0, stream, d_chunks, n_chunks, k);
+    launch_find_clean(d_chunks, n_chunks, k, stream);
 }
 
 void launch_scan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunks, int k, uint32_t solid, hipStream_t stream) {
@@ -1280,6 +1388,7 @@ void launch_scan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunk
     hipLaunchKernelGGL(scan_batch_kernel, dim3(gx, gy), dim3(SC_THREADS), 0, stream, d_chunks, n_chunks, T);
     hipLaunchKernelGGL(classify_batch_kernel, dim3(gx, gy), dim3(256), 0, stream, d_chunks, n_chunks, k, solid);
     hipLaunchKernelGGL(find_sync_batch_kernel, dim3(gx, gy), dim3(256), 0, stream, d_chunks, n_chunks, k);
+    launch_find_clean(d_chunks, n_chunks, k, stream);
 }
 
 static int blocks_for(int64_t items, int per_block) {
@@ -1308,9 +1417,11 @@ void launch_seg_init(SegDev *d_segs, int n_segs, const uint8_t *const *d_chunk_t
     dim3 grid(n_segs >= 512 ? 4 : 64, n_segs < 4096 ? n_segs : 4096);
     hipLaunchKernelGGL(seg_init_kernel, grid, dim3(256), 0, stream, d_segs, n_segs, d_chunk_text);
 }
-void launch_seg_walk(const TableDev &T, SegDev *d_segs, int n_segs, PolishParams pp, int pass, ScratchPool pool, hipStream_t stream) {
+void launch_seg_walk(const TableDev &T, SegDev *d_segs, int n_segs, PolishParams pp, int pass, ScratchPool pool, unsigned int *d_ticket,
+                     hipStream_t stream) {
     if (n_segs <= 0) return;
-    hipLaunchKernelGGL(seg_walk_kernel, dim3(n_segs), dim3(64), 0, stream, T, d_segs, n_segs, pp, pass, pool);
+    (void)hipMemsetAsync(d_ticket, 0, sizeof(unsigned int), stream);
+    hipLaunchKernelGGL(seg_walk_kernel, dim3(n_segs), dim3(64), 0, stream, T, d_segs, n_segs, pp, pass, pool, d_ticket);
 }
 void launch_seg_gather(const SegDev *d_segs, int n_segs, const int64_t *idx_base, const uint32_t *seq_base, const uint32_t *rec_off,
                        const uint32_t *aux_off, FixRec *out_recs, uint8_t *out_aux, hipStream_t stream) {

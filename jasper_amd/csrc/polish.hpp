@@ -71,6 +71,12 @@ struct SegDev {
     int64_t start_i;     // local position where the walk starts (0 for the first segment of a chunk)
     int64_t stop_orig;   // the walk ends when it arrives at an event whose pass-start chunk coordinate is >= this
     int32_t first, last; // first / last segment of its chunk: chunk-start / chunk-end semantics are real there
+    // A segment whose left boundary is a CLEAN-ZONE boundary (not a sync point) does not know where the walk arrives: it
+    // takes the arrival position its predecessor publishes (chain_in = 1).  Every segment publishes the chunk coordinate
+    // (pass-start text) at which it handed over in *arrive: ARRIVE_PENDING until then, ARRIVE_FAIL if it gave up.
+    int32_t chain_in;
+    int32_t took_shortcut;   // out: the range held no event, the arrival was computed instead of walked
+    long long *arrive;   // this segment's slot; the predecessor's is arrive[-1]
     const uint8_t *cls;  // PosClass per window start of the chunk at pass start (chunk coordinates), cls_n entries
     int64_t cls_n;
     FixRec *recs;
@@ -90,6 +96,9 @@ struct SegDev {
     int64_t own_lo, own_hi;   // local range of the polished text this segment contributes
     int64_t out_off;          // where it goes in the chunk's new text
 };
+
+constexpr long long ARRIVE_PENDING = (long long)0x8080808080808080ull;   // what hipMemset(0x80) leaves
+constexpr long long ARRIVE_FAIL = -2, ARRIVE_END = -1;
 
 struct PolishParams {
     int k;
@@ -111,7 +120,10 @@ struct ScanChunk {
     unsigned int cand_cap;
     int32_t want_sync;
     const uint8_t *flags;   // one byte per 64 text positions: the previous pass changed text there (rescan only)
+    int64_t *clean_cand;    // per CLEAN_CELL positions: a position whose windows [p-4k, p+k) are all CLEAN, or -1
+    uint32_t n_cells;
 };
+constexpr int64_t CLEAN_CELL = 65536;
 // pass 0: dense scan + classes + sync-point candidates of every chunk
 void launch_scan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunks, int k, uint32_t solid, hipStream_t stream);
 // later passes: classes were carried over by the stitch; recompute the 64-window tiles next to changed text, then candidates
@@ -124,7 +136,9 @@ void launch_classify(const uint32_t *d_cnt, const uint8_t *d_valid, int64_t nwin
 void launch_find_sync(const uint8_t *d_cls, int64_t nwin, int k, int64_t *d_out, unsigned int *d_count, unsigned int cap,
                       hipStream_t stream);
 void launch_seg_init(SegDev *d_segs, int n_segs, const uint8_t *const *d_chunk_text, hipStream_t stream);
-void launch_seg_walk(const TableDev &T, SegDev *d_segs, int n_segs, PolishParams pp, int pass, ScratchPool pool, hipStream_t stream);
+// d_ticket: one device word (zeroed by the call); d_segs[i].arrive must point into an array preset to ARRIVE_PENDING
+void launch_seg_walk(const TableDev &T, SegDev *d_segs, int n_segs, PolishParams pp, int pass, ScratchPool pool, unsigned int *d_ticket,
+                     hipStream_t stream);
 // d_cls_out / d_flags may be null (last pass): then only the text is stitched
 void launch_seg_stitch(const SegDev *d_segs, int n_segs, uint8_t *const *d_chunk_out, uint8_t *const *d_cls_out, uint8_t *const *d_flags,
                        hipStream_t stream);

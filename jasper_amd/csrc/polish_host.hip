@@ -38,6 +38,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     const int64_t W = 4ll * k;        // clean window required left of a sync point
     const int64_t M = 3ll * k;        // text kept right of the next sync point
     const int64_t TMIN = 1024;        // minimum distance between sync points
+    const int64_t CMIN = 32768;       // minimum distance between a clean-zone boundary and its neighbours
     hipStream_t st = T.stream;
     HIPCHK(hipSetDevice(T.device));
     if (T.materialize(err)) return -1;
@@ -58,7 +59,9 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     const double t_begin = now();
     // ---------------- layout ----------------
     std::vector<int64_t> len(lens, lens + n_chunks), cap(n_chunks);
-    std::vector<size_t> off_text(n_chunks), off_pos(n_chunks), off_cand(n_chunks), off_flag(n_chunks);
+    std::vector<size_t> off_text(n_chunks), off_pos(n_chunks), off_cand(n_chunks), off_flag(n_chunks), off_cell(n_chunks);
+    std::vector<uint32_t> n_cells(n_chunks);
+    size_t cell_items = 0;
     std::vector<uint32_t> cand_cap(n_chunks);
     size_t text_bytes = 0, pos_items = 0, cand_items = 0, flag_items = 0, seg_text_bound = 0, seg_rec_bound = 0, seg_aux_bound = 0;
     int64_t max_segs = 0;
@@ -69,6 +72,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         cand_cap[c] = (uint32_t)std::min<int64_t>(1 << 28, cap[c] / (4 * k) + 16);
         off_cand[c] = cand_items;  cand_items += cand_cap[c];
         off_flag[c] = flag_items;  flag_items += al256((size_t)(cap[c] >> 6) + 2);
+        n_cells[c] = (uint32_t)(cap[c] / CLEAN_CELL + 1);
+        off_cell[c] = cell_items;  cell_items += n_cells[c];
         const int64_t ms = cap[c] / TMIN + 2;
         max_segs += ms;
         const int64_t tb = cap[c] + ms * (W + M + 64);
@@ -76,7 +81,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         seg_rec_bound += (size_t)(2 * tb / k + 16 * ms);
         seg_aux_bound += (size_t)(2 * tb + 1024 * ms);
     }
-    DevBuf b_textA, b_textB, b_cnt, b_valid, b_cls, b_clsB, b_flags, b_ptrCA, b_ptrCB, b_ptrF, b_segedit, b_cand, b_ccount, b_ptrA, b_ptrB, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks, b_scan;
+    DevBuf b_textA, b_textB, b_cnt, b_valid, b_cls, b_clsB, b_flags, b_ptrCA, b_ptrCB, b_ptrF, b_segedit, b_cells, b_arrive, b_cand, b_ccount, b_ptrA, b_ptrB, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks, b_scan, b_ticket;
     int ws_next = 0;
     auto dmalloc = [&](DevBuf &b, size_t bytes) -> bool {      // persistent: slot of the table's workspace
         if (ws_next >= Table::WS_POLISH_MAX) { err = "polish: workspace slots exhausted"; return false; }
@@ -87,7 +92,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     if (!dmalloc(b_textA, text_bytes) || !dmalloc(b_textB, text_bytes) || !dmalloc(b_cnt, pos_items * 4) || !dmalloc(b_valid, pos_items) ||
         !dmalloc(b_cls, pos_items) || !dmalloc(b_clsB, pos_items) || !dmalloc(b_flags, flag_items) ||
         !dmalloc(b_ptrCA, n_chunks * sizeof(void *)) || !dmalloc(b_ptrCB, n_chunks * sizeof(void *)) || !dmalloc(b_ptrF, n_chunks * sizeof(void *)) ||
-        !dmalloc(b_segedit, seg_rec_bound * sizeof(EditRec)) || !dmalloc(b_cand, cand_items * 8) || !dmalloc(b_ccount, n_chunks * 4) ||
+        !dmalloc(b_segedit, seg_rec_bound * sizeof(EditRec)) || !dmalloc(b_cells, cell_items * 8) ||
+        !dmalloc(b_arrive, ((size_t)max_segs + 4) * 8) || !dmalloc(b_cand, cand_items * 8) || !dmalloc(b_ccount, n_chunks * 4) ||
         !dmalloc(b_ptrA, n_chunks * sizeof(void *)) || !dmalloc(b_ptrB, n_chunks * sizeof(void *)) ||
         !dmalloc(b_segs, (size_t)max_segs * sizeof(SegDev)) || !dmalloc(b_segtext, seg_text_bound) ||
         !dmalloc(b_segrec, seg_rec_bound * sizeof(FixRec)) || !dmalloc(b_segaux, seg_aux_bound))
@@ -100,7 +106,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     pool.off_front = al256((size_t)pool.node_cap * 4);
     pool.off_patch = pool.off_front + al256((size_t)pool.front_cap * 80);
     pool.stride = pool.off_patch + al256(pool.patch_cap);
-    if (!dmalloc(b_pool, pool.stride * pool.nslots) || !dmalloc(b_locks, pool.nslots * 4) || !dmalloc(b_scan, sizeof(ScanChunk) * n_chunks)) return -2;
+    if (!dmalloc(b_pool, pool.stride * pool.nslots) || !dmalloc(b_locks, pool.nslots * 4) || !dmalloc(b_scan, sizeof(ScanChunk) * n_chunks) ||
+        !dmalloc(b_ticket, 256)) return -2;
     pool.base = b_pool.as<uint8_t>();
     pool.locks = b_locks.as<unsigned int>();
     HIPCHK(hipMemsetAsync(pool.locks, 0, pool.nslots * 4, st));
@@ -141,6 +148,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     std::vector<SegDev> segs;
     std::vector<ScanChunk> sc(n_chunks);            // lives across passes: the async H2D copy reads it after the call returns
     std::vector<int64_t> all_cands(cand_items);     // every chunk's sync-point candidates, fetched with one copy per pass
+    std::vector<int64_t> all_cells(cell_items);     // clean-zone boundary candidates, one per CLEAN_CELL positions
     std::vector<unsigned int> ccount(n_chunks);
     std::vector<int64_t> cands;
     std::vector<uint32_t> aux_total(n_chunks, 0);   // aux bytes gathered so far per chunk (all passes)
@@ -165,6 +173,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                 S.cand_count = b_ccount.as<unsigned int>() + c;
                 S.cand_cap = cand_cap[c];
                 S.want_sync = (len[c] - k + 1) > 2 * TMIN;
+                S.clean_cand = b_cells.as<int64_t>() + off_cell[c];
+                S.n_cells = (uint32_t)std::min<int64_t>(n_cells[c], std::max<int64_t>(0, len[c] - k + 1) / CLEAN_CELL + 1);
             }
             HIPCHK(hipMemcpyAsync(b_scan.p, sc.data(), sizeof(ScanChunk) * n_chunks, hipMemcpyHostToDevice, st));
             if (pass == 0) launch_scan_batch(T.d, b_scan.as<ScanChunk>(), n_chunks, k, pp.solid, st);
@@ -173,6 +183,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ccount.data(), b_ccount.p, n_chunks * 4, hipMemcpyDeviceToHost, st));
         if (cand_items) HIPCHK(hipMemcpyAsync(all_cands.data(), b_cand.p, cand_items * 8, hipMemcpyDeviceToHost, st));
+        if (cell_items) HIPCHK(hipMemcpyAsync(all_cells.data(), b_cells.p, cell_items * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(jk_stream_wait(st));
 
         // ---- 2. segments
@@ -189,6 +200,25 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                     for (int64_t p : cands)
                         if (p - last >= TMIN && len[c] - p >= TMIN) { sync.push_back(p); last = p; }
                 }
+                // clean-zone boundaries inside the stretches the sync points leave long: the segment to the right of one
+                // is chained to its left neighbour (it starts where that one's walk arrives)
+                std::vector<char> chained(sync.size(), 0);
+                if (speculate && len[c] - k + 1 > 2 * CMIN) {
+                    const uint32_t nc = sc[c].n_cells;
+                    std::vector<int64_t> merged;
+                    std::vector<char> mtype;
+                    size_t si = 0;
+                    int64_t last = 0;
+                    for (uint32_t g = 0; g <= nc; ++g) {
+                        const int64_t p = g < nc ? all_cells[off_cell[c] + g] : INT64_MAX;
+                        while (si < sync.size() && sync[si] <= p) { merged.push_back(sync[si]); mtype.push_back(0); last = sync[si]; ++si; }
+                        if (g == nc || p < 0) continue;
+                        const int64_t next = si < sync.size() ? sync[si] : len[c];
+                        if (p - last >= CMIN && next - p >= CMIN) { merged.push_back(p); mtype.push_back(1); last = p; }
+                    }
+                    sync.swap(merged);
+                    chained.swap(mtype);
+                }
                 const int m = (int)sync.size();
                 for (int j = 0; j <= m; ++j) {
                     SegDev S;
@@ -198,6 +228,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                     S.last = (j == m);
                     S.seg_lo = j == 0 ? 0 : sync[j - 1] - W;
                     S.start_i = j == 0 ? 0 : W;
+                    S.chain_in = j > 0 && chained[j - 1];
+                    S.arrive = b_arrive.as<long long>() + 1 + out.size();     // (slot 0 is never read: a first segment is not chained)
                     S.stop_orig = j == m ? INT64_MAX : sync[j];
                     const int64_t seg_hi = j == m ? len[c] : std::min<int64_t>(len[c], sync[j] + M);
                     S.len0 = seg_hi - S.seg_lo;
@@ -229,7 +261,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             if (sv.empty()) return 0;
             if (hipMemcpyAsync(b_segs.p, sv.data(), sv.size() * sizeof(SegDev), hipMemcpyHostToDevice, st) != hipSuccess) { e2 = "polish: H2D segs"; return -1; }
             launch_seg_init(b_segs.as<SegDev>(), (int)sv.size(), (const uint8_t *const *)ptrIn, st);
-            launch_seg_walk(T.d, b_segs.as<SegDev>(), (int)sv.size(), pp, pass, pool, st);
+            if (hipMemsetAsync(b_arrive.p, 0x80, (sv.size() + 2) * 8, st) != hipSuccess) { e2 = "polish: memset"; return -1; }   // ARRIVE_PENDING
+            launch_seg_walk(T.d, b_segs.as<SegDev>(), (int)sv.size(), pp, pass, pool, b_ticket.as<unsigned int>(), st);
             if (hipGetLastError() != hipSuccess) { e2 = "polish: kernel launch failed"; return -1; }
             if (hipMemcpyAsync(sv.data(), b_segs.p, sv.size() * sizeof(SegDev), hipMemcpyDeviceToHost, st) != hipSuccess) { e2 = "polish: D2H segs"; return -1; }
             if (jk_stream_wait(st) != hipSuccess) { e2 = "polish: kernel execution failed"; return -1; }

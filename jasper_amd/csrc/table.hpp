@@ -230,7 +230,7 @@ struct Table {
     uint64_t size_hint = 0;   // caller's expected number of distinct k-mers (`jellyfish count -s`); 0 = none given
     // grow-only device workspace reused by the polisher across calls (hipMalloc of GBs costs far more than the kernels)
     struct WsBuf { void *p = nullptr; size_t bytes = 0; };
-    static constexpr int WS_POLISH_MAX = 32, WS_COUNT = 32, WS_SLOTS = 36;
+    static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_SLOTS = 44;
     WsBuf ws[WS_SLOTS];   // 0..WS_POLISH_MAX-1: polisher (polish_host.hip, in allocation order); WS_COUNT..+3: partitioned counting
     void *workspace(int id, size_t bytes, std::string &err);
 

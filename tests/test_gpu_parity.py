@@ -57,7 +57,10 @@ def test_count_histogram_lookup_vs_oracle(KT, O, k, G, seed):
 
 
 @pytest.mark.parametrize("k,G,seed,thre,passes", [(37, 300_000, 11, 3, 2), (25, 200_000, 12, 3, 2), (31, 100_000, 13, 4, 3),
-                                                    (21, 80_000, 14, 3, 1), (37, 120_000, 15, 5, 4)])
+                                                    (21, 80_000, 14, 3, 1), (37, 120_000, 15, 5, 4),
+                                                    # chunks of 230 kb: later passes find no sync points and cut at clean
+                                                    # zones instead (segments chained through their arrival positions)
+                                                    (37, 1_600_000, 16, 3, 2), (25, 1_200_000, 17, 3, 3)])
 def test_polish_vs_oracle(KT, O, k, G, seed, thre, passes):
     from jasper_amd import polisher
     genome, reads, asm = workload(seed, G, k, asm_err=2e-3)
