@@ -268,16 +268,22 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
             // A. my 16 records (all loads in flight), their region, a rank in the tile's region histogram
             uint64_t rec[PT_GROUP];
             uint32_t br[PT_GROUP];
+            uint32_t sl;                                                      // slice of my first record: largest x with s_pref[x] <= i
+            {
+                const uint32_t i = tile0 + t;
+                uint32_t lo = 0, hi = nmine - 1;
+                while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= i) lo = mid; else hi = mid - 1; }
+                sl = lo;
+            }
 #pragma unroll
             for (int j = 0; j < PT_GROUP; ++j) {
                 const uint32_t i = tile0 + (uint32_t)j * PT_THREADS + t;
                 rec[j] = 0ull;
                 br[j] = 0xFFFFFFFFu;
                 if (i < total) {
-                    uint32_t lo = 0, hi = nmine - 1;                          // slice: largest x with s_pref[x] <= i
-                    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= i) lo = mid; else hi = mid - 1; }
-                    rec[j] = src0[(uint64_t)lo * G.nblk2 * G.cap1 + (i - s_pref[lo])];
-                    br[j] = lo;                                               // (reused below)
+                    while (s_pref[sl + 1] <= i) ++sl;                         // my records are 1024 apart: the slice moves on slowly
+                    rec[j] = src0[(uint64_t)sl * G.nblk2 * G.cap1 + (i - s_pref[sl])];
+                    br[j] = sl;                                               // (reused below)
                 }
             }
 #pragma unroll
@@ -364,6 +370,38 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *
         for (uint32_t x = 0; x < nsl; ++x) total += cnt[(uint64_t)region * nsl + x];
         if (total == 0 && !fresh_table && !histo) continue;                  // block-uniform (a fresh table must still be zeroed here)
         const uint64_t first = (uint64_t)region << G.rbits;        // first slot of the region
+        const uint64_t b1 = region >> G.p2;
+        auto insert = [&](uint64_t rec) {
+            // the record holds the low recbits hash bits; the bits above the slot index of this region are implied
+            // by the list it is in, so slot and remainder come from the record alone (no 128-bit arithmetic here)
+            const uint64_t rem = rec & rmask;
+            const uint32_t local = (uint32_t)(rec >> rs) & (R - 1);
+            bool done = false;
+            for (uint32_t off = 0; off < MAXPROBE && !done; ++off) {
+                uint32_t idx = local + off;
+                if (nregions == 1) idx &= (R - 1);             // whole table in LDS: wrap like the global probe
+                else if (idx >= span) break;                   // beyond the halo: deferred to the direct path
+                const unsigned long long want = tag_of(rem, off);
+                unsigned long long cur = s_img[2 * idx];
+                if (cur == 0ull) {
+                    cur = atomicCAS(&s_img[2 * idx], 0ull, want);   // LDS compare-and-swap
+                    if (cur == 0ull) { ++fresh; cur = want; }
+                }
+                if (cur == want) {
+                    atomicAdd(&s_img[2 * idx + 1], 1ull);      // LDS add
+                    done = true;
+                }
+            }
+            if (!done) defer_record(T, hash_of(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
+        };
+        // the first 16 records per lane of the region's first slice (a region holds ~16 K, and normally in ONE slice) are
+        // requested before the image is set up: one latency instead of four, overlapped with the set-up
+        constexpr int PF = 4;
+        const uint32_t nrec0 = cnt[(uint64_t)region * nsl];
+        const uint64_t *src0 = lists + (uint64_t)region * nsl * cap;
+        uint64_t pre[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { const uint32_t i = (uint32_t)u * PT_THREADS + t; pre[u] = i < nrec0 ? src0[i] : 0ull; }
         // image in: coalesced 16-B loads (the halo wraps around the end of the table).  On a lazily cleared table the slot
         // memory is garbage except for what this pass has already written: nothing yet in the even launch; in the odd
         // launch the even regions, i.e. this region's own first `halo` slots (its left neighbour's halo) and its own halo.
@@ -375,40 +413,19 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *
             s_img[2 * i + 1] = e.y;
         }
         __syncthreads();
-        const uint64_t b1 = region >> G.p2;
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if ((uint32_t)u * PT_THREADS + t < nrec0) insert(pre[u]);
         for (uint32_t x = 0; x < nsl; ++x) {
-            const uint32_t nrec = cnt[(uint64_t)region * nsl + x];
-            const uint64_t *src = lists + ((uint64_t)region * nsl + x) * cap;
-            for (uint32_t i0 = 0; i0 < nrec; i0 += 4 * PT_THREADS) {
-              uint64_t recs[4];
+            const uint32_t nrec = x == 0 ? nrec0 : cnt[(uint64_t)region * nsl + x];
+            const uint64_t *src = src0 + (uint64_t)x * cap;
+            for (uint32_t i0 = x == 0 ? PF * PT_THREADS : 0; i0 < nrec; i0 += 4 * PT_THREADS) {
+                uint64_t recs[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * PT_THREADS + t; recs[u] = i < nrec ? src[i] : 0ull; }   // 4 loads in flight
+                for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * PT_THREADS + t; recs[u] = i < nrec ? src[i] : 0ull; }   // 4 loads in flight
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                if (i0 + u * PT_THREADS + t >= nrec) continue;
-                const uint64_t rec = recs[u];
-                // the record holds the low recbits hash bits; the bits above the slot index of this region are implied
-                // by the list it is in, so slot and remainder come from the record alone (no 128-bit arithmetic here)
-                const uint64_t rem = rec & rmask;
-                const uint32_t local = (uint32_t)(rec >> rs) & (R - 1);
-                bool done = false;
-                for (uint32_t off = 0; off < MAXPROBE && !done; ++off) {
-                    uint32_t idx = local + off;
-                    if (nregions == 1) idx &= (R - 1);             // whole table in LDS: wrap like the global probe
-                    else if (idx >= span) break;                   // beyond the halo: deferred to the direct path
-                    const unsigned long long want = tag_of(rem, off);
-                    unsigned long long cur = s_img[2 * idx];
-                    if (cur == 0ull) {
-                        cur = atomicCAS(&s_img[2 * idx], 0ull, want);   // LDS compare-and-swap
-                        if (cur == 0ull) { ++fresh; cur = want; }
-                    }
-                    if (cur == want) {
-                        atomicAdd(&s_img[2 * idx + 1], 1ull);      // LDS add
-                        done = true;
-                    }
-                }
-                if (!done) defer_record(T, hash_of(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
-              }
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * PT_THREADS + t < nrec) insert(recs[u]);
             }
         }
         __syncthreads();
@@ -466,7 +483,10 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     nblk1 = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(nblk1, ntiles), 256));   // one 1024-thread block (152 KB of LDS) per CU
     G.nblk1 = (uint32_t)nblk1;
     G.cap1 = list_cap((double)piece_bases / ((double)(1u << p1) * (double)nblk1));
-    G.nblk2 = p2 ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nblk1, 8)) : 1;
+    // one slice per region list: part2 runs one 1024-thread block per CU, and 2^p1 >= 256 buckets already fill the chip;
+    // lds_insert_kernel then reads a region's records as one contiguous list
+    static const int nblk2_exp = getenv("JASPER_EXPERIMENT_NBLK2") ? atoi(getenv("JASPER_EXPERIMENT_NBLK2")) : 0;   // tuning experiments only
+    G.nblk2 = p2 ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nblk1, nblk2_exp > 0 ? nblk2_exp : ((1u << p1) >= 256 ? 1 : 8))) : 1;
     G.cap2 = p2 ? list_cap((double)piece_bases / ((double)(1ull << (p1 + p2)) * (double)G.nblk2)) : 0;
     return true;
 }
