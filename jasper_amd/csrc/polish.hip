@@ -1273,8 +1273,8 @@ __global__ __launch_bounds__(256) void find_sync_batch_kernel(const ScanChunk *_
             for (int64_t q = 1; q < k - 1 && ok; ++q) ok = cls[p + q] == PC_BAD;
             for (int64_t q = 2; q <= W && ok; ++q) ok = cls[p - q] == PC_CLEAN;
             if (!ok) continue;
-            const unsigned int idx = atomicAdd(C.cand_count, 1u);
-            if (idx < C.cand_cap) C.cand[idx] = p;
+            const unsigned int idx = atomicAdd(C.cand_count, 1u);        // ONE list for the whole batch: (chunk << 40) | position
+            if (idx < C.cand_cap) C.cand[idx] = ((int64_t)ci << 40) | p;
         }
     }
 }

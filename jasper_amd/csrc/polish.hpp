@@ -115,8 +115,8 @@ struct ScanChunk {
     uint32_t *cnt;
     uint8_t *valid;
     uint8_t *cls;
-    int64_t *cand;
-    unsigned int *cand_count;
+    int64_t *cand;             // sync-point candidates of the WHOLE batch: (chunk << 40) | position, unordered
+    unsigned int *cand_count;  // one counter for the batch
     unsigned int cand_cap;
     int32_t want_sync;
     const uint8_t *flags;   // one byte per 64 text positions: the previous pass changed text there (rescan only)

@@ -81,7 +81,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         seg_rec_bound += (size_t)(2 * tb / k + 16 * ms);
         seg_aux_bound += (size_t)(2 * tb + 1024 * ms);
     }
-    DevBuf b_textA, b_textB, b_cnt, b_valid, b_cls, b_clsB, b_flags, b_ptrCA, b_ptrCB, b_ptrF, b_segedit, b_cells, b_arrive, b_cand, b_ccount, b_ptrA, b_ptrB, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks, b_scan, b_ticket;
+    DevBuf b_textA, b_textB, b_cnt, b_valid, b_cls, b_clsB, b_flags, b_segedit, b_cells, b_arrive, b_cand, b_ccount, b_ptrA, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks, b_scan, b_ticket;
     int ws_next = 0;
     auto dmalloc = [&](DevBuf &b, size_t bytes) -> bool {      // persistent: slot of the table's workspace
         if (ws_next >= Table::WS_POLISH_MAX) { err = "polish: workspace slots exhausted"; return false; }
@@ -91,10 +91,9 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     };
     if (!dmalloc(b_textA, text_bytes) || !dmalloc(b_textB, text_bytes) || !dmalloc(b_cnt, pos_items * 4) || !dmalloc(b_valid, pos_items) ||
         !dmalloc(b_cls, pos_items) || !dmalloc(b_clsB, pos_items) || !dmalloc(b_flags, flag_items) ||
-        !dmalloc(b_ptrCA, n_chunks * sizeof(void *)) || !dmalloc(b_ptrCB, n_chunks * sizeof(void *)) || !dmalloc(b_ptrF, n_chunks * sizeof(void *)) ||
         !dmalloc(b_segedit, seg_rec_bound * sizeof(EditRec)) || !dmalloc(b_cells, cell_items * 8) ||
-        !dmalloc(b_arrive, ((size_t)max_segs + 4) * 8) || !dmalloc(b_cand, cand_items * 8) || !dmalloc(b_ccount, n_chunks * 4) ||
-        !dmalloc(b_ptrA, n_chunks * sizeof(void *)) || !dmalloc(b_ptrB, n_chunks * sizeof(void *)) ||
+        !dmalloc(b_arrive, ((size_t)max_segs + 4) * 8) || !dmalloc(b_cand, cand_items * 8) || !dmalloc(b_ccount, 256) ||
+        !dmalloc(b_ptrA, (size_t)6 * n_chunks * sizeof(void *)) ||
         !dmalloc(b_segs, (size_t)max_segs * sizeof(SegDev)) || !dmalloc(b_segtext, seg_text_bound) ||
         !dmalloc(b_segrec, seg_rec_bound * sizeof(FixRec)) || !dmalloc(b_segaux, seg_aux_bound))
         return -2;
@@ -112,24 +111,26 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     pool.locks = b_locks.as<unsigned int>();
     HIPCHK(hipMemsetAsync(pool.locks, 0, pool.nslots * 4, st));
 
-    uint8_t *textIn = b_textA.as<uint8_t>(), *textOut = b_textB.as<uint8_t>();
     uint8_t *clsIn = b_cls.as<uint8_t>(), *clsOut = b_clsB.as<uint8_t>();
-    std::vector<uint8_t *> hptrA(n_chunks), hptrB(n_chunks), hptrCA(n_chunks), hptrCB(n_chunks), hptrF(n_chunks);
+    // Pointer tables (one upload): [0] the text the next pass READS per chunk, [1] where it WRITES, [2] the third arena's
+    // turn, [3] classes A, [4] classes B, [5] changed-text flags.  Chunk records that are already in HBM are read where
+    // they lie by pass 0 (U -> B -> A -> B ...); host records are copied into arena A first (A -> B -> A ...).
+    std::vector<uint8_t *> tables((size_t)6 * n_chunks);
+    uint8_t **hIn = tables.data(), **hOut = hIn + n_chunks, **hSpare = hOut + n_chunks, **hCA = hSpare + n_chunks, **hCB = hCA + n_chunks,
+            **hF = hCB + n_chunks;
     for (int c = 0; c < n_chunks; ++c) {
-        hptrA[c] = b_textA.as<uint8_t>() + off_text[c];
-        hptrB[c] = b_textB.as<uint8_t>() + off_text[c];
-        hptrCA[c] = b_cls.as<uint8_t>() + off_pos[c];
-        hptrCB[c] = b_clsB.as<uint8_t>() + off_pos[c];
-        hptrF[c] = b_flags.as<uint8_t>() + off_flag[c];
-        if (len[c]) HIPCHK(hipMemcpyAsync(hptrA[c], seqs[c], (size_t)len[c], device_in ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        uint8_t *a = b_textA.as<uint8_t>() + off_text[c];
+        hIn[c] = device_in ? reinterpret_cast<uint8_t *>(const_cast<char *>(seqs[c])) : a;
+        hOut[c] = b_textB.as<uint8_t>() + off_text[c];
+        hSpare[c] = a;
+        hCA[c] = b_cls.as<uint8_t>() + off_pos[c];
+        hCB[c] = b_clsB.as<uint8_t>() + off_pos[c];
+        hF[c] = b_flags.as<uint8_t>() + off_flag[c];
+        if (len[c] && !device_in) HIPCHK(hipMemcpyAsync(a, seqs[c], (size_t)len[c], hipMemcpyHostToDevice, st));
     }
-    HIPCHK(hipMemcpyAsync(b_ptrA.p, hptrA.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b_ptrB.p, hptrB.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b_ptrCA.p, hptrCA.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b_ptrCB.p, hptrCB.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b_ptrF.p, hptrF.data(), n_chunks * sizeof(void *), hipMemcpyHostToDevice, st));
-    uint8_t **ptrIn = b_ptrA.as<uint8_t *>(), **ptrOut = b_ptrB.as<uint8_t *>();
-    uint8_t **ptrClsIn = b_ptrCA.as<uint8_t *>(), **ptrClsOut = b_ptrCB.as<uint8_t *>();
+    HIPCHK(hipMemcpyAsync(b_ptrA.p, tables.data(), tables.size() * sizeof(void *), hipMemcpyHostToDevice, st));
+    uint8_t **dIn = b_ptrA.as<uint8_t *>(), **dOut = dIn + n_chunks, **dSpare = dOut + n_chunks;
+    uint8_t **ptrClsIn = dSpare + n_chunks, **ptrClsOut = ptrClsIn + n_chunks, **ptrFlags = ptrClsOut + n_chunks;
 
     if (dbg) { (void)jk_stream_wait(st); fprintf(stderr, "[polish] setup + H2D: %.2f ms\n", now() - t_begin); }
     const double t_loop = now();
@@ -149,7 +150,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     std::vector<ScanChunk> sc(n_chunks);            // lives across passes: the async H2D copy reads it after the call returns
     std::vector<int64_t> all_cands(cand_items);     // every chunk's sync-point candidates, fetched with one copy per pass
     std::vector<int64_t> all_cells(cell_items);     // clean-zone boundary candidates, one per CLEAN_CELL positions
-    std::vector<unsigned int> ccount(n_chunks);
+    std::vector<std::vector<int64_t>> chunk_cands(n_chunks);
     std::vector<int64_t> cands;
     std::vector<uint32_t> aux_total(n_chunks, 0);   // aux bytes gathered so far per chunk (all passes)
     std::vector<std::vector<uint8_t>> aux_pass;      // raw aux bytes per pass, regrouped per chunk at the end
@@ -159,19 +160,19 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     for (int pass = 0; pass <= passes && rc == 0; ++pass) {                                   // src/jasper.py:25
         // ---- 1. position classes + sync-point candidates: a dense scan in pass 0; afterwards the stitch has carried the
         //         classes of untouched windows over and only the tiles next to changed text are recomputed
-        HIPCHK(hipMemsetAsync(b_ccount.p, 0, n_chunks * 4, st));
+        HIPCHK(hipMemsetAsync(b_ccount.p, 0, 4, st));
         {
             for (int c = 0; c < n_chunks; ++c) {
                 ScanChunk &S = sc[c];
-                S.text = textIn + off_text[c];
+                S.text = hIn[c];
                 S.len = len[c];
                 S.cnt = b_cnt.as<uint32_t>() + off_pos[c];
                 S.valid = b_valid.as<uint8_t>() + off_pos[c];
                 S.cls = clsIn + off_pos[c];
                 S.flags = b_flags.as<uint8_t>() + off_flag[c];
-                S.cand = b_cand.as<int64_t>() + off_cand[c];
-                S.cand_count = b_ccount.as<unsigned int>() + c;
-                S.cand_cap = cand_cap[c];
+                S.cand = b_cand.as<int64_t>();
+                S.cand_count = b_ccount.as<unsigned int>();
+                S.cand_cap = (unsigned int)std::min<size_t>(cand_items, 0x7fffffffu);
                 S.want_sync = (len[c] - k + 1) > 2 * TMIN;
                 S.clean_cand = b_cells.as<int64_t>() + off_cell[c];
                 S.n_cells = (uint32_t)std::min<int64_t>(n_cells[c], std::max<int64_t>(0, len[c] - k + 1) / CLEAN_CELL + 1);
@@ -181,10 +182,24 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             else launch_rescan_batch(T.d, b_scan.as<ScanChunk>(), n_chunks, k, pp.solid, st);
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(ccount.data(), b_ccount.p, n_chunks * 4, hipMemcpyDeviceToHost, st));
-        if (cand_items) HIPCHK(hipMemcpyAsync(all_cands.data(), b_cand.p, cand_items * 8, hipMemcpyDeviceToHost, st));
+        // the candidate list is fetched optimistically: its count and its first CAND_PRE entries in one round trip
+        const size_t CAND_PRE = std::min<size_t>(cand_items, 32768);
+        unsigned int n_cand = 0;
+        HIPCHK(hipMemcpyAsync(&n_cand, b_ccount.p, 4, hipMemcpyDeviceToHost, st));
+        if (CAND_PRE) HIPCHK(hipMemcpyAsync(all_cands.data(), b_cand.p, CAND_PRE * 8, hipMemcpyDeviceToHost, st));
         if (cell_items) HIPCHK(hipMemcpyAsync(all_cells.data(), b_cells.p, cell_items * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(jk_stream_wait(st));
+        n_cand = (unsigned int)std::min<size_t>(n_cand, cand_items);
+        if (n_cand > CAND_PRE) {
+            HIPCHK(hipMemcpyAsync(all_cands.data() + CAND_PRE, b_cand.as<int64_t>() + CAND_PRE, (n_cand - CAND_PRE) * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(jk_stream_wait(st));
+        }
+        for (int c = 0; c < n_chunks; ++c) chunk_cands[c].clear();
+        for (unsigned int i = 0; i < n_cand; ++i) {
+            const int64_t v = all_cands[i];
+            const int64_t c = v >> 40;
+            if (c >= 0 && c < n_chunks) chunk_cands[c].push_back(v & ((1ll << 40) - 1));
+        }
 
         // ---- 2. segments
         auto build_segments = [&](const std::vector<int> &chunks, bool speculate, std::vector<SegDev> &out, std::string &e2) -> int {
@@ -192,9 +207,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             size_t tpos = 0, rpos = 0, apos = 0;
             for (int c : chunks) {
                 std::vector<int64_t> sync;
-                if (speculate && ccount[c] > 0) {
-                    const unsigned int nc = std::min(ccount[c], cand_cap[c]);
-                    cands.assign(all_cands.begin() + off_cand[c], all_cands.begin() + off_cand[c] + nc);
+                if (speculate && !chunk_cands[c].empty()) {
+                    cands = chunk_cands[c];
                     std::sort(cands.begin(), cands.end());
                     int64_t last = 0;
                     for (int64_t p : cands)
@@ -260,7 +274,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         auto run_segments = [&](std::vector<SegDev> &sv, std::string &e2) -> int {
             if (sv.empty()) return 0;
             if (hipMemcpyAsync(b_segs.p, sv.data(), sv.size() * sizeof(SegDev), hipMemcpyHostToDevice, st) != hipSuccess) { e2 = "polish: H2D segs"; return -1; }
-            launch_seg_init(b_segs.as<SegDev>(), (int)sv.size(), (const uint8_t *const *)ptrIn, st);
+            launch_seg_init(b_segs.as<SegDev>(), (int)sv.size(), (const uint8_t *const *)dIn, st);
             if (hipMemsetAsync(b_arrive.p, 0x80, (sv.size() + 2) * 8, st) != hipSuccess) { e2 = "polish: memset"; return -1; }   // ARRIVE_PENDING
             launch_seg_walk(T.d, b_segs.as<SegDev>(), (int)sv.size(), pp, pass, pool, b_ticket.as<unsigned int>(), st);
             if (hipGetLastError() != hipSuccess) { e2 = "polish: kernel launch failed"; return -1; }
@@ -400,12 +414,14 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         }
         const bool carry = pass < passes;           // another pass follows: carry the classes over, flag changed text
         if (carry) HIPCHK(hipMemsetAsync(b_flags.p, 0, flag_items, st));
-        launch_seg_stitch(b_segs.as<SegDev>(), (int)ns, (uint8_t *const *)ptrOut, carry ? (uint8_t *const *)ptrClsOut : nullptr,
-                          carry ? (uint8_t *const *)b_ptrF.as<uint8_t *>() : nullptr, st);
+        launch_seg_stitch(b_segs.as<SegDev>(), (int)ns, (uint8_t *const *)dOut, carry ? (uint8_t *const *)ptrClsOut : nullptr,
+                          carry ? (uint8_t *const *)ptrFlags : nullptr, st);
         HIPCHK(hipGetLastError());
         for (int c = 0; c < n_chunks; ++c) len[c] = newlen[c];
-        std::swap(textIn, textOut);
-        std::swap(ptrIn, ptrOut);
+        // the text just written is read next; the next pass writes into the arena that is free (never into the caller's buffer)
+        std::swap(hIn, hOut);
+        std::swap(dIn, dOut);
+        if (pass == 0) { hOut = hSpare; dOut = dSpare; }
         std::swap(clsIn, clsOut);
         std::swap(ptrClsIn, ptrClsOut);
     }
@@ -417,11 +433,11 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         if (keep_on_device) {
             R.d_seqs.resize(n_chunks);
             R.d_lens.assign(len.begin(), len.end());
-            for (int c = 0; c < n_chunks; ++c) R.d_seqs[c] = textIn + off_text[c];
+            for (int c = 0; c < n_chunks; ++c) R.d_seqs[c] = hIn[c];
         }
         for (int c = 0; c < n_chunks && !keep_on_device; ++c) {
             R.seqs[c].resize((size_t)len[c]);
-            if (len[c]) HIPCHK(hipMemcpyAsync(&R.seqs[c][0], textIn + off_text[c], (size_t)len[c], hipMemcpyDeviceToHost, st));
+            if (len[c]) HIPCHK(hipMemcpyAsync(&R.seqs[c][0], hIn[c], (size_t)len[c], hipMemcpyDeviceToHost, st));
         }
         HIPCHK(jk_stream_wait(st));
         float ms = 0;

@@ -185,8 +185,12 @@ class KmerTable:
 
     def histo_rows(self):
         """non-zero rows (multiplicity, n_distinct) as `jellyfish histo` prints them (JF::sub_commands/histo_main.cc:82-84)"""
-        h = self.histogram()
-        return [(m, h[m]) for m in range(1, 10002) if h[m]]
+        import numpy as np
+        out = (C.c_uint64 * 10002)()
+        check(self._L.jasper_histogram(self._h, out))
+        h = np.frombuffer(out, dtype=np.uint64)
+        nz = np.flatnonzero(h[1:]) + 1
+        return list(zip(nz.tolist(), h[nz].tolist()))
 
     # ---- qf[MerDNA(s).get_canonical()] -------------------------------------------------------------
     def lookup(self, strings):
