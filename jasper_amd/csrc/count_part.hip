@@ -47,6 +47,7 @@ constexpr int RG_MAXBITS = 13;                   // region <= 8192 slots = 128 K
 constexpr int RG_HALO = 128;                     // slots of the next region a probe may run into
 
 struct PartGeom {
+    int th1;             // threads per part1 block (1024: one block per CU; 512: two half-size blocks)
     int p1, p2, rbits;       // p1 + p2 + rbits == s
     int recbits;             // 2k - p1  (<= 64): bits kept in a record
     uint32_t nblk1;          // part1 grid: every block owns one SLICE of every level-1 list
@@ -80,16 +81,17 @@ constexpr int P1_MAXB = 1024;          // part1 handles p1 <= 10; larger p1 fall
 // WIDE = (k > 32): the k-mer needs two 64-bit words; its inner loop is written out on word pairs with the shift amounts
 // fixed by WIDE (the generic u128 helpers shift by run-time amounts: a scalar branch per helper call, ~8 per k-mer, and
 // twice the ALU work where one word would do).  Hashing is ALU-bound here, so instruction count is what matters.
-template <bool WIDE>
-__global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t ntiles, uint64_t emit_from,
+template <bool WIDE, int TH>
+__global__ __launch_bounds__(TH) void part1_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t ntiles, uint64_t emit_from,
                                                             TableDev T, PartGeom G, uint64_t *__restrict__ out1, unsigned int *__restrict__ cnt1,
                                                             unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
                                                             uint64_t deferred_cap) {
     extern __shared__ __align__(16) unsigned char s_raw[];
-    uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_raw);                               // PT_TILE records
-    uint32_t *s_code = reinterpret_cast<uint32_t *>(s_raw + (size_t)PT_TILE * 8);         // PT_THREADS + PT_HALO
-    uint32_t *s_inv = s_code + (PT_THREADS + PT_HALO);
-    unsigned int *s_cur = s_inv + (PT_THREADS + PT_HALO);                                  // P1_MAXB   slice cursors (persistent)
+    uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_raw);                               // (TH * PT_GROUP) records
+    // the staged base codes are consumed (into registers) before the first record is staged: they share the stage's memory
+    uint32_t *s_code = reinterpret_cast<uint32_t *>(s_raw);                                // TH + PT_HALO
+    uint32_t *s_inv = s_code + (TH + PT_HALO);
+    unsigned int *s_cur = reinterpret_cast<unsigned int *>(s_raw + (size_t)(TH * PT_GROUP) * 8);   // P1_MAXB   slice cursors (persistent)
     unsigned int *s_cnt = s_cur + P1_MAXB;                                                 // P1_MAXB   records of this tile per bucket
     unsigned int *s_off = s_cnt + P1_MAXB;                                                 // P1_MAXB+1 exclusive prefix of s_cnt
     unsigned int *s_wsum = s_off + P1_MAXB + 1;                                            // 16 wave totals
@@ -108,16 +110,16 @@ __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__rest
     const uint64_t recmask = G.recbits >= 64 ? ~0ull : ((1ull << G.recbits) - 1ull);
     const int bsh = WIDE && !rec64 ? 64 - G.recbits : 0;                        // hi word's place in the bucket number
     unsigned long long added = 0, fresh = 0;
-    for (int i = t; i < nb; i += PT_THREADS) { s_cur[i] = 0; s_cnt[i] = 0; }
+    for (int i = t; i < nb; i += TH) { s_cur[i] = 0; s_cnt[i] = 0; }
     __syncthreads();
     // my 16 bases of the NEXT tile are requested while the current one is processed (one block per CU: nothing else
     // would hide that latency)
-    Raw16 raw = load16(bases, (int64_t)(blockIdx.x * (uint64_t)PT_TILE) + (int64_t)t * PT_GROUP, (int64_t)n);
+    Raw16 raw = load16(bases, (int64_t)(blockIdx.x * (uint64_t)(TH * PT_GROUP)) + (int64_t)t * PT_GROUP, (int64_t)n);
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t base0 = (int64_t)(tile * PT_TILE);
+        const int64_t base0 = (int64_t)(tile * (TH * PT_GROUP));
         uint32_t c, iv;
         encode16(raw.w, c, iv);
-        if (tile + gridDim.x < ntiles) raw = load16(bases, (int64_t)((tile + gridDim.x) * PT_TILE) + (int64_t)t * PT_GROUP, (int64_t)n);
+        if (tile + gridDim.x < ntiles) raw = load16(bases, (int64_t)((tile + gridDim.x) * (TH * PT_GROUP)) + (int64_t)t * PT_GROUP, (int64_t)n);
         s_code[t + PT_HALO] = c;
         s_inv[t + PT_HALO] = iv;
         if (t < PT_HALO) {
@@ -174,9 +176,13 @@ __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__rest
             }
         }
         __syncthreads();
-        // B. exclusive prefix of the bucket counts (one bucket per thread, wave scan + 16 wave totals)
+        // B. exclusive prefix of the bucket counts (P1_MAXB / TH buckets per thread, wave scan + wave totals)
         {
-            const unsigned int v = t < nb ? s_cnt[t] : 0u;
+            constexpr int BPT = P1_MAXB / TH;
+            unsigned int vb[BPT];
+            unsigned int v = 0;
+#pragma unroll
+            for (int u = 0; u < BPT; ++u) { vb[u] = t * BPT + u < nb ? s_cnt[t * BPT + u] : 0u; v += vb[u]; }
             unsigned int inc = v;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
@@ -184,8 +190,10 @@ __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__rest
             __syncthreads();
             unsigned int wbase = 0;
             for (int w = 0; w < (t >> 6); ++w) wbase += s_wsum[w];
-            if (t < nb) s_off[t] = wbase + inc - v;
-            if (t == PT_THREADS - 1) s_off[nb] = wbase + inc;                 // tile total (nb <= 1024 = PT_THREADS)
+            unsigned int ex = wbase + inc - v;
+#pragma unroll
+            for (int u = 0; u < BPT; ++u) { if (t * BPT + u < nb) s_off[t * BPT + u] = ex; ex += vb[u]; }
+            if (t == TH - 1) s_off[nb] = wbase + inc;                         // tile total
         }
         __syncthreads();
         // C. records into LDS in bucket order
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__rest
         {
             const int g16 = t >> 4, r16 = t & 15;
 #pragma unroll 4
-            for (int b = g16; b < nb; b += PT_THREADS / 16) {
+            for (int b = g16; b < nb; b += TH / 16) {
                 const unsigned int off = s_off[b], cnt = s_cnt[b], cur = s_cur[b];
                 uint64_t *dst = out1 + ((uint64_t)b * G.nblk1 + blockIdx.x) * G.cap1;
                 for (unsigned int q = r16; q < cnt; q += 16) {
@@ -210,18 +218,18 @@ __global__ __launch_bounds__(PT_THREADS) void part1_kernel(const uint8_t *__rest
             }
         }
         __syncthreads();
-        if (t < nb) { s_cur[t] += s_cnt[t]; s_cnt[t] = 0; }
+        for (int i = t; i < nb; i += TH) { s_cur[i] += s_cnt[i]; s_cnt[i] = 0; }
         // (the next tile's first barrier orders this against its histogram updates)
     }
     __syncthreads();
-    for (int i = t; i < nb; i += PT_THREADS) cnt1[(uint64_t)i * G.nblk1 + blockIdx.x] = s_cur[i] < G.cap1 ? s_cur[i] : G.cap1;
+    for (int i = t; i < nb; i += TH) cnt1[(uint64_t)i * G.nblk1 + blockIdx.x] = s_cur[i] < G.cap1 ? s_cur[i] : G.cap1;
     for (int o = 32; o > 0; o >>= 1) { added += __shfl_xor(added, o); fresh += __shfl_xor(fresh, o); }
     if ((threadIdx.x & 63) == 0) {
         if (added) atomicAdd(&T.stats[ST_OCCURRENCES], added);
         if (fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
     }
 }
-constexpr size_t P1_LDS = (size_t)PT_TILE * 8 + (size_t)(PT_THREADS + PT_HALO) * 8 + (size_t)(3 * P1_MAXB + 1 + 16) * 4;
+constexpr size_t p1_lds(int th) { return (size_t)th * PT_GROUP * 8 + (size_t)(3 * P1_MAXB + 1 + 16) * 4; }
 
 // ---- level 2: every bucket list -> 2^p2 region lists ---------------------------------------------------------
 // grid (nblk2, buckets): block (x, b1) reads the level-1 slices x, x+nblk2, ... of bucket b1 (as one concatenated
@@ -230,7 +238,7 @@ constexpr size_t P1_LDS = (size_t)PT_TILE * 8 + (size_t)(PT_THREADS + PT_HALO) *
 // order, so a wave writes whole runs of one list.  (The first version appended each record straight from the lane that
 // loaded it, with wave-level "match any" ballots to share the cursor atomics: ~100 instructions per record, and every
 // store instruction touched ~64 different lines -- the kernel was instruction-bound at 2.3 TB/s.)
-constexpr int P2_MAXSL = 256;          // level-1 slices per bucket (= nblk1 <= 256)
+constexpr int P2_MAXSL = 512;          // level-1 slices per bucket (= nblk1 <= 512)
 __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__restrict__ out1, const unsigned int *__restrict__ cnt1, TableDev T,
                                                             PartGeom G, uint64_t *__restrict__ out2, unsigned int *__restrict__ cnt2,
                                                             unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
@@ -478,9 +486,12 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     if (p2 > 11) return false;
     G.p1 = p1; G.p2 = p2; G.rbits = s - p1 - p2; G.recbits = B - p1;
     // slices should hold >= ~512 records on average so that their 1.25x + 8 sigma capacity wastes little
-    const uint64_t ntiles = (piece_bases + PT_TILE - 1) / PT_TILE;
+    static const int th1_env = getenv("JASPER_EXPERIMENT_P1THREADS") ? atoi(getenv("JASPER_EXPERIMENT_P1THREADS")) : 0;   // tuning experiments only
+    G.th1 = th1_env == 512 ? 512 : 1024;
+    const uint64_t tile1 = (uint64_t)G.th1 * PT_GROUP;
+    const uint64_t ntiles = (piece_bases + tile1 - 1) / tile1;
     uint64_t nblk1 = piece_bases / ((uint64_t)(1u << p1) * 512);
-    nblk1 = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(nblk1, ntiles), 256));   // one 1024-thread block (152 KB of LDS) per CU
+    nblk1 = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(nblk1, ntiles), 256 * (1024 / G.th1)));   // one 1024-thread block (152 KB of LDS) per CU, or two of 512
     G.nblk1 = (uint32_t)nblk1;
     G.cap1 = list_cap((double)piece_bases / ((double)(1u << p1) * (double)nblk1));
     // one slice per region list: part2 runs one 1024-thread block per CU, and 2^p1 >= 256 buckets already fill the chip;
@@ -505,18 +516,22 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     unsigned long long *defer_n = defer;                    // first 8 bytes: counter; entries start 64 bytes in
     unsigned long long *defer_e = defer + 8;
     HIPCHK(hipMemsetAsync(defer_n, 0, 64, stream));
-    const uint64_t ntiles = (len + PT_TILE - 1) / PT_TILE;
+    const uint64_t ntiles = (len + (uint64_t)G.th1 * PT_GROUP - 1) / ((uint64_t)G.th1 * PT_GROUP);
     for (int i = 0; i < 6; ++i) if (!ev_stage_t[i]) HIPCHK(hipEventCreate(&ev_stage_t[i]));
     HIPCHK(hipEventRecord(ev_k0, stream));
     HIPCHK(hipEventRecord(ev_stage_t[0], stream));
     static bool attr1_set = false;
     if (!attr1_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr1_set = true;
     }
-    if (k > 32) hipLaunchKernelGGL(part1_kernel<true>, dim3(G.nblk1), dim3(PT_THREADS), P1_LDS, stream, d_piece, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, deferred_cap);
-    else hipLaunchKernelGGL(part1_kernel<false>, dim3(G.nblk1), dim3(PT_THREADS), P1_LDS, stream, d_piece, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, deferred_cap);
+#define JK_P1_LAUNCH(W, TH_) hipLaunchKernelGGL((part1_kernel<W, TH_>), dim3(G.nblk1), dim3(TH_), p1_lds(TH_), stream, d_piece, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, deferred_cap)
+    if (G.th1 == 512) { if (k > 32) JK_P1_LAUNCH(true, 512); else JK_P1_LAUNCH(false, 512); }
+    else { if (k > 32) JK_P1_LAUNCH(true, 1024); else JK_P1_LAUNCH(false, 1024); }
+#undef JK_P1_LAUNCH
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_stage_t[1], stream));
     const uint64_t *lists = out1;
