@@ -62,6 +62,12 @@ int jasper_table_create(int k, uint64_t min_slots, int device, jasper_table **ou
  * the file header like jf.QueryMerFile(path) does (JF::swig/mer_file.i:18-36); errors use Jellyfish's wording */
 int jasper_table_load_jf(const char *path, int device, jasper_table **out);
 void jasper_table_destroy(jasper_table *t);
+/* the table as a Jellyfish "binary/sorted" database: what `jellyfish count -o mer_counts$K.jf` leaves behind
+ * (src/jasper.sh:177; format JF::include/jellyfish/file_header.hpp:26-108, binary_dumper.hpp:36-40,148-199), readable by
+ * jellyfish 2.3.0 query/dump/histo, QueryMerFile and jasper_table_load_jf.  cmdline[] is recorded in the header. */
+int jasper_table_write_jf(jasper_table *t, const char *path, const char *const *cmdline, int n_cmdline);
+/* test hook (host arithmetic only, no GPU): the table's bijective k-mer hash (inverse = 0) or its inverse (1) */
+int jasper_debug_mix(int k, int inverse, uint64_t hi, uint64_t lo, uint64_t out2[2]);
 int jasper_table_info(jasper_table *t, int *k, uint64_t *slots, uint64_t *distinct, uint64_t *occurrences);
 int jasper_table_sync(jasper_table *t);
 /* forget every k-mer (slots and counters zeroed in place; capacity kept) */

@@ -7,7 +7,9 @@ polisher.  Lines are cited as src/jasper.sh:N.
 Differences that are deliberate and documented in DESIGN.md:
   * contigs are written to <asm>.polished.fasta in input order (the reference's order is perl-hash random, :220)
   * column sums for the QV are exact integers (gawk behaviour)
-  * `mer_counts$K.jf` is not written (the table lives in HBM); an existing one, or -j, is read into HBM
+  * `mer_counts$K.jf` is written like the reference does (:177 `tee $JF_DB`) -- as a Jellyfish binary/sorted file that
+    jellyfish 2.3.0 and the reference's own jasper.py read -- unless JASPER_AMD_NO_JF=1; an existing one, or -j, is read
+    into HBM
 """
 import datetime
 import glob
@@ -312,6 +314,10 @@ def run(argv):
             log("Creating jellyfish database mer_counts%d.jf" % kmer)
             table = KmerTable(kmer, min_slots=max(1 << 20, 2 * o.jf_size), device=o.device)
             table.count_files(reads)
+            if os.environ.get("JASPER_AMD_NO_JF", "") not in ("1", "true", "yes"):
+                # :177 `... | tee $JF_DB | ...`: leave the database behind for reruns and for other Jellyfish tools
+                table.write_jf(jf_file + ".tmp", ["count", "-C", "-t", str(o.num_threads), "-s", str(o.jf_size), "-m", str(kmer), "-o", jf_file] + reads)
+                os.replace(jf_file + ".tmp", jf_file)
             with open(histo_file + ".tmp", "w") as f:
                 for m, n in table.histo_rows():
                     f.write("%d %d\n" % (m, n))

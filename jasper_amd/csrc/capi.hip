@@ -93,6 +93,19 @@ int jasper_table_load_jf(const char *path, int device, jasper_table **out) {
     return JASPER_OK;
 }
 
+int jasper_table_write_jf(jasper_table *t, const char *path, const char *const *cmdline, int n_cmdline) {
+    if (!t || !path || n_cmdline < 0 || (n_cmdline && !cmdline)) { g_err = "null argument"; return JASPER_ERR; }
+    return t->t.write_jf(path, cmdline, n_cmdline, g_err) ? JASPER_ERR : JASPER_OK;
+}
+
+int jasper_debug_mix(int k, int inverse, uint64_t hi, uint64_t lo, uint64_t out2[2]) {
+    if (k < 1 || k > 64 || !out2) { g_err = "bad arguments"; return JASPER_ERR; }
+    const u128 r = inverse ? unmix(mk(hi, lo), 2 * k) : mix(mk(hi, lo), 2 * k);
+    out2[0] = r.hi;
+    out2[1] = r.lo;
+    return JASPER_OK;
+}
+
 void jasper_table_destroy(jasper_table *t) {
     if (!t) return;
     if (t->pending) (void)result_fetch(t->pending);   // a live result must not lose its text with the table

@@ -146,6 +146,39 @@ JK_HD u128 mix(u128 x, int B) {
     return mk((x.hi ^ f) & hm, lo);
 }
 
+// inverse of mix (needed only to write k-mers out again: the .jf writer)
+JK_HD uint64_t inv_odd64(uint64_t a) {          // a * inv == 1 mod 2^64 (Newton: doubles the correct bits each round)
+    uint64_t x = a;                             // correct to 3 bits
+    for (int i = 0; i < 5; ++i) x *= 2 - a * x;
+    return x;
+}
+JK_HD uint64_t unmix64_from_mid(uint64_t mid) {  // mid = state after mix64's first multiply
+    uint64_t x = mid * inv_odd64(JK_C1);
+    x ^= x >> 32;
+    return x;
+}
+JK_HD u128 unmix(u128 h, int B) {
+    if (B <= 64) {
+        const uint64_t m = B == 64 ? ~0ull : ((1ull << B) - 1);
+        const int hh = B / 2;
+        uint64_t v = h.lo & m;
+        v ^= v >> hh;                            // xor-shift by half the width is its own inverse
+        v = (v * inv_odd64(JK_C2)) & m;
+        v ^= v >> hh;
+        v = (v * inv_odd64(JK_C1)) & m;
+        return mk(0, v);
+    }
+    const int hb = B - 64;
+    uint64_t y = h.lo;
+    y ^= y >> 32;
+    y *= inv_odd64(JK_C2);
+    y = y ^ (y >> 29) ^ (y >> 58);               // inverse of y ^= y >> 29
+    const uint64_t mid = y;
+    const uint64_t lo = unmix64_from_mid(mid);
+    const uint64_t hm = hb == 64 ? ~0ull : ((1ull << hb) - 1);
+    return mk((h.hi ^ (mid >> (64 - hb))) & hm, lo);
+}
+
 // ---- slot word ------------------------------------------------------------------------------------
 // A slot is 16 bytes: { uint64 tag, uint64 count }.  tag == 0  <=>  empty.
 // tag = 1<<63 | remainder << OFFBITS | probe_offset, where the B-bit hash is split as

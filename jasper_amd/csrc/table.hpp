@@ -261,6 +261,8 @@ struct Table {
     int import_packed(const void *d_src, uint64_t n, int mode, std::string &err);
     int reserve(uint64_t min_slots, std::string &err);
     int add_kmers(const unsigned long long *h_entries, uint64_t n, std::string &err);   // (kmer hi, lo, count) as stored in a .jf
+    // the table as a Jellyfish binary/sorted database (jfwrite.hip); cmdline goes into the header like jellyfish's own
+    int write_jf(const char *path, const char *const *cmdline, int n_cmd, std::string &err);
 };
 
 }  // namespace jk

@@ -117,6 +117,12 @@ class KmerTable:
         self.k = self.info()["k"]
         return self
 
+    def write_jf(self, path, cmdline=()):
+        """write the table as a Jellyfish binary/sorted DB (what `jellyfish count -o` produces, src/jasper.sh:177)"""
+        args = [a.encode() for a in cmdline]
+        arr = (C.c_char_p * max(len(args), 1))(*args)
+        check(self._L.jasper_table_write_jf(self._h, path.encode(), arr, len(args)))
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._L.jasper_table_destroy(self._h)

@@ -59,3 +59,79 @@ def test_cli_with_jf_database(hip, tmp_path):
     assert open(tmp_path / "jfhisto31.csv").read() == open(os.path.join(c.dir, "histo.csv")).read()   # named after -k, content from the DB
     polished = open(tmp_path / "asm.fa.polished.fasta").read().split("\n")
     assert polished[0] == ">ctg1" and len(polished[1]) > 3900
+
+
+def _read_jf(path):
+    """(header dict, [(key int, count)]) of a binary/sorted file, in file order"""
+    import json
+    raw = open(path, "rb").read()
+    hlen = int(raw[:9])
+    hdr = json.loads(raw[9:9 + hlen].rstrip(b"\0").decode())
+    kb = (hdr["key_len"] + 7) // 8
+    rec = kb + hdr["counter_len"]
+    body = raw[9 + hlen:]
+    assert (9 + hlen) % 8 == 0 and len(body) % rec == 0
+    out = []
+    for i in range(0, len(body), rec):
+        out.append((int.from_bytes(body[i:i + kb], "little"), int.from_bytes(body[i + kb:i + rec], "little")))
+    return hdr, out
+
+
+def _jf_pos(hdr, key):
+    """matrix1 * key & (size-1) as the reader computes it (JF::include/jellyfish/rectangular_binary_matrix.hpp:224-262:
+    key bit i selects column c-1-i; identity form = the low r bits)"""
+    m = hdr["matrix1"]
+    if m.get("identity"):
+        return key & ((1 << m["r"]) - 1) & (hdr["size"] - 1)
+    res = 0
+    for i in range(m["c"]):
+        if (key >> i) & 1:
+            res ^= m["columns"][m["c"] - 1 - i]
+    return res & (hdr["size"] - 1)
+
+
+@pytest.mark.parametrize("name", ["simple_k25", "simple_k37"])
+def test_write_jf_round_trip_and_reader_order(hip, name, tmp_path):
+    """jasper_table_write_jf: same records as the reference's own DB of the same reads, in the order its reader needs
+    ((pos, key) ascending, pos from the header's matrix), loadable again, and usable by the CLI's reuse path"""
+    from jasper_amd import KmerTable
+    c = Case(name)
+    t = KmerTable(c.k, min_slots=1 << 16)
+    t.count_text(c.reads_text())
+    out = str(tmp_path / "mer_counts.jf")
+    t.write_jf(out, ["count", "-C", "-m", str(c.k)])
+    hdr, recs = _read_jf(out)
+    ref_hdr, ref_recs = _read_jf(os.path.join(c.dir, "db.jf"))
+    assert hdr["format"] == "binary/sorted" and hdr["key_len"] == 2 * c.k and hdr["counter_len"] == 4 and hdr["canonical"] is True
+    assert hdr["cmdline"] == ["count", "-C", "-m", str(c.k)] and hdr["size"] == 1 << hdr["matrix1"]["r"]
+    assert sorted(recs) == sorted(ref_recs)                                   # same (k-mer, count) set as real jellyfish
+    order = [(_jf_pos(hdr, k), k) for k, _ in recs]
+    assert order == sorted(order) and len(set(order)) == len(order)
+    # the reference file obeys the same rule under ITS matrix (checks that _jf_pos restates the reader correctly)
+    ref_order = [(_jf_pos(ref_hdr, k), k) for k, _ in ref_recs]
+    assert ref_order == sorted(ref_order)
+    t2 = KmerTable.from_jf(out)
+    assert t2.k == c.k and t2.histogram() == t.histogram() and t2.info()["distinct"] == len(recs)
+    d = c.dump()
+    kmers = sorted(d)[:2000]
+    assert t2.lookup(kmers) == [d[x] for x in kmers]
+    t.close()
+    t2.close()
+
+
+def test_write_jf_small_k_and_empty(hip, tmp_path):
+    from jasper_amd import KmerTable
+    for k, text in ((15, "ACGTTGCATGCAAGTCCGATAGGCTAACGT" * 3), (32, "ACGTTGCATGCAAGTCCGATAGGCTAACGTTTGACCATGACAGATTACA" * 2), (21, "")):
+        t = KmerTable(k, min_slots=1 << 12)
+        if text:
+            t.count_bases(text)
+        p = str(tmp_path / ("k%d.jf" % k))
+        t.write_jf(p)
+        hdr, recs = _read_jf(p)
+        assert len(recs) == t.info()["distinct"]
+        order = [(_jf_pos(hdr, key), key) for key, _ in recs]
+        assert order == sorted(order)
+        t2 = KmerTable.from_jf(p)
+        assert t2.histogram() == t.histogram()
+        t.close()
+        t2.close()

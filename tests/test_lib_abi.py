@@ -45,3 +45,34 @@ def test_missing_library_fails_loudly(monkeypatch):
     import pytest
     with pytest.raises(ImportError):
         _lib.lib()
+
+
+def test_kmer_hash_is_a_bijection_with_working_inverse():
+    """the table stores only part of the hash, so the hash must be a bijection on 2k-bit keys; the .jf writer needs its
+    inverse (host arithmetic through the C-ABI test hook: no GPU involved)"""
+    import ctypes as C
+    import random
+    from jasper_amd import _lib
+    L = _lib.lib()
+    rng = random.Random(5)
+    out = (C.c_uint64 * 2)()
+    for k in list(range(1, 65)):
+        B = 2 * k
+        seen = set()
+        keys = [0, (1 << B) - 1, 1, 1 << (B - 1)] + [rng.getrandbits(B) for _ in range(40)]
+        for key in keys:
+            assert L.jasper_debug_mix(k, 0, key >> 64, key & ((1 << 64) - 1), out) == 0
+            h = (out[0] << 64) | out[1]
+            assert h < (1 << B)
+            assert L.jasper_debug_mix(k, 1, out[0], out[1], out) == 0
+            assert ((out[0] << 64) | out[1]) == key, (k, hex(key))
+            seen.add(h)
+        assert len(seen) == len(set(keys))
+    # small k exhaustively: every 2k-bit value is hit exactly once
+    for k in (1, 2, 3, 5, 7):
+        B = 2 * k
+        img = set()
+        for key in range(1 << B):
+            L.jasper_debug_mix(k, 0, 0, key, out)
+            img.add(out[1])
+        assert len(img) == 1 << B and max(img) < (1 << B)
