@@ -231,22 +231,75 @@ __host__ __device__ __forceinline__ uint32_t part_of(u128 h, int B, uint32_t npa
 }
 
 // scans slots [first, first+span) (mod table size): a key homed in partition `part` sits at most MAXPROBE-1 slots
-// behind its home, so one partition costs 1/nparts of a table pass
-__global__ __launch_bounds__(256) void export_packed_kernel(TableDev T, ulonglong2 *__restrict__ out, unsigned long long *__restrict__ counter,
-                                                            uint64_t cap, uint32_t part, uint32_t nparts, uint64_t first, uint64_t span) {
+// behind its home, so one partition costs 1/nparts of a table pass.  Two passes over that range, no global atomic: block b
+// owns the contiguous slice [b*chunk, (b+1)*chunk) of it; pass 1 counts its matching entries, a one-block scan turns the
+// counts into output offsets, pass 2 writes -- compact and in slot order.  (One shared cursor, even with one returning
+// atomic per wave, serialises at ~80 M atomics/s on a single address: 100 ms for half of a 2^30-slot table.)
+__device__ __forceinline__ bool packed_entry_of(const TableDev &T, uint64_t i, uint32_t part, uint32_t nparts, int sh, ulonglong2 &o) {
+    const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * i);
+    if (e.x == 0ull) return false;
+    const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
+    const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
+    const uint64_t home = (i - off) & T.mask;
+    const u128 h = hash_from(home, rem, T.B, T.s);
+    if (nparts > 1 && part_of(h, T.B, nparts) != part) return false;
+    if (sh && (e.y >> (64 - sh)) != 0ull) { atomicExch(&T.stats[ST_FATAL], 2ull); return false; }   // count does not fit the packing
+    o = make_ulonglong2(h.lo, h.hi | (sh ? (e.y << sh) : 0ull));
+    return true;
+}
+constexpr int EXP_BLOCKS = 2048;
+__global__ __launch_bounds__(256) void export_packed_count_kernel(TableDev T, uint32_t part, uint32_t nparts, uint64_t first, uint64_t span,
+                                                                  uint64_t chunk, unsigned long long *__restrict__ counts) {
+    __shared__ unsigned int s_w[4];
     const int sh = packed_count_shift(T.B);
-    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < span; q += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t i = (first + q) & T.mask;
-        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * i);
-        if (e.x == 0ull) continue;
-        const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
-        const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
-        const uint64_t home = (i - off) & T.mask;
-        const u128 h = hash_from(home, rem, T.B, T.s);
-        if (nparts > 1 && part_of(h, T.B, nparts) != part) continue;
-        if (sh && (e.y >> (64 - sh)) != 0ull) { atomicExch(&T.stats[ST_FATAL], 2ull); continue; }   // count does not fit the packing
-        const unsigned long long idx = atomicAdd(counter, 1ull);
-        if (idx < cap) out[idx] = make_ulonglong2(h.lo, h.hi | (sh ? (e.y << sh) : 0ull));
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < span ? lo + chunk : span;
+    unsigned int n = 0;
+    for (uint64_t q = lo + threadIdx.x; q < hi; q += blockDim.x) {
+        ulonglong2 o;
+        n += packed_entry_of(T, (first + q) & T.mask, part, nparts, sh, o) ? 1u : 0u;
+    }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = (unsigned long long)s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+// exclusive scan of EXP_BLOCKS counts in place; counts[EXP_BLOCKS] = total
+__global__ __launch_bounds__(1024) void export_packed_scan_kernel(unsigned long long *__restrict__ counts) {
+    __shared__ unsigned long long s_w[16];
+    const int t = threadIdx.x;
+    const unsigned long long a = counts[2 * t], b = counts[2 * t + 1];
+    unsigned long long inc = a + b;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
+    if ((t & 63) == 63) s_w[t >> 6] = inc;
+    __syncthreads();
+    unsigned long long wbase = 0;
+    for (int w = 0; w < (t >> 6); ++w) wbase += s_w[w];
+    const unsigned long long ex = wbase + inc - (a + b);
+    counts[2 * t] = ex;
+    counts[2 * t + 1] = ex + a;
+    if (t == 1023) counts[EXP_BLOCKS] = wbase + inc;
+}
+__global__ __launch_bounds__(256) void export_packed_write_kernel(TableDev T, ulonglong2 *__restrict__ out, uint64_t cap, uint32_t part, uint32_t nparts,
+                                                                  uint64_t first, uint64_t span, uint64_t chunk,
+                                                                  const unsigned long long *__restrict__ bases) {
+    __shared__ unsigned int s_w[4];
+    const int sh = packed_count_shift(T.B);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < span ? lo + chunk : span;
+    unsigned long long cursor = bases[blockIdx.x];
+    for (uint64_t q0 = lo; q0 < hi; q0 += blockDim.x) {          // block-uniform trip count
+        const uint64_t q = q0 + threadIdx.x;
+        ulonglong2 o = make_ulonglong2(0ull, 0ull);
+        const bool have = q < hi && packed_entry_of(T, (first + q) & T.mask, part, nparts, sh, o);
+        const uint64_t m = __ballot(have);
+        if (lane == 0) s_w[wave] = (unsigned int)__popcll(m);
+        __syncthreads();
+        unsigned int before = 0, total = 0;
+        for (int w = 0; w < 4; ++w) { const unsigned int c = s_w[w]; total += c; if (w < wave) before += c; }
+        const unsigned long long idx = cursor + before + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+        if (have && idx < cap) out[idx] = o;
+        cursor += total;
+        __syncthreads();
     }
 }
 
@@ -813,9 +866,6 @@ int Table::reserve(uint64_t min_slots, std::string &err) {
 int Table::export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t part, uint32_t nparts, std::string &err) {
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
-    unsigned long long *d_ctr = nullptr;
-    HIPCHK(hipMalloc((void **)&d_ctr, sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(d_ctr, 0, sizeof(unsigned long long), stream));
     uint64_t first = 0, span = nslots;
     if (nparts > 1) {
         // partition p = keys whose top-32 hash bits t satisfy floor(t * nparts / 2^32) == p, i.e. t in [t_lo, t_hi);
@@ -830,13 +880,17 @@ int Table::export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t pa
             span = std::min<uint64_t>(nslots, last_excl - first + MAXPROBE);
         }   // (B < 32: tiny key space, scan everything)
     }
-    hipLaunchKernelGGL(export_packed_kernel, dim3(grid_for(span, 256 * 16)), dim3(256), 0, stream, d, (ulonglong2 *)d_dst, d_ctr, cap, part, nparts,
-                       first, span);
+    unsigned long long *d_counts = reinterpret_cast<unsigned long long *>(workspace(WS_COUNT + 2, (EXP_BLOCKS + 8) * 8 + 256, err));   // (free between counting calls)
+    if (!d_counts) return -1;
+    const uint64_t chunk = ((span + EXP_BLOCKS - 1) / EXP_BLOCKS + 255) / 256 * 256;
+    hipLaunchKernelGGL(export_packed_count_kernel, dim3(EXP_BLOCKS), dim3(256), 0, stream, d, part, nparts, first, span, chunk, d_counts);
+    hipLaunchKernelGGL(export_packed_scan_kernel, dim3(1), dim3(1024), 0, stream, d_counts);
+    if (cap) hipLaunchKernelGGL(export_packed_write_kernel, dim3(EXP_BLOCKS), dim3(256), 0, stream, d, (ulonglong2 *)d_dst, cap, part, nparts, first, span,
+                                chunk, d_counts);
     HIPCHK(hipGetLastError());
     unsigned long long got = 0;
-    HIPCHK(hipMemcpyAsync(&got, d_ctr, sizeof got, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(&got, d_counts + EXP_BLOCKS, sizeof got, hipMemcpyDeviceToHost, stream));
     HIPCHK(jk_stream_wait(stream));
-    HIPCHK(hipFree(d_ctr));
     if (read_stats(err)) return -1;
     if (h_stats[ST_FATAL] == 2) { err = "a count does not fit the packed exchange format"; return -2; }
     *n_out = got;   // may exceed cap: the caller sizes its buffer with a first call (cap = 0) or from info()

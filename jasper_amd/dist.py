@@ -113,19 +113,29 @@ def merge_tables(table, device, group=None):
     slots = torch.tensor([table.info()["slots"]], dtype=torch.int64, device=device)
     dist.all_reduce(slots, op=dist.ReduceOp.MAX, group=group)
     table.reserve(int(slots.item()))
-    # 2. what I hold of every owner's range
-    counts = torch.tensor([table.export_packed(0, 0, o, world) for o in range(world)], dtype=torch.int64, device=device)
+    # 2. what I hold of every owner's range: ONE pass over the table (each owner's keys sit in their own slot range).
+    #    Row length from an estimate (my distinct keys / world + 25 %), agreed by all ranks; the rare overflow falls back
+    #    to exact sizes.  libjasper_hip works on its own HIP stream: torch memory must be idle (no pending fill / no
+    #    pending work of a previous owner of the cached block) before it is handed over, hence empty() + synchronize,
+    #    never zeros()
+    est = torch.tensor([int(table.info()["distinct"] / world * 1.25) + (1 << 16)], dtype=torch.int64, device=device)
+    dist.all_reduce(est, op=dist.ReduceOp.MAX, group=group)
+    mx = int(est.item())
+    send = torch.empty((world, mx, 2), dtype=torch.int64, device=device)
+    _sync(device)
+    mine_counts = [0 if o == rank else table.export_packed(send[o].data_ptr(), mx, o, world) for o in range(world)]
+    counts = torch.tensor(mine_counts, dtype=torch.int64, device=device)
     allc = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(allc, counts, group=group)
     allc = torch.stack(allc).cpu()                     # allc[src][dst]
-    mx = max(int(allc.max().item()), 1)
-    # libjasper_hip works on its own HIP stream: torch memory must be idle (no pending fill / no pending work of a previous
-    # owner of the cached block) before it is handed over, hence empty() + synchronize, never zeros()
-    send = torch.empty((world, mx, 2), dtype=torch.int64, device=device)   # rows beyond the exact counts are never imported
-    _sync(device)
-    for o in range(world):
-        if o != rank and int(allc[rank][o]):
-            table.export_packed(send[o].data_ptr(), mx, o, world)
+    if int(allc.max().item()) > mx:                    # (every rank sees the same matrix and takes the same branch)
+        mx = int(allc.max().item())
+        del send
+        send = torch.empty((world, mx, 2), dtype=torch.int64, device=device)
+        _sync(device)
+        for o in range(world):
+            if o != rank and int(allc[rank][o]):
+                table.export_packed(send[o].data_ptr(), mx, o, world)
     _sync(device)
     recv = _all_to_all_rows(send, group)
     _sync(device)
