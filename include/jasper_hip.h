@@ -80,6 +80,9 @@ int jasper_count_bases_device(jasper_table *t, const void *d_bases, uint64_t n);
 int jasper_count_reads_text(jasper_table *t, const char *text, uint64_t n);
 int jasper_count_reads_files(jasper_table *t, const char *const *paths, int n_paths);
 
+/* of the last jasper_count_reads_files call: text bytes parsed by the GPU kernels / by the host state machine (the
+ * fallback for multi-line records, DOS line ends, malformed input and stream tails) */
+int jasper_last_ingest(jasper_table *t, uint64_t *gpu_bytes, uint64_t *host_bytes);
 int jasper_histogram(jasper_table *t, uint64_t *out10002);
 /* 1 if the histogram is already known because the last counting call binned the final counts while it wrote them
  * (one partitioned pass over the whole input into an empty table); jasper_histogram then costs one small copy */

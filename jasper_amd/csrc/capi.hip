@@ -153,11 +153,22 @@ int jasper_count_reads_text(jasper_table *t, const char *text, uint64_t n) {
 int jasper_count_reads_files(jasper_table *t, const char *const *paths, int n_paths) {
     t->t.reset_timing();
     Table *T = &t->t;
+    T->ingest_gpu_bytes = T->ingest_host_bytes = 0;
+    if (!getenv("JASPER_INGEST_HOST")) {       // text parsed on the GPU; the host state machine takes over whatever is not plain 4-line FASTQ / FASTA
+        const int rc = T->count_files_gpu(paths, n_paths, &T->ingest_gpu_bytes, &T->ingest_host_bytes, g_err);
+        return rc < -1 ? rc : (rc ? JASPER_ERR : JASPER_OK);
+    }
     FastxParser p([T](const char *b, size_t m) { return T->count_host(b, m, g_err); });
     std::string e;
     int rc = parse_files(paths, n_paths, p, e);
     if (rc && !e.empty()) g_err = e;
     return rc;
+}
+
+int jasper_last_ingest(jasper_table *t, uint64_t *gpu_bytes, uint64_t *host_bytes) {
+    if (gpu_bytes) *gpu_bytes = t->t.ingest_gpu_bytes;
+    if (host_bytes) *host_bytes = t->t.ingest_host_bytes;
+    return JASPER_OK;
 }
 
 int jasper_last_count_timing(jasper_table *t, double *kernel_ms, uint64_t *launches) {

@@ -22,7 +22,7 @@ int FastxParser::line(const char *p, size_t n, bool /*has_newline*/) {
     while (n && p[0] == '\r') { ++p; --n; }          // skip_newlines() eats leading '\r' too
     while (n && p[n - 1] == '\r') --n;               // trailing '\r' of DOS files
     if (mode_ == UNKNOWN) {
-        if (n == 0) return 0;                         // (an empty first line: peek() would see '\n' -> unsupported)
+        if (n == 0) { err_ = "Unsupported format"; return -3; }   // an empty first line: the reference's peek() sees '\n' (:134-148)
         if (p[0] == '>') { mode_ = FASTA; ++records_; return 0; }
         if (p[0] == '@') { mode_ = FASTQ; fq_ = FQ_SEQ; seq_len_ = 0; ++records_; return 0; }
         err_ = "Unsupported format";
@@ -86,6 +86,13 @@ int FastxParser::feed(const char *data, size_t n) {
         i += len + 1;
     }
     return 0;
+}
+
+void FastxParser::resume(int mode) {
+    mode_ = mode == 1 ? FASTA : mode == 2 ? FASTQ : UNKNOWN;
+    fq_ = FQ_HEADER;
+    seq_len_ = qual_len_ = 0;
+    carry_.clear();
 }
 
 int FastxParser::finish() {

@@ -23,6 +23,9 @@ class FastxParser {
         : sink_(std::move(sink)), flush_bytes_(flush_bytes) {}
     int feed(const char *data, size_t n);  // 0 ok, <0 error (message in error())
     int finish();
+    // continue a stream whose beginning somebody else has parsed: `mode` 0 = unknown (decide from the first byte),
+    // 1 = FASTA at a line start, 2 = FASTQ at a record start (ingest_gpu.hip hands over like this)
+    void resume(int mode);
     const std::string &error() const { return err_; }
     uint64_t records() const { return records_; }
 

@@ -1,0 +1,315 @@
+// ingest_gpu.hip -- FASTA / FASTQ text -> base stream ON THE GPU (the step before the hot path).
+//
+// The host only moves bytes: file (plain or gzip) -> pinned buffer -> HBM.  The text of a chunk is then parsed by kernels
+// with the record rules of `jellyfish count` (JF::include/jellyfish/mer_overlap_sequence_parser.hpp:120-307, restated in
+// ingest.hpp), and the bases are appended to a device buffer that goes to Table::count_device in large pieces (so file
+// input takes the partitioned counting path too).
+//
+// What makes this exact rather than heuristic: lines are numbered from the START of the stream (newline prefix sums), so
+// in a FASTQ whose records are the usual four lines "line number mod 4" decides what a line is -- no guessing whether an
+// '@' starts a header or a quality string.  Everything else is VERIFIED, not assumed: every line 0 mod 4 starts with '@',
+// every line 2 mod 4 with '+', no sequence line starts with '+', sequence and quality lines have equal lengths, there
+// is no '\r' anywhere.  A chunk that fails any check is handed, from its first byte (a record boundary), to the host
+// state machine (FastxParser, resumed in the right mode), which implements the reference's rules for multi-line records,
+// DOS line ends and malformed input, and which then keeps the rest of the stream.  FASTA needs no such assumption: a line
+// is a header iff it starts with '>'.
+#include "ingest.hpp"
+#include "table.hpp"
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <zlib.h>
+#include <rocprim/device/device_scan.hpp>
+
+namespace jk {
+
+namespace {
+
+constexpr int IG_THREADS = 256;
+constexpr int IG_BYTES = IG_THREADS * 16;       // text bytes per block
+enum { IGF_CR = 1, IGF_BAD = 2 };
+
+struct Raw { uint32_t w[4]; };
+__device__ __forceinline__ Raw load_text16(const uint8_t *__restrict__ text, uint64_t pos, uint64_t n) {
+    Raw r;
+    if (pos + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(text + pos);     // chunk buffers are 16-byte aligned, pos % 16 == 0
+        r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+    } else {
+        r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
+        for (int j = 0; j < 16; ++j)
+            if (pos + j < n) r.w[j >> 2] |= (uint32_t)text[pos + j] << (8 * (j & 3));
+    }
+    return r;
+}
+__device__ __forceinline__ uint32_t byte_of(const Raw &r, int j) { return (r.w[j >> 2] >> (8 * (j & 3))) & 0xFFu; }
+
+// exclusive prefix over the block of a per-thread count; returns the block total through s_tot
+__device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t *s_w, uint32_t &total) {
+    const int t = threadIdx.x;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
+    if ((t & 63) == 63) s_w[t >> 6] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    total = 0;
+    for (int w = 0; w < IG_THREADS / 64; ++w) { if (w < (t >> 6)) wbase += s_w[w]; total += s_w[w]; }
+    __syncthreads();
+    return wbase + inc - v;
+}
+
+// pass 1: newlines per block, and "is there a '\r' at all"
+__global__ __launch_bounds__(IG_THREADS) void ig_count_nl_kernel(const uint8_t *__restrict__ text, uint64_t n, uint32_t *__restrict__ blk_nl,
+                                                                 unsigned int *__restrict__ flags) {
+    __shared__ uint32_t s_w[IG_THREADS / 64];
+    const uint64_t pos = (uint64_t)blockIdx.x * IG_BYTES + (uint64_t)threadIdx.x * 16;
+    uint32_t c = 0;
+    bool cr = false;
+    if (pos < n) {
+        const Raw r = load_text16(text, pos, n);
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t b = byte_of(r, j);
+            if (pos + j < n) { c += b == '\n'; cr = cr || b == '\r'; }
+        }
+    }
+    uint32_t total;
+    (void)block_exclusive(c, s_w, total);
+    if (threadIdx.x == 0) blk_nl[blockIdx.x] = total;
+    if (__ballot(cr) && (threadIdx.x & 63) == 0) atomicOr(flags, (unsigned int)IGF_CR);
+}
+
+// pass 2: position of every newline: nlpos[line] = byte offset of the '\n' that ends line `line` (chunk-relative numbering)
+__global__ __launch_bounds__(IG_THREADS) void ig_nlpos_kernel(const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ blk_base,
+                                                              uint32_t *__restrict__ nlpos) {
+    __shared__ uint32_t s_w[IG_THREADS / 64];
+    const uint64_t pos = (uint64_t)blockIdx.x * IG_BYTES + (uint64_t)threadIdx.x * 16;
+    uint32_t c = 0;
+    Raw r;
+    r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
+    if (pos < n) {
+        r = load_text16(text, pos, n);
+        for (int j = 0; j < 16; ++j) c += (pos + j < n && byte_of(r, j) == '\n');
+    }
+    uint32_t total;
+    uint32_t line = blk_base[blockIdx.x] + block_exclusive(c, s_w, total);
+    if (pos < n)
+        for (int j = 0; j < 16; ++j)
+            if (pos + j < n && byte_of(r, j) == '\n') nlpos[line++] = (uint32_t)(pos + j);
+}
+
+// FASTQ: the four-line shape of every record, verified
+__global__ __launch_bounds__(256) void ig_check_fastq_kernel(const uint8_t *__restrict__ text, const uint32_t *__restrict__ nlpos, uint64_t nrec,
+                                                             unsigned int *__restrict__ flags) {
+    bool bad = false;
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < nrec; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t e0 = nlpos[4 * r], e1 = nlpos[4 * r + 1], e2 = nlpos[4 * r + 2], e3 = nlpos[4 * r + 3];
+        const uint32_t s0 = r ? nlpos[4 * r - 1] + 1 : 0u;
+        const uint32_t len1 = e1 - e0 - 1, len3 = e3 - e2 - 1;
+        bad = bad || e0 == s0 || text[s0] != '@';                        // header line: not empty, starts with '@'
+        bad = bad || e2 == e1 + 1 || text[e1 + 1] != '+';                // separator line starts with '+'
+        bad = bad || (len1 && text[e0 + 1] == '+');                      // a sequence line starting with '+' would be taken as the separator
+        bad = bad || len1 != len3;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(flags, (unsigned int)IGF_BAD);
+}
+
+// what a text byte contributes to the base stream: 0 nothing, else the byte to emit
+__device__ __forceinline__ uint32_t emit_of(const uint8_t *__restrict__ text, const uint32_t *__restrict__ nlpos, int fastq, uint32_t line, uint32_t b,
+                                            uint64_t p) {
+    if (fastq) {
+        if ((line & 3u) != 1u) return 0u;
+        return b == '\n' ? (uint32_t)'N' : b;                            // the sequence line; its newline becomes the record separator
+    }
+    const uint32_t start = line ? nlpos[line - 1] + 1 : 0u;
+    if (text[start] == '>') return p == start ? (uint32_t)'N' : 0u;      // header line: one separator
+    return b == '\n' ? 0u : b;                                           // sequence lines are concatenated
+}
+
+// pass 3 (write == 0): emitted bytes per block; pass 4 (write == 1): emit them at out + blk_out[block]
+template <int WRITE>
+__global__ __launch_bounds__(IG_THREADS) void ig_emit_kernel(const uint8_t *__restrict__ text, uint64_t n_use, const uint32_t *__restrict__ blk_base,
+                                                             const uint32_t *__restrict__ nlpos, int fastq, uint32_t *__restrict__ blk_emit,
+                                                             const uint32_t *__restrict__ blk_out, uint8_t *__restrict__ out) {
+    __shared__ uint32_t s_w[IG_THREADS / 64];
+    const uint64_t pos = (uint64_t)blockIdx.x * IG_BYTES + (uint64_t)threadIdx.x * 16;
+    uint32_t c = 0;
+    Raw r;
+    r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
+    if (pos < n_use) {
+        r = load_text16(text, pos, n_use);
+        for (int j = 0; j < 16; ++j) c += (pos + j < n_use && byte_of(r, j) == '\n');
+    }
+    uint32_t total;
+    uint32_t line = blk_base[blockIdx.x] + block_exclusive(c, s_w, total);
+    uint8_t em[16];
+    uint32_t ne = 0;
+    if (pos < n_use)
+        for (int j = 0; j < 16; ++j) {
+            if (pos + j >= n_use) break;
+            const uint32_t b = byte_of(r, j);
+            const uint32_t e = emit_of(text, nlpos, fastq, line, b, pos + j);
+            if (e) em[ne++] = (uint8_t)e;
+            if (b == '\n') ++line;
+        }
+    uint32_t tot2;
+    const uint32_t off = block_exclusive(ne, s_w, tot2);
+    if (!WRITE) {
+        if (threadIdx.x == 0) blk_emit[blockIdx.x] = tot2;
+    } else {
+        uint8_t *dst = out + blk_out[blockIdx.x] + off;
+        for (uint32_t q = 0; q < ne; ++q) dst[q] = em[q];
+    }
+}
+
+struct Reader {           // the concatenation of all input files as one byte stream (src/jasper.sh:177 `zcat -f $READS`)
+    const char *const *paths;
+    int n_paths, cur = 0;
+    gzFile g = nullptr;
+    std::string err;
+    // fills buf with up to want bytes; returns bytes read, 0 at the end of the last file, -1 on error
+    long read(char *buf, size_t want) {
+        size_t got = 0;
+        while (got < want) {
+            if (!g) {
+                if (cur >= n_paths) break;
+                g = gzopen(paths[cur], "rb");
+                if (!g) { err = std::string("cannot open ") + paths[cur]; return -1; }
+                gzbuffer(g, 1u << 20);
+            }
+            const int r = gzread(g, buf + got, (unsigned)std::min<size_t>(want - got, 1u << 30));
+            if (r < 0) { err = std::string("read error in ") + paths[cur]; return -1; }
+            if (r == 0) { gzclose(g); g = nullptr; ++cur; continue; }
+            got += (size_t)r;
+        }
+        return (long)got;
+    }
+    ~Reader() { if (g) gzclose(g); }
+};
+
+}  // namespace
+
+#define HIPCHK(x)                                                                     \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            err = std::string(#x) + ": " + hipGetErrorString(e_);                     \
+            return -1;                                                                \
+        }                                                                             \
+    } while (0)
+
+// returns 0 ok; <0 error (message in err).  `gpu_bytes` / `host_bytes`: how much of the stream each parser handled.
+int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_bytes, uint64_t *host_bytes, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    const size_t CHUNK = 128u << 20;                      // text bytes per chunk (+ carry)
+    const size_t BASES_CAP = 3ull << 30;                  // device base buffer: counted and emptied when it is this full
+    uint64_t n_gpu = 0, n_host = 0;
+    Reader rd;
+    rd.paths = paths;
+    rd.n_paths = n_paths;
+    char *h_buf = nullptr;
+    HIPCHK(hipHostMalloc((void **)&h_buf, 2 * CHUNK + 64, hipHostMallocDefault));
+    struct Free { char *p; ~Free() { if (p) (void)hipHostFree(p); } } free_h{h_buf};
+    uint8_t *d_text = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 0, 2 * CHUNK + 64, err));
+    uint8_t *d_bases = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 1, BASES_CAP + 2 * CHUNK + 64, err));
+    const size_t max_blocks = (2 * CHUNK + IG_BYTES - 1) / IG_BYTES + 1;
+    uint32_t *d_blk = reinterpret_cast<uint32_t *>(workspace(WS_INGEST + 2, (3 * max_blocks + 16) * 4, err));
+    if (!d_text || !d_bases || !d_blk) return -1;
+    uint32_t *d_blk_nl = d_blk, *d_blk_emit = d_blk + max_blocks, *d_blk_out = d_blk_emit + max_blocks;
+    unsigned int *d_flags = reinterpret_cast<unsigned int *>(d_blk_out + max_blocks);
+    size_t scan_tmp_bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, scan_tmp_bytes, d_blk_nl, d_blk_nl, 0u, max_blocks, rocprim::plus<uint32_t>(), stream));
+    void *d_scan_tmp = workspace(WS_INGEST + 3, scan_tmp_bytes + 256, err);
+    if (!d_scan_tmp) return -1;
+
+    struct Report { uint64_t *g, *h; uint64_t &ng, &nh; ~Report() { if (g) *g = ng; if (h) *h = nh; } } report{gpu_bytes, host_bytes, n_gpu, n_host};
+    uint64_t bases_len = 0;
+    auto flush_bases = [&]() -> int {
+        if (!bases_len) return 0;
+        const int rc = count_device(d_bases, bases_len, err);
+        bases_len = 0;
+        return rc;
+    };
+    // the host state machine takes over from here (and keeps the rest of the stream)
+    FastxParser hp([this, &err](const char *b, size_t m) { return this->count_host(b, m, err); });
+    auto host_rest = [&](int mode, const char *first, size_t first_n) -> int {
+        if (int rc = flush_bases()) return rc;
+        hp.resume(mode);
+        int rc = hp.feed(first, first_n);
+        n_host += first_n;
+        while (!rc) {
+            const long got = rd.read(h_buf, CHUNK);
+            if (got < 0) { err = rd.err; return -1; }
+            if (got == 0) break;
+            rc = hp.feed(h_buf, (size_t)got);
+            n_host += (uint64_t)got;
+        }
+        if (!rc) rc = hp.finish();
+        if (rc && !hp.error().empty()) err = hp.error();
+        return rc;
+    };
+
+    int mode = 0;                 // 0 unknown, 1 FASTA, 2 FASTQ (FastxParser's numbering)
+    size_t carry = 0;             // bytes at the start of h_buf left over from the previous chunk (an incomplete record / line)
+    for (;;) {
+        if (carry > CHUNK) return host_rest(mode, h_buf, carry);                  // a line / record longer than a chunk
+        const long got = rd.read(h_buf + carry, CHUNK);
+        if (got < 0) { err = rd.err; return -1; }
+        size_t n = carry + (size_t)got;
+        const bool eof = got == 0;
+        if (n == 0) break;
+        if (mode == 0) {
+            // format from the first byte of the stream (:134-148); leading empty lines make the reference's peek() see '\n'
+            if (h_buf[0] == '>') mode = 1;
+            else if (h_buf[0] == '@') mode = 2;
+            else return host_rest(0, h_buf, n);                                   // (the host parser words the error)
+        }
+        if (eof) return host_rest(mode, h_buf, n);                                // the tail: at most one incomplete record / line
+        HIPCHK(hipMemcpyAsync(d_text, h_buf, n, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemsetAsync(d_flags, 0, 8, stream));
+        const uint32_t nblk = (uint32_t)((n + IG_BYTES - 1) / IG_BYTES);
+        hipLaunchKernelGGL(ig_count_nl_kernel, dim3(nblk), dim3(IG_THREADS), 0, stream, d_text, (uint64_t)n, d_blk_nl, d_flags);
+        HIPCHK(rocprim::exclusive_scan(d_scan_tmp, scan_tmp_bytes, d_blk_nl, d_blk_nl, 0u, (size_t)nblk + 1, rocprim::plus<uint32_t>(), stream));
+        uint32_t n_lines = 0;
+        unsigned int flags = 0;
+        HIPCHK(hipMemcpyAsync(&n_lines, d_blk_nl + nblk, 4, hipMemcpyDeviceToHost, stream));      // (entry nblk of the exclusive scan = total)
+        HIPCHK(hipMemcpyAsync(&flags, d_flags, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(jk_stream_wait(stream));
+        if (flags & IGF_CR) return host_rest(mode, h_buf, n);
+        const uint64_t use_lines = mode == 2 ? (uint64_t)(n_lines / 4) * 4 : n_lines;
+        if (use_lines == 0) {                                                     // not even one whole record in the chunk
+            carry = n;
+            continue;
+        }
+        uint32_t *d_nlpos = reinterpret_cast<uint32_t *>(workspace(WS_INGEST + 4, ((size_t)n_lines + 16) * 4, err));
+        if (!d_nlpos) return -1;
+        hipLaunchKernelGGL(ig_nlpos_kernel, dim3(nblk), dim3(IG_THREADS), 0, stream, d_text, (uint64_t)n, d_blk_nl, d_nlpos);
+        uint32_t end_nl = 0;
+        HIPCHK(hipMemcpyAsync(&end_nl, d_nlpos + (use_lines - 1), 4, hipMemcpyDeviceToHost, stream));
+        if (mode == 2) hipLaunchKernelGGL(ig_check_fastq_kernel, dim3(1024), dim3(256), 0, stream, d_text, d_nlpos, use_lines / 4, d_flags);
+        HIPCHK(hipMemcpyAsync(&flags, d_flags, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(jk_stream_wait(stream));
+        if (flags & IGF_BAD) return host_rest(mode, h_buf, n);
+        const uint64_t n_use = (uint64_t)end_nl + 1;                              // whole records / lines only
+        const uint32_t ublk = (uint32_t)((n_use + IG_BYTES - 1) / IG_BYTES);
+        hipLaunchKernelGGL(ig_emit_kernel<0>, dim3(ublk), dim3(IG_THREADS), 0, stream, d_text, n_use, d_blk_nl, d_nlpos, mode == 2 ? 1 : 0, d_blk_emit,
+                           (const uint32_t *)nullptr, (uint8_t *)nullptr);
+        HIPCHK(rocprim::exclusive_scan(d_scan_tmp, scan_tmp_bytes, d_blk_emit, d_blk_out, 0u, (size_t)ublk + 1, rocprim::plus<uint32_t>(), stream));
+        uint32_t n_emit = 0;
+        HIPCHK(hipMemcpyAsync(&n_emit, d_blk_out + ublk, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(jk_stream_wait(stream));
+        if (bases_len + n_emit > BASES_CAP + 2 * CHUNK) { if (int rc = flush_bases()) return rc; }
+        hipLaunchKernelGGL(ig_emit_kernel<1>, dim3(ublk), dim3(IG_THREADS), 0, stream, d_text, n_use, d_blk_nl, d_nlpos, mode == 2 ? 1 : 0, d_blk_emit,
+                           d_blk_out, d_bases + bases_len);
+        HIPCHK(hipGetLastError());
+        HIPCHK(jk_stream_wait(stream));           // h_buf is rewritten next
+        bases_len += n_emit;
+        n_gpu += n_use;
+        if (bases_len >= BASES_CAP) { if (int rc = flush_bases()) return rc; }
+        carry = n - (size_t)n_use;
+        if (carry) memmove(h_buf, h_buf + n_use, carry);
+    }
+    return flush_bases();
+}
+
+}  // namespace jk

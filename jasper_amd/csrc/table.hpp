@@ -230,7 +230,7 @@ struct Table {
     uint64_t size_hint = 0;   // caller's expected number of distinct k-mers (`jellyfish count -s`); 0 = none given
     // grow-only device workspace reused by the polisher across calls (hipMalloc of GBs costs far more than the kernels)
     struct WsBuf { void *p = nullptr; size_t bytes = 0; };
-    static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_SLOTS = 44;
+    static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_INGEST = 44, WS_SLOTS = 50;
     WsBuf ws[WS_SLOTS];   // 0..WS_POLISH_MAX-1: polisher (polish_host.hip, in allocation order); WS_COUNT..+3: partitioned counting
     void *workspace(int id, size_t bytes, std::string &err);
 
@@ -251,6 +251,10 @@ struct Table {
     int after_batch(std::string &err);                // spill / fatal / growth handling
     int count_device(const uint8_t *d_bases, uint64_t n, std::string &err);
     int count_host(const char *bases, uint64_t n, std::string &err);
+    // FASTA/FASTQ files (plain or gzip, one concatenated stream) parsed on the GPU, host state machine as the fallback
+    // (ingest_gpu.hip); reports how many text bytes each parser handled
+    int count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_bytes, uint64_t *host_bytes, std::string &err);
+    uint64_t ingest_gpu_bytes = 0, ingest_host_bytes = 0;
     int histogram(uint64_t *out10002, std::string &err);
     int lookup_strings(const char *chars, const int64_t *offsets, uint64_t n, uint32_t *out, std::string &err);
     int export_entries(uint64_t *n_out, unsigned long long **d_entries_out, std::string &err);  // 3 words each

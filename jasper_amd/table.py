@@ -139,6 +139,12 @@ class KmerTable:
         arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
         check(self._L.jasper_count_reads_files(self._h, arr, len(paths)))
 
+    def last_ingest(self):
+        """(text bytes parsed on the GPU, text bytes parsed by the host state machine) of the last count_files call"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(self._L.jasper_last_ingest(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def count_text(self, text):
         if isinstance(text, str):
             text = text.encode()

@@ -365,3 +365,74 @@ def test_partitioned_counting_equals_direct_counting(KT, k):
     assert tp.lookup(qs) == td.lookup(qs)
     tp.close()
     td.close()
+
+
+def _ingest_cases():
+    rng = np.random.default_rng(77)
+    genome = synth.make_genome(rng, 30000, repeat_frac=0)
+    stream = synth.make_reads_stream(rng, genome, 12, 90, 0.01).tobytes().decode()
+    reads = [r for r in stream.split("N") if r]
+    quals = lambda r, i: ("@" if i % 3 == 0 else "I") + "I" * (len(r) - 1)      # quality strings that start with '@' too
+    fq = "".join("@r%d some text\n%s\n+%s\n%s\n" % (i, r, "r%d" % i if i % 2 else "", quals(r, i)) for i, r in enumerate(reads))
+    fa = "".join(">r%d\n%s\n" % (i, "\n".join(r[j:j + 37] for j in range(0, len(r), 37))) for i, r in enumerate(reads))
+    multi = "".join("@r%d\n%s\n%s\n+\n%s\n%s\n" % (i, r[:40], r[40:], "I" * 40, "I" * (len(r) - 40)) for i, r in enumerate(reads[:200]))
+    cases = {
+        "fastq4": ([fq], "gpu"),
+        "fastq4_no_final_newline": ([fq[:-1]], "gpu+tail"),
+        "fastq4_two_files_joined_mid_record": ([fq[:len(fq) // 2 + 7], fq[len(fq) // 2 + 7:]], "gpu"),
+        "fasta_multiline": ([fa], "gpu"),
+        "fasta_with_empty_lines_and_empty_records": ([">x\n\nACGTACGTACGTACGTACGTACGTACG\n\n>y\n>z\n" + fa], "gpu"),
+        "fastq_with_N_lower_and_short_reads": (["".join("@q%d\n%s\n+\n%s\n" % (i, s, "#" * len(s)) for i, s in
+                                                        enumerate([r.lower() if i % 5 == 0 else r[:30] + "N" + r[31:] if i % 7 == 0 else r[:i % 25]
+                                                                   for i, r in enumerate(reads)]))], "gpu"),
+        "fastq_multiline_records": ([multi + fq], "host"),
+        "fastq_crlf": ([fq.replace("\n", "\r\n")], "host"),
+        "fastq_then_broken_record": ([fq + "@bad\nACGTACGTACGTACGTACGTACGTAC\n+\nIIII\n"], "error"),
+        "fastq_empty_sequence_record": ([fq[:len(fq) // 2].rsplit("@r", 1)[0] + "@e\n\n+\n\n" + fq], "gpu"),
+        "leading_blank_line": (["\n" + fq], "unsupported"),
+    }
+    return cases
+
+
+@pytest.mark.parametrize("name", sorted(_ingest_cases()))
+def test_gpu_text_ingest_equals_host_parser_and_oracle(KT, O, tmp_path, name):
+    """jasper_count_reads_files parses FASTA/FASTQ text on the GPU (ingest_gpu.hip) and hands anything that is not plain
+    4-line FASTQ / FASTA to the host state machine; both must give the table the oracle's parser rules give"""
+    from jasper_amd._lib import JasperHipError
+    k = 21
+    files, expect = _ingest_cases()[name]
+    paths = []
+    for i, text in enumerate(files):
+        p = tmp_path / ("f%d.txt" % i)
+        p.write_bytes(text.encode())
+        paths.append(str(p))
+    whole = "".join(files)
+    db = O.OracleDB(k)
+    t = KT(k, min_slots=1 << 16)
+    if expect in ("error", "unsupported"):
+        with pytest.raises(JasperHipError, match="Invalid fastq" if expect == "error" else "Unsupported format"):
+            t.count_files(paths)
+        with pytest.raises(RuntimeError):
+            db.count_text(whole)                       # the oracle's parser rejects it too
+        t.close()
+        return
+    db.count_text(whole)
+    t.count_files(paths)
+    g, h = t.last_ingest()
+    assert g + h == len(whole)
+    if expect == "gpu":
+        assert g > 0.9 * len(whole), (g, h)
+    elif expect == "gpu+tail":
+        assert g > 0.9 * len(whole) and h > 0
+    else:
+        assert g == 0 and h == len(whole)
+    assert t.histogram() == db.histo() and t.info()["occurrences"] == sum(c for _, c in db.items())
+    os.environ["JASPER_INGEST_HOST"] = "1"
+    try:
+        t2 = KT(k, min_slots=1 << 16)
+        t2.count_files(paths)
+    finally:
+        del os.environ["JASPER_INGEST_HOST"]
+    assert t2.histogram() == t.histogram()
+    t.close()
+    t2.close()
