@@ -19,6 +19,10 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <zlib.h>
 #include <rocprim/device/device_scan.hpp>
 
@@ -165,26 +169,76 @@ __global__ __launch_bounds__(IG_THREADS) void ig_emit_kernel(const uint8_t *__re
 struct Reader {           // the concatenation of all input files as one byte stream (src/jasper.sh:177 `zcat -f $READS`)
     const char *const *paths;
     int n_paths, cur = 0;
-    gzFile g = nullptr;
+    gzFile g = nullptr;   // gzip members are inflated by zlib ...
+    int fd = -1;          // ... anything else is read as it is (what `zcat -f` does): pread by a few threads, because one
+    off_t off = 0, size = 0;   // thread copies out of the page cache at only ~7 GB/s
     std::string err;
+    static constexpr int READ_THREADS = 4;
     // fills buf with up to want bytes; returns bytes read, 0 at the end of the last file, -1 on error
     long read(char *buf, size_t want) {
         size_t got = 0;
         while (got < want) {
-            if (!g) {
+            if (!g && fd < 0) {
                 if (cur >= n_paths) break;
-                g = gzopen(paths[cur], "rb");
-                if (!g) { err = std::string("cannot open ") + paths[cur]; return -1; }
-                gzbuffer(g, 1u << 20);
+                fd = open(paths[cur], O_RDONLY);
+                if (fd < 0) { err = std::string("cannot open ") + paths[cur]; return -1; }
+                unsigned char magic[2] = {0, 0};
+                const ssize_t m = pread(fd, magic, 2, 0);
+                struct stat st;
+                if (m == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+                    close(fd);
+                    fd = -1;
+                    g = gzopen(paths[cur], "rb");
+                    if (!g) { err = std::string("cannot open ") + paths[cur]; return -1; }
+                    gzbuffer(g, 1u << 20);
+                } else if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {       // pipes etc.: sequential reads through zlib's pass-through
+                    close(fd);
+                    fd = -1;
+                    g = gzopen(paths[cur], "rb");
+                    if (!g) { err = std::string("cannot open ") + paths[cur]; return -1; }
+                } else {
+                    off = 0;
+                    size = st.st_size;
+                }
             }
-            const int r = gzread(g, buf + got, (unsigned)std::min<size_t>(want - got, 1u << 30));
-            if (r < 0) { err = std::string("read error in ") + paths[cur]; return -1; }
-            if (r == 0) { gzclose(g); g = nullptr; ++cur; continue; }
+            long r = 0;
+            if (g) {
+                r = gzread(g, buf + got, (unsigned)std::min<size_t>(want - got, 1u << 30));
+                if (r < 0) { err = std::string("read error in ") + paths[cur]; return -1; }
+            } else {
+                const size_t todo = (size_t)std::min<off_t>((off_t)(want - got), size - off);
+                if (todo) {
+                    const size_t part = (todo + READ_THREADS - 1) / READ_THREADS;
+                    bool ok[READ_THREADS];
+                    std::thread th[READ_THREADS];
+                    auto work = [&](int i) {
+                        size_t lo = (size_t)i * part, hi = std::min(todo, lo + part);
+                        ok[i] = true;
+                        while (lo < hi) {
+                            const ssize_t k = pread(fd, buf + got + lo, hi - lo, off + (off_t)lo);
+                            if (k <= 0) { ok[i] = false; return; }
+                            lo += (size_t)k;
+                        }
+                    };
+                    for (int i = 1; i < READ_THREADS; ++i) th[i] = std::thread(work, i);
+                    work(0);
+                    for (int i = 1; i < READ_THREADS; ++i) th[i].join();
+                    for (int i = 0; i < READ_THREADS; ++i)
+                        if (!ok[i]) { err = std::string("read error in ") + paths[cur]; return -1; }
+                    off += (off_t)todo;
+                    r = (long)todo;
+                }
+            }
+            if (r == 0) {
+                if (g) { gzclose(g); g = nullptr; } else { close(fd); fd = -1; }
+                ++cur;
+                continue;
+            }
             got += (size_t)r;
         }
         return (long)got;
     }
-    ~Reader() { if (g) gzclose(g); }
+    ~Reader() { if (g) gzclose(g); if (fd >= 0) close(fd); }
 };
 
 }  // namespace
@@ -201,15 +255,32 @@ struct Reader {           // the concatenation of all input files as one byte st
 // returns 0 ok; <0 error (message in err).  `gpu_bytes` / `host_bytes`: how much of the stream each parser handled.
 int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_bytes, uint64_t *host_bytes, std::string &err) {
     HIPCHK(hipSetDevice(device));
-    const size_t CHUNK = 128u << 20;                      // text bytes per chunk (+ carry)
-    const size_t BASES_CAP = 3ull << 30;                  // device base buffer: counted and emptied when it is this full
+    // sizes follow the input (pinning and device allocation cost ~0.1 ms per MB): text chunk <= 128 MiB (+ carry), device
+    // base buffer <= 3 GiB (counted and emptied whenever it is that full)
+    uint64_t est = 0;
+    for (int i = 0; i < n_paths; ++i) {
+        struct stat st;
+        if (stat(paths[i], &st) == 0 && S_ISREG(st.st_mode)) {
+            const size_t L = strlen(paths[i]);
+            est += (uint64_t)st.st_size * ((L > 3 && !strcmp(paths[i] + L - 3, ".gz")) ? 5 : 1);
+        } else est += 1ull << 32;
+    }
+    size_t CHUNK = 128u << 20;
+    while (CHUNK > (4u << 20) && CHUNK / 2 >= est) CHUNK /= 2;
+    if (const char *e = getenv("JASPER_INGEST_CHUNK")) CHUNK = std::max<size_t>(4096, strtoull(e, nullptr, 10));   // tests: many small chunks
+    else if (ingest_chunk > CHUNK) CHUNK = ingest_chunk;  // the pinned buffer of an earlier call is kept
+    const size_t BASES_CAP = (size_t)std::min<uint64_t>(3ull << 30, std::max<uint64_t>(est, 16u << 20));
     uint64_t n_gpu = 0, n_host = 0;
     Reader rd;
     rd.paths = paths;
     rd.n_paths = n_paths;
-    char *h_buf = nullptr;
-    HIPCHK(hipHostMalloc((void **)&h_buf, 2 * CHUNK + 64, hipHostMallocDefault));
-    struct Free { char *p; ~Free() { if (p) (void)hipHostFree(p); } } free_h{h_buf};
+    if (!h_ingest || ingest_chunk < CHUNK) {              // kept with the table between calls
+        if (h_ingest) (void)hipHostFree(h_ingest);
+        h_ingest = nullptr;
+        HIPCHK(hipHostMalloc((void **)&h_ingest, 2 * CHUNK + 64, hipHostMallocDefault));
+        ingest_chunk = CHUNK;
+    }
+    char *h_buf = h_ingest;
     uint8_t *d_text = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 0, 2 * CHUNK + 64, err));
     uint8_t *d_bases = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 1, BASES_CAP + 2 * CHUNK + 64, err));
     const size_t max_blocks = (2 * CHUNK + IG_BYTES - 1) / IG_BYTES + 1;

@@ -461,6 +461,8 @@ void Table::destroy() {
     if (d.spill) (void)hipFree(d.spill);
     if (d_histo) (void)hipFree(d_histo);
     d_histo = nullptr;
+    if (h_ingest) (void)hipHostFree(h_ingest);
+    h_ingest = nullptr;
     if (h_stats) (void)hipHostFree(h_stats);
     if (ev_k0) (void)hipEventDestroy(ev_k0);
     if (ev_k1) (void)hipEventDestroy(ev_k1);

@@ -255,6 +255,8 @@ struct Table {
     // (ingest_gpu.hip); reports how many text bytes each parser handled
     int count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_bytes, uint64_t *host_bytes, std::string &err);
     uint64_t ingest_gpu_bytes = 0, ingest_host_bytes = 0;
+    char *h_ingest = nullptr;      // pinned text staging of count_files_gpu
+    size_t ingest_chunk = 0;
     int histogram(uint64_t *out10002, std::string &err);
     int lookup_strings(const char *chars, const int64_t *offsets, uint64_t n, uint32_t *out, std::string &err);
     int export_entries(uint64_t *n_out, unsigned long long **d_entries_out, std::string &err);  // 3 words each

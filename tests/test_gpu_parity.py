@@ -434,5 +434,18 @@ def test_gpu_text_ingest_equals_host_parser_and_oracle(KT, O, tmp_path, name):
     finally:
         del os.environ["JASPER_INGEST_HOST"]
     assert t2.histogram() == t.histogram()
+    # the same stream in many small chunks: records and lines straddle chunk ends and are carried over
+    for chunk in (4096, 50_000):
+        os.environ["JASPER_INGEST_CHUNK"] = str(chunk)
+        try:
+            t3 = KT(k, min_slots=1 << 16)
+            t3.count_files(paths)
+        finally:
+            del os.environ["JASPER_INGEST_CHUNK"]
+        g3, h3 = t3.last_ingest()
+        assert g3 + h3 == len(whole) and t3.histogram() == t.histogram(), (chunk, g3, h3)
+        if expect == "gpu":
+            assert g3 > 0.9 * len(whole)
+        t3.close()
     t.close()
     t2.close()

@@ -23,5 +23,10 @@ with open(fq, "wb") as f:
     for i in range(r2.shape[0]):
         f.write(b"@r%d\n" % i); f.write(r2[i].tobytes()); f.write(b"\n+\n"); f.write(q); f.write(b"\n")
 sz = os.path.getsize(fq)
-t0 = time.perf_counter(); t.count_files([fq]); t.sync(); t1 = time.perf_counter()
-print("FASTQ file: %.0f MB in %.1f ms -> %.2f GB/s of text, %.2f Gk-mers/s (parse + PCIe inclusive, 1 host thread)" % (sz / 1e6, (t1 - t0) * 1e3, sz / (t1 - t0) / 1e9, kmers / (t1 - t0) / 1e9))
+for label, env in (("GPU text parser", None), ("GPU text parser (again)", None), ("host state machine", "1")):
+    if env:
+        os.environ["JASPER_INGEST_HOST"] = env
+    t.clear()
+    t0 = time.perf_counter(); t.count_files([fq]); t.sync(); t1 = time.perf_counter()
+    print("FASTQ file, %s: %.0f MB in %.1f ms -> %.2f GB/s of text, %.2f Gk-mers/s (file read + PCIe inclusive); parsed on GPU/host: %s"
+          % (label, sz / 1e6, (t1 - t0) * 1e3, sz / (t1 - t0) / 1e9, kmers / (t1 - t0) / 1e9, t.last_ingest()), flush=True)
