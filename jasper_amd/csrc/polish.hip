@@ -5,7 +5,7 @@
 // repair), so parallelism comes from these places:
 //   * chunks are independent (the reference's own xargs -P parallelism, src/jasper.sh:212);
 //   * a chunk is cut at sync points -- starts of runs of >= k-1 bad k-mers preceded by >= 4k clean positions, found
-//     by a dense scan (scan_kernel / classify_kernel / find_sync_kernel).  Any stride phase lands inside such a run
+//     by a dense scan (scan_batch_kernel / classify_batch_kernel / find_sync_batch_kernel).  Any stride phase lands inside such a run
 //     and handle_bad_kmers() then finds the same run bounds, so the walk right of a sync point is independent of
 //     everything left of it except a coordinate shift: segments are walked concurrently and stitched afterwards.
 //     A walk that touches text outside what its segment may assume raises spec_fail and the chunk is redone as one
@@ -1000,98 +1000,6 @@ __global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, 
 // ---------------------------------------------------------------------------------------------------------
 constexpr int SC_THREADS = 256, SC_GROUP = 16, SC_TILE = SC_THREADS * SC_GROUP, SC_HALO = 4;
 
-__global__ __launch_bounds__(SC_THREADS) void scan_kernel(const uint8_t *__restrict__ text, int64_t n, int64_t ntiles,
-                                                           uint32_t *__restrict__ cnt, uint8_t *__restrict__ valid, TableDev T) {
-    __shared__ uint32_t s_code[SC_THREADS + SC_HALO];
-    __shared__ uint32_t s_inv[SC_THREADS + SC_HALO];
-    const int t = threadIdx.x;
-    const int k = T.k;
-    const u128 kmask = maskbits(2 * k);
-    auto stage = [&](int64_t pos, uint32_t &codes, uint32_t &inv) {
-        codes = 0; inv = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int64_t p = pos + j;
-            const int c = (p >= 0 && p < n) ? code(text[p]) : -1;
-            codes = (codes << 2) | (uint32_t)(c & 3);
-            inv = (inv << 1) | (uint32_t)(c < 0);
-        }
-    };
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t base0 = tile * SC_TILE;
-        uint32_t c, iv;
-        stage(base0 + (int64_t)t * SC_GROUP, c, iv);
-        s_code[t + SC_HALO] = c;
-        s_inv[t + SC_HALO] = iv;
-        if (t < SC_HALO) {
-            uint32_t hc, hiv;
-            stage(base0 - (int64_t)(SC_HALO - t) * SC_GROUP, hc, hiv);
-            s_code[t] = hc;
-            s_inv[t] = hiv;
-        }
-        __syncthreads();
-        const uint32_t w4 = s_code[t], w3 = s_code[t + 1], w2 = s_code[t + 2], w1 = s_code[t + 3];
-        const uint64_t ivprev = ((uint64_t)s_inv[t] << 48) | ((uint64_t)s_inv[t + 1] << 32) | ((uint64_t)s_inv[t + 2] << 16) |
-                                (uint64_t)s_inv[t + 3];
-        const uint32_t own = c, owninv = iv;
-        __syncthreads();
-        u128 fwd = band(mk(((uint64_t)w4 << 32) | w3, ((uint64_t)w2 << 32) | w1), kmask);
-        u128 rc = revcomp(fwd, k);
-        int run = ivprev ? (int)__builtin_ctzll(ivprev) : 64;
-#pragma unroll 4
-        for (int j = 0; j < SC_GROUP; ++j) {
-            const uint32_t cj = (own >> (30 - 2 * j)) & 3u;
-            const bool bad = (owninv >> (15 - j)) & 1u;
-            fwd = band(bor(shl(fwd, 2), mk(0, cj)), kmask);
-            rc = bor(shr(rc, 2), shl(mk(0, 3u - cj), 2 * (k - 1)));
-            run = bad ? 0 : run + 1;
-            const int64_t e = base0 + (int64_t)t * SC_GROUP + j;    // window end
-            const int64_t p = e - k + 1;                            // window start
-            if (p >= 0 && e < n) {
-                if (run >= k) {
-                    const u128 canon = lt(rc, fwd) ? rc : fwd;
-                    cnt[p] = clamp32(table_get(T, mix(canon, T.B)));
-                    valid[p] = 1;
-                } else {
-                    cnt[p] = 0;
-                    valid[p] = 0;
-                }
-            }
-        }
-    }
-}
-
-// class of every window start (see PosClass): what the walk's main loop (src/jasper.py:56-100) does there
-__global__ __launch_bounds__(256) void classify_kernel(const uint32_t *__restrict__ cnt, const uint8_t *__restrict__ valid, int64_t nwin,
-                                                       int k, uint32_t solid, uint8_t *__restrict__ cls) {
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nwin; p += (int64_t)gridDim.x * blockDim.x) {
-        uint8_t c;
-        if (!valid[p]) c = PC_OTHER;
-        else if (cnt[p] < solid) c = PC_BAD;
-        else if (p > 0) {
-            const int64_t q = p - k > 0 ? p - k : 0;               // seq[max(0,i-k):max(k,i)]  (:80)
-            c = (!valid[q] || 50ull * cnt[p] < (unsigned long long)cnt[q]) ? PC_OTHER : PC_CLEAN;
-        } else c = PC_CLEAN;
-        cls[p] = c;
-    }
-}
-
-// sync points: p with cls[p-4k .. p) all CLEAN and cls[p .. p+k-1) all BAD
-__global__ __launch_bounds__(256) void find_sync_kernel(const uint8_t *__restrict__ cls, int64_t nwin, int k, int64_t *__restrict__ out,
-                                                        unsigned int *__restrict__ count, unsigned int cap) {
-    const int64_t W = 4ll * k;
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nwin; p += (int64_t)gridDim.x * blockDim.x) {
-        if (p < W || p + k - 1 > nwin) continue;
-        if (cls[p] != PC_BAD || cls[p - 1] != PC_CLEAN) continue;
-        bool ok = true;
-        for (int64_t q = 1; q < k - 1 && ok; ++q) ok = cls[p + q] == PC_BAD;
-        for (int64_t q = 2; q <= W && ok; ++q) ok = cls[p - q] == PC_CLEAN;
-        if (!ok) continue;
-        const unsigned int idx = atomicAdd(count, 1u);
-        if (idx < cap) out[idx] = p;
-    }
-}
-
 // copy each segment's text range out of its chunk into the segment's gap buffer (text right of the gap)
 __global__ __launch_bounds__(256) void seg_init_kernel(SegDev *segs, int n_segs, const uint8_t *const *chunk_text) {
     for (int s = blockIdx.y; s < n_segs; s += gridDim.y) {
@@ -1391,27 +1299,6 @@ void launch_scan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunk
     launch_find_clean(d_chunks, n_chunks, k, stream);
 }
 
-static int blocks_for(int64_t items, int per_block) {
-    int64_t b = (items + per_block - 1) / per_block;
-    if (b > 2048) b = 2048;
-    if (b < 1) b = 1;
-    return (int)b;
-}
-
-void launch_scan(const TableDev &T, const uint8_t *d_text, int64_t len, uint32_t *d_cnt, uint8_t *d_valid, hipStream_t stream) {
-    if (len <= 0) return;
-    const int64_t ntiles = (len + SC_TILE - 1) / SC_TILE;
-    hipLaunchKernelGGL(scan_kernel, dim3(blocks_for(ntiles, 1)), dim3(SC_THREADS), 0, stream, d_text, len, ntiles, d_cnt, d_valid, T);
-}
-void launch_classify(const uint32_t *d_cnt, const uint8_t *d_valid, int64_t nwin, int k, uint32_t solid, uint8_t *d_cls, hipStream_t stream) {
-    if (nwin <= 0) return;
-    hipLaunchKernelGGL(classify_kernel, dim3(blocks_for(nwin, 256 * 8)), dim3(256), 0, stream, d_cnt, d_valid, nwin, k, solid, d_cls);
-}
-void launch_find_sync(const uint8_t *d_cls, int64_t nwin, int k, int64_t *d_out, unsigned int *d_count, unsigned int cap,
-                      hipStream_t stream) {
-    if (nwin <= 0) return;
-    hipLaunchKernelGGL(find_sync_kernel, dim3(blocks_for(nwin, 256 * 8)), dim3(256), 0, stream, d_cls, nwin, k, d_out, d_count, cap);
-}
 void launch_seg_init(SegDev *d_segs, int n_segs, const uint8_t *const *d_chunk_text, hipStream_t stream) {
     if (n_segs <= 0) return;
     dim3 grid(n_segs >= 512 ? 4 : 64, n_segs < 4096 ? n_segs : 4096);

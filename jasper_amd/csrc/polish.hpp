@@ -129,12 +129,6 @@ void launch_scan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunk
 // later passes: classes were carried over by the stitch; recompute the 64-window tiles next to changed text, then candidates
 void launch_rescan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunks, int k, uint32_t solid, hipStream_t stream);
 
-// dense scan of one contiguous text: count of every window (0xFFFFFFFF clamp as in lookups) + validity
-void launch_scan(const TableDev &T, const uint8_t *d_text, int64_t len, uint32_t *d_cnt, uint8_t *d_valid, hipStream_t stream);
-void launch_classify(const uint32_t *d_cnt, const uint8_t *d_valid, int64_t nwin, int k, uint32_t solid, uint8_t *d_cls, hipStream_t stream);
-// sync-point candidates of one chunk: appends chunk coordinates to d_out (unsorted), count in *d_count
-void launch_find_sync(const uint8_t *d_cls, int64_t nwin, int k, int64_t *d_out, unsigned int *d_count, unsigned int cap,
-                      hipStream_t stream);
 void launch_seg_init(SegDev *d_segs, int n_segs, const uint8_t *const *d_chunk_text, hipStream_t stream);
 // d_ticket: one device word (zeroed by the call); d_segs[i].arrive must point into an array preset to ARRIVE_PENDING
 void launch_seg_walk(const TableDev &T, SegDev *d_segs, int n_segs, PolishParams pp, int pass, ScratchPool pool, unsigned int *d_ticket,
