@@ -449,3 +449,29 @@ def test_gpu_text_ingest_equals_host_parser_and_oracle(KT, O, tmp_path, name):
         t3.close()
     t.close()
     t2.close()
+
+
+def test_polish_many_small_chunks_vs_oracle(KT, O):
+    """a batch of hundreds of short chunk records (contigs of 0.1-6 kb, some shorter than k, some empty): the batched
+    kernels index chunks through blockIdx.y and the candidate list is shared by the whole batch"""
+    from jasper_amd import polisher
+    k = 25
+    genome, reads, asm = workload(23, 400_000, k, asm_err=3e-3)
+    rng = np.random.default_rng(9)
+    names, seqs, pos = [], [], 0
+    while pos < len(asm) and len(seqs) < 400:
+        n = int(rng.choice([0, 7, k - 1, k, k + 1, 120, 800, 2500, 6000]))
+        names.append("c%d" % len(seqs))
+        seqs.append(asm[pos:pos + n])
+        pos += max(n, 1)
+    t = KT(k, min_slots=1 << 20)
+    t.count_bases(reads)
+    db = O.OracleDB(k)
+    db.count_bases(reads)
+    fixed_o, rows_o, qv_o, _ = db.polish_batch(names, seqs, 3, 2)
+    fixed, rows, qv, res = polisher.polish_batch(t, names, seqs, 3, 2)
+    assert qv == qv_o and fixed == fixed_o
+    for it in range(2):
+        assert polisher.fix_csv_text(rows[it]) == "Contig Base_coord Original Mutation\r\n" + rows_o[it]
+    assert sum(len(r) for r in rows) > 50
+    t.close()
