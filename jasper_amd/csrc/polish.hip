@@ -148,9 +148,24 @@ struct Walker {
         const u128 m = encode_words(w, n, nv);
         return clamp32(table_get(T, mix(canonical(m, k), T.B)));
     }
-    // same for a string in LDS / global scratch
+    // same for a string in LDS / global scratch: all byte loads are issued before the first is used (the loop that stops at
+    // the first non-ACGT byte made every load wait for the previous one)
     __device__ __forceinline__ uint32_t cnt_str(const uint8_t *p, int n) const {
-        const u128 m = encode_padded(k, (long)n, [&](int q) { return p[q]; });
+        const int lim = n < k ? n : k;
+        uint32_t w[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const int q = 4 * x + y;
+                const uint32_t b = q < lim ? (uint32_t)p[q] : 0u;
+                v |= b << (8 * y);
+            }
+            w[x] = v;
+        }
+        int nv;
+        const u128 m = encode_words(w, lim, nv);
         return clamp32(table_get(T, mix(canonical(m, k), T.B)));
     }
 
@@ -508,7 +523,23 @@ struct Walker {
                     const FrontEntry *fe = &F[pp];
                     const int tl = fe->tlen;
                     const uint8_t bj = (uint8_t)("ACGT"[jj]);
-                    const u128 m = encode_padded(k, (long)k, [&](int q) { return q < k - 1 ? fe->tail[tl - (k - 1) + q] : bj; });
+                    // km1 + base: the last k-1 tail bytes with four 16-B loads in flight (tl <= k+3, so the 64 bytes read
+                    // from tail + tl-(k-1) end inside tail[72]), then the candidate base as byte k-1
+                    uint32_t w[16];
+                    const uint8_t *src = fe->tail + (tl - (k - 1));
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const U16 v = *reinterpret_cast<const U16 *>(src + 16 * c4);
+                        w[4 * c4] = v.w[0]; w[4 * c4 + 1] = v.w[1]; w[4 * c4 + 2] = v.w[2]; w[4 * c4 + 3] = v.w[3];
+                    }
+                    {
+                        const int bi = k - 1;
+#pragma unroll
+                        for (int x = 0; x < 16; ++x)
+                            if (x == (bi >> 2)) w[x] = (w[x] & ~(0xFFu << (8 * (bi & 3)))) | ((uint32_t)bj << (8 * (bi & 3)));
+                    }
+                    int nv;
+                    const u128 m = encode_words(w, k, nv);
                     score = clamp32(table_get(T, mix(canonical(m, k), T.B)));
                 }
                 const uint32_t gend = (last_path - g) < 16u ? (last_path - g) : 16u;
@@ -524,9 +555,10 @@ struct Walker {
                         const uint8_t bj = (uint8_t)("ACGT"[j]);
                         if (i >= min_overlap && i >= min_patch_len) {           // :557
                             // last_bases[-5:] == good_k_mer_after[0:5]         (:558) ; last_bases = km1 + base
-                            bool same = true;
-                            for (int u = 0; u < 4; ++u) same = same && (F[p].tail[tl - 4 + u] == s_gka[u]);
-                            same = same && (bj == s_gka[4]);
+                            struct __attribute__((packed, aligned(1))) U4 { uint32_t v; };
+                            const uint32_t last4 = reinterpret_cast<const U4 *>(F[p].tail + (tl - 4))->v;
+                            const uint32_t want4 = (uint32_t)s_gka[0] | ((uint32_t)s_gka[1] << 8) | ((uint32_t)s_gka[2] << 16) | ((uint32_t)s_gka[3] << 24);
+                            const bool same = last4 == want4 && bj == s_gka[4];
                             if (same) {
                                 // path_connected = (start_km1 + path_before + base + gka[-(k-5):])[-(2k-1):]  (:560/:563)
                                 int n = 0;
