@@ -59,7 +59,7 @@ struct Walker {
     int pass;
     int status;
     uint64_t nlook;
-    uint64_t tk[4];
+    uint64_t tk[12];
     uint8_t *s_tbf, *s_t1, *s_t2, *s_gkb, *s_gka;
     // segment context
     int64_t delta;        // len - len0: how far text right of the last edit has shifted
@@ -634,37 +634,44 @@ struct Walker {
 
     // ---------------- src/jasper.py:226-332 fixing_sid ----------------
     // tbf in s_tbf (only when n <= k), L = len(to_be_fixed). Emits records, splices the chunk.
+    template <typename F>
+    __device__ __forceinline__ auto timed(int slot, F f) -> decltype(f()) {
+        const uint64_t t0 = wall_clock64();
+        auto r = f();
+        tk[slot] += wall_clock64() - t0;
+        return r;
+    }
     __device__ void fixing_sid(int64_t L64, uint32_t thr, int64_t n, int64_t gb, int64_t ga) {
         int64_t s0 = gb - k + 2; if (s0 < 0) s0 = 0;
         const int L = (int)L64;
         int outlen = 0;
         if (n == k) {                                                          // :232
-            uint8_t b = fix_k_case_sub(L, thr, outlen);
+            uint8_t b = timed(4, [&]() { return fix_k_case_sub(L, thr, outlen); });
             if (b) {
                 emit('s', ga - 1, b, at(ga - 1), 1, 0, 0);                    // :235-237
                 replace(s0, ga + k - 1, s_t1, outlen);                        // :238
             } else {
-                b = fix_insert(L, thr, outlen);
+                b = timed(5, [&]() { return fix_insert(L, thr, outlen); });
                 if (b) {
                     emit('i', ga - 1, '-', at(ga - 1), 1, 0, 0);              // :242-244
                     replace(s0, ga + k - 1, s_t1, outlen);
                 }
             }
         } else if (n == k - 1) {                                               // :247
-            uint8_t b = fix_del(L, thr, outlen);
+            uint8_t b = timed(6, [&]() { return fix_del(L, thr, outlen); });
             if (b) {
                 emit('d', ga, b, '-', 1, 0, 0);                               // :250-253
                 replace(s0, ga + k - 1, s_t1, outlen);
             } else {
                 uint8_t left = 0, right = 0;
-                const uint8_t lr = fixdiploid(L, thr, gb, ga, left, right, outlen);
+                const uint8_t lr = timed(7, [&]() { return fixdiploid(L, thr, gb, ga, left, right, outlen); });
                 if (lr) {
                     if (lr == 's') emit('s', ga - 1, left, at(ga - 1), 1, 0, 0);   // :257-260
                     else emit('s', gb + 1, right, at(gb + 1), 1, 0, 0);            // :262-264
                     replace(s0, ga + k - 1, s_t1, outlen);
                 } else if (status == PS_OK) {
                     int idx = 0, rep = 0; uint8_t bs = 0;
-                    if (fix_same_base_insertion(L, thr, idx, bs, rep, outlen)) {    // :267-272
+                    if (timed(9, [&]() { return fix_same_base_insertion(L, thr, idx, bs, rep, outlen); })) {    // :267-272
                         emit('i', idx + s0, '-', bs, (uint32_t)rep, 0, 0);
                         replace(s0, ga + k - 1, s_t1, outlen);
                     }
@@ -672,17 +679,17 @@ struct Walker {
             }
         } else if (n < k - 1 && n > 1 && L64 >= k) {                           // :274
             int idx = 0, rep = 0; uint8_t bs = 0;
-            if (fix_same_base_del(L, thr, idx, bs, rep, outlen)) {             // :275-280
+            if (timed(8, [&]() { return fix_same_base_del(L, thr, idx, bs, rep, outlen); })) {             // :275-280
                 emit('d', idx + s0, bs, '-', (uint32_t)rep, 0, 0);
                 replace(s0, ga + k - 1, s_t1, outlen);
             } else if (status == PS_OK) {
                 uint8_t left = 0, right = 0;
-                const uint8_t lr = fixdiploid(L, thr, gb, ga, left, right, outlen);
+                const uint8_t lr = timed(7, [&]() { return fixdiploid(L, thr, gb, ga, left, right, outlen); });
                 if (lr) {
                     if (lr == 's') emit('s', ga - 1, left, at(ga - 1), 1, 0, 0);
                     else emit('s', gb + 1, right, at(gb + 1), 1, 0, 0);
                     replace(s0, ga + k - 1, s_t1, outlen);
-                } else if (status == PS_OK && fix_same_base_insertion(L, thr, idx, bs, rep, outlen)) {  // :294-299
+                } else if (status == PS_OK && timed(9, [&]() { return fix_same_base_insertion(L, thr, idx, bs, rep, outlen); })) {  // :294-299
                     emit('i', idx + s0, '-', bs, (uint32_t)rep, 0, 0);
                     replace(s0, ga + k - 1, s_t1, outlen);
                 }
@@ -696,7 +703,7 @@ struct Walker {
             cp_seq(s_gkb, blo, bhi);
             cp_seq(s_gka, alo, ahi);
             sync();
-            const int64_t plen = base_extension(L64, (int)(bhi - blo), (int)(ahi - alo), thr);
+            const int64_t plen = timed(10, [&]() { return base_extension(L64, (int)(bhi - blo), (int)(ahi - alo), thr); });
             sync();
             if (plen >= 0 && status == PS_OK) {
                 // record: patch ++ original segment seq[gb+1:ga]; the host aligns them (src/jasper.py:309-329)
@@ -1004,7 +1011,7 @@ __global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, 
     w.T = T; w.k = P.k; w.step = P.step; w.lane = threadIdx.x; w.solid = P.solid;
     w.buf = C->buf; w.len = C->len; w.gs = C->gs; w.glen = C->glen; w.cap = C->cap;
     w.C = C; w.chunk_id = C->chunk; w.nrec = 0; w.naux = 0; w.seqno = 0; w.nedit = 0; w.pass = pass;
-    w.status = PS_OK; w.nlook = 0; w.tk[0] = w.tk[1] = w.tk[2] = w.tk[3] = 0;
+    w.status = PS_OK; w.nlook = 0; for (int q = 0; q < 12; ++q) w.tk[q] = 0;
     w.s_tbf = s_tbf; w.s_t1 = s_t1; w.s_t2 = s_t2; w.s_gkb = s_gkb; w.s_gka = s_gka;
     w.delta = 0; w.dirty_end = INT64_MIN / 2; w.glo = P.k;
     w.is_first = C->first != 0; w.is_last = C->last != 0; w.spec_fail = 0;
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, 
     w.release_scratch();
     if (threadIdx.x == 0) {
         C->ticks = wall_clock64() - t0;
-        for (int q = 0; q < 4; ++q) C->tk[q] = w.tk[q];
+        for (int q = 0; q < 12; ++q) C->tk[q] = w.tk[q];
         C->len = w.len; C->gs = w.gs; C->glen = w.glen;
         C->nrec = w.nrec; C->naux = w.naux; C->nedit = w.nedit; C->status = w.status; C->spec_fail = w.spec_fail;
         C->wrong = wrong;

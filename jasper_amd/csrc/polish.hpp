@@ -91,7 +91,9 @@ struct SegDev {
     int64_t wrong;       // bad k-mers counted in this segment during this pass
     uint64_t lookups;
     uint64_t ticks;      // wall_clock64() ticks (100 MHz) this segment's walk took -- tuning aid
-    uint64_t tk[4];      // of which: skipping good k-mers, finding the bad run, choosing a fix, splicing the text
+    uint64_t tk[12];     // of which: [0] skipping good k-mers, [1] finding the bad run, [2] choosing a fix, [3] splicing the text;
+                         // [4..10] inside [2]: fix_k_case_sub, fix_insert, fix_del, fixdiploid, fix_same_base_del,
+                         // fix_same_base_insertion, base_extension
     // filled by the host before stitching
     int64_t own_lo, own_hi;   // local range of the polished text this segment contributes
     int64_t out_off;          // where it goes in the chunk's new text

@@ -329,10 +329,10 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
 
         if (getenv("JASPER_POLISH_DEBUG")) {
             uint64_t mx = 0, sum = 0, mxl = 0; int64_t mxlen = 0; size_t nrecs = 0, mxrec = 0;
-            uint64_t tks[4] = {0, 0, 0, 0};
+            uint64_t tks[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (const SegDev &S : segs) {
                 sum += S.ticks; nrecs += S.nrec;
-                for (int q = 0; q < 4; ++q) tks[q] += S.tk[q];
+                for (int q = 0; q < 12; ++q) tks[q] += S.tk[q];
                 if (S.ticks > mx) { mx = S.ticks; mxl = S.lookups; mxlen = S.len0; mxrec = S.nrec; }
             }
             fprintf(stderr, "[polish] pass %d: %zu segments, %zu records, walk ticks(10ns): mean %.0f max %llu (that segment: len %lld, %llu lookups, %zu records)\n",
@@ -340,6 +340,9 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                     (unsigned long long)mxl, mxrec);
             fprintf(stderr, "[polish]   of all walk ticks: skip_good %.1f%%, find run %.1f%%, choose fix %.1f%% (of which splice %.1f%%)\n",
                     100.0 * tks[0] / (sum + 1), 100.0 * tks[1] / (sum + 1), 100.0 * tks[2] / (sum + 1), 100.0 * tks[3] / (sum + 1));
+            fprintf(stderr, "[polish]   inside choose fix: k_case_sub %.1f%%, insert %.1f%%, del %.1f%%, diploid %.1f%%, same_base_del %.1f%%, same_base_ins %.1f%%, path search %.1f%%\n",
+                    100.0 * tks[4] / (sum + 1), 100.0 * tks[5] / (sum + 1), 100.0 * tks[6] / (sum + 1), 100.0 * tks[7] / (sum + 1),
+                    100.0 * tks[8] / (sum + 1), 100.0 * tks[9] / (sum + 1), 100.0 * tks[10] / (sum + 1));
             // histogram of segment times in ms buckets
             int hb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (const SegDev &S : segs) { double ms = S.ticks * 1e-5; int b = ms < 0.1 ? 0 : ms < 0.3 ? 1 : ms < 1 ? 2 : ms < 2 ? 3 : ms < 4 ? 4 : ms < 8 ? 5 : ms < 16 ? 6 : 7; hb[b]++; }
