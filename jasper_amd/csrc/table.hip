@@ -638,11 +638,11 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
         // a new key"; the spill list / deferred list / growth still catch a piece that turns out less repetitive
         if ((pos > 0 || have_ratio) && dup_ratio < 0.6) piece = std::max<uint64_t>(piece, (uint64_t)((double)room / std::max(0.05, 1.5 * dup_ratio)));
         if (mem_have) piece = std::min<uint64_t>(piece, std::max<uint64_t>(mem_have / 28, 1u << 20));
-        piece = std::min<uint64_t>(piece, 1ull << 31);
+        piece = std::min<uint64_t>(piece, 1ull << 33);   // (positions are 64-bit throughout; slice counters are 32-bit but per slice)
         // do not leave a small tail for a separate launch (the 1.5x safety factor covers a quarter more)
-        if ((pos > 0 || have_ratio) && dup_ratio < 0.6 && n - pos <= piece + piece / 4 && n - pos <= (1ull << 31)) piece = n - pos;
+        if ((pos > 0 || have_ratio) && dup_ratio < 0.6 && n - pos <= piece + piece / 4 && n - pos <= (1ull << 33)) piece = n - pos;
         // the caller's own promise (size hint = expected distinct k-mers of this input) fits the free room: one piece
-        if (have_ratio && pos == 0 && (double)n * dup_ratio <= (double)room && n <= (1ull << 31) && (!mem_have || n <= mem_have / 28)) piece = n;
+        if (have_ratio && pos == 0 && (double)n * dup_ratio <= (double)room && n <= (1ull << 33) && (!mem_have || n <= mem_have / 28)) piece = n;
         if (const char *e = getenv("JASPER_EXPERIMENT_PIECE")) piece = strtoull(e, nullptr, 10);   // tuning experiments only
         {   // make room up front for the new keys this piece is expected to bring (worst case for the first piece)
             const uint64_t todo = std::min<uint64_t>(piece, n - pos);
