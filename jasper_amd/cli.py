@@ -30,6 +30,20 @@ def _tty():
         return False
 
 
+_T0 = [None]
+
+
+def _timing(label):
+    """JASPER_AMD_TIMING=1: seconds since the previous mark, on stderr (not part of the reference's output)"""
+    import time
+    if not os.environ.get("JASPER_AMD_TIMING"):
+        return
+    now = time.perf_counter()
+    if _T0[0] is not None:
+        sys.stderr.write("[timing] %-28s %.3f s\n" % (label, now - _T0[0]))
+    _T0[0] = now
+
+
 def log(msg):  # :30-33
     d = datetime.datetime.now().astimezone().strftime("%a %b %d %H:%M:%S %Z %Y")
     if _tty():
@@ -274,6 +288,7 @@ def run(argv):
         batch_size = bs
         if batch_size > MAX_BATCH_SIZE:
             batch_size = MAX_BATCH_SIZE
+    _timing("start")
     log("Using BATCH SIZE %d" % batch_size)
     if not re.match(r"^-?[0-9]+$", str(o.passes)) or int(o.passes) - 1 < 0:
         error_exit("The number of passes supplied by -p must be a positive integer")
@@ -311,13 +326,16 @@ def run(argv):
                 os.remove("jasper.no_cat.success")
             table = KmerTable.from_jf(jf_file, device=o.device)
         else:
+            _timing("split")
             log("Creating jellyfish database mer_counts%d.jf" % kmer)
             table = KmerTable(kmer, min_slots=max(1 << 20, 2 * o.jf_size), device=o.device)
             table.count_files(reads)
+            _timing("count reads (files -> table)")
             if os.environ.get("JASPER_AMD_NO_JF", "") not in ("1", "true", "yes"):
                 # :177 `... | tee $JF_DB | ...`: leave the database behind for reruns and for other Jellyfish tools
                 table.write_jf(jf_file + ".tmp", ["count", "-C", "-t", str(o.num_threads), "-s", str(o.jf_size), "-m", str(kmer), "-o", jf_file] + reads)
                 os.replace(jf_file + ".tmp", jf_file)
+                _timing("write mer_counts.jf")
             with open(histo_file + ".tmp", "w") as f:
                 for m, n in table.histo_rows():
                     f.write("%d %d\n" % (m, n))
@@ -345,6 +363,7 @@ def run(argv):
         open("jasper.histo.success", "w").close()
 
     if not os.path.exists("jasper.correct.success"):                    # :195-216
+        _timing("histogram")
         log("Polishing")
         txt, status = polisher.threshold_from_histo_file(histo_file)
         if status == 0:
@@ -364,6 +383,7 @@ def run(argv):
         open("jasper.correct.success", "w").close()
 
     if not os.path.exists("jasper.join.success"):                       # :218-232
+        _timing("polish batches")
         log("Joining")
         if contigs is None:
             contigs = read_assembly(o.query)
@@ -400,6 +420,7 @@ def run(argv):
         log("After Polishing: Q value = %s" % qv.q_value(b1, t1, kmer))
         for p in glob.glob("*qValCalcHelper.csv"):
             os.remove(p)
+    _timing("join + QV")
     log("Polished sequence is in %s.polished.fasta" % qfn)
     if table is not None:
         table.close()
