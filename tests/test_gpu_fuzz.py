@@ -1,0 +1,58 @@
+"""GPU: randomised differential test HIP path vs oracle, with the case generator that pinned the oracle against the real
+reference (tests/golden/fuzz_vs_reference.py: homopolymers, tandem repeats, diploid sites, high-copy elements, coverage gaps,
+sub/ins/del/lower-case/N/IUPAC edits, every read-file format, random k / passes / threshold / chunking)."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+def _one(seed, KmerTable, polisher, O, G, F, tmp_path):
+    rng, spec, haps, chunks = F.random_case(seed)
+    k = spec["k"]
+    reads = G.sample_reads(rng, haps, spec["cov"], spec["rl"], spec["err"])
+    if not reads:
+        reads = [haps[0][0][:spec["rl"]]]
+    ext = "fq" if spec["fmt"].startswith("fq") else "fa"
+    rpath = str(tmp_path / ("reads%d.%s" % (seed, ext)))
+    G.write_reads(rpath, reads, spec["fmt"], rng)
+    text = open(rpath, "rb").read()
+    odb = O.OracleDB(k)
+    odb.count_text(text)
+    t = KmerTable(k, min_slots=1 << 16)
+    t.count_files([rpath])
+    items = list(odb.items())
+    assert t.info()["distinct"] == len(items) and t.histogram() == odb.histo(), (seed, spec)
+    sample = items[:: max(1, len(items) // 200)]
+    assert t.lookup([km for km, _ in sample]) == [min(c, 0xFFFFFFFF) for _, c in sample], (seed, spec)
+    names = [c[0] for c in chunks]
+    seqs = [c[1] for c in chunks]
+    try:
+        fixed_o, rows_o, qv_o, _ = odb.polish_batch(names, seqs, spec["thre"], spec["passes"])
+        ok_o = True
+    except RuntimeError:
+        ok_o = False
+    try:
+        fixed, rows, qv, _ = polisher.polish_batch(t, names, seqs, spec["thre"], spec["passes"])
+        ok = True
+    except Exception:
+        ok = False
+    assert ok == ok_o, (seed, spec)
+    if ok:
+        assert qv == qv_o and fixed == fixed_o, (seed, spec)
+        for it in range(spec["passes"]):
+            assert polisher.fix_csv_text(rows[it]) == "Contig Base_coord Original Mutation\r\n" + rows_o[it], (seed, spec, it)
+    t.close()
+
+
+def test_fuzz_hip_vs_oracle(hip, tmp_path):
+    from jasper_amd import KmerTable, polisher
+    from oracle import oracle as O
+    import make_golden as G              # generator helpers only; nothing of the reference is touched
+    import fuzz_vs_reference as F
+    for seed in range(5000, 5300):
+        _one(seed, KmerTable, polisher, O, G, F, tmp_path)
