@@ -87,7 +87,7 @@ int jasper_table_load_jf(const char *path, int device, jasper_table **out) {
     rc = jasper_table_create(h.key_len / 2, std::max<uint64_t>(1u << 16, 2 * h.n_records), device, &t);
     if (rc) return rc;
     Table *T = &t->t;
-    rc = jf_read_records(path, h, [T](const unsigned long long *e, size_t n) { return T->add_kmers(e, n, g_err); }, g_err);
+    rc = T->load_jf_records(path, h.data_offset, h.n_records, h.key_len, h.counter_len, g_err);
     if (rc) { jasper_table_destroy(t); return rc < -1 ? rc : JASPER_ERR; }
     *out = t;
     return JASPER_OK;

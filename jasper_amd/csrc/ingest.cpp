@@ -165,32 +165,4 @@ int jf_read_header(const char *path, JfHeader &h, std::string &err) {
     return 0;
 }
 
-int jf_read_records(const char *path, const JfHeader &h, std::function<int(const unsigned long long *, size_t)> sink, std::string &err) {
-    FILE *f = fopen(path, "rb");
-    if (!f) { err = std::string("Can't open file '") + path + "'"; return -1; }
-    fseek(f, (long)h.data_offset, SEEK_SET);
-    const size_t kb = (size_t)((h.key_len + 7) / 8), cl = (size_t)h.counter_len, rec = kb + cl;
-    const size_t block = 1u << 20;
-    std::vector<unsigned char> raw(block * rec);
-    std::vector<unsigned long long> ent(block * 3);
-    uint64_t left = h.n_records;
-    while (left) {
-        const size_t n = (size_t)std::min<uint64_t>(left, block);
-        if (fread(raw.data(), rec, n, f) != n) { fclose(f); err = "truncated Jellyfish database"; return -1; }
-        for (size_t i = 0; i < n; ++i) {
-            const unsigned char *p = raw.data() + i * rec;
-            unsigned long long lo = 0, hi = 0, c = 0;
-            for (size_t b = 0; b < kb && b < 8; ++b) lo |= (unsigned long long)p[b] << (8 * b);
-            for (size_t b = 8; b < kb; ++b) hi |= (unsigned long long)p[b] << (8 * (b - 8));
-            for (size_t b = 0; b < cl; ++b) c |= (unsigned long long)p[kb + b] << (8 * b);
-            ent[3 * i] = hi; ent[3 * i + 1] = lo; ent[3 * i + 2] = c;
-        }
-        const int rc = sink(ent.data(), n);
-        if (rc) { fclose(f); return rc; }
-        left -= n;
-    }
-    fclose(f);
-    return 0;
-}
-
 }  // namespace jk

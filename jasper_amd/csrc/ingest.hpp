@@ -50,7 +50,7 @@ int parse_files(const char *const *paths, int n_paths, FastxParser &parser, std:
 
 // Jellyfish "binary/sorted" database (JF::include/jellyfish/generic_file_header.hpp:88-143,
 // JF::include/jellyfish/binary_dumper.hpp:36-40,103-108): 9 ASCII digits = header length, JSON header (NUL padded),
-// then records [key: ceil(key_len/8) bytes LE][count: counter_len bytes LE].
+// then records [key: ceil(key_len/8) bytes LE][count: counter_len bytes LE] (unpacked on the device: jfwrite.hip).
 struct JfHeader {
     int key_len = 0;        // bits = 2k
     int counter_len = 0;    // bytes
@@ -58,7 +58,5 @@ struct JfHeader {
     uint64_t data_offset = 0, n_records = 0;
 };
 int jf_read_header(const char *path, JfHeader &h, std::string &err);
-// calls sink(entries, n) with blocks of (kmer hi, kmer lo, count) triples
-int jf_read_records(const char *path, const JfHeader &h, std::function<int(const unsigned long long *, size_t)> sink, std::string &err);
 
 }  // namespace jk

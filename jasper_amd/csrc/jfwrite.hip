@@ -76,6 +76,37 @@ __global__ __launch_bounds__(256) void swap_words_kernel(const unsigned long lon
     }
 }
 
+// the file's record bytes, formatted on the device: [key: kb bytes LE][count: 4 bytes LE] per sorted entry
+__global__ __launch_bounds__(256) void format_records_kernel(const unsigned long long *__restrict__ key_word, const HiCnt *__restrict__ other, uint64_t n0,
+                                                             uint64_t m, int B, int r, int kb, uint8_t *__restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
+        const HiCnt o = other[n0 + i];                                             // (the other word, count) -- HiCnt and LoCnt share a layout
+        const u128 K = B > 64 ? mk(key_word[n0 + i], o.hi) : mk(0, key_word[n0 + i]);
+        const u128 key = r == 0 || r == B ? K : bor(shl(band(K, maskbits(B - r)), r), shr(K, B - r));
+        uint8_t *dst = out + i * (uint64_t)(kb + 4);
+        for (int b = 0; b < kb; ++b) dst[b] = (uint8_t)((b < 8 ? key.lo >> (8 * b) : key.hi >> (8 * (b - 8))) & 0xFFu);
+        for (int b = 0; b < 4; ++b) dst[kb + b] = (uint8_t)((o.cnt >> (8 * b)) & 0xFFu);
+    }
+}
+
+// the reverse: raw file records -> table.  Keys are inserted AS STORED (no canonicalisation), so that a lookup of
+// canonical(query) hits exactly when the reference's binary search would (JF::include/jellyfish/binary_dumper.hpp:148-199)
+__global__ __launch_bounds__(256) void add_jf_records_kernel(const uint8_t *__restrict__ raw, uint64_t n, int kb, int cl, TableDev T) {
+    unsigned long long fresh = 0;
+    const u128 kmask = maskbits(T.B);
+    const int rec = kb + cl;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t *p = raw + i * (uint64_t)rec;
+        unsigned long long lo = 0, hi = 0, c = 0;
+        for (int b = 0; b < kb && b < 8; ++b) lo |= (unsigned long long)p[b] << (8 * b);
+        for (int b = 8; b < kb; ++b) hi |= (unsigned long long)p[b] << (8 * (b - 8));
+        for (int b = 0; b < cl; ++b) c |= (unsigned long long)p[kb + b] << (8 * b);
+        if (c) fresh += table_add_or_spill(T, mix(band(mk(hi, lo), kmask), T.B), c);
+    }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+}
+
 static std::string json_str(const char *s) {
     std::string o = "\"";
     for (; *s; ++s) {
@@ -94,6 +125,8 @@ int Table::write_jf(const char *path, const char *const *cmdline, int n_cmd, std
     HiCnt *d_hic[2] = {nullptr, nullptr};
     LoCnt *d_loc[2] = {nullptr, nullptr};
     void *d_tmp = nullptr;
+    uint8_t *d_fmt = nullptr, *h_fmt = nullptr;
+    hipEvent_t ev_fmt[2] = {nullptr, nullptr};
     const int B = d.B;
     const int r = d.s < B ? d.s : B;                 // rows of the identity matrix = log2(size)
     const int kb = (B + 7) / 8;
@@ -165,29 +198,35 @@ int Table::write_jf(const char *path, const char *const *cmdline, int n_cmd, std
         if (pad && fwrite(zeros, 1, pad, f) != pad) { err = "write error"; rc = -1; goto done; }
     }
     {
-        // ---- records, in blocks through pageable host buffers
+        // ---- records: formatted on the device, copied through two pinned buffers; the fwrite of a block overlaps the
+        //      formatting + copy of the next one
         const uint64_t BLK = 1u << 22;
-        std::vector<unsigned long long> w0(BLK);
-        std::vector<HiCnt> w1(BLK);          // HiCnt and LoCnt share a layout: (other word, count)
-        std::vector<unsigned char> out((size_t)BLK * (kb + 4));
+        const size_t rec = (size_t)kb + 4;
         const unsigned long long *src_key = B > 64 ? d_khi[1] : d_klo[1];
-        const void *src_pay = B > 64 ? (const void *)d_loc[1] : (const void *)d_hic[1];
-        for (uint64_t pos = 0; pos < n; pos += BLK) {
-            const uint64_t m = std::min<uint64_t>(BLK, n - pos);
-            HIPCHK(hipMemcpyAsync(w0.data(), src_key + pos, m * 8, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(w1.data(), (const HiCnt *)src_pay + pos, m * sizeof(HiCnt), hipMemcpyDeviceToHost, stream));
-            HIPCHK(jk_stream_wait(stream));
-            unsigned char *o = out.data();
-            for (uint64_t i = 0; i < m; ++i) {
-                const u128 K = B > 64 ? mk(w0[i], w1[i].hi) : mk(0, w0[i]);       // (hi, lo)
-                const u128 key = r == 0 || r == B ? K : bor(shl(band(K, maskbits(B - r)), r), shr(K, B - r));
-                const unsigned long long words[2] = {key.lo, key.hi};
-                memcpy(o, words, (size_t)kb);
-                const unsigned int c = w1[i].cnt;
-                memcpy(o + kb, &c, 4);
-                o += kb + 4;
+        const HiCnt *src_pay = B > 64 ? reinterpret_cast<const HiCnt *>(d_loc[1]) : d_hic[1];
+        HIPCHK(hipMalloc((void **)&d_fmt, 2 * BLK * rec));
+        HIPCHK(hipHostMalloc((void **)&h_fmt, 2 * BLK * rec, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&ev_fmt[0], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_fmt[1], hipEventDisableTiming));
+        const uint64_t nblk = (n + BLK - 1) / BLK;
+        auto issue = [&](uint64_t b) -> hipError_t {
+            const uint64_t pos = b * BLK, m = std::min<uint64_t>(BLK, n - pos);
+            uint8_t *d = d_fmt + (b & 1) * BLK * rec;
+            hipLaunchKernelGGL(format_records_kernel, dim3(2048), dim3(256), 0, stream, src_key, src_pay, pos, m, B, r, kb, d);
+            hipError_t e = hipMemcpyAsync(h_fmt + (b & 1) * BLK * rec, d, m * rec, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipEventRecord(ev_fmt[b & 1], stream);
+            return e;
+        };
+        if (nblk) HIPCHK(issue(0));
+        for (uint64_t b = 0; b < nblk; ++b) {
+            if (b + 1 < nblk) HIPCHK(issue(b + 1));
+            for (;;) {                                   // poll: hipEventSynchronize may sleep for milliseconds
+                const hipError_t q = hipEventQuery(ev_fmt[b & 1]);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) { err = std::string("event: ") + hipGetErrorString(q); rc = -1; goto done; }
             }
-            if (fwrite(out.data(), (size_t)(kb + 4), m, f) != m) { err = "write error"; rc = -1; goto done; }
+            const uint64_t m = std::min<uint64_t>(BLK, n - b * BLK);
+            if (fwrite(h_fmt + (b & 1) * BLK * rec, rec, m, f) != m) { err = "write error"; rc = -1; goto done; }
         }
     }
 done:
@@ -198,6 +237,56 @@ done:
     for (int i = 0; i < 2; ++i) { if (d_klo[i]) (void)hipFree(d_klo[i]); if (d_hic[i]) (void)hipFree(d_hic[i]); }
     if (d_tmp) (void)hipFree(d_tmp);
     if (d_counter) (void)hipFree(d_counter);
+    if (d_fmt) (void)hipFree(d_fmt);
+    if (h_fmt) (void)hipHostFree(h_fmt);
+    for (int i = 0; i < 2; ++i) if (ev_fmt[i]) (void)hipEventDestroy(ev_fmt[i]);
+    return rc;
+}
+
+}  // namespace jk
+
+namespace jk {
+
+// records of a binary/sorted file (after its header) -> table: raw blocks through a pinned buffer, unpacked on the device
+int Table::load_jf_records(const char *path, uint64_t data_offset, uint64_t n_records, int key_len_bits, int counter_len, std::string &err) {
+    int rc = 0;
+    histo_cached = false;
+    if (hipSetDevice(device) != hipSuccess) { err = "hipSetDevice failed"; return -1; }
+    if (materialize(err)) return -1;
+    const int kb = (key_len_bits + 7) / 8, cl = counter_len;
+    const size_t rec = (size_t)kb + (size_t)cl;
+    const uint64_t BLK = 1u << 22;
+    FILE *f = fopen(path, "rb");
+    if (!f) { err = std::string("Can't open file '") + path + "'"; return -1; }
+    uint8_t *h_raw = nullptr, *d_raw = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    uint64_t left = n_records;
+    int b = 0;
+    if (fseek(f, (long)data_offset, SEEK_SET) != 0) { err = "truncated Jellyfish database"; rc = -1; goto done; }
+    if (ensure_capacity(n_records, err)) { rc = -1; goto done; }
+    HIPCHK(hipHostMalloc((void **)&h_raw, 2 * BLK * rec, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&d_raw, 2 * BLK * rec));
+    HIPCHK(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    for (; left; b ^= 1) {
+        const uint64_t m = std::min<uint64_t>(left, BLK);
+        if (ev[b]) {                                   // the copy that last used this half must have left the pinned buffer
+            for (;;) { const hipError_t q = hipEventQuery(ev[b]); if (q == hipSuccess) break; if (q != hipErrorNotReady) { err = "event query failed"; rc = -1; goto done; } }
+        }
+        if (fread(h_raw + (size_t)b * BLK * rec, rec, m, f) != m) { err = "truncated Jellyfish database"; rc = -1; goto done; }
+        HIPCHK(hipMemcpyAsync(d_raw + (size_t)b * BLK * rec, h_raw + (size_t)b * BLK * rec, m * rec, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipEventRecord(ev[b], stream));
+        hipLaunchKernelGGL(add_jf_records_kernel, dim3(2048), dim3(256), 0, stream, d_raw + (size_t)b * BLK * rec, m, kb, cl, d);
+        HIPCHK(hipGetLastError());
+        left -= m;
+    }
+    rc = after_batch(err);
+done:
+    (void)jk_stream_wait(stream);
+    fclose(f);
+    if (h_raw) (void)hipHostFree(h_raw);
+    if (d_raw) (void)hipFree(d_raw);
+    for (int i = 0; i < 2; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);
     return rc;
 }
 

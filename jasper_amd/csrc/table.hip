@@ -352,20 +352,6 @@ __global__ __launch_bounds__(256) void zero_kernel(ulonglong2 *__restrict__ p, u
         p[i] = make_ulonglong2(0ull, 0ull);
 }
 
-// raw k-mers (hi, lo, count) as stored in a Jellyfish DB: keys are inserted AS STORED (no canonicalisation), so that a
-// lookup of canonical(query) hits exactly when the reference's binary search would (JF::include/jellyfish/binary_dumper.hpp:148-199)
-__global__ __launch_bounds__(256) void add_kmers_kernel(const unsigned long long *__restrict__ entries, uint64_t n, TableDev T) {
-    unsigned long long fresh = 0;
-    const u128 kmask = maskbits(T.B);
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const u128 m = band(mk(entries[3 * i + 0], entries[3 * i + 1]), kmask);
-        const unsigned long long c = entries[3 * i + 2];
-        if (c) fresh += table_add_or_spill(T, mix(m, T.B), c);
-    }
-    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
-    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
-}
-
 // rehash straight from an old slot array into a (larger) table
 __global__ __launch_bounds__(256) void rehash_kernel(TableDev oldT, TableDev newT) {
     unsigned long long fresh = 0;
@@ -839,23 +825,6 @@ int Table::import_entries(const unsigned long long *d_entries, uint64_t n, std::
         if (rc) return rc;
     }
     return 0;
-}
-
-int Table::add_kmers(const unsigned long long *h_entries, uint64_t n, std::string &err) {
-    histo_cached = false;
-    HIPCHK(hipSetDevice(device));
-    if (materialize(err)) return -1;
-    if (!n) return 0;
-    if (read_stats(err)) return -1;
-    if (ensure_capacity(n, err)) return -1;
-    unsigned long long *d_e = nullptr;
-    HIPCHK(hipMalloc((void **)&d_e, n * 24));
-    HIPCHK(hipMemcpyAsync(d_e, h_entries, n * 24, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(add_kmers_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_e, n, d);
-    HIPCHK(hipGetLastError());
-    int rc = after_batch(err);
-    HIPCHK(hipFree(d_e));
-    return rc;
 }
 
 int Table::reserve(uint64_t min_slots, std::string &err) {

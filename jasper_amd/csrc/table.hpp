@@ -266,9 +266,9 @@ struct Table {
     int export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t part, uint32_t nparts, std::string &err);
     int import_packed(const void *d_src, uint64_t n, int mode, std::string &err);
     int reserve(uint64_t min_slots, std::string &err);
-    int add_kmers(const unsigned long long *h_entries, uint64_t n, std::string &err);   // (kmer hi, lo, count) as stored in a .jf
     // the table as a Jellyfish binary/sorted database (jfwrite.hip); cmdline goes into the header like jellyfish's own
     int write_jf(const char *path, const char *const *cmdline, int n_cmd, std::string &err);
+    int load_jf_records(const char *path, uint64_t data_offset, uint64_t n_records, int key_len_bits, int counter_len, std::string &err);
 };
 
 }  // namespace jk
