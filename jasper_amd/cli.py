@@ -328,7 +328,7 @@ def run(argv):
         else:
             _timing("split")
             log("Creating jellyfish database mer_counts%d.jf" % kmer)
-            table = KmerTable(kmer, min_slots=max(1 << 20, 2 * o.jf_size), device=o.device)
+            table = KmerTable(kmer, min_slots=max(1 << 20, int(1.25 * o.jf_size)), device=o.device)
             table.count_files(reads)
             _timing("count reads (files -> table)")
             if os.environ.get("JASPER_AMD_NO_JF", "") not in ("1", "true", "yes"):
