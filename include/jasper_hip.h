@@ -128,6 +128,8 @@ int jasper_result_lookups(const jasper_result *r, uint64_t *n);
 double jasper_result_seconds(const jasper_result *r);         /* device time of the passes (HIP events) */
 /* how the batch was parallelised: segments walked over all passes, chunks redone unsegmented after a failed speculation */
 int jasper_result_segments(const jasper_result *r, uint64_t *n_segments, uint64_t *n_respeculated);
+/* 1 if the batch had to be repeated with larger internal buffers (results are the same either way) */
+int jasper_result_retried(const jasper_result *r);
 void jasper_result_free(jasper_result *r);
 
 /* kernel timing for bench.py: HIP-event time of the last counting call on this table, and its launch count */

@@ -30,6 +30,7 @@ struct jasper_result {
     uint64_t lookups = 0;
     double seconds = 0;
     uint64_t n_segments = 0, n_respeculated = 0;
+    int retried = 0;                     // the batch was repeated with 8x the room because a bound was exceeded
 };
 
 static_assert(sizeof(jasper_fixrec) == sizeof(FixRec), "public and device record layouts must match");
@@ -272,7 +273,12 @@ static int polish_common(jasper_table *t, int n_chunks, const char *const *seqs,
     jasper_result *R = new jasper_result();
     *out = R;
     PolishOut po;
-    const int rc = run_polish(T, n_chunks, seqs, lens, solid_thre, passes, fix, po, g_err, device_io, device_io);
+    int rc = run_polish(T, n_chunks, seqs, lens, solid_thre, passes, fix, po, g_err, device_io, device_io);
+    if (rc == -2) {                      // a slack / record / scratch bound was too small for this input: once more with 8x the room
+        R->retried = 1;
+        po = PolishOut();
+        rc = run_polish(T, n_chunks, seqs, lens, solid_thre, passes, fix, po, g_err, device_io, device_io, 1);
+    }
     R->seqs.swap(po.seqs);
     R->aux.swap(po.aux);
     R->recs.resize(po.recs.size());
@@ -353,6 +359,7 @@ int jasper_result_segments(const jasper_result *r, uint64_t *n_segments, uint64_
     if (n_respeculated) *n_respeculated = r->n_respeculated;
     return JASPER_OK;
 }
+int jasper_result_retried(const jasper_result *r) { return r ? r->retried : 0; }
 void jasper_result_free(jasper_result *r) {
     if (r && r->owner && r->owner->pending == r) r->owner->pending = nullptr;
     delete r;

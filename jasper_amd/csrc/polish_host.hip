@@ -33,7 +33,12 @@ struct DevBuf {  // a slot of the table's grow-only workspace (not owned) or a t
 }  // namespace
 
 int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *lens, int solid_thre, int passes, int fix,
-               PolishOut &R, std::string &err, bool device_in, bool keep_on_device) {
+               PolishOut &R, std::string &err, bool device_in, bool keep_on_device, int roomy) {
+    // `roomy`: every slack / bound below is a guess about how much a pass can add; the default guesses are generous for
+    // real polishing (edits are ~0.1 % of the text).  If one is exceeded the call fails cleanly with -2 and the caller
+    // repeats it with roomy = 1: 8x the slack (nothing of a failed call is kept, so the repeat is exact).
+    const int64_t RM = roomy ? 8 : 1;
+    const bool tight = !roomy && getenv("JASPER_POLISH_TIGHT") != nullptr;   // tests: make the first attempt run out of room
     const int k = T.k;
     const int64_t W = 4ll * k;        // clean window required left of a sync point
     const int64_t M = 3ll * k;        // text kept right of the next sync point
@@ -66,7 +71,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     size_t text_bytes = 0, pos_items = 0, cand_items = 0, flag_items = 0, seg_text_bound = 0, seg_rec_bound = 0, seg_aux_bound = 0;
     int64_t max_segs = 0;
     for (int c = 0; c < n_chunks; ++c) {
-        cap[c] = len[c] + std::max<int64_t>(4096, len[c] / 8) + 64;
+        cap[c] = len[c] + RM * std::max<int64_t>(4096, len[c] / 8) + 64;
         off_text[c] = text_bytes;  text_bytes += al256((size_t)cap[c]);
         off_pos[c] = pos_items;    pos_items += al256((size_t)cap[c]);
         cand_cap[c] = (uint32_t)std::min<int64_t>(1 << 28, cap[c] / (4 * k) + 16);
@@ -77,9 +82,9 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         const int64_t ms = cap[c] / TMIN + 2;
         max_segs += ms;
         const int64_t tb = cap[c] + ms * (W + M + 64);
-        seg_text_bound += (size_t)(tb + tb / 8 + ms * 1280);
-        seg_rec_bound += (size_t)(2 * tb / k + 16 * ms);
-        seg_aux_bound += (size_t)(2 * tb + 1024 * ms);
+        seg_text_bound += (size_t)(tb + RM * (tb / 8 + ms * 1280));
+        seg_rec_bound += (size_t)(RM * (2 * tb / k + 16 * ms));
+        seg_aux_bound += (size_t)(RM * (2 * tb + 1024 * ms));
     }
     DevBuf b_textA, b_textB, b_cnt, b_valid, b_cls, b_clsB, b_flags, b_segedit, b_cells, b_arrive, b_cand, b_ccount, b_ptrA, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks, b_scan, b_ticket;
     int ws_next = 0;
@@ -99,9 +104,10 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         return -2;
     ScratchPool pool;
     pool.nslots = 256;
-    pool.node_cap = 1u << 18;
-    pool.front_cap = 20480;
-    pool.patch_cap = 1u << 16;
+    pool.node_cap = (uint32_t)(RM << 18);
+    pool.front_cap = 20480;            // (the search gives up beyond 5000 live paths, src/jasper.py:543-546; each adds <= 3 siblings per level)
+    pool.patch_cap = (uint32_t)(RM << 16);
+    if (roomy) pool.nslots = 64;
     pool.off_front = al256((size_t)pool.node_cap * 4);
     pool.off_patch = pool.off_front + al256((size_t)pool.front_cap * 80);
     pool.stride = pool.off_patch + al256(pool.patch_cap);
@@ -248,13 +254,13 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                     const int64_t seg_hi = j == m ? len[c] : std::min<int64_t>(len[c], sync[j] + M);
                     S.len0 = seg_hi - S.seg_lo;
                     S.len = S.len0;
-                    S.cap = S.len0 + std::max<int64_t>(1024, S.len0 / 8);
+                    S.cap = S.len0 + (tight ? 2 : RM * std::max<int64_t>(1024, S.len0 / 8));
                     S.gs = 0;
                     S.glen = S.cap - S.len0;
                     S.cls = (len[c] - k + 1 > 0) ? clsIn + off_pos[c] : nullptr;
                     S.cls_n = std::max<int64_t>(0, len[c] - k + 1);
-                    S.rec_cap = (uint32_t)std::min<int64_t>(0x7fffffff, 2 * S.len0 / k + 16);
-                    S.aux_cap = (uint32_t)std::min<int64_t>(0x7fffffff, 2 * S.len0 + 1024);
+                    S.rec_cap = (uint32_t)std::min<int64_t>(0x7fffffff, RM * (2 * S.len0 / k + 16));
+                    S.aux_cap = (uint32_t)std::min<int64_t>(0x7fffffff, RM * (2 * S.len0 + 1024));
                     S.buf = b_segtext.as<uint8_t>() + tpos;            tpos += al256((size_t)S.cap);
                     S.recs = b_segrec.as<FixRec>() + rpos;
                     S.edits = b_segedit.as<EditRec>() + rpos;          // one edit list entry per possible record

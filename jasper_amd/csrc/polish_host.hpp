@@ -23,6 +23,6 @@ struct PolishOut {
 // seqs[c] are host pointers, or device pointers when `device_in`.  With `keep_on_device` the polished text is not copied
 // to the host: R.d_seqs/d_lens point into the table's workspace, valid until the next run_polish on the same table.
 int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *lens, int solid_thre, int passes, int fix,
-               PolishOut &R, std::string &err, bool device_in = false, bool keep_on_device = false);
+               PolishOut &R, std::string &err, bool device_in = false, bool keep_on_device = false, int roomy = 0);
 
 }  // namespace jk

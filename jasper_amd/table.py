@@ -30,6 +30,7 @@ class PolishResult:
         self.seconds = seconds
         self.segments = 0
         self.respeculated = 0
+        self.retried = False
 
     def __del__(self):
         try:
@@ -316,6 +317,7 @@ class KmerTable:
             pr = PolishResult(self._L, res, n, want_str, raw, aux, tuple(qv), nl.value, secs)
             res = None   # owned by the PolishResult from here on
             pr.segments, pr.respeculated = nseg.value, nredo.value
+            pr.retried = bool(self._L.jasper_result_retried(pr._h))
             return pr
         finally:
             if res:

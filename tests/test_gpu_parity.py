@@ -475,3 +475,25 @@ def test_polish_many_small_chunks_vs_oracle(KT, O):
         assert polisher.fix_csv_text(rows[it]) == "Contig Base_coord Original Mutation\r\n" + rows_o[it]
     assert sum(len(r) for r in rows) > 50
     t.close()
+
+
+def test_polish_retries_with_more_room_when_a_bound_is_exceeded(KT, O):
+    """slack for growing text, record and scratch bounds are guesses; a call that exceeds one fails cleanly inside the
+    library and is repeated with 8x the room -- the caller sees the same result as always"""
+    from jasper_amd import polisher
+    k = 25
+    genome, reads, asm = workload(29, 200_000, k, asm_err=3e-3)
+    recs = synth.chunk_records("c", len(asm), 30_000)
+    names = [r[0] for r in recs]
+    seqs = [asm[a:b] for _, a, b in recs]
+    t = KT(k, min_slots=1 << 20)
+    t.count_bases(reads)
+    want = polisher.polish_batch(t, names, seqs, 3, 2)
+    os.environ["JASPER_POLISH_TIGHT"] = "1"        # gap buffers with 2 bytes of slack: any net insertion of 3+ bases overflows
+    try:
+        got = polisher.polish_batch(t, names, seqs, 3, 2)
+    finally:
+        del os.environ["JASPER_POLISH_TIGHT"]
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+    assert got[3].retried and not want[3].retried
+    t.close()
