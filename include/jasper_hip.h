@@ -124,6 +124,8 @@ int jasper_result_seq_device(const jasper_result *r, int chunk, const void **d_s
 int jasper_result_records(const jasper_result *r, const jasper_fixrec **recs, uint64_t *n);
 int jasper_result_aux(const jasper_result *r, int chunk, const char **aux, uint64_t *n);
 int jasper_result_qv(const jasper_result *r, int64_t out4[4]); /* bad0,total0,badP,totalP  (src/jasper.py:107-111) */
+/* the same four counters for one chunk record (a caller that polishes several batch files in one call splits them again) */
+int jasper_result_qv_chunk(const jasper_result *r, int chunk, int64_t out4[4]);
 int jasper_result_lookups(const jasper_result *r, uint64_t *n);
 double jasper_result_seconds(const jasper_result *r);         /* device time of the passes (HIP events) */
 /* how the batch was parallelised: segments walked over all passes, chunks redone unsegmented after a failed speculation */

@@ -62,6 +62,7 @@ SYMBOLS = {
     "jasper_result_records": (C.c_int, [_P, C.POINTER(C.POINTER(FixRec)), C.POINTER(C.c_uint64)]),
     "jasper_result_aux": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "jasper_result_qv": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "jasper_result_qv_chunk": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
     "jasper_result_lookups": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "jasper_result_seconds": (C.c_double, [_P]),
     "jasper_result_segments": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

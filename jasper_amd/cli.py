@@ -375,9 +375,22 @@ def run(argv):
         thresh = int(open("threshold.txt").read().split()[0])
         log("Lower threshold for unreliable kmers is %d" % thresh)
         batch_files = sorted(glob.glob("%s.batch.*.fa" % glob.escape(qfn)))   # `ls` order
+        # the reference starts one jasper.py process per batch file (:207-212); chunk records are independent, so all
+        # files go through the GPU in groups (<= ~1 Gbase of text per call) and leave the same per-file artefacts
+        group, group_bytes = [], 0
+        def flush_group():
+            if group:
+                polisher.main_many(group, kmer, True, True, table, thresh, passes)
+                for bf in group:
+                    os.replace("_iter%d_%s.fixed.fa.tmp" % (last_it, bf), "_iter%d_%s.fixed.fa" % (last_it, bf))
+                del group[:]
         for bf in batch_files:
-            polisher.main(None, bf, kmer, True, True, bf + ".fix.csv", bf + ".fixed.fa.tmp", table, thresh, passes)
-            os.replace("_iter%d_%s.fixed.fa.tmp" % (last_it, bf), "_iter%d_%s.fixed.fa" % (last_it, bf))
+            group.append(bf)
+            group_bytes += os.path.getsize(bf)
+            if group_bytes > (1 << 30):
+                flush_group()
+                group_bytes = 0
+        flush_group()
         if os.path.exists("jasper.join.success"):
             os.remove("jasper.join.success")
         open("jasper.correct.success", "w").close()

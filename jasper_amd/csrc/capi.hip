@@ -27,6 +27,7 @@ struct jasper_result {
     std::vector<jasper_fixrec> recs;
     std::vector<std::string> aux;
     int64_t qv[4] = {0, 0, 0, 0};
+    std::vector<int64_t> qv_chunk;
     uint64_t lookups = 0;
     double seconds = 0;
     uint64_t n_segments = 0, n_respeculated = 0;
@@ -284,6 +285,7 @@ static int polish_common(jasper_table *t, int n_chunks, const char *const *seqs,
     R->recs.resize(po.recs.size());
     if (!po.recs.empty()) memcpy(R->recs.data(), po.recs.data(), po.recs.size() * sizeof(FixRec));
     for (int i = 0; i < 4; ++i) R->qv[i] = po.qv[i];
+    R->qv_chunk.swap(po.qv_chunk);
     R->lookups = po.lookups;
     R->seconds = po.seconds;
     R->n_segments = po.n_segments;
@@ -357,6 +359,11 @@ double jasper_result_seconds(const jasper_result *r) { return r->seconds; }
 int jasper_result_segments(const jasper_result *r, uint64_t *n_segments, uint64_t *n_respeculated) {
     if (n_segments) *n_segments = r->n_segments;
     if (n_respeculated) *n_respeculated = r->n_respeculated;
+    return JASPER_OK;
+}
+int jasper_result_qv_chunk(const jasper_result *r, int chunk, int64_t out4[4]) {
+    if (chunk < 0 || (size_t)(4 * chunk + 3) >= r->qv_chunk.size()) { g_err = "chunk out of range"; return JASPER_ERR; }
+    for (int i = 0; i < 4; ++i) out4[i] = r->qv_chunk[4 * (size_t)chunk + i];
     return JASPER_OK;
 }
 int jasper_result_retried(const jasper_result *r) { return r ? r->retried : 0; }

@@ -53,6 +53,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     R.aux.assign(n_chunks, std::string());
     R.recs.clear();
     R.qv[0] = R.qv[1] = R.qv[2] = R.qv[3] = 0;
+    R.qv_chunk.assign((size_t)4 * n_chunks, 0);
     R.lookups = 0;
     R.seconds = 0;
     R.n_segments = 0;
@@ -386,13 +387,13 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             nrec_pass += S.nrec;
             naux_pass += S.naux;
             R.lookups += S.lookups;
-            if (pass == 0) R.qv[0] += S.wrong;
-            if (pass == passes) R.qv[2] += S.wrong;
+            if (pass == 0) { R.qv[0] += S.wrong; R.qv_chunk[4 * (size_t)c + 0] += S.wrong; }
+            if (pass == passes) { R.qv[2] += S.wrong; R.qv_chunk[4 * (size_t)c + 2] += S.wrong; }
         }
         if (rc) break;
         for (int c = 0; c < n_chunks; ++c) {
-            if (pass == 0) R.qv[1] += len[c] - k + 1;                                           // src/jasper.py:51,107-111
-            if (pass == passes) R.qv[3] += len[c] - k + 1;
+            if (pass == 0) { R.qv[1] += len[c] - k + 1; R.qv_chunk[4 * (size_t)c + 1] += len[c] - k + 1; }   // src/jasper.py:51,107-111
+            if (pass == passes) { R.qv[3] += len[c] - k + 1; R.qv_chunk[4 * (size_t)c + 3] += len[c] - k + 1; }
             if (newlen[c] > cap[c]) { err = "polish: chunk grew beyond its slack"; rc = -2; }
         }
         if (rc) break;

@@ -13,6 +13,7 @@ struct PolishOut {
     std::vector<FixRec> recs;        // ordered by chunk, pass, emission; index in chunk coordinates
     std::vector<std::string> aux;    // per chunk: bytes referenced by its 'x' records
     int64_t qv[4];                   // bad0, total0, badP, totalP   (src/jasper.py:107-111)
+    std::vector<int64_t> qv_chunk;   // the same four per chunk record (4 * n_chunks): callers that group chunks into files
     uint64_t lookups;
     double seconds;                  // device time of all passes (HIP events on the table's stream)
     uint64_t n_segments;             // segments walked (all passes)

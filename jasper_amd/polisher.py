@@ -178,10 +178,71 @@ def main(contigs, query_path, k, test, fix, fout, fixedout, db, thre, num_iter):
             with open(out_path, 'w') as of:                                 # :120-128
                 for seqname, seq in zip(names, fixed):
                     of.write(">{}\n".format(seqname))
-                    for l in split_output(seq, 60):
-                        of.write(l + "\n")
+                    lines = split_output(seq, 60)
+                    if lines:
+                        of.write("\n".join(lines) + "\n")   # (the reference writes them one by one: same bytes)
             return out_path
         return None
+    except SystemExit:
+        raise
+    except BaseException:
+        exception_type, exception_object, exception_traceback = sys.exc_info()
+        print(exception_traceback.tb_lineno)
+        print(sys.exc_info())
+        sys.exit(1)
+
+
+def main_many(query_paths, k, test, fix, db, thre, num_iter):
+    """what `xargs -P $THREADS jasper.py ...` (src/jasper.sh:207-212) leaves behind for a LIST of batch files, computed in
+    ONE GPU call (chunk records are independent): per file the same artefacts as main() -- `_iter{i}_<file>.fix.csv`,
+    `_iter{P-1}_<file>.fixed.fa.tmp`, one line per file in {0,P}qValCalcHelper.csv, in the order of `query_paths`."""
+    try:
+        if not isinstance(db, KmerTable):
+            raise TypeError("db must be a jasper_amd.KmerTable resident in HBM")
+        per_file = []
+        names, seqs = [], []
+        for qp in query_paths:
+            d = parse_fasta(qp)
+            per_file.append((qp, len(names), len(d)))
+            names.extend(d.keys())
+            seqs.extend(d.values())
+        do_fix = bool(fix)
+        fixed, _, _, res = polish_batch(db, names, seqs, thre, num_iter, fix=do_fix)
+        rows_by_chunk = {}
+        if do_fix:
+            for r in res.records:
+                rows_by_chunk.setdefault((r["pass_"], r["chunk"]), []).append((r["seqno"], rows_from_record(names[r["chunk"]], r)))
+        outs = []
+        for qp, first, n in per_file:
+            if test:                                                            # :107-111, one line per process
+                q = [0, 0, 0, 0]
+                for c in range(first, first + n):
+                    qc = res.qv_chunk(c)
+                    q = [a + b for a, b in zip(q, qc)]
+                with open("0qValCalcHelper.csv", 'a') as f:
+                    f.write("{} {}\n".format(q[0], q[1]))
+                if num_iter != 0:
+                    with open(str(num_iter) + "qValCalcHelper.csv", 'a') as f:
+                        f.write("{} {}\n".format(q[2], q[3]))
+            if do_fix:
+                fo = os.path.split(qp + ".fix.csv")
+                for ite in range(num_iter):
+                    flat = []
+                    for c in range(first, first + n):
+                        for _, rr in sorted(rows_by_chunk.get((ite, c), []), key=lambda x: x[0]):
+                            flat.extend(rr)
+                    with open(fo[0] + "_iter" + str(ite) + "_" + fo[1], 'w', newline='') as csvf:
+                        csvf.write(fix_csv_text(flat))
+                ff = os.path.split(qp + ".fixed.fa.tmp")
+                out_path = ff[0] + "_iter" + str(num_iter - 1) + "_" + ff[1]
+                with open(out_path, 'w') as of:
+                    for seqname, seq in zip(names[first:first + n], fixed[first:first + n]):
+                        of.write(">{}\n".format(seqname))
+                        lines = split_output(seq, 60)
+                        if lines:
+                            of.write("\n".join(lines) + "\n")
+                outs.append(out_path)
+        return outs
     except SystemExit:
         raise
     except BaseException:

@@ -53,6 +53,12 @@ class PolishResult:
         check(self._L.jasper_result_seq_len(self._h, i, C.byref(ln)))
         return ln.value
 
+    def qv_chunk(self, i):
+        """(bad0, total0, badP, totalP) of chunk record i alone"""
+        q = (C.c_int64 * 4)()
+        check(self._L.jasper_result_qv_chunk(self._h, i, q))
+        return tuple(q)
+
     def seq_device(self, i):
         """(device pointer, length) of polished chunk i while the text is still in HBM (polish_batch_device results, until
         the next polish call on the same table or the first host access)"""
