@@ -169,6 +169,27 @@ struct Walker {
         return clamp32(table_get(T, mix(canonical(m, k), T.B)));
     }
 
+    // the same for a string given by a function q -> byte q (a trial string that is never materialised)
+    template <typename F>
+    __device__ __forceinline__ uint32_t cnt_fn(int n, F get) const {
+        const int lim = n < k ? n : k;
+        uint32_t w[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const int q = 4 * x + y;
+                const uint32_t b = q < lim ? (uint32_t)get(q) : 0u;
+                v |= b << (8 * y);
+            }
+            w[x] = v;
+        }
+        int nv;
+        const u128 m = encode_words(w, lim, nv);
+        return clamp32(table_get(T, mix(canonical(m, k), T.B)));
+    }
+
     // ---------------- gap buffer ----------------
     __device__ void move_gap(int64_t to) {
         if (to == gs) return;
@@ -436,6 +457,46 @@ struct Walker {
             if (new_bad == 0) { ridx = k - 1; rbase = sb; rrep = deleted; outlen = n; return true; }
             if (new_bad >= current_bad) break;
             current_bad = new_bad;
+        }
+        // trials "tbf without its character i", i = L-k .. L-2, first one whose check_sequence samples are all solid (:507-520).
+        // The trials are independent: several are evaluated per round, (trial, sample) per lane, straight from tbf; the
+        // winner -- the FIRST passing i, as in the sequential loop -- is then written out.  (This loop was the slowest
+        // thing a segment could meet: up to k-1 rounds of dependent lookups.)
+        {
+            const int n1 = L - 1;
+            const int nmid = (n1 - k > step) ? (n1 - k - step + step - 1) / step : 0;     // len(range(step, n1-k, step))
+            const int jobs = 2 + nmid;
+            const int i_first = L - k > 0 ? L - k : 0;
+            if (jobs <= 64) {
+                const int tpr = 64 / jobs;                                           // trials per round
+                for (int i0 = i_first; i0 < L - 1; i0 += tpr) {
+                    const int ti = lane / jobs, j = lane - ti * jobs, i = i0 + ti;
+                    const bool active = ti < tpr && i < L - 1;
+                    bool bad = false;
+                    if (active) {
+                        int p, len;
+                        if (j == 0) { p = 0; len = n1 < k ? n1 : k; }
+                        else if (j == 1) { p = n1 > k ? n1 - k : 0; len = n1 - p; }
+                        else { p = step * (j - 1); len = k; }
+                        const uint32_t c = cnt_fn(len, [&](int q) { const int sidx = p + q; return s_tbf[sidx < i ? sidx : sidx + 1]; });
+                        bad = c < thr;
+                    }
+                    const uint64_t mb = __ballot(active && bad);
+                    for (int tt = 0; tt < tpr && i0 + tt < L - 1; ++tt) {
+                        const uint64_t lanes = (jobs == 64 ? ~0ull : ((1ull << jobs) - 1ull)) << (tt * jobs);
+                        nlook += (uint64_t)jobs;
+                        if ((mb & lanes) == 0ull) {
+                            const int iw = i0 + tt;
+                            cp_mem(s_t1, s_tbf, iw);
+                            cp_mem(s_t1 + iw, s_tbf + iw + 1, L - iw - 1);
+                            sync();
+                            ridx = iw; rbase = s_tbf[iw]; rrep = 1; outlen = L - 1;
+                            return true;
+                        }
+                    }
+                }
+                return false;
+            }
         }
         for (int i = L - k; i < L - 1; ++i) {
             if (i < 0) continue;

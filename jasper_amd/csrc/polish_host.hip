@@ -336,11 +336,11 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
 
         if (getenv("JASPER_POLISH_DEBUG")) {
             uint64_t mx = 0, sum = 0, mxl = 0; int64_t mxlen = 0; size_t nrecs = 0, mxrec = 0;
-            uint64_t tks[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            uint64_t tks[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mxtk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (const SegDev &S : segs) {
                 sum += S.ticks; nrecs += S.nrec;
                 for (int q = 0; q < 12; ++q) tks[q] += S.tk[q];
-                if (S.ticks > mx) { mx = S.ticks; mxl = S.lookups; mxlen = S.len0; mxrec = S.nrec; }
+                if (S.ticks > mx) { mx = S.ticks; mxl = S.lookups; mxlen = S.len0; mxrec = S.nrec; for (int q = 0; q < 12; ++q) mxtk[q] = S.tk[q]; }
             }
             fprintf(stderr, "[polish] pass %d: %zu segments, %zu records, walk ticks(10ns): mean %.0f max %llu (that segment: len %lld, %llu lookups, %zu records)\n",
                     pass, segs.size(), nrecs, segs.empty() ? 0.0 : (double)sum / segs.size(), (unsigned long long)mx, (long long)mxlen,
@@ -350,6 +350,10 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             fprintf(stderr, "[polish]   inside choose fix: k_case_sub %.1f%%, insert %.1f%%, del %.1f%%, diploid %.1f%%, same_base_del %.1f%%, same_base_ins %.1f%%, path search %.1f%%\n",
                     100.0 * tks[4] / (sum + 1), 100.0 * tks[5] / (sum + 1), 100.0 * tks[6] / (sum + 1), 100.0 * tks[7] / (sum + 1),
                     100.0 * tks[8] / (sum + 1), 100.0 * tks[9] / (sum + 1), 100.0 * tks[10] / (sum + 1));
+            fprintf(stderr, "[polish]   slowest segment (10ns ticks): skip %llu, find run %llu, choose fix %llu [sub %llu ins %llu del %llu diploid %llu sb_del %llu sb_ins %llu path %llu], splice %llu\n",
+                    (unsigned long long)mxtk[0], (unsigned long long)mxtk[1], (unsigned long long)mxtk[2], (unsigned long long)mxtk[4], (unsigned long long)mxtk[5],
+                    (unsigned long long)mxtk[6], (unsigned long long)mxtk[7], (unsigned long long)mxtk[8], (unsigned long long)mxtk[9], (unsigned long long)mxtk[10],
+                    (unsigned long long)mxtk[3]);
             // histogram of segment times in ms buckets
             int hb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (const SegDev &S : segs) { double ms = S.ticks * 1e-5; int b = ms < 0.1 ? 0 : ms < 0.3 ? 1 : ms < 1 ? 2 : ms < 2 ? 3 : ms < 4 ? 4 : ms < 8 ? 5 : ms < 16 ? 6 : 7; hb[b]++; }
