@@ -1043,9 +1043,12 @@ __global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, 
         // (2) where does the walk arrive?  Blocks are dispatched in index order, so the predecessor is resident or done.
         long long a = 0;
         if (lane == 0) {
-            for (;;) {
+            // (bounded: a predecessor that never publishes -- which no code path allows -- must not hang the GPU; after
+            // ~2^27 polls, seconds, the segment gives up and the host redoes the chunk unsegmented)
+            for (uint32_t spins = 0;; ++spins) {
                 a = __hip_atomic_load(C->arrive - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (a != ARRIVE_PENDING) break;
+                if (spins > (1u << 27)) { a = ARRIVE_FAIL; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
         }
