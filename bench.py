@@ -234,8 +234,8 @@ def main():
         "unit": "Mbp/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "configs[1] chr21-sized: %.0f Mb synthetic genome x %d GPU(s) + %dx %d-bp reads, k=%d, %d passes, "
-                               "chunked as jasper.sh -t %d (BATCH_SIZE %d)" % (a.genome_mb, world, COVERAGE, READ_LEN, K, PASSES,
+        "config": {"workload": "%s: %.0f Mb synthetic genome x %d GPU(s) + %dx %d-bp reads, k=%d, %d passes, "
+                               "chunked as jasper.sh -t %d (BATCH_SIZE %d)" % ("configs[1] chr21-sized" if a.genome_mb == 47.0 else "custom size", a.genome_mb, world, COVERAGE, READ_LEN, K, PASSES,
                                                                                THREADS_FOR_BATCH_RULE, bs),
                    "chunks_per_gpu": len(seqs), "reads_per_gpu": nreads, "table_slots": T["slots"], "distinct_kmers": T["distinct"],
                    "threshold": T["thr"], "parallelism": "read shards + chunk shards, table merge over RCCL" if world > 1 else "single GPU"},
