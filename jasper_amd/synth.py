@@ -157,3 +157,54 @@ def torch_reads_stream(gen, genome, nreads, read_len=150, err=0.003, block=1 << 
         r = torch.where(flip[:, None], rc, r)
         out[a:a + m, :read_len] = r
     return out.reshape(-1)
+
+
+def write_cli_inputs(d, genome_mb=47.0, seed=2, coverage=30, read_len=150, err=0.003):
+    """reads.fq (4-line FASTQ, header "@r", quality 'I') + asm.fa (one contig, 60 columns) in directory d; byte-identical
+    for the same arguments wherever numpy is the same -- the build container runs the REAL reference on them
+    (tests/golden/ref_fullsize.py), the GPU box runs the drop-in, and the outputs are compared by digest."""
+    import os
+    rng = np.random.default_rng(seed)
+    genome = make_genome(rng, int(genome_mb * 1e6))
+    reads = make_reads_stream(rng, genome, coverage, read_len, err).reshape(-1, read_len + 1)[:, :read_len]
+    n = reads.shape[0]
+    rec = np.empty((n, 2 * read_len + 7), dtype=np.uint8)
+    rec[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+    rec[:, 3:3 + read_len] = reads
+    rec[:, 3 + read_len:6 + read_len] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, 6 + read_len:6 + 2 * read_len] = ord("I")
+    rec[:, 6 + 2 * read_len] = ord("\n")
+    rec.tofile(os.path.join(d, "reads.fq"))
+    asm = make_assembly(rng, genome)
+    a = asm.tobytes()
+    with open(os.path.join(d, "asm.fa"), "wb") as f:
+        f.write(b">chr1\n")
+        f.write(b"\n".join(a[i:i + 60] for i in range(0, len(a), 60)))
+        f.write(b"\n")
+    return n, len(asm)
+
+
+def output_digests(d, asm_name="asm.fa", k=37):
+    """what identifies a run's results: sha256 of the polished FASTA (records sorted by name: the reference's contig order
+    is perl-hash order), of fixes.csv, of the histogram file, and the threshold"""
+    import hashlib, os
+    recs, name, seq = {}, None, []
+    for ln in open(os.path.join(d, asm_name + ".polished.fasta")):
+        ln = ln.rstrip("\n")
+        if ln.startswith(">"):
+            if name is not None:
+                recs[name] = "".join(seq)
+            name, seq = ln, []
+        else:
+            seq.append(ln)
+    if name is not None:
+        recs[name] = "".join(seq)
+    h = hashlib.sha256()
+    for nm in sorted(recs):
+        h.update(nm.encode() + b"\n" + recs[nm].encode() + b"\n")
+    out = {"polished_fasta_sha256": h.hexdigest(), "polished_bases": sum(len(v) for v in recs.values())}
+    out["fixes_csv_sha256"] = hashlib.sha256(open(os.path.join(d, asm_name + ".fixes.csv"), "rb").read()).hexdigest()
+    out["fixes_csv_lines"] = sum(1 for _ in open(os.path.join(d, asm_name + ".fixes.csv"), "rb"))
+    out["jfhisto_sha256"] = hashlib.sha256(open(os.path.join(d, "jfhisto%d.csv" % k), "rb").read()).hexdigest()
+    out["threshold"] = open(os.path.join(d, "threshold.txt")).read()
+    return out

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Build container only: the REAL reference (bash src/jasper.sh + Jellyfish 2.3.0 + unmodified jasper.py, 8 vCPU) on the
+full-size cfg-2 synthetic input (47 Mb genome, 30x 150-bp reads, k=37, 2 passes) -> tests/golden/fullsize_cfg2.json:
+wall time per stage and digests of its outputs.  tests/test_gpu_cli_fullsize.py regenerates the same input on the GPU
+box (jasper_amd.synth.write_cli_inputs is deterministic), runs `python -m jasper_amd.cli` and compares the digests.
+
+usage: python3 tests/golden/ref_fullsize.py [genome_mb] [threads]"""
+import json, os, shutil, subprocess, sys, tempfile, time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import make_golden as G
+from jasper_amd import synth
+
+gmb = float(sys.argv[1]) if len(sys.argv) > 1 else 47.0
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+work = tempfile.mkdtemp(prefix="ref_full_", dir="/tmp")
+run_dir = os.path.join(work, "run")
+os.makedirs(run_dir)
+t0 = time.time()
+nreads, asm_len = synth.write_cli_inputs(run_dir, gmb, 2)
+print("inputs: %d reads, %d assembly bases, %.1f s" % (nreads, asm_len, time.time() - t0), flush=True)
+pp = os.path.join(work, "pp")
+os.makedirs(os.path.join(pp, "Bio"))
+for fn in ("dna_jellyfish.py", "_dna_jellyfish.so"):
+    shutil.copy(os.path.join(G.JF_PY, fn), pp)
+shutil.copy(os.path.join(G.REF, "jellyfish.py"), pp)
+open(os.path.join(pp, "Bio", "__init__.py"), "w").write("")
+stub = G.DRIVER.split("# --- stand-in")[1].split("Bio = types.ModuleType")[0]
+open(os.path.join(pp, "Bio", "pairwise2.py"), "w").write(
+    "# stand-in" + stub + "\nimport types\nalign = types.SimpleNamespace(globalms=_globalms)\ndef format_alignment(*a, **k): return ''\n")
+bindir = os.path.join(work, "bin")
+os.makedirs(bindir)
+for fn in ("jasper.sh", "jasper.py", "jellyfish.py"):
+    shutil.copy(os.path.join(G.REF, fn), bindir)
+    os.chmod(os.path.join(bindir, fn), 0o755)
+env = dict(os.environ, PATH=bindir + ":" + os.path.dirname(G.JF_BIN) + ":" + os.environ["PATH"], PYTHONPATH=pp,
+           LD_LIBRARY_PATH=os.path.join(os.path.dirname(os.path.dirname(G.JF_BIN)), "lib"))
+t1 = time.time()
+p = subprocess.run(["bash", os.path.join(bindir, "jasper.sh"), "-r", "reads.fq", "-a", "asm.fa", "-k", "37", "-t", str(threads), "-p", "2"],
+                   cwd=run_dir, env=env, capture_output=True, text=True)
+wall = time.time() - t1
+print(p.stdout[-3000:])
+print(p.stderr[-1500:])
+print("exit", p.returncode, "wall %.1f s" % wall, flush=True)
+out = dict(genome_mb=gmb, threads=threads, k=37, passes=2, seed=2, reads=nreads, assembly_bases=asm_len, exit=p.returncode,
+           reference_wall_seconds=round(wall, 1), host="build container, %d vCPU" % (os.cpu_count() or 0),
+           stdout=[G.re_sub_date(l) for l in p.stdout.splitlines()])
+if p.returncode == 0:
+    out.update(synth.output_digests(run_dir))
+name = "fullsize_cfg2.json" if gmb == 47.0 else "fullsize_%gmb.json" % gmb
+json.dump(out, open(os.path.join(HERE, name), "w"), indent=1, sort_keys=True)
+print(json.dumps({k: v for k, v in out.items() if k != "stdout"}, indent=1))
+shutil.rmtree(work)

@@ -1,0 +1,39 @@
+"""GPU: the drop-in at BASELINE configs[1] size against the REAL reference.
+
+tests/golden/fullsize_cfg2.json holds what the unmodified reference (bash src/jasper.sh, Jellyfish 2.3.0, jasper.py; 107 s on
+the 8 vCPU of the build container) produced for the 47 Mb / 30x / k=37 / 2-pass synthetic input of
+jasper_amd.synth.write_cli_inputs(seed 2): digests of the polished FASTA (records sorted by name), of fixes.csv, of the
+histogram file, and the threshold.  The same input is regenerated here (deterministic numpy), `python -m jasper_amd.cli`
+runs with the same flags, and every digest must be identical."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cli_fullsize_cfg2_matches_real_reference(hip, tmp_path):
+    from jasper_amd import synth
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_cfg2.json")))
+    d = str(tmp_path)
+    nreads, asm_len = synth.write_cli_inputs(d, ref["genome_mb"], ref["seed"])
+    assert nreads == ref["reads"] and asm_len == ref["assembly_bases"]
+    env = dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_NO_JF="1")
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-r", "reads.fq", "-a", "asm.fa", "-k", str(ref["k"]), "-t", str(ref["threads"]),
+                        "-p", str(ref["passes"])], cwd=d, env=env, capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - t0
+    assert p.returncode == 0, p.stdout + p.stderr
+    got = synth.output_digests(d)
+    for key in ("threshold", "jfhisto_sha256", "polished_bases", "polished_fasta_sha256", "fixes_csv_lines", "fixes_csv_sha256"):
+        assert got[key] == ref[key], (key, got[key], ref[key])
+    # same log lines (dates and Q digits aside: bc is missing in the build container, so the reference printed "Inf")
+    import re
+    strip = lambda ls: [re.sub(r"Q value = .*", "Q value =", re.sub(r"^\[[^\]]*\]", "[DATE]", ln)) for ln in ls]
+    assert strip(p.stdout.splitlines()) == strip(ref["stdout"])
+    print("drop-in wall %.1f s vs reference %.1f s on %s" % (wall, ref["reference_wall_seconds"], ref["host"]))
