@@ -4,7 +4,8 @@ full-size cfg-2 synthetic input (47 Mb genome, 30x 150-bp reads, k=37, 2 passes)
 wall time per stage and digests of its outputs.  tests/test_gpu_cli_fullsize.py regenerates the same input on the GPU
 box (jasper_amd.synth.write_cli_inputs is deterministic), runs `python -m jasper_amd.cli` and compares the digests.
 
-usage: python3 tests/golden/ref_fullsize.py [genome_mb] [threads]"""
+usage: python3 tests/golden/ref_fullsize.py [genome_mb] [threads] [k] [passes] [seed] [name]
+       (defaults = cfg 2: 47 8 37 2 2 fullsize_cfg2;   cfg 1 = 4.6 8 25 1 1 fullsize_cfg1)"""
 import json, os, shutil, subprocess, sys, tempfile, time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -16,11 +17,15 @@ from jasper_amd import synth
 
 gmb = float(sys.argv[1]) if len(sys.argv) > 1 else 47.0
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 37
+P = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+seed = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+name = (sys.argv[6] if len(sys.argv) > 6 else "fullsize_cfg2") + ".json"
 work = tempfile.mkdtemp(prefix="ref_full_", dir="/tmp")
 run_dir = os.path.join(work, "run")
 os.makedirs(run_dir)
 t0 = time.time()
-nreads, asm_len = synth.write_cli_inputs(run_dir, gmb, 2)
+nreads, asm_len = synth.write_cli_inputs(run_dir, gmb, seed)
 print("inputs: %d reads, %d assembly bases, %.1f s" % (nreads, asm_len, time.time() - t0), flush=True)
 pp = os.path.join(work, "pp")
 os.makedirs(os.path.join(pp, "Bio"))
@@ -39,18 +44,17 @@ for fn in ("jasper.sh", "jasper.py", "jellyfish.py"):
 env = dict(os.environ, PATH=bindir + ":" + os.path.dirname(G.JF_BIN) + ":" + os.environ["PATH"], PYTHONPATH=pp,
            LD_LIBRARY_PATH=os.path.join(os.path.dirname(os.path.dirname(G.JF_BIN)), "lib"))
 t1 = time.time()
-p = subprocess.run(["bash", os.path.join(bindir, "jasper.sh"), "-r", "reads.fq", "-a", "asm.fa", "-k", "37", "-t", str(threads), "-p", "2"],
+p = subprocess.run(["bash", os.path.join(bindir, "jasper.sh"), "-r", "reads.fq", "-a", "asm.fa", "-k", str(K), "-t", str(threads), "-p", str(P)],
                    cwd=run_dir, env=env, capture_output=True, text=True)
 wall = time.time() - t1
 print(p.stdout[-3000:])
 print(p.stderr[-1500:])
 print("exit", p.returncode, "wall %.1f s" % wall, flush=True)
-out = dict(genome_mb=gmb, threads=threads, k=37, passes=2, seed=2, reads=nreads, assembly_bases=asm_len, exit=p.returncode,
+out = dict(genome_mb=gmb, threads=threads, k=K, passes=P, seed=seed, reads=nreads, assembly_bases=asm_len, exit=p.returncode,
            reference_wall_seconds=round(wall, 1), host="build container, %d vCPU" % (os.cpu_count() or 0),
            stdout=[G.re_sub_date(l) for l in p.stdout.splitlines()])
 if p.returncode == 0:
-    out.update(synth.output_digests(run_dir))
-name = "fullsize_cfg2.json" if gmb == 47.0 else "fullsize_%gmb.json" % gmb
+    out.update(synth.output_digests(run_dir, k=K))
 json.dump(out, open(os.path.join(HERE, name), "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v for k, v in out.items() if k != "stdout"}, indent=1))
 shutil.rmtree(work)

@@ -17,9 +17,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cli_fullsize_cfg2_matches_real_reference(hip, tmp_path):
+@pytest.mark.parametrize("name", ["fullsize_cfg1", "fullsize_cfg2"])
+def test_cli_fullsize_matches_real_reference(hip, tmp_path, name):
+    """cfg1 = BASELINE configs[0] (4.6 Mb, k=25, 1 pass: the reference's own CPU-runnable case), cfg2 = configs[1]"""
     from jasper_amd import synth
-    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_cfg2.json")))
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", name + ".json")))
     d = str(tmp_path)
     nreads, asm_len = synth.write_cli_inputs(d, ref["genome_mb"], ref["seed"])
     assert nreads == ref["reads"] and asm_len == ref["assembly_bases"]
@@ -29,7 +31,7 @@ def test_cli_fullsize_cfg2_matches_real_reference(hip, tmp_path):
                         "-p", str(ref["passes"])], cwd=d, env=env, capture_output=True, text=True, timeout=900)
     wall = time.perf_counter() - t0
     assert p.returncode == 0, p.stdout + p.stderr
-    got = synth.output_digests(d)
+    got = synth.output_digests(d, k=ref["k"])
     for key in ("threshold", "jfhisto_sha256", "polished_bases", "polished_fasta_sha256", "fixes_csv_lines", "fixes_csv_sha256"):
         assert got[key] == ref[key], (key, got[key], ref[key])
     # same log lines (dates and Q digits aside: bc is missing in the build container, so the reference printed "Inf")
