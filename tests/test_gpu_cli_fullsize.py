@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", ["fullsize_cfg1", "fullsize_cfg2"])
+# the 140 Mb case (11 GB of FASTQ) runs only on request: JASPER_TEST_BIG=1
+@pytest.mark.parametrize("name", ["fullsize_cfg1", "fullsize_cfg2"] + (["fullsize_cfg3like"] if os.environ.get("JASPER_TEST_BIG") else []))
 def test_cli_fullsize_matches_real_reference(hip, tmp_path, name):
     """cfg1 = BASELINE configs[0] (4.6 Mb, k=25, 1 pass: the reference's own CPU-runnable case), cfg2 = configs[1]"""
     from jasper_amd import synth
