@@ -1119,6 +1119,7 @@ __global__ __launch_bounds__(256) void seg_init_kernel(SegDev *segs, int n_segs,
 constexpr uint32_t STITCH_MAX_EDITS = 32;   // beyond this the whole segment is flagged (always safe: flagged = recomputed)
 __global__ __launch_bounds__(256) void seg_stitch_kernel(const SegDev *segs, int n_segs, uint8_t *const *chunk_out, uint8_t *const *cls_out,
                                                          uint8_t *const *flags) {
+    struct __attribute__((packed, aligned(1))) V16 { uint32_t w[4]; };
     for (int s = blockIdx.y; s < n_segs; s += gridDim.y) {
         const SegDev S = segs[s];
         uint8_t *dst = chunk_out[S.chunk] + S.out_off;
@@ -1126,24 +1127,53 @@ __global__ __launch_bounds__(256) void seg_stitch_kernel(const SegDev *segs, int
         uint8_t *fl = cls_out ? flags[S.chunk] : nullptr;
         const int64_t n = S.own_hi - S.own_lo;
         const bool all_dirty = S.nedit > STITCH_MAX_EDITS;
-        for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
-            const int64_t p = S.own_lo + q;
-            dst[q] = S.buf[p < S.gs ? p : p + S.glen];
-            if (!cdst) continue;
-            int64_t l = p;
-            bool dirty = all_dirty;
-            if (!dirty)
+        const int64_t nblk = (n + 15) >> 4;
+        for (int64_t blk = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; blk < nblk; blk += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t q0 = blk << 4;
+            const int64_t p0 = S.own_lo + q0;
+            const bool full = q0 + 16 <= n;
+            bool text_done = false, cls_done = !cdst;
+            if (full && (p0 + 16 <= S.gs || p0 >= S.gs)) {                 // sixteen text bytes on one side of the gap
+                *reinterpret_cast<V16 *>(dst + q0) = *reinterpret_cast<const V16 *>(S.buf + (p0 < S.gs ? p0 : p0 + S.glen));
+                text_done = true;
+            }
+            if (full && cdst && !all_dirty) {
+                // sixteen classes with one common shift: trace the block's two ends through the edits together; as long as
+                // both lie on the same side of every edit (and outside its one-position margin) so does everything between
+                int64_t lA = p0, lB = p0 + 15;
+                bool uniform = true;
                 for (int e = (int)S.nedit - 1; e >= 0; --e) {
                     const EditRec E = S.edits[e];
-                    if (l > E.a + E.plen) l -= (int64_t)E.plen - E.oldlen;
-                    else if (l >= E.a - 1) { dirty = true; break; }
+                    if (lA > E.a + E.plen) { const int64_t d = (int64_t)E.plen - E.oldlen; lA -= d; lB -= d; }
+                    else if (lB < E.a - 1) { }
+                    else { uniform = false; break; }
                 }
-            if (dirty) {
-                fl[(S.out_off + q) >> 6] = 1;
-                cdst[q] = PC_OTHER;
-            } else {
-                const int64_t old = S.seg_lo + l;
-                cdst[q] = old < S.cls_n ? S.cls[old] : (uint8_t)PC_OTHER;
+                if (uniform && S.seg_lo + lB < S.cls_n) {
+                    *reinterpret_cast<V16 *>(cdst + q0) = *reinterpret_cast<const V16 *>(S.cls + S.seg_lo + lA);
+                    cls_done = true;
+                }
+            }
+            if (text_done && cls_done) continue;
+            const int64_t qe = q0 + 16 < n ? q0 + 16 : n;
+            for (int64_t q = q0; q < qe; ++q) {
+                const int64_t p = S.own_lo + q;
+                if (!text_done) dst[q] = S.buf[p < S.gs ? p : p + S.glen];
+                if (cls_done) continue;
+                int64_t l = p;
+                bool dirty = all_dirty;
+                if (!dirty)
+                    for (int e = (int)S.nedit - 1; e >= 0; --e) {
+                        const EditRec E = S.edits[e];
+                        if (l > E.a + E.plen) l -= (int64_t)E.plen - E.oldlen;
+                        else if (l >= E.a - 1) { dirty = true; break; }
+                    }
+                if (dirty) {
+                    fl[(S.out_off + q) >> 6] = 1;
+                    cdst[q] = PC_OTHER;
+                } else {
+                    const int64_t old = S.seg_lo + l;
+                    cdst[q] = old < S.cls_n ? S.cls[old] : (uint8_t)PC_OTHER;
+                }
             }
         }
     }
