@@ -1105,11 +1105,17 @@ constexpr int SC_THREADS = 256, SC_GROUP = 16, SC_TILE = SC_THREADS * SC_GROUP, 
 
 // copy each segment's text range out of its chunk into the segment's gap buffer (text right of the gap)
 __global__ __launch_bounds__(256) void seg_init_kernel(SegDev *segs, int n_segs, const uint8_t *const *chunk_text) {
+    struct __attribute__((packed, aligned(1))) V16 { uint32_t w[4]; };
     for (int s = blockIdx.y; s < n_segs; s += gridDim.y) {
         const SegDev S = segs[s];
         const uint8_t *src = chunk_text[S.chunk] + S.seg_lo;
         uint8_t *dst = S.buf + S.glen;
-        for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < S.len0; q += (int64_t)gridDim.x * blockDim.x) dst[q] = src[q];
+        const int64_t nblk = (S.len0 + 15) >> 4;
+        for (int64_t blk = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; blk < nblk; blk += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t q0 = blk << 4;
+            if (q0 + 16 <= S.len0) *reinterpret_cast<V16 *>(dst + q0) = *reinterpret_cast<const V16 *>(src + q0);
+            else for (int64_t q = q0; q < S.len0; ++q) dst[q] = src[q];
+        }
     }
 }
 
