@@ -1307,21 +1307,36 @@ __global__ __launch_bounds__(256) void classify_batch_kernel(const ScanChunk *__
 }
 
 __global__ __launch_bounds__(256) void find_sync_batch_kernel(const ScanChunk *__restrict__ chunks, int n_chunks, int k) {
+    struct __attribute__((packed, aligned(1))) V16 { uint32_t w[4]; };
     const int64_t W = 4ll * k;
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
         const ScanChunk C = chunks[ci];
         if (!C.want_sync) continue;
         const int64_t nwin = C.len - k + 1;
         const uint8_t *__restrict__ cls = C.cls;
-        for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nwin; p += (int64_t)gridDim.x * blockDim.x) {
-            if (p < W || p + k - 1 > nwin) continue;
-            if (cls[p] != PC_BAD || cls[p - 1] != PC_CLEAN) continue;
-            bool ok = true;
-            for (int64_t q = 1; q < k - 1 && ok; ++q) ok = cls[p + q] == PC_BAD;
-            for (int64_t q = 2; q <= W && ok; ++q) ok = cls[p - q] == PC_CLEAN;
-            if (!ok) continue;
-            const unsigned int idx = atomicAdd(C.cand_count, 1u);        // ONE list for the whole batch: (chunk << 40) | position
-            if (idx < C.cand_cap) C.cand[idx] = ((int64_t)ci << 40) | p;
+        static_assert(PC_CLEAN == 0 && PC_BAD == 1 && PC_OTHER == 2, "the block test below looks at bit 0 of the class bytes");
+        // sixteen positions per thread: a candidate is a BAD position whose left neighbour is CLEAN -- rare, so most
+        // blocks are rejected after one 16-B load
+        const int64_t nblk = (nwin + 15) >> 4;
+        for (int64_t blk = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; blk < nblk; blk += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t p0 = blk << 4;
+            uint32_t w[4];
+            if (p0 + 16 <= nwin) {
+                const V16 v = *reinterpret_cast<const V16 *>(cls + p0);
+                w[0] = v.w[0]; w[1] = v.w[1]; w[2] = v.w[2]; w[3] = v.w[3];
+                if (!((w[0] | w[1] | w[2] | w[3]) & 0x01010101u)) continue;       // no BAD (= 1; CLEAN 0, OTHER 2) in the block
+            }
+            const int64_t pe = p0 + 16 < nwin ? p0 + 16 : nwin;
+            for (int64_t p = p0; p < pe; ++p) {
+                if (p < W || p + k - 1 > nwin) continue;
+                if (cls[p] != PC_BAD || cls[p - 1] != PC_CLEAN) continue;
+                bool ok = true;
+                for (int64_t q = 1; q < k - 1 && ok; ++q) ok = cls[p + q] == PC_BAD;
+                for (int64_t q = 2; q <= W && ok; ++q) ok = cls[p - q] == PC_CLEAN;
+                if (!ok) continue;
+                const unsigned int idx = atomicAdd(C.cand_count, 1u);        // ONE list for the whole batch: (chunk << 40) | position
+                if (idx < C.cand_cap) C.cand[idx] = ((int64_t)ci << 40) | p;
+            }
         }
     }
 }
