@@ -211,6 +211,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         // ---- 2. segments
         auto build_segments = [&](const std::vector<int> &chunks, bool speculate, std::vector<SegDev> &out, std::string &e2) -> int {
             out.clear();
+            if (speculate) out.reserve((size_t)std::min<int64_t>(max_segs, 1 << 16));   // (kept across passes: no regrowth in the loop)
             size_t tpos = 0, rpos = 0, apos = 0;
             for (int c : chunks) {
                 std::vector<int64_t> sync;
@@ -242,15 +243,15 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                 }
                 const int m = (int)sync.size();
                 for (int j = 0; j <= m; ++j) {
-                    SegDev S;
-                    memset(&S, 0, sizeof S);
+                    out.emplace_back();                      // value-initialised in place: zeros, no copy of the ~400-byte struct
+                    SegDev &S = out.back();
                     S.chunk = (uint32_t)c;
                     S.first = (j == 0);
                     S.last = (j == m);
                     S.seg_lo = j == 0 ? 0 : sync[j - 1] - W;
                     S.start_i = j == 0 ? 0 : W;
                     S.chain_in = j > 0 && chained[j - 1];
-                    S.arrive = b_arrive.as<long long>() + 1 + out.size();     // (slot 0 is never read: a first segment is not chained)
+                    S.arrive = b_arrive.as<long long>() + out.size();         // (= 1 + its index; slot 0 is never read: a first segment is not chained)
                     S.stop_orig = j == m ? INT64_MAX : sync[j];
                     const int64_t seg_hi = j == m ? len[c] : std::min<int64_t>(len[c], sync[j] + M);
                     S.len0 = seg_hi - S.seg_lo;
@@ -270,7 +271,6 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                     // owned part of the text: chunk coordinates [B_j, B_{j+1}), B = sync - 2k
                     S.own_lo = j == 0 ? 0 : 2ll * k;                   // local (no edit can precede it)
                     S.own_hi = j == m ? -1 : (sync[j] - 2ll * k) - S.seg_lo;   // local, before adding this segment's delta
-                    out.push_back(S);
                 }
             }
             if (tpos > seg_text_bound || rpos > seg_rec_bound || apos > seg_aux_bound || (int64_t)out.size() > max_segs) {
@@ -291,8 +291,11 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         };
         std::vector<int> all(n_chunks);
         for (int c = 0; c < n_chunks; ++c) all[c] = c;
+        const double tb0 = dbg ? now() : 0;
         if ((rc = build_segments(all, true, segs, err))) break;
+        const double tb1 = dbg ? now() : 0;
         if ((rc = run_segments(segs, err))) break;
+        if (dbg) fprintf(stderr, "[polish]   host: build %zu segments %.3f ms, upload + walk + download %.3f ms\n", segs.size(), tb1 - tb0, now() - tb1);
         R.n_segments += segs.size();
 
         // ---- 3. chunks whose speculation failed are redone as a single segment (= the plain sequential walk)
