@@ -86,7 +86,11 @@ def one_step(torch, dev_index, table, reads, d_chunks, world, timers):
         merged = jdist.merge_tables(table, torch.device("cuda", dev_index))
         table.sync()
     t2 = time.perf_counter()
-    rows = table.histo_rows()
+    if world > 1:      # every rank bins the key range it owns, the bins are summed over ranks
+        h = jdist.histogram_merged(table, torch.device("cuda", dev_index))
+        rows = [(m, h[m]) for m in range(1, 10002) if h[m]]
+    else:
+        rows = table.histo_rows()
     txt, status = polisher.threshold_from_histo_rows(rows)
     if status != 0 or not txt:
         raise RuntimeError("synthetic histogram has no usable local minimum (threshold script would abort)")

@@ -84,6 +84,9 @@ int jasper_count_reads_files(jasper_table *t, const char *const *paths, int n_pa
  * fallback for multi-line records, DOS line ends, malformed input and stream tails) */
 int jasper_last_ingest(jasper_table *t, uint64_t *gpu_bytes, uint64_t *host_bytes);
 int jasper_histogram(jasper_table *t, uint64_t *out10002);
+/* the same over the keys of ONE owner partition (as in jasper_table_export_packed): after a multi-GPU merge every rank
+ * bins the range it owns and the 10002 bins are summed over ranks, instead of every rank scanning the whole table */
+int jasper_histogram_part(jasper_table *t, uint32_t part, uint32_t nparts, uint64_t *out10002);
 /* 1 if the histogram is already known because the last counting call binned the final counts while it wrote them
  * (one partitioned pass over the whole input into an empty table); jasper_histogram then costs one small copy */
 int jasper_histogram_is_fused(jasper_table *t);

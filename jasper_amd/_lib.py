@@ -41,6 +41,7 @@ SYMBOLS = {
     "jasper_table_write_jf": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]),
     "jasper_debug_mix": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "jasper_last_ingest": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "jasper_histogram_part": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     "jasper_histogram_is_fused": (C.c_int, [_P]),
     "jasper_histogram": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "jasper_lookup": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64), C.c_uint64, C.POINTER(C.c_uint32)]),

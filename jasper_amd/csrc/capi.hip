@@ -185,6 +185,10 @@ int jasper_last_count_stages(jasper_table *t, double stage_ms[5], uint64_t *part
     return JASPER_OK;
 }
 
+int jasper_histogram_part(jasper_table *t, uint32_t part, uint32_t nparts, uint64_t *out10002) {
+    if (nparts == 0 || part >= nparts || !out10002) { g_err = "bad partition"; return JASPER_ERR; }
+    return t->t.histogram_part(part, nparts, out10002, g_err) ? JASPER_ERR : JASPER_OK;
+}
 int jasper_histogram_is_fused(jasper_table *t) { return t && t->t.histo_cached ? 1 : 0; }
 
 int jasper_histogram(jasper_table *t, uint64_t *out10002) { return t->t.histogram(out10002, g_err); }

@@ -762,6 +762,42 @@ int Table::histogram(uint64_t *out, std::string &err) {
     return 0;
 }
 
+// histogram of the keys of ONE partition (multi-GPU: every rank bins the range it owns, the bins are summed over ranks)
+__global__ __launch_bounds__(256) void histo_part_kernel(TableDev T, uint32_t part, uint32_t nparts, uint64_t first, uint64_t span,
+                                                         unsigned long long *__restrict__ out) {
+    __shared__ unsigned int bins[HISTO_BINS];
+    for (int i = threadIdx.x; i < HISTO_BINS; i += blockDim.x) bins[i] = 0;
+    __syncthreads();
+    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < span; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = (first + q) & T.mask;
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * i);
+        if (e.x == 0ull || e.y == 0ull) continue;
+        const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
+        const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
+        const uint64_t home = (i - off) & T.mask;
+        if (nparts > 1 && part_of(hash_from(home, rem, T.B, T.s), T.B, nparts) != part) continue;
+        const uint32_t c = clamp32(e.y);
+        atomicAdd(&bins[c > 10001u ? 10001u : c], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HISTO_BINS; i += blockDim.x)
+        if (bins[i]) atomicAdd(&out[i], (unsigned long long)bins[i]);
+}
+
+int Table::histogram_part(uint32_t part, uint32_t nparts, uint64_t *out, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
+    uint64_t first, span;
+    part_span(part, nparts, first, span);
+    unsigned long long *d_out = d_histo + HISTO_WORDS;
+    HIPCHK(hipMemsetAsync(d_out, 0, HISTO_BINS * sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(histo_part_kernel, dim3(grid_for(span, 256 * 16)), dim3(256), 0, stream, d, part, nparts, first, span, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, HISTO_BINS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIPCHK(jk_stream_wait(stream));
+    return 0;
+}
+
 int Table::lookup_strings(const char *chars, const int64_t *offsets, uint64_t n, uint32_t *out, std::string &err) {
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
@@ -834,23 +870,27 @@ int Table::reserve(uint64_t min_slots, std::string &err) {
     return 0;
 }
 
+// slots that can hold keys of partition part/nparts: partition p = keys whose top-32 hash bits t satisfy
+// floor(t * nparts / 2^32) == p, i.e. t in [t_lo, t_hi); their home slots are a contiguous range, and an entry sits
+// < MAXPROBE slots behind its home
+void Table::part_span(uint32_t part, uint32_t nparts, uint64_t &first, uint64_t &span) const {
+    first = 0;
+    span = nslots;
+    if (nparts <= 1 || d.B < 32) return;        // (B < 32: tiny key space, scan everything)
+    const uint64_t t_lo = (((uint64_t)part << 32) + nparts - 1) / nparts;
+    const uint64_t t_hi = ((((uint64_t)part + 1) << 32) + nparts - 1) / nparts;   // exclusive
+    const int s_ = d.s;
+    uint64_t last_excl;
+    if (s_ <= 32) { first = t_lo >> (32 - s_); last_excl = ((t_hi - 1) >> (32 - s_)) + 1; }
+    else { first = t_lo << (s_ - 32); last_excl = t_hi << (s_ - 32); }
+    span = std::min<uint64_t>(nslots, last_excl - first + MAXPROBE);
+}
+
 int Table::export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t part, uint32_t nparts, std::string &err) {
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
     uint64_t first = 0, span = nslots;
-    if (nparts > 1) {
-        // partition p = keys whose top-32 hash bits t satisfy floor(t * nparts / 2^32) == p, i.e. t in [t_lo, t_hi);
-        // their home slots are a contiguous range, and an entry sits < MAXPROBE slots behind its home
-        const uint64_t t_lo = (((uint64_t)part << 32) + nparts - 1) / nparts;
-        const uint64_t t_hi = ((((uint64_t)part + 1) << 32) + nparts - 1) / nparts;   // exclusive
-        const int s_ = d.s;
-        uint64_t last_excl;
-        if (d.B >= 32) {
-            if (s_ <= 32) { first = t_lo >> (32 - s_); last_excl = ((t_hi - 1) >> (32 - s_)) + 1; }
-            else { first = t_lo << (s_ - 32); last_excl = t_hi << (s_ - 32); }
-            span = std::min<uint64_t>(nslots, last_excl - first + MAXPROBE);
-        }   // (B < 32: tiny key space, scan everything)
-    }
+    part_span(part, nparts, first, span);
     unsigned long long *d_counts = reinterpret_cast<unsigned long long *>(workspace(WS_COUNT + 2, (EXP_BLOCKS + 8) * 8 + 256, err));   // (free between counting calls)
     if (!d_counts) return -1;
     const uint64_t chunk = ((span + EXP_BLOCKS - 1) / EXP_BLOCKS + 255) / 256 * 256;

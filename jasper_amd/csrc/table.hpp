@@ -258,6 +258,8 @@ struct Table {
     char *h_ingest = nullptr;      // pinned text staging of count_files_gpu
     size_t ingest_chunk = 0;
     int histogram(uint64_t *out10002, std::string &err);
+    int histogram_part(uint32_t part, uint32_t nparts, uint64_t *out10002, std::string &err);
+    void part_span(uint32_t part, uint32_t nparts, uint64_t &first, uint64_t &span) const;
     int lookup_strings(const char *chars, const int64_t *offsets, uint64_t n, uint32_t *out, std::string &err);
     int export_entries(uint64_t *n_out, unsigned long long **d_entries_out, std::string &err);  // 3 words each
     int import_entries(const unsigned long long *d_entries, uint64_t n, std::string &err);

@@ -173,6 +173,19 @@ def merge_tables(table, device, group=None):
     return received
 
 
+def histogram_merged(table, device, group=None):
+    """histogram of a table that merge_tables has made identical on all ranks: every rank bins the key range it owns
+    (1/world of a table pass), the 10002 bins are summed over ranks"""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return table.histogram()
+    world = dist.get_world_size(group)
+    h = torch.tensor(table.histogram_part(dist.get_rank(group), world), dtype=torch.int64, device=device)
+    dist.all_reduce(h, group=group)
+    return [int(x) for x in h.tolist()]
+
+
 def all_reduce_ints(values, device=None):
     """sum a short list of python ints over ranks (QV counters, k-mer totals)"""
     import torch

@@ -202,6 +202,12 @@ class KmerTable:
         check(self._L.jasper_histogram(self._h, out))
         return list(out)
 
+    def histogram_part(self, part, nparts):
+        """multiplicity histogram of the keys of owner partition part/nparts only"""
+        out = (C.c_uint64 * 10002)()
+        check(self._L.jasper_histogram_part(self._h, int(part), int(nparts), out))
+        return list(out)
+
     def histo_rows(self):
         """non-zero rows (multiplicity, n_distinct) as `jellyfish histo` prints them (JF::sub_commands/histo_main.cc:82-84)"""
         import numpy as np

@@ -41,6 +41,7 @@ def _worker(rank, world, port, q):
         dev = torch.device("cuda", 0)
         merged = jd.merge_tables(t, dev)
         h = t.histogram()
+        assert jd.histogram_merged(t, dev) == h             # owner ranges binned per rank + all_reduce == full scan
         info = t.info()
         # chunk shard
         bs = 20_000

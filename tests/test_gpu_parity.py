@@ -196,6 +196,20 @@ def test_packed_partition_exchange_primitives(KT, O):
         t.close()
 
 
+def test_partition_histograms_sum_to_the_full_histogram(KT):
+    k = 37
+    _, reads, _ = workload(33, 200_000, k)
+    t = KT(k, min_slots=1 << 18)
+    t.count_bases(reads)
+    full = t.histogram()
+    for nparts in (1, 2, 3, 8):
+        acc = [0] * 10002
+        for p in range(nparts):
+            acc = [a + b for a, b in zip(acc, t.histogram_part(p, nparts))]
+        assert acc == full, nparts
+    t.close()
+
+
 def test_device_resident_stream_equals_host_stream(KT):
     """jasper_count_bases_device on an HBM-resident (and deliberately misaligned) buffer == host path"""
     import torch
