@@ -3,19 +3,21 @@
 // Why: the direct kernel (table.hip: count_kernel) issues one scattered 64-bit atomic per k-mer, and MI355X retires
 // only ~20 G scattered atomics/s chip-wide whatever the working set (measured: hashing alone 190 Gk-mers/s, hashing +
 // one random 8-B load 48 Gk-mers/s, full insert 18 Gk-mers/s, unchanged when the touched slots fit in L2; see
-// DESIGN.md 6).  Here the table is updated with LDS atomics instead:
+// DESIGN.md 4.1).  Here the table is updated with LDS atomics instead:
 //
 //   part1_kernel   bases -> mixed hash -> bucket = top p1 hash bits; the remaining (2k-p1 <= 64) bits go, as one
 //                  8-byte record, into the bucket's list.  Per 16 K-record tile: LDS histogram (returning LDS
-//                  atomics give every record its rank), ONE global reservation per non-empty bucket, scattered 8-B
-//                  stores that the XCD's L2 merges into full lines.
+//                  atomics give every record its rank), block scan, records sorted by bucket inside LDS, copied out in
+//                  bucket order: whole 128-B runs into the block's own slice of every bucket list (no global atomic).
 //   part2_kernel   same scheme on each bucket, by the next p2 hash bits  ->  2^(p1+p2) lists, one per table REGION
 //                  of 2^rbits <= 8192 consecutive slots (home slot = top hash bits, so a region is a hash range).
 //   lds_insert_kernel  one workgroup per region: region (+128-slot halo so a probe may run past the region end) is
-//                  loaded into LDS (130 KB), records are inserted with LDS compare-and-swap / add, image written back.
+//                  loaded into LDS (130 KB; started from zeros on a lazily cleared table), records are inserted with
+//                  LDS compare-and-swap / add, image written back -- and, when this pass produces the final counts
+//                  of the whole table, binned into the multiplicity histogram on the way out.
 //                  Even and odd regions run in two launches, so no two resident images overlap.
-//   A record that finds no room (bucket list full, probe beyond the halo) takes the direct path: immediately during
-//   part1/part2 (no LDS image exists yet), deferred to a list that import_kernel drains after the last lds_insert.
+//   A record that finds no room (slice full, probe beyond the halo) goes to a deferred list that import3_kernel drains
+//   through the direct path after the last lds_insert.
 //
 // The table layout, tags and probe order are exactly those of the direct path, so lookups, histogram, export, growth
 // and the polisher do not know which path filled the table.  HBM traffic per k-mer: 1 B base + 8 B x 2 (part1 list)
