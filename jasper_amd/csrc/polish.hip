@@ -10,6 +10,12 @@
 //     everything left of it except a coordinate shift: segments are walked concurrently and stitched afterwards.
 //     A walk that touches text outside what its segment may assume raises spec_fail and the chunk is redone as one
 //     segment (= the plain sequential walk);
+//   * where sync points are scarce (later passes), a chunk is also cut inside long CLEAN stretches; the segment to the
+//     right of such a cut takes its start position from the arrival position its left neighbour publishes (waves take
+//     segments by ticket, so the neighbour is already running), and a segment whose range holds no event at all
+//     computes its arrival instead of walking;
+//   * the position classes are computed densely only in pass 0; afterwards the stitch carries the classes of
+//     untouched windows over and rescan_batch_kernel recomputes the 64-window tiles next to edited text;
 //   * inside a chunk the wave evaluates 64 stride positions i, i+(k-1), ... at once, ballots "needs
 //     attention" and jumps to the first such position (positions that are plainly good only ever do
 //     `i += k-1`, src/jasper.py:97,100);
