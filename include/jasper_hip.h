@@ -110,6 +110,26 @@ int jasper_table_import_packed(jasper_table *t, const void *d_src, uint64_t n_en
 /* grow to at least min_slots slots (ranks agree on one geometry before exchanging slot-range partitions) */
 int jasper_table_reserve(jasper_table *t, uint64_t min_slots);
 
+/* Owner-sharded table ("keep the table key-sharded and route lookups").  Instead of replicating the merged
+ * table on every GPU, owner o of n keeps ONLY the keys with jasper_owner_of(hash) == o, and every lookup -- the polishing
+ * kernels', jasper_lookup's -- reads the owner's slot array directly: its own HBM, or a peer's over xGMI.
+ *   jasper_table_export_owner: all entries of t in the exchange format above, grouped by owner; segment o starts at
+ *     d_dst + o * cap_entries * 16 bytes and holds counts[o] entries (if any counts[o] > cap_entries nothing beyond cap was
+ *     written: call again with more room).  One pass over the table whatever n_owners is.
+ *   jasper_table_ipc_handle: 64 bytes that let another PROCESS map this table's slot array (hipIpcGetMemHandle).
+ *   jasper_table_attach_ipc: handles = n x 64 bytes in owner order (entry `self` unused).  All owners' tables must have
+ *     the geometry of t (same k, same slot count: jasper_table_reserve after agreeing on the maximum).
+ *   jasper_table_attach_tables: the same for shard tables living in this process.
+ *   jasper_table_detach: back to a whole table.  Growing a table detaches it.
+ * The owners' tables must not be written while any GPU reads them; that ordering is the caller's (a barrier). */
+int jasper_table_export_owner(jasper_table *t, void *d_dst, uint64_t cap_entries, uint32_t n_owners, uint64_t *counts);
+int jasper_table_ipc_handle(jasper_table *t, void *out64);
+int jasper_table_attach_ipc(jasper_table *t, const void *handles, uint32_t n, uint32_t self);
+int jasper_table_attach_tables(jasper_table *t, jasper_table *const *shards, uint32_t n, uint32_t self);
+int jasper_table_detach(jasper_table *t);
+/* owner of a packed entry's hash among n (host-side restatement of the device function, for tests and routing) */
+uint32_t jasper_owner_of(uint64_t hash_lo, uint64_t hash_hi, uint32_t n);
+
 /* one batch of chunk records through `passes` fixing passes + the final QV pass (src/jasper.py:25-26) */
 int jasper_polish_batch(jasper_table *t, int n_chunks, const char *const *seqs, const int64_t *lens,
                         int solid_thre, int passes, int fix, jasper_result **out);

@@ -230,6 +230,28 @@ int jasper_table_import_packed(jasper_table *t, const void *d_src, uint64_t n_en
 }
 int jasper_table_reserve(jasper_table *t, uint64_t min_slots) { return t->t.reserve(min_slots, g_err); }
 
+int jasper_table_export_owner(jasper_table *t, void *d_dst, uint64_t cap_entries, uint32_t n_owners, uint64_t *counts) {
+    if (!counts) { g_err = "counts is null"; return JASPER_ERR; }
+    return t->t.export_owner(d_dst, cap_entries, n_owners, counts, g_err);
+}
+int jasper_table_ipc_handle(jasper_table *t, void *out64) { return t->t.ipc_handle(out64, g_err) ? JASPER_ERR : JASPER_OK; }
+int jasper_table_attach_ipc(jasper_table *t, const void *handles, uint32_t n, uint32_t self) {
+    return t->t.attach_ipc(handles, n, self, g_err) ? JASPER_ERR : JASPER_OK;
+}
+int jasper_table_attach_tables(jasper_table *t, jasper_table *const *shards, uint32_t n, uint32_t self) {
+    if (n < 1 || n > MAX_SHARDS || !shards) { g_err = "attach: 1..8 shards"; return JASPER_ERR; }
+    Table *p[MAX_SHARDS] = {};
+    for (uint32_t i = 0; i < n; ++i) p[i] = shards[i] ? &shards[i]->t : nullptr;
+    return t->t.attach_tables(p, n, self, g_err) ? JASPER_ERR : JASPER_OK;
+}
+int jasper_table_detach(jasper_table *t) {
+    if (hipSetDevice(t->t.device) != hipSuccess) { g_err = "hipSetDevice"; return JASPER_ERR; }
+    (void)jk_stream_wait(t->t.stream);
+    t->t.detach_shards();
+    return JASPER_OK;
+}
+uint32_t jasper_owner_of(uint64_t hash_lo, uint64_t hash_hi, uint32_t n) { return owner_of(mk(hash_hi, hash_lo), n); }
+
 int jasper_device_free(jasper_table *t, void *d_ptr) {
     CHK(hipSetDevice(t->t.device));
     CHK(hipFree(d_ptr));

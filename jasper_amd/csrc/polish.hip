@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(SC_THREADS) void scan_batch_kernel(const ScanChunk 
                     ok[u] = run >= k && e - k + 1 >= 0 && e < n;
                     hs[u] = mix(lt(rc, fwd) ? rc : fwd, T.B);
                     ent[u] = make_ulonglong2(0ull, 0ull);
-                    if (ok[u]) ent[u] = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * home_of(hs[u], T.B, T.s));
+                    if (ok[u]) ent[u] = *reinterpret_cast<const ulonglong2 *>(read_slots(T, hs[u]) + 2 * home_of(hs[u], T.B, T.s));
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {

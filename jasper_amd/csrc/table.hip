@@ -244,10 +244,11 @@ __device__ __forceinline__ bool packed_entry_of(const TableDev &T, uint64_t i, u
     const u128 h = hash_from(home, rem, T.B, T.s);
     if (nparts > 1 && part_of(h, T.B, nparts) != part) return false;
     if (sh && (e.y >> (64 - sh)) != 0ull) { atomicExch(&T.stats[ST_FATAL], 2ull); return false; }   // count does not fit the packing
-    o = make_ulonglong2(h.lo, h.hi | (sh ? (e.y << sh) : 0ull));
+    o = make_ulonglong2(h.lo, sh ? (h.hi | (e.y << sh)) : e.y);   // (B <= 64: the whole second word is the count)
     return true;
 }
 constexpr int EXP_BLOCKS = 2048;
+constexpr int EXP_STRIDE = EXP_BLOCKS + 8;   // words per count array (EXP_BLOCKS block counts, then the total)
 __global__ __launch_bounds__(256) void export_packed_count_kernel(TableDev T, uint32_t part, uint32_t nparts, uint64_t first, uint64_t span,
                                                                   uint64_t chunk, unsigned long long *__restrict__ counts) {
     __shared__ unsigned int s_w[4];
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(256) void export_packed_count_kernel(TableDev T, ui
 __global__ __launch_bounds__(1024) void export_packed_scan_kernel(unsigned long long *__restrict__ counts) {
     __shared__ unsigned long long s_w[16];
     const int t = threadIdx.x;
+    counts += (size_t)blockIdx.x * EXP_STRIDE;   // one array per block (export_owner: one per owner)
     const unsigned long long a = counts[2 * t], b = counts[2 * t + 1];
     unsigned long long inc = a + b;
     for (int o = 1; o < 64; o <<= 1) { const unsigned long long u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
@@ -299,6 +301,84 @@ __global__ __launch_bounds__(256) void export_packed_write_kernel(TableDev T, ul
         const unsigned long long idx = cursor + before + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
         if (have && idx < cap) out[idx] = o;
         cursor += total;
+        __syncthreads();
+    }
+}
+
+// ---- owner-sharded table: every entry of the table, grouped by owner_of(hash, nown), in ONE pass over the slots ----
+// Same two atomic-free passes as above with one count array per owner: counts[o * EXP_STRIDE + block].
+__device__ __forceinline__ bool owner_entry_of(const TableDev &T, uint64_t i, uint32_t nown, int sh, ulonglong2 &o, uint32_t &owner) {
+    const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * i);
+    if (e.x == 0ull) return false;
+    const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
+    const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
+    const u128 h = hash_from((i - off) & T.mask, rem, T.B, T.s);
+    if (sh && (e.y >> (64 - sh)) != 0ull) { atomicExch(&T.stats[ST_FATAL], 2ull); return false; }
+    owner = owner_of(h, nown);
+    o = make_ulonglong2(h.lo, sh ? (h.hi | (e.y << sh)) : e.y);   // (B <= 64: the whole second word is the count)
+    return true;
+}
+__global__ __launch_bounds__(256) void export_owner_count_kernel(TableDev T, uint32_t nown, uint64_t chunk, unsigned long long *__restrict__ counts) {
+    __shared__ unsigned int s_w[4][MAX_SHARDS];
+    const int sh = packed_count_shift(T.B);
+    const uint64_t span = T.mask + 1;
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < span ? lo + chunk : span;
+    unsigned int n[MAX_SHARDS];
+#pragma unroll
+    for (uint32_t w = 0; w < MAX_SHARDS; ++w) n[w] = 0;
+    for (uint64_t q = lo + threadIdx.x; q < hi; q += blockDim.x) {
+        ulonglong2 o;
+        uint32_t owner = 0;
+        if (owner_entry_of(T, q, nown, sh, o, owner)) {
+#pragma unroll
+            for (uint32_t w = 0; w < MAX_SHARDS; ++w) n[w] += owner == w ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (uint32_t w = 0; w < MAX_SHARDS; ++w) {
+        unsigned int v = n[w];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6][w] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < nown)
+        counts[(size_t)threadIdx.x * EXP_STRIDE + blockIdx.x] =
+            (unsigned long long)s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void export_owner_write_kernel(TableDev T, ulonglong2 *__restrict__ out, uint64_t cap, uint32_t nown, uint64_t chunk,
+                                                                 const unsigned long long *__restrict__ bases) {
+    __shared__ unsigned int s_w[4][MAX_SHARDS];
+    const int sh = packed_count_shift(T.B);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t span = T.mask + 1;
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < span ? lo + chunk : span;
+    unsigned long long cursor[MAX_SHARDS];
+#pragma unroll
+    for (uint32_t w = 0; w < MAX_SHARDS; ++w) cursor[w] = w < nown ? bases[(size_t)w * EXP_STRIDE + blockIdx.x] : 0ull;
+    for (uint64_t q0 = lo; q0 < hi; q0 += blockDim.x) {          // block-uniform trip count
+        const uint64_t q = q0 + threadIdx.x;
+        ulonglong2 o = make_ulonglong2(0ull, 0ull);
+        uint32_t owner = 0;
+        const bool have = q < hi && owner_entry_of(T, q, nown, sh, o, owner);
+        uint64_t mine = 0;     // ballot of my owner's lanes in this wave
+#pragma unroll
+        for (uint32_t w = 0; w < MAX_SHARDS; ++w) {
+            const uint64_t m = __ballot(have && owner == w);
+            if (lane == 0) s_w[wave][w] = (unsigned int)__popcll(m);
+            if (owner == w) mine = m;
+        }
+        __syncthreads();
+        unsigned int before = 0;
+        unsigned long long cur = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < MAX_SHARDS; ++w) {
+            unsigned int tot = 0, bef = 0;
+            for (int v = 0; v < 4; ++v) { const unsigned int c = s_w[v][w]; tot += c; if (v < wave) bef += c; }
+            if (owner == w) { before = bef; cur = cursor[w]; }
+            cursor[w] += tot;
+        }
+        const unsigned long long idx = cur + before + (unsigned long long)__popcll(mine & ((1ull << lane) - 1ull));
+        if (have && idx < cap) out[(size_t)owner * cap + idx] = o;
         __syncthreads();
     }
 }
@@ -436,6 +516,7 @@ void *Table::workspace(int id, size_t bytes, std::string &err) {
 void Table::destroy() {
     (void)hipSetDevice(device);
     if (stream) (void)jk_stream_wait(stream);
+    detach_shards();
     for (WsBuf &b : ws) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
     for (int i = 0; i < 2; ++i) {
         if (d_stage[i]) (void)hipFree(d_stage[i]);
@@ -494,6 +575,7 @@ int Table::read_stats(std::string &err) {
 int Table::grow(int new_s, std::string &err) {
     if (new_s > d.B) new_s = d.B;
     if (new_s <= d.s) return 0;
+    detach_shards();      // the slot array moves and its geometry changes: the owners have to agree and attach again
     if (slots_dirty) {   // logically empty: nothing to rehash, the new slot array stays lazily cleared as well
         unsigned long long *ns = nullptr;
         HIPCHK(hipMalloc((void **)&ns, (1ull << new_s) * 16));
@@ -905,6 +987,91 @@ int Table::export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t pa
     if (read_stats(err)) return -1;
     if (h_stats[ST_FATAL] == 2) { err = "a count does not fit the packed exchange format"; return -2; }
     *n_out = got;   // may exceed cap: the caller sizes its buffer with a first call (cap = 0) or from info()
+    return 0;
+}
+
+int Table::export_owner(void *d_dst, uint64_t cap, uint32_t nown, uint64_t *counts_out, std::string &err) {
+    if (nown < 1 || nown > MAX_SHARDS) { err = "export_owner: 1..8 owners"; return -1; }
+    HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
+    unsigned long long *d_counts = reinterpret_cast<unsigned long long *>(workspace(WS_COUNT + 2, (size_t)MAX_SHARDS * EXP_STRIDE * 8 + 256, err));
+    if (!d_counts) return -1;
+    const uint64_t chunk = ((nslots + EXP_BLOCKS - 1) / EXP_BLOCKS + 255) / 256 * 256;
+    hipLaunchKernelGGL(export_owner_count_kernel, dim3(EXP_BLOCKS), dim3(256), 0, stream, d, nown, chunk, d_counts);
+    hipLaunchKernelGGL(export_packed_scan_kernel, dim3(nown), dim3(1024), 0, stream, d_counts);
+    if (cap) hipLaunchKernelGGL(export_owner_write_kernel, dim3(EXP_BLOCKS), dim3(256), 0, stream, d, (ulonglong2 *)d_dst, cap, nown, chunk, d_counts);
+    HIPCHK(hipGetLastError());
+    unsigned long long got[MAX_SHARDS];
+    HIPCHK(hipMemcpy2DAsync(got, 8, d_counts + EXP_BLOCKS, (size_t)EXP_STRIDE * 8, 8, nown, hipMemcpyDeviceToHost, stream));
+    HIPCHK(jk_stream_wait(stream));
+    if (read_stats(err)) return -1;
+    if (h_stats[ST_FATAL] == 2) { err = "a count does not fit the packed exchange format"; return -2; }
+    for (uint32_t o = 0; o < nown; ++o) counts_out[o] = got[o];
+    return 0;
+}
+
+// ---- shards: lookups through this table read the owner's slot array ---------------------------------------------
+void Table::detach_shards() {
+    for (uint32_t i = 0; i < MAX_SHARDS; ++i) {
+        if (ipc_mapped[i]) { (void)hipIpcCloseMemHandle(ipc_mapped[i]); ipc_mapped[i] = nullptr; }
+        d.shard[i] = nullptr;
+    }
+    d.nshard = 0;
+}
+
+int Table::ipc_handle(void *out64, std::string &err) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C-ABI hands IPC handles over as 64 bytes");
+    HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, d.slots));
+    memcpy(out64, &h, 64);
+    return 0;
+}
+
+// handles64: n handles of 64 bytes, one per owner in owner order (entry `self` is ignored: that is this table).  Every
+// owner's table must have this table's geometry -- the caller agrees on it before (dist.shard_tables).
+int Table::attach_ipc(const void *handles64, uint32_t n, uint32_t self, std::string &err) {
+    if (n < 1 || n > MAX_SHARDS || self >= n) { err = "attach: 1..8 shards, self among them"; return -1; }
+    HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
+    HIPCHK(jk_stream_wait(stream));
+    detach_shards();
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i == self) { d.shard[i] = d.slots; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)handles64 + 64 * (size_t)i, 64);
+        void *p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            err = std::string("hipIpcOpenMemHandle (shard ") + std::to_string(i) + "): " + hipGetErrorString(e);
+            detach_shards();
+            return -1;
+        }
+        ipc_mapped[i] = p;
+        d.shard[i] = (const unsigned long long *)p;
+    }
+    d.nshard = n;
+    return 0;
+}
+
+// the same for shard tables that live in THIS process (one GPU holding several shards: tests, or a table larger than
+// one allocation)
+int Table::attach_tables(Table *const *peers, uint32_t n, uint32_t self, std::string &err) {
+    if (n < 1 || n > MAX_SHARDS || self >= n) { err = "attach: 1..8 shards, self among them"; return -1; }
+    HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
+    detach_shards();
+    for (uint32_t i = 0; i < n; ++i) {
+        Table *p = i == self ? this : peers[i];
+        if (!p || p->d.s != d.s || p->d.B != d.B) { err = "attach: all shards must have the same k and slot count"; detach_shards(); return -1; }
+        if (p != this) {
+            if (p->materialize(err)) { detach_shards(); return -1; }
+            HIPCHK(jk_stream_wait(p->stream));
+        }
+        d.shard[i] = p->d.slots;
+    }
+    d.nshard = n;
     return 0;
 }
 

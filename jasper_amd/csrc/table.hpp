@@ -12,6 +12,7 @@
 namespace jk {
 
 // what kernels receive (by value)
+constexpr uint32_t MAX_SHARDS = 8;   // the GPUs of one node
 struct TableDev {
     unsigned long long *slots;  // 2 words per slot: tag, count
     uint64_t mask;              // nslots - 1
@@ -21,7 +22,29 @@ struct TableDev {
     unsigned long long *stats;  // [0] distinct keys  [1] spilled insertions  [2] k-mer occurrences added  [3] fatal
     unsigned long long *spill;  // 3 words per spilled insertion: hash.hi, hash.lo, increment
     uint64_t spill_cap;
+    // Owner-sharded table (multi-GPU): READS of a key go to the slot array of the GPU that owns the key; shard[i] is the
+    // i-th owner's slot array (this GPU's own, or a peer's HBM mapped over xGMI), all of one geometry.  nshard <= 1: the
+    // table is whole and `slots` is read.  Insertions always go to `slots`.
+    const unsigned long long *shard[MAX_SHARDS];
+    uint32_t nshard;
 };
+
+// The owner of a key among n shards: a second mix of the hash, so that the keys of one owner are spread evenly over the
+// slots of its table whatever the table size is.
+JK_HD uint32_t owner_of(u128 h, uint32_t n) {
+    uint32_t x = (uint32_t)h.lo ^ (uint32_t)(h.lo >> 32) ^ (uint32_t)h.hi;
+    x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+    return (uint32_t)(((uint64_t)x * n) >> 32);
+}
+// slot array a lookup of hash h has to read
+__device__ __forceinline__ const unsigned long long *read_slots(const TableDev &T, u128 h) {
+    if (T.nshard <= 1) return T.slots;
+    const uint32_t o = owner_of(h, T.nshard);
+    const unsigned long long *b = T.shard[0];
+#pragma unroll
+    for (uint32_t i = 1; i < MAX_SHARDS; ++i) b = (o == i) ? T.shard[i] : b;   // selects on constant indices: no scratch
+    return b;
+}
 
 enum { ST_DISTINCT = 0, ST_SPILL = 1, ST_OCCURRENCES = 2, ST_FATAL = 3, ST_WORDS = 8 };
 
@@ -108,9 +131,10 @@ __device__ __forceinline__ unsigned table_add_or_spill(const TableDev &T, u128 h
 __device__ __forceinline__ unsigned long long table_get(const TableDev &T, u128 h) {
     const uint64_t home = home_of(h, T.B, T.s);
     const uint64_t rem = rem_of(h, T.B, T.s);
+    const unsigned long long *S = read_slots(T, h);
     for (uint32_t off = 0; off < MAXPROBE; ++off) {
         const uint64_t slot = (home + off) & T.mask;
-        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * slot);  // tag + count, one 16-B load
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(S + 2 * slot);  // tag + count, one 16-B load
         if (e.x == tag_of(rem, off)) return e.y;
         if (e.x == 0ull) return 0ull;
     }
@@ -123,9 +147,10 @@ __device__ __forceinline__ unsigned long long table_get_prefetched(const TableDe
     const uint64_t rem = rem_of(h, T.B, T.s);
     if (e0.x == tag_of(rem, 0)) return e0.y;
     if (e0.x == 0ull) return 0ull;
+    const unsigned long long *S = read_slots(T, h);
     for (uint32_t off = 1; off < MAXPROBE; ++off) {
         const uint64_t slot = (home + off) & T.mask;
-        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * slot);
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(S + 2 * slot);
         if (e.x == tag_of(rem, off)) return e.y;
         if (e.x == 0ull) return 0ull;
     }
@@ -268,6 +293,15 @@ struct Table {
     int export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t part, uint32_t nparts, std::string &err);
     int import_packed(const void *d_src, uint64_t n, int mode, std::string &err);
     int reserve(uint64_t min_slots, std::string &err);
+    // Owner-sharded table (table.hip, "shards"): all entries of this table in ONE pass, grouped by owner_of(hash, nown)
+    // -- segment o starts at d_dst + o * cap entries, counts_out[o] entries long (may exceed cap: nothing is written past
+    // cap, the caller retries with a larger buffer); attach = lookups through this table read shard o's slot array.
+    int export_owner(void *d_dst, uint64_t cap, uint32_t nown, uint64_t *counts_out, std::string &err);
+    int ipc_handle(void *out64, std::string &err);
+    int attach_ipc(const void *handles64, uint32_t n, uint32_t self, std::string &err);
+    int attach_tables(Table *const *peers, uint32_t n, uint32_t self, std::string &err);
+    void detach_shards();
+    void *ipc_mapped[MAX_SHARDS] = {};   // peers' slot arrays opened with hipIpcOpenMemHandle (closed by detach_shards)
     // the table as a Jellyfish binary/sorted database (jfwrite.hip); cmdline goes into the header like jellyfish's own
     int write_jf(const char *path, const char *const *cmdline, int n_cmd, std::string &err);
     int load_jf_records(const char *path, uint64_t data_offset, uint64_t n_records, int key_len_bits, int counter_len, std::string &err);

@@ -173,6 +173,101 @@ def merge_tables(table, device, group=None):
     return received
 
 
+class ShardAttachError(RuntimeError):
+    """the owners' slot arrays could not be mapped into this process (no IPC / no peer access between the GPUs)"""
+
+
+def shard_tables(local, shard, device, group=None):
+    """key-wise sum of the per-GPU tables WITHOUT replicating the result: owner o keeps the keys with owner_of(hash) == o
+    in `shard`, and lookups through `shard` (polishing, Table.lookup) read the owner's HBM directly -- their own, or a
+    peer's over xGMI (IPC-mapped).  Per rank: one pass over `local` (export grouped by owner), ONE all_to_all of 16-byte
+    entries (the reduce-scatter half of merge_tables), add what arrived -- nothing is all-gathered and no rank ever holds
+    more than 1/world of the keys, so the cost per GPU does not grow with the number of GPUs and the table of configs[3]/[4]
+    fits.  `shard` keeps its size from call to call (it only ever grows), so repeated calls do not rehash.
+
+    Collective: every rank calls it with its own `local` (counts of its read shard) and `shard` (same k).  Afterwards
+    `local` is unchanged.  Returns the number of entries this rank received (its own included).
+    """
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        raise RuntimeError("shard_tables needs an initialised process group of more than one rank")
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    # 1. my entries grouped by owner: one pass over the local table.  Row length from an estimate agreed by all ranks
+    #    (owners are a hash of the key: rows are even), exact sizes on the rare overflow.  libjasper_hip works on its own
+    #    HIP stream: torch memory must be idle before it is handed over, hence empty() + synchronize, never zeros()
+    est = torch.tensor([int(local.info()["distinct"] / world * 1.05) + (1 << 16)], dtype=torch.int64, device=device)
+    dist.all_reduce(est, op=dist.ReduceOp.MAX, group=group)
+    mx = int(est.item())
+    send = torch.empty((world, mx, 2), dtype=torch.int64, device=device)
+    _sync(device)
+    counts = local.export_owner(send.data_ptr(), mx, world)
+    ct = torch.tensor(counts, dtype=torch.int64, device=device)
+    allc = [torch.zeros_like(ct) for _ in range(world)]
+    dist.all_gather(allc, ct, group=group)
+    allc = torch.stack(allc).cpu()                     # allc[src][dst]
+    if int(allc.max().item()) > mx:                    # (every rank sees the same matrix and takes the same branch)
+        mx = int(allc.max().item())
+        del send
+        send = torch.empty((world, mx, 2), dtype=torch.int64, device=device)
+        _sync(device)
+        local.export_owner(send.data_ptr(), mx, world)
+    _sync(device)                                      # (device-wide: every rank has also finished reading the old shards)
+    recv = _all_to_all_rows(send, group)
+    _sync(device)
+    del send
+    # 2. my shard: empty it (after the exchange -- no peer still reads it), add what arrived
+    shard.clear()
+    incoming = int(allc[:, rank].sum().item())
+    shard.reserve(incoming)                            # a first guess (keys shared between sources make it generous)
+    for src in range(world):
+        n = int(allc[src][rank])
+        if n:
+            shard.import_packed(recv[src].data_ptr(), n, 0)
+    del recv
+    # 3. one geometry for all owners, then (re)attach if any slot array moved
+    slots = torch.tensor([shard.info()["slots"]], dtype=torch.int64, device=device)
+    dist.all_reduce(slots, op=dist.ReduceOp.MAX, group=group)
+    shard.reserve(int(slots.item()))
+    shard.sync()
+    handle = shard.ipc_handle()
+    sig = (handle, shard.info()["slots"])
+    changed = torch.tensor([0 if getattr(shard, "_attached_sig", None) == sig else 1], dtype=torch.int64, device=device)
+    dist.all_reduce(changed, op=dist.ReduceOp.MAX, group=group)
+    if int(changed.item()):
+        mine = torch.frombuffer(bytearray(handle), dtype=torch.uint8).to(device)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        handles = [bytes(p.cpu().numpy().tobytes()) for p in parts]
+        ok = 1
+        why = ""
+        try:
+            shard.attach_ipc(handles, rank)
+        except RuntimeError as e:                      # collective decision: either every rank is attached or none
+            ok, why = 0, str(e)
+        okt = torch.tensor([ok], dtype=torch.int64, device=device)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
+        if not int(okt.item()):
+            shard.detach()
+            shard._attached_sig = None
+            raise ShardAttachError("owner-sharded table: mapping the peers' slot arrays failed on some rank" + (": " + why if why else ""))
+        shard._attached_sig = sig
+    # 4. nobody reads a shard before every owner has finished writing its own
+    _sync(device)
+    dist.barrier(group=group)
+    return incoming
+
+
+def histogram_sharded(shard, device, group=None):
+    """histogram of an owner-sharded table: every owner bins its own keys, the 10002 bins are summed over ranks"""
+    import torch
+    import torch.distributed as dist
+    h = torch.tensor(shard.histogram(), dtype=torch.int64, device=device)
+    dist.all_reduce(h, group=group)
+    return [int(x) for x in h.tolist()]
+
+
 def histogram_merged(table, device, group=None):
     """histogram of a table that merge_tables has made identical on all ranks: every rank bins the key range it owns
     (1/world of a table pass), the 10002 bins are summed over ranks"""

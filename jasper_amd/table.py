@@ -274,6 +274,34 @@ class KmerTable:
     def reserve(self, min_slots):
         check(self._L.jasper_table_reserve(self._h, int(min_slots)))
 
+    # ---- owner-sharded table (include/jasper_hip.h, "Owner-sharded table") ----------------------------
+    def export_owner(self, dev_ptr, cap_entries, n_owners):
+        """all entries grouped by owner into device memory (segment o at dev_ptr + o*cap*16); returns the n counts"""
+        counts = (C.c_uint64 * int(n_owners))()
+        check(self._L.jasper_table_export_owner(self._h, C.c_void_p(dev_ptr), int(cap_entries), int(n_owners), counts))
+        return [int(c) for c in counts]
+
+    def ipc_handle(self):
+        buf = C.create_string_buffer(64)
+        check(self._L.jasper_table_ipc_handle(self._h, buf))
+        return buf.raw
+
+    def attach_ipc(self, handles, self_index):
+        """handles: list of 64-byte IPC handles in owner order (the entry at self_index is not used)"""
+        blob = b"".join(bytes(h) for h in handles)
+        assert len(blob) == 64 * len(handles)
+        check(self._L.jasper_table_attach_ipc(self._h, blob, len(handles), int(self_index)))
+
+    def attach_tables(self, shards, self_index):
+        """shards: the owners' Table objects (same process, same device) in owner order"""
+        arr = (C.c_void_p * len(shards))(*[t._h for t in shards])
+        check(self._L.jasper_table_attach_tables(self._h, arr, len(shards), int(self_index)))
+        self._shard_refs = list(shards)      # keep the owners alive while their slot arrays are read through this table
+
+    def detach(self):
+        check(self._L.jasper_table_detach(self._h))
+        self._shard_refs = None
+
     def import_device(self, dev_ptr, n):
         check(self._L.jasper_table_import_device(self._h, C.c_void_p(dev_ptr), int(n)))
 

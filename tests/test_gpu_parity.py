@@ -159,11 +159,11 @@ def test_merge_by_export_import_is_keywise_sum(KT, O):
     tb.close()
 
 
-def test_packed_partition_exchange_primitives(KT, O):
+@pytest.mark.parametrize("k", [37, 25])      # both layouts of the 16-byte exchange entry (count beside / above the hash)
+def test_packed_partition_exchange_primitives(KT, O, k):
     """the pieces of dist.merge_tables on one GPU: slot-range partitions are a disjoint cover; add-import sums; set-import
     overwrites partial counts with final ones"""
     import torch
-    k = 37
     _, reads, _ = workload(23, 120_000, k)
     cut = reads.index(b"N", len(reads) // 2) + 1
     ta, tb, full = KT(k, min_slots=1 << 21), KT(k, min_slots=1 << 21), KT(k, min_slots=1 << 21)
