@@ -5,15 +5,16 @@
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One STEP = one pass of the whole hot path over one batch of synthetic input that is already resident in HBM:
-    new table -> count canonical 37-mers of the read shard (K1+K2) -> [N>1: key-wise merge of the per-GPU tables
-    over RCCL] -> histogram (K3) -> threshold (src/jellyfish.py) -> P fixing passes + 1 QV pass over this rank's
+    new table -> count canonical 37-mers of the read shard (K1+K2) -> [N>1: key-wise sum of the per-GPU tables
+    over RCCL, the result kept key-sharded over the GPUs] -> histogram (K3) -> threshold (src/jellyfish.py) -> P fixing passes + 1 QV pass over this rank's
     chunk records (K4-K6) -> polished text (left in HBM, like the inputs) + fix records and QV counters on the host.
 After the timed region the same polish call is repeated with host buffers in and out (`polish_host_io_ms`, the
 PCIe-inclusive figure) and its text is compared with the HBM-resident result.
 Workload at N=1 = BASELINE.json configs[1]: "human chr21"-sized synthetic genome (47 Mb) + 30x 150-bp reads, k=37,
 2 passes, chunked as `jasper.sh -t 16` would (BATCH_SIZE = int(47e6/16*.9)).  For N>1 the genome, the reads and
 the assembly grow with N (weak scaling): every rank counts 1/N of the reads of the N x 47 Mb genome and polishes
-its share of the chunks, with the table merge in between.
+its share of the chunks, with the exchange in between: one all_to_all sends every (key, count) to the key's owner GPU,
+and the polishing kernels then read each key from its owner's HBM (their own, or a peer's over xGMI).
 
 Prints ONE JSON line (rank 0). `value` = assembly bases polished per second of whole-job wall time (Mbp/s);
 the counting rate, the polishing-only rate, the roofline of the dominant kernel (count_kernel, HIP-event timed
@@ -70,7 +71,8 @@ def build_workload(torch, dev, rank, world, genome_mb, seed):
     return reads, names, seqs, (d_asm, offs), len(asm), bs, hi - lo
 
 
-def one_step(torch, dev_index, table, reads, d_chunks, world, timers):
+def one_step(torch, dev_index, table, reads, d_chunks, world, timers, shard=None):
+    """shard: this rank's owner table when the merged table is kept key-sharded over the GPUs (N>1), else None"""
     from jasper_amd import polisher, dist as jdist
     t0 = time.perf_counter()
     table.clear()          # a step starts from an empty table (zeroing 16 B/slot is part of the timed path)
@@ -83,11 +85,17 @@ def one_step(torch, dev_index, table, reads, d_chunks, world, timers):
     stages, part_launches = table.count_stages()
     merged = 0
     if world > 1:
-        merged = jdist.merge_tables(table, torch.device("cuda", dev_index))
-        table.sync()
+        if shard is not None:    # one all_to_all: owner o ends up with the summed counts of the keys it owns
+            merged = jdist.shard_tables(table, shard, torch.device("cuda", dev_index))
+        else:                    # reduce-scatter + all-gather: the merged table on every GPU
+            merged = jdist.merge_tables(table, torch.device("cuda", dev_index))
+            table.sync()
     t2 = time.perf_counter()
-    if world > 1:      # every rank bins the key range it owns, the bins are summed over ranks
-        h = jdist.histogram_merged(table, torch.device("cuda", dev_index))
+    if world > 1:      # every rank bins the keys it owns, the bins are summed over ranks
+        if shard is not None:
+            h = jdist.histogram_sharded(shard, torch.device("cuda", dev_index))
+        else:
+            h = jdist.histogram_merged(table, torch.device("cuda", dev_index))
         rows = [(m, h[m]) for m in range(1, 10002) if h[m]]
     else:
         rows = table.histo_rows()
@@ -96,13 +104,16 @@ def one_step(torch, dev_index, table, reads, d_chunks, world, timers):
         raise RuntimeError("synthetic histogram has no usable local minimum (threshold script would abort)")
     thr = int(txt)
     t3 = time.perf_counter()
-    res = table.polish_batch_device(d_chunks[0], d_chunks[1], thr, PASSES, fix=True)   # returns when the GPU is done
+    lookup_table = shard if shard is not None else table      # (sharded: lookups read the owner's HBM, own or peer)
+    res = lookup_table.polish_batch_device(d_chunks[0], d_chunks[1], thr, PASSES, fix=True)   # returns when the GPU is done
     t4 = time.perf_counter()
     info = table.info()
     timers.append(dict(count=t1 - t0, clear=t0b - t0, merge=t2 - t1, histo=t3 - t2, polish=t4 - t3, kernel_ms=kms, launches=launches, stages=stages, part_launches=part_launches,
                        polish_dev=res.seconds, thr=thr, qv=res.qv, nfix=res.n_records, merged=merged,
                        distinct=info["distinct"], occurrences=info["occurrences"], slots=info["slots"], lookups=res.lookups,
-                       segments=res.segments, respeculated=res.respeculated))
+                       segments=res.segments, respeculated=res.respeculated,
+                       shard_distinct=shard.info()["distinct"] if shard is not None else None,
+                       shard_slots=shard.info()["slots"] if shard is not None else None))
     return res
 
 
@@ -145,6 +156,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: all ranks share GPU 0")
+    ap.add_argument("--table", choices=("auto", "sharded", "replicated"), default="auto",
+                    help="N>1: keep the merged table key-sharded over the GPUs (lookups read the owner's HBM over xGMI) or replicate "
+                         "it on every GPU; auto = sharded, replicated only if the peers' memory cannot be mapped")
     a = ap.parse_args()
 
     import torch
@@ -172,10 +186,13 @@ def main():
 
     reads, names, seqs, d_chunks, asm_len, bs, nreads = build_workload(torch, dev, rank, world, a.genome_mb, a.seed)
     # size hint like jasper.sh: JF_SIZE = FASTQ bytes / 10 (src/jasper.sh:82); FASTQ ~ 2.1 bytes per base
-    jf_size = int(nreads * world * READ_LEN * 2.1 / 10)
+    from jasper_amd import KmerTable, dist as jdist
+    sharded = world > 1 and a.table != "replicated"
+    # (a sharded run's local table only ever holds this rank's read shard; a replicated one holds everything)
+    jf_size = int(nreads * (1 if sharded else world) * READ_LEN * 2.1 / 10)
     min_slots = max(1 << 21, int(1.25 * jf_size))
-    from jasper_amd import KmerTable
     table = KmerTable(K, min_slots=min_slots, device=local)   # allocated once, like the reference's -s sized hash
+    shard = KmerTable(K, min_slots=1 << 21, device=local) if sharded else None   # grows to its size in the first warm-up step
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -184,22 +201,41 @@ def main():
         torch.cuda.synchronize(dev)
 
     timers = []
-    for _ in range(a.warmup):
-        one_step(torch, local, table, reads, d_chunks, world, timers)
+
+    def step():
+        nonlocal shard
+        try:
+            return one_step(torch, local, table, reads, d_chunks, world, timers, shard)
+        except jdist.ShardAttachError as e:     # raised on every rank together
+            if a.table == "sharded":
+                raise
+            if rank == 0:
+                sys.stderr.write("bench.py: %s -- replicating the merged table instead\n" % e)
+            shard.close()
+            shard = None
+            table.reserve(max(1 << 21, int(1.25 * nreads * world * READ_LEN * 2.1 / 10)))
+            return one_step(torch, local, table, reads, d_chunks, world, timers, None)
+
+    for i in range(a.warmup):
+        step()
+        if i == 0 and shard is not None:
+            # the size hint (FASTQ bytes / 10, as jasper.sh passes to `jellyfish count -s`) is low for a read shard of an
+            # N times larger genome, and growing on demand overshoots: settle the local table at load <= 1/2 once
+            table.fit(0.5)
     timers.clear()
     barrier()
     t0 = time.perf_counter()
     res = None
     for _ in range(a.steps):
         res = None          # the consumer is done with the previous batch's result before the next batch starts
-        res = one_step(torch, local, table, reads, d_chunks, world, timers)
+        res = step()
     barrier()
     dt = time.perf_counter() - t0
     # untimed: the same batch with host buffers in and out (PCIe-inclusive), and a check that both give the same text
     host_ms = []
     for _ in range(3):
         th = time.perf_counter()
-        res_h = table.polish_batch(seqs, timers[-1]["thr"], PASSES, fix=True)
+        res_h = (shard if shard is not None else table).polish_batch(seqs, timers[-1]["thr"], PASSES, fix=True)
         host_ms.append((time.perf_counter() - th) * 1e3)
     same_text = all(bytes(res.seq_view(i)) == bytes(res_h.seq_view(i)) for i in range(len(seqs)))
     if not same_text or res.qv != res_h.qv or res.n_records != res_h.n_records:
@@ -242,7 +278,13 @@ def main():
                                "chunked as jasper.sh -t %d (BATCH_SIZE %d)" % ("configs[1] chr21-sized" if a.genome_mb == 47.0 else "custom size", a.genome_mb, world, COVERAGE, READ_LEN, K, PASSES,
                                                                                THREADS_FOR_BATCH_RULE, bs),
                    "chunks_per_gpu": len(seqs), "reads_per_gpu": nreads, "table_slots": T["slots"], "distinct_kmers": T["distinct"],
-                   "threshold": T["thr"], "parallelism": "read shards + chunk shards, table merge over RCCL" if world > 1 else "single GPU"},
+                   "threshold": T["thr"],
+                   "parallelism": "single GPU" if world == 1 else
+                                  "read shards + chunk shards; counts summed by key owner in one all_to_all over RCCL" if shard is not None else
+                                  "read shards + chunk shards; table merge (reduce-scatter + all-gather by key range) over RCCL",
+                   "table": "whole" if world == 1 else
+                            "owner-sharded: each GPU keeps 1/N of the keys (%d keys in %d slots here), lookups read the owner's HBM over xGMI"
+                            % (T["shard_distinct"], T["shard_slots"]) if shard is not None else "replicated on every GPU"},
         "kmers_counted_Gk_per_s": round(kmers_rank * world / mean("count") / 1e9, 3),
         "polish_only_Mbp_per_s": round(asm_total / 1e6 / mean("polish"), 3),
         "phase_ms": {k: round(mean(k) * 1e3, 2) for k in ("clear", "count", "merge", "histo", "polish")},
@@ -272,6 +314,9 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Mbp/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     if world > 1:
+        barrier()           # nobody frees a shard that a peer may still be reading
+        if shard is not None:
+            shard.close()
         dist.barrier()
         dist.destroy_process_group()
 

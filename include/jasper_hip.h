@@ -109,6 +109,8 @@ int jasper_table_export_packed(jasper_table *t, void *d_dst, uint64_t cap_entrie
 int jasper_table_import_packed(jasper_table *t, const void *d_src, uint64_t n_entries, int mode);
 /* grow to at least min_slots slots (ranks agree on one geometry before exchanging slot-range partitions) */
 int jasper_table_reserve(jasper_table *t, uint64_t min_slots);
+/* rehash into the smallest slot count that holds the present keys at a load of at most max_load (0.05 .. 0.9); may shrink */
+int jasper_table_fit(jasper_table *t, double max_load);
 
 /* Owner-sharded table ("keep the table key-sharded and route lookups").  Instead of replicating the merged
  * table on every GPU, owner o of n keeps ONLY the keys with jasper_owner_of(hash) == o, and every lookup -- the polishing

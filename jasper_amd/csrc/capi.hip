@@ -230,6 +230,7 @@ int jasper_table_import_packed(jasper_table *t, const void *d_src, uint64_t n_en
 }
 int jasper_table_reserve(jasper_table *t, uint64_t min_slots) { return t->t.reserve(min_slots, g_err); }
 
+int jasper_table_fit(jasper_table *t, double max_load) { return t->t.fit(max_load, g_err); }
 int jasper_table_export_owner(jasper_table *t, void *d_dst, uint64_t cap_entries, uint32_t n_owners, uint64_t *counts) {
     if (!counts) { g_err = "counts is null"; return JASPER_ERR; }
     return t->t.export_owner(d_dst, cap_entries, n_owners, counts, g_err);

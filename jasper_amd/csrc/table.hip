@@ -575,6 +575,27 @@ int Table::read_stats(std::string &err) {
 int Table::grow(int new_s, std::string &err) {
     if (new_s > d.B) new_s = d.B;
     if (new_s <= d.s) return 0;
+    return resize(new_s, err);
+}
+
+// smallest table that holds the present keys at a load of at most max_load (never below the tag format's minimum): an
+// owner's shard is sized from a guess before its keys arrive and cut to size once, after the first exchange
+int Table::fit(double max_load, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
+    if (read_stats(err)) return -1;
+    if (!(max_load > 0.05 && max_load <= 0.9)) { err = "fit: load must be in (0.05, 0.9]"; return -1; }
+    int ns = min_log2_slots(k);
+    while ((double)h_stats[ST_DISTINCT] > max_load * (double)(1ull << ns) && ns < d.B) ++ns;
+    if (ns == d.s) return 0;
+    histo_cached = false;
+    if (resize(ns, err)) return -1;
+    return after_batch(err);      // (a rehash into fewer slots may spill; that path grows again)
+}
+
+// rehash into 2^new_s slots (more or fewer than now)
+int Table::resize(int new_s, std::string &err) {
+    if (new_s == d.s) return 0;
     detach_shards();      // the slot array moves and its geometry changes: the owners have to agree and attach again
     if (slots_dirty) {   // logically empty: nothing to rehash, the new slot array stays lazily cleared as well
         unsigned long long *ns = nullptr;

@@ -272,7 +272,9 @@ struct Table {
     int materialize(std::string &err) { if (!slots_dirty) return 0; slots_dirty = false; return zero_slots(d.slots, nslots, err); }
     int clear(std::string &err);
     int ensure_capacity(uint64_t upcoming_kmers, std::string &err);
-    int grow(int new_s, std::string &err);            // rehash into 2^new_s slots
+    int grow(int new_s, std::string &err);            // rehash into 2^new_s slots if that is more than now
+    int resize(int new_s, std::string &err);
+    int fit(double max_load, std::string &err);
     int after_batch(std::string &err);                // spill / fatal / growth handling
     int count_device(const uint8_t *d_bases, uint64_t n, std::string &err);
     int count_host(const char *bases, uint64_t n, std::string &err);

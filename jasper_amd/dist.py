@@ -220,12 +220,17 @@ def shard_tables(local, shard, device, group=None):
     # 2. my shard: empty it (after the exchange -- no peer still reads it), add what arrived
     shard.clear()
     incoming = int(allc[:, rank].sum().item())
-    shard.reserve(incoming)                            # a first guess (keys shared between sources make it generous)
+    first = not getattr(shard, "_fitted", False)
+    if first:
+        shard.reserve(2 * incoming)                    # a guess that never has to grow (sources share keys: generous)
     for src in range(world):
         n = int(allc[src][rank])
         if n:
             shard.import_packed(recv[src].data_ptr(), n, 0)
     del recv
+    if first:                                          # ... cut to size once; later calls reuse the slot array as it is
+        shard.fit(0.5)
+        shard._fitted = True
     # 3. one geometry for all owners, then (re)attach if any slot array moved
     slots = torch.tensor([shard.info()["slots"]], dtype=torch.int64, device=device)
     dist.all_reduce(slots, op=dist.ReduceOp.MAX, group=group)

@@ -274,6 +274,9 @@ class KmerTable:
     def reserve(self, min_slots):
         check(self._L.jasper_table_reserve(self._h, int(min_slots)))
 
+    def fit(self, max_load=0.5):
+        check(self._L.jasper_table_fit(self._h, float(max_load)))
+
     # ---- owner-sharded table (include/jasper_hip.h, "Owner-sharded table") ----------------------------
     def export_owner(self, dev_ptr, cap_entries, n_owners):
         """all entries grouped by owner into device memory (segment o at dev_ptr + o*cap*16); returns the n counts"""

@@ -126,6 +126,22 @@ def test_growing_an_attached_table_detaches_it(KT):
         t.close()
 
 
+def test_fit_cuts_an_oversized_table_to_size(KT):
+    k = 37
+    _, reads, asm = workload(11, 100_000, k)
+    t = KT(k, min_slots=1 << 24)
+    t.count_bases(reads)
+    qs = [asm[i:i + k] for i in range(0, 20_000, 3)]
+    want, h, d = t.lookup(qs), t.histogram(), t.info()["distinct"]
+    t.fit(0.5)
+    slots = t.info()["slots"]
+    assert slots < (1 << 24) and d <= 0.5 * slots and (d > 0.25 * slots or slots == 1 << 21)
+    assert t.info()["distinct"] == d and t.lookup(qs) == want and t.histogram() == h
+    t.fit(0.5)                                    # already fitting: nothing moves
+    assert t.info()["slots"] == slots
+    t.close()
+
+
 # ---- two processes, IPC-mapped peers -------------------------------------------------------------------------------
 def _free_port():
     s = socket.socket()
