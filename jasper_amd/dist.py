@@ -2,11 +2,15 @@
 
 What shards and what is exchanged:
   * reads are independent units and counts form a commutative monoid (sum by key)  ->  every rank counts its own
-    shard of the reads into its own HBM table; the per-GPU tables are then merged KEY-WISE.  Per-GPU open-addressed
-    tables do not share slot positions, so a dense all-reduce over raw tables would be wrong; instead every rank
-    exports its (mixed hash, count) entries, the entry lists are all-gathered (equal-size padded buffers, one
-    collective that uses every xGMI link), and each rank re-inserts the other ranks' entries into its own table.
-    This is the role of `jellyfish merge` (JF::jellyfish/merge_files.cc:44-176) in the reference's tool set.
+    shard of the reads into its own HBM table; the per-GPU tables are then summed KEY-WISE.  Per-GPU open-addressed
+    tables do not share slot positions, so a dense all-reduce over raw tables would be wrong.  Two ways to do it:
+      shard_tables  (default for N>1)  every key has an OWNER GPU (a hash of the key); one all_to_all sends each rank's
+                    (mixed hash, count) entries to their owners, who add them up.  The sum stays key-sharded: the
+                    polishing kernels read a key from its owner's HBM -- their own or, IPC-mapped, a peer's over xGMI.
+                    Cost per GPU independent of the number of GPUs; the table of configs[3]/[4] fits.
+      merge_tables  the same reduce-scatter followed by an all-gather: every GPU ends up with the whole merged table
+                    (what `jellyfish merge`, JF::jellyfish/merge_files.cc:44-176, would leave on disk).  Cost per GPU
+                    grows with the number of GPUs; kept for runs where the peers' memory cannot be mapped.
   * chunk records are independent (the reference's own xargs -P parallelism, src/jasper.sh:212)  ->  greedy
     size-balanced assignment of chunks to ranks; nothing is exchanged except two integers per rank for the QV.
 
@@ -236,21 +240,24 @@ def shard_tables(local, shard, device, group=None):
     dist.all_reduce(slots, op=dist.ReduceOp.MAX, group=group)
     shard.reserve(int(slots.item()))
     shard.sync()
-    handle = shard.ipc_handle()
+    ok, why = 1, ""
+    try:
+        handle = shard.ipc_handle()
+    except RuntimeError as e:                          # (decided collectively below: a rank must not leave the others waiting)
+        handle, ok, why = bytes(64), 0, str(e)
     sig = (handle, shard.info()["slots"])
-    changed = torch.tensor([0 if getattr(shard, "_attached_sig", None) == sig else 1], dtype=torch.int64, device=device)
+    changed = torch.tensor([0 if ok and getattr(shard, "_attached_sig", None) == sig else 1], dtype=torch.int64, device=device)
     dist.all_reduce(changed, op=dist.ReduceOp.MAX, group=group)
     if int(changed.item()):
         mine = torch.frombuffer(bytearray(handle), dtype=torch.uint8).to(device)
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine, group=group)
         handles = [bytes(p.cpu().numpy().tobytes()) for p in parts]
-        ok = 1
-        why = ""
-        try:
-            shard.attach_ipc(handles, rank)
-        except RuntimeError as e:                      # collective decision: either every rank is attached or none
-            ok, why = 0, str(e)
+        if ok:
+            try:
+                shard.attach_ipc(handles, rank)
+            except RuntimeError as e:                  # either every rank is attached or none
+                ok, why = 0, str(e)
         okt = torch.tensor([ok], dtype=torch.int64, device=device)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
         if not int(okt.item()):

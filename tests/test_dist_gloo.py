@@ -56,3 +56,144 @@ def test_entry_exchange_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True, 12), (1, True, 5)]
+
+
+# ---- dist.shard_tables: the collective protocol, with a dict standing in for the HBM table -----------------------------
+class FakeTable:
+    """the methods dist.shard_tables calls, over host memory: entries are (key, 0 | count) int64 pairs, owner = key % n"""
+
+    def __init__(self, fail_attach=False, tag=0):
+        self.d = {}
+        self.slots = 1 << 4
+        self.attached = None
+        self.fail_attach = fail_attach
+        self.tag = tag
+        self.handle_epoch = 0
+        self.calls = []
+
+    @staticmethod
+    def _view(ptr, n):
+        import ctypes
+        import numpy as np
+        return np.ctypeslib.as_array((ctypes.c_int64 * (2 * n)).from_address(ptr)).reshape(n, 2)
+
+    def info(self):
+        return {"distinct": len(self.d), "slots": self.slots}
+
+    def export_owner(self, ptr, cap, n):
+        groups = [[(k, c) for k, c in sorted(self.d.items()) if k % n == o] for o in range(n)]
+        if cap:
+            v = self._view(ptr, n * cap)
+            for o, g in enumerate(groups):
+                for i, (k, c) in enumerate(g[:cap]):
+                    v[o * cap + i] = (k, c)
+        return [len(g) for g in groups]
+
+    def clear(self):
+        self.d = {}
+
+    def sync(self):
+        pass
+
+    def reserve(self, min_slots):
+        while self.slots < min_slots:
+            self.slots *= 2
+            self.handle_epoch += 1            # a moved slot array has a new handle
+
+    def fit(self, load):
+        want = 16
+        while len(self.d) > load * want:
+            want *= 2
+        if want != self.slots:
+            self.slots = want
+            self.handle_epoch += 1
+
+    def import_packed(self, ptr, n, mode):
+        assert mode == 0
+        for k, c in self._view(ptr, n):
+            self.d[int(k)] = self.d.get(int(k), 0) + int(c)
+        while len(self.d) > 0.5 * self.slots:     # grows like the real table
+            self.slots *= 2
+            self.handle_epoch += 1
+
+    def ipc_handle(self):
+        return bytes([self.tag, self.handle_epoch % 256]) + bytes(62)
+
+    def attach_ipc(self, handles, me):
+        self.calls.append("attach")
+        if self.fail_attach:
+            raise RuntimeError("no peer access")
+        self.attached = [h[:2] for h in handles]
+
+    def detach(self):
+        self.attached = None
+
+
+def _shard_worker(rank, world, port, q, fail_on):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from jasper_amd import dist as jd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        local, shard = FakeTable(), FakeTable(fail_attach=(rank == fail_on), tag=rank + 1)
+        out = []
+        for step in range(3):
+            # rank r holds keys r*5 .. r*5+n-1 (overlapping between ranks), uneven sizes, step 1 overflows the row estimate
+            if step == 1 and rank == 1:
+                local.d = {2 * k: 3 for k in range(200000)}        # all owned by rank 0: more than the agreed row length
+            else:
+                n = 40 if rank == 0 else 9
+                local.d = {k: (k % 7) + 1 + step for k in range(rank * 5, rank * 5 + n)}
+            try:
+                got = jd.shard_tables(local, shard, dev)
+            except jd.ShardAttachError:
+                out.append("attach-failed")
+                continue
+            out.append((got, dict(shard.d) if len(shard.d) < 100 else len(shard.d), shard.slots, list(shard.attached), list(shard.calls)))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_shard(fail_on):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_shard_worker, args=(r, 2, port, q, fail_on)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_shard_tables_protocol_world2():
+    res = _run_shard(fail_on=-1)
+    for step in (0, 2):
+        exp = {}
+        for r in range(2):
+            n = 40 if r == 0 else 9
+            for k in range(r * 5, r * 5 + n):
+                exp[k] = exp.get(k, 0) + (k % 7) + 1 + step
+        for r in range(2):
+            got, d, slots, attached, calls = res[r][step]
+            assert d == {k: c for k, c in exp.items() if k % 2 == r}          # owner r holds exactly its keys, summed
+            assert got == sum(1 for rr in range(2) for k in range(rr * 5, rr * 5 + (40 if rr == 0 else 9)) if k % 2 == r)
+    # step 1: the row estimate (from the local sizes) was too small for rank 1's table -> exact resend, nothing lost
+    assert res[0][1][1] == 200000 and res[1][1][1] == {k: (k % 7) + 2 for k in range(40) if k % 2}
+    # one geometry on both owners at every step; re-attached exactly when a slot array moved (steps 0 and 1, not step 2)
+    for step in range(3):
+        assert res[0][step][2] == res[1][step][2]
+        assert res[0][step][3] == res[1][step][3]                                 # both ranks hold the same handle list
+    assert res[0][0][4] == ["attach"] and len(res[0][1][4]) == 2 and len(res[0][2][4]) == 2   # nothing moved in step 2: no re-attach
+
+
+def test_shard_tables_attach_failure_is_collective():
+    res = _run_shard(fail_on=1)
+    assert res[0] == ["attach-failed"] * 3 and res[1] == ["attach-failed"] * 3      # both ranks raise together, nobody hangs
