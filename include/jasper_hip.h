@@ -65,6 +65,9 @@ void jasper_table_destroy(jasper_table *t);
 /* the table as a Jellyfish "binary/sorted" database: what `jellyfish count -o mer_counts$K.jf` leaves behind
  * (src/jasper.sh:177; format JF::include/jellyfish/file_header.hpp:26-108, binary_dumper.hpp:36-40,148-199), readable by
  * jellyfish 2.3.0 query/dump/histo, QueryMerFile and jasper_table_load_jf.  cmdline[] is recorded in the header. */
+/* records [n*part/nparts, n*(part+1)/nparts) of the database only: one GPU's shard of an existing DB (dist.shard_tables
+ * then routes every key to its owner) */
+int jasper_table_load_jf_part(const char *path, int device, uint32_t part, uint32_t nparts, jasper_table **out);
 int jasper_table_write_jf(jasper_table *t, const char *path, const char *const *cmdline, int n_cmdline);
 /* test hook (host arithmetic only, no GPU): the table's bijective k-mer hash (inverse = 0) or its inverse (1) */
 int jasper_debug_mix(int k, int inverse, uint64_t hi, uint64_t lo, uint64_t out2[2]);
@@ -79,6 +82,11 @@ int jasper_count_bases(jasper_table *t, const char *bases, uint64_t n);
 int jasper_count_bases_device(jasper_table *t, const void *d_bases, uint64_t n);
 int jasper_count_reads_text(jasper_table *t, const char *text, uint64_t n);
 int jasper_count_reads_files(jasper_table *t, const char *const *paths, int n_paths);
+/* the same over a byte range [begins[i], ends[i]) of every file (ends[i] < 0: to its end) -- one GPU's shard of the reads.
+ * Ranges must start at record boundaries (jasper_amd/dist.py plan_read_shards finds them); a gzip file cannot be cut: it
+ * is read whole if its range starts at 0 and skipped otherwise.  Counts are sums over reads, so the shards' tables add up
+ * to the table of the whole input. */
+int jasper_count_reads_file_ranges(jasper_table *t, const char *const *paths, const int64_t *begins, const int64_t *ends, int n_paths);
 
 /* of the last jasper_count_reads_files call: text bytes parsed by the GPU kernels / by the host state machine (the
  * fallback for multi-line records, DOS line ends, malformed input and stream tails) */

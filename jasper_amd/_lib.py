@@ -38,6 +38,8 @@ SYMBOLS = {
     "jasper_count_bases_device": (C.c_int, [_P, _P, C.c_uint64]),
     "jasper_count_reads_text": (C.c_int, [_P, C.c_char_p, C.c_uint64]),
     "jasper_count_reads_files": (C.c_int, [_P, C.POINTER(C.c_char_p), C.c_int]),
+    "jasper_count_reads_file_ranges": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
+    "jasper_table_load_jf_part": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "jasper_table_write_jf": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]),
     "jasper_debug_mix": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "jasper_last_ingest": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

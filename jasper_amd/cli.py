@@ -44,7 +44,12 @@ def _timing(label):
     _T0[0] = now
 
 
+_QUIET = [False]      # multi-GPU runs: only rank 0 talks
+
+
 def log(msg):  # :30-33
+    if _QUIET[0]:
+        return
     d = datetime.datetime.now().astimezone().strftime("%a %b %d %H:%M:%S %Z %Y")
     if _tty():
         print("\033[0;32m[%s]\033[0m %s" % (d, msg), flush=True)
@@ -54,7 +59,8 @@ def log(msg):  # :30-33
 
 def error_exit(msg, code=1):  # :35-39
     d = datetime.datetime.now().astimezone().strftime("%a %b %d %H:%M:%S %Z %Y")
-    sys.stderr.write("[%s] %s\n" % (d, msg))
+    if not _QUIET[0]:
+        sys.stderr.write("[%s] %s\n" % (d, msg))
     sys.exit(code)
 
 
@@ -270,8 +276,229 @@ def merge_fix_csvs(csv_files):
     return "".join(out)
 
 
+def _write_histo(path, rows):
+    with open(path + ".tmp", "w") as f:
+        for m, n in rows:
+            f.write("%d %d\n" % (m, n))
+    os.replace(path + ".tmp", path)
+
+
+def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
+    """the stages of run() below with the work of one node's GPUs divided as SURVEY.md 8e says: every rank counts its byte
+    ranges of the read files (or its record range of an existing database) into a local table, dist.shard_tables sums the
+    counts by key owner, and every rank polishes its share of the batch files with lookups served from the owners' HBM.
+    Rank 0 alone splits, joins, writes the histogram / threshold / sentinels and talks; the stage decisions (which
+    sentinels exist) are taken by rank 0 and shared, so that no rank sees a file another one is just creating.
+    Not written in a multi-GPU run: mer_counts$K.jf (no GPU holds the whole table; an existing one, or -j, is read)."""
+    import torch
+    import torch.distributed as tdist
+    from . import dist as jdist
+    is0 = rank == 0
+    last_it = passes - 1
+    qfn = o.query_fn
+
+    def bar():
+        torch.cuda.synchronize(dev)
+        tdist.barrier()
+
+    def decide(cond):
+        return bool(jdist.all_reduce_ints([1 if (is0 and cond()) else 0], device=dev)[0])
+
+    if decide(lambda: not os.path.exists("jasper.split.success")):      # :152-159
+        if is0:
+            log("Splitting query into batches for parallel execution")
+            for p in glob.glob("%s.batch.*.fa" % glob.escape(qfn)):
+                os.remove(p)
+            try:
+                split_batches(read_assembly(o.query), batch_size, qfn)
+            except OSError:
+                error_exit("Splitting files failed, do you have enough disk space?")
+            if os.path.exists("jasper.correct.success"):
+                os.remove("jasper.correct.success")
+            open("jasper.split.success", "w").close()
+        bar()
+
+    histo_file = "jfhisto%d.csv" % kmer
+    counted = False
+    if o.jf_db is None:                                                 # :162-185
+        reads = o.reads.split()
+        for fn in reads:
+            if not (os.path.isfile(fn) and os.path.getsize(fn) > 0):
+                error_exit("The reads file  %s does not exist. Please supply a series of valid reads files separated by space and wrapped in one pair of quotation marks." % fn)
+        jf_file = "mer_counts%d.jf" % kmer
+        if decide(lambda: os.path.isfile(jf_file) and os.path.getsize(jf_file) > 0):     # :171-173
+            log("Using existing jellyfish database %s" % jf_file)
+            if is0 and os.path.exists("jasper.no_cat.success"):
+                os.remove("jasper.no_cat.success")
+            local = KmerTable.from_jf_part(jf_file, rank, world, device=o.device)
+        else:
+            _timing("split")
+            log("Creating jellyfish database mer_counts%d.jf" % kmer)
+            local = KmerTable(kmer, min_slots=max(1 << 20, int(1.25 * o.jf_size / world)), device=o.device)
+            local.count_file_ranges(jdist.plan_read_shards(reads, world)[rank])
+            _timing("count reads (file ranges -> local table)")
+            counted = True
+    else:
+        try:
+            local = KmerTable.from_jf_part(o.jf_db, rank, world, device=o.device)
+        except Exception as e:
+            error_exit("Computing mer counts histogram from %s failed, please make sure that %s is a valid Jellyfish mer counts file (%s)"
+                       % (o.jf_db, o.jf_db, e))
+    # key-wise sum over the GPUs; the result stays sharded by key owner unless the peers' HBM cannot be mapped
+    table = KmerTable(local.k, min_slots=1 << 21, device=o.device)
+    try:
+        jdist.shard_tables(local, table, dev)
+        local.close()
+        h = jdist.histogram_sharded(table, dev)
+    except jdist.ShardAttachError as e:
+        if is0:
+            sys.stderr.write("jasper_amd: %s -- replicating the merged table on every GPU instead\n" % e)
+        table.close()
+        table = local
+        jdist.merge_tables(table, dev)
+        h = jdist.histogram_merged(table, dev)
+    rows = [(m, h[m]) for m in range(1, 10002) if h[m]]
+    _timing("sum counts over the GPUs + histogram")
+    if counted and is0:
+        _write_histo(histo_file, rows)
+        open("jasper.no_cat.success", "w").close()
+        open("jasper.histo.success", "w").close()
+        if os.path.exists("jasper.correct.success"):
+            os.remove("jasper.correct.success")
+    bar()
+
+    if decide(lambda: not os.path.exists("jasper.histo.success") or not (os.path.isfile(histo_file) and os.path.getsize(histo_file) > 0)):   # :187-193
+        log("Computing K-mer histogram")
+        if is0:
+            _write_histo(histo_file, rows)
+            if os.path.exists("jasper.correct.success"):
+                os.remove("jasper.correct.success")
+            open("jasper.histo.success", "w").close()
+        bar()
+
+    if decide(lambda: not os.path.exists("jasper.correct.success")):    # :195-216
+        log("Polishing")
+        if is0:
+            txt, status = polisher.threshold_from_histo_file(histo_file)
+            if status == 0:
+                with open("threshold.txt.tmp", "w") as f:
+                    f.write(txt)
+                os.replace("threshold.txt.tmp", "threshold.txt")
+        bar()
+        if not (os.path.isfile("threshold.txt") and os.path.getsize("threshold.txt") > 0):
+            error_exit("Local min of kmer counts is smaller than 4. The input read data is not suitable for polishing.")
+        thresh = int(open("threshold.txt").read().split()[0])
+        log("Lower threshold for unreliable kmers is %d" % thresh)
+        batch_files = sorted(glob.glob("%s.batch.*.fa" % glob.escape(qfn)))   # `ls` order
+        owner = jdist.assign_chunks([os.path.getsize(bf) for bf in batch_files], world)
+        group, group_bytes = [], 0
+
+        def flush_group():
+            if group:
+                polisher.main_many(group, kmer, True, True, table, thresh, passes)
+                for bf in group:
+                    os.replace("_iter%d_%s.fixed.fa.tmp" % (last_it, bf), "_iter%d_%s.fixed.fa" % (last_it, bf))
+                del group[:]
+        for bf, ow in zip(batch_files, owner):
+            if ow != rank:
+                continue
+            group.append(bf)
+            group_bytes += os.path.getsize(bf)
+            if group_bytes > (1 << 30):
+                flush_group()
+                group_bytes = 0
+        flush_group()
+        bar()
+        if is0:
+            if os.path.exists("jasper.join.success"):
+                os.remove("jasper.join.success")
+            open("jasper.correct.success", "w").close()
+        bar()
+
+    if decide(lambda: not os.path.exists("jasper.join.success")):       # :218-232
+        _timing("polish batches")
+        log("Joining")
+        if is0:
+            _join_and_merge(o, qfn, batch_size, last_it, read_assembly(o.query))
+        bar()
+    if is0:
+        _qv_block(passes, kmer)
+    _timing("join + QV")
+    log("Polished sequence is in %s.polished.fasta" % qfn)
+    bar()                       # nobody frees a shard that a peer may still be reading
+    table.close()
+    bar()
+    tdist.destroy_process_group()
+    return 0
+
+
+def _join_and_merge(o, qfn, batch_size, last_it, contigs):
+    """src/jasper.sh:218-232"""
+    fixed_files = sorted(glob.glob("_iter%d_%s.batch.*.fa.fixed.fa" % (last_it, glob.escape(qfn))))
+    text = join_polished(fixed_files, batch_size, [c[0] for c in contigs])
+    with open(qfn + ".fixed.fasta.tmp", "w") as f:
+        f.write(text)
+    os.replace(qfn + ".fixed.fasta.tmp", qfn + ".polished.fasta")
+    for p in glob.glob("_iter*_%s.batch.*.fa.fixed.fa" % glob.escape(qfn)) + glob.glob("_iter*_%s.batch.*.fa.fixed.fa.tmp" % glob.escape(qfn)):
+        os.remove(p)
+    csvs = sorted(glob.glob("_iter*_%s.batch.*.fa.fix.csv" % glob.escape(qfn)))
+    with open(qfn + ".fixes.csv.tmp", "w", newline="") as f:
+        f.write(merge_fix_csvs(csvs))
+    os.replace(qfn + ".fixes.csv.tmp", qfn + ".fixes.csv")
+    open("jasper.join.success", "w").close()
+    if not o.debug:
+        for p in csvs + glob.glob("%s.batch.*.fa" % glob.escape(qfn)):
+            if os.path.exists(p):
+                os.remove(p)
+
+
+def _qv_block(passes, kmer):
+    """src/jasper.sh:235-257"""
+    def colsum(path):
+        a = b = 0
+        with open(path) as f:
+            for ln in f:
+                F = ln.split()
+                if len(F) >= 2:
+                    a += int(F[0]); b += int(F[1])
+        return a, b
+    if os.path.exists("0qValCalcHelper.csv") and os.path.exists("%dqValCalcHelper.csv" % passes):
+        b0, t0 = colsum("0qValCalcHelper.csv")
+        b1, t1 = colsum("%dqValCalcHelper.csv" % passes)
+        log("Before Polishing: Q value = %s" % qv.q_value(b0, t0, kmer))
+        log("After Polishing: Q value = %s" % qv.q_value(b1, t1, kmer))
+        for p in glob.glob("*qValCalcHelper.csv"):
+            os.remove(p)
+
+
+def _init_multi(o):
+    """one process per GPU under `python -m torch.distributed.run` (RANK / WORLD_SIZE / LOCAL_RANK in the environment):
+    returns (rank, world, torch device) after joining the process group (RCCL; JASPER_AMD_DIST_BACKEND=gloo and
+    JASPER_AMD_ONE_GPU=1 rehearse it on one GPU)"""
+    from . import dist as jdist
+    rank, world, local = jdist.env_world()
+    if world <= 1:
+        return 0, 1, None
+    import torch
+    import torch.distributed as tdist
+    if os.environ.get("JASPER_AMD_ONE_GPU", "") not in ("1", "true", "yes"):
+        o.device = local
+    torch.cuda.set_device(o.device)
+    dev = torch.device("cuda", o.device)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("JASPER_AMD_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        tdist.init_process_group(backend, rank=rank, world_size=world)
+    _QUIET[0] = rank != 0
+    return rank, world, dev
+
+
 def run(argv):
     o = parse_args(argv)
+    rank, world, dev = _init_multi(o)
+    multi = world > 1
     if not (os.path.isfile(o.query) and os.path.getsize(o.query) > 0):
         error_exit("The query file does not exist. Please supply a valid fasta file to be polished with -a option.")
     batch_size = o.batch_size
@@ -298,6 +525,8 @@ def run(argv):
     last_it = passes - 1
     qfn = o.query_fn
     contigs = None
+    if multi:
+        return _run_multi(o, rank, world, dev, batch_size, passes, kmer)
 
     if not os.path.exists("jasper.split.success"):                      # :152-159
         log("Splitting query into batches for parallel execution")

@@ -95,6 +95,23 @@ int jasper_table_load_jf(const char *path, int device, jasper_table **out) {
     return JASPER_OK;
 }
 
+int jasper_table_load_jf_part(const char *path, int device, uint32_t part, uint32_t nparts, jasper_table **out) {
+    if (!out || !path || nparts == 0 || part >= nparts) { g_err = "bad argument"; return JASPER_ERR; }
+    JfHeader h;
+    int rc = jf_read_header(path, h, g_err);
+    if (rc) return rc == -3 ? JASPER_ERR_FORMAT : JASPER_ERR;
+    const uint64_t lo = h.n_records / nparts * part + std::min<uint64_t>(part, h.n_records % nparts);
+    const uint64_t n = h.n_records / nparts + (part < h.n_records % nparts ? 1 : 0);
+    const uint64_t rec = (uint64_t)((h.key_len + 7) / 8) + (uint64_t)h.counter_len;
+    jasper_table *t = nullptr;
+    rc = jasper_table_create(h.key_len / 2, std::max<uint64_t>(1u << 16, 2 * n), device, &t);
+    if (rc) return rc;
+    rc = t->t.load_jf_records(path, h.data_offset + lo * rec, n, h.key_len, h.counter_len, g_err);
+    if (rc) { jasper_table_destroy(t); return rc < -1 ? rc : JASPER_ERR; }
+    *out = t;
+    return JASPER_OK;
+}
+
 int jasper_table_write_jf(jasper_table *t, const char *path, const char *const *cmdline, int n_cmdline) {
     if (!t || !path || n_cmdline < 0 || (n_cmdline && !cmdline)) { g_err = "null argument"; return JASPER_ERR; }
     return t->t.write_jf(path, cmdline, n_cmdline, g_err) ? JASPER_ERR : JASPER_OK;
@@ -150,6 +167,18 @@ int jasper_count_reads_text(jasper_table *t, const char *text, uint64_t n) {
     if (!rc) rc = p.finish();
     if (rc && !p.error().empty()) g_err = p.error();
     return rc;
+}
+
+int jasper_count_reads_file_ranges(jasper_table *t, const char *const *paths, const int64_t *begins, const int64_t *ends, int n_paths) {
+    if (!begins || !ends) { g_err = "null range arrays"; return JASPER_ERR; }
+    t->t.reset_timing();
+    Table *T = &t->t;
+    T->ingest_gpu_bytes = T->ingest_host_bytes = 0;
+    T->ingest_begin = begins;
+    T->ingest_end = ends;
+    const int rc = T->count_files_gpu(paths, n_paths, &T->ingest_gpu_bytes, &T->ingest_host_bytes, g_err);
+    T->ingest_begin = T->ingest_end = nullptr;
+    return rc < -1 ? rc : (rc ? JASPER_ERR : JASPER_OK);
 }
 
 int jasper_count_reads_files(jasper_table *t, const char *const *paths, int n_paths) {

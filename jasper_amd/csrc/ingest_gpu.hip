@@ -169,6 +169,9 @@ __global__ __launch_bounds__(IG_THREADS) void ig_emit_kernel(const uint8_t *__re
 struct Reader {           // the concatenation of all input files as one byte stream (src/jasper.sh:177 `zcat -f $READS`)
     const char *const *paths;
     int n_paths, cur = 0;
+    // optional byte range [begins[i], ends[i]) of plain file i (ends[i] < 0: to the end); a gzip member or a pipe cannot be
+    // cut and is read whole when its range starts at 0 and skipped otherwise (multi-GPU read shards)
+    const int64_t *begins = nullptr, *ends = nullptr;
     gzFile g = nullptr;   // gzip members are inflated by zlib ...
     int fd = -1;          // ... anything else is read as it is (what `zcat -f` does): pread by a few threads, because one
     off_t off = 0, size = 0;   // thread copies out of the page cache at only ~7 GB/s
@@ -185,6 +188,14 @@ struct Reader {           // the concatenation of all input files as one byte st
                 unsigned char magic[2] = {0, 0};
                 const ssize_t m = pread(fd, magic, 2, 0);
                 struct stat st;
+                const int64_t rb = begins ? begins[cur] : 0, re = ends ? ends[cur] : -1;
+                const bool whole = m == 2 && magic[0] == 0x1f && magic[1] == 0x8b ? true : (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode));
+                if ((whole && rb != 0) || (re >= 0 && re <= rb)) {       // not this reader's part of the input
+                    close(fd);
+                    fd = -1;
+                    ++cur;
+                    continue;
+                }
                 if (m == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
                     close(fd);
                     fd = -1;
@@ -197,8 +208,8 @@ struct Reader {           // the concatenation of all input files as one byte st
                     g = gzopen(paths[cur], "rb");
                     if (!g) { err = std::string("cannot open ") + paths[cur]; return -1; }
                 } else {
-                    off = 0;
-                    size = st.st_size;
+                    off = (off_t)std::min<int64_t>(rb, (int64_t)st.st_size);
+                    size = re >= 0 ? (off_t)std::min<int64_t>(re, (int64_t)st.st_size) : st.st_size;
                 }
             }
             long r = 0;
@@ -274,6 +285,8 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
     Reader rd;
     rd.paths = paths;
     rd.n_paths = n_paths;
+    rd.begins = ingest_begin;
+    rd.ends = ingest_end;
     if (!h_ingest || ingest_chunk < CHUNK) {              // kept with the table between calls
         if (h_ingest) (void)hipHostFree(h_ingest);
         h_ingest = nullptr;

@@ -282,6 +282,7 @@ struct Table {
     // (ingest_gpu.hip); reports how many text bytes each parser handled
     int count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_bytes, uint64_t *host_bytes, std::string &err);
     uint64_t ingest_gpu_bytes = 0, ingest_host_bytes = 0;
+    const int64_t *ingest_begin = nullptr, *ingest_end = nullptr;   // per-file byte ranges of the next count_files_gpu call (or null)
     char *h_ingest = nullptr;      // pinned text staging of count_files_gpu
     size_t ingest_chunk = 0;
     int histogram(uint64_t *out10002, std::string &err);

@@ -42,6 +42,92 @@ def assign_chunks(lengths, world):
     return owner
 
 
+def _fastq_record_start(buf):
+    """offset in buf of the first line that starts a 4-line FASTQ record, judged on two consecutive records ('@' / bases /
+    '+' / as many quality symbols as bases, twice): a quality line may start with '@' as well, a header cannot be told from
+    it on its own.  None if the window holds no such place."""
+    starts = []
+    i = buf.find(b"\n")
+    while i >= 0 and len(starts) < 4096:
+        starts.append(i + 1)
+        i = buf.find(b"\n", i + 1)
+    for a in range(len(starts) - 8):
+        L = [buf[starts[a + j]:starts[a + j + 1] - 1] for j in range(8)]
+        if (L[0][:1] == b"@" and L[2][:1] == b"+" and L[4][:1] == b"@" and L[6][:1] == b"+" and len(L[1]) == len(L[3]) and len(L[5]) == len(L[7])
+                and L[1][:1] not in (b"@", b"+", b"") and L[5][:1] not in (b"@", b"+", b"")):
+            return starts[a]
+    return None
+
+
+def plan_read_shards(paths, world):
+    """Which bytes of the read files each rank counts: shards[rank] = [(path, begin, end), ...] (end -1 = to the end).
+
+    The reference counts ONE stream, `zcat -f file1 file2 ...` (src/jasper.sh:177); counts are sums over reads, so the
+    stream may be cut at any record boundary.  Plain files whose first bytes agree ('@' or '>') and which end in a newline
+    are each cut into `world` byte ranges, every cut moved forward to the next record start.  Anything else is not cut:
+    gzip files go whole to one rank each (largest first), and input that only makes sense as one stream (formats that
+    differ between files, a file without a final newline, multi-line FASTQ where no 4-line record start is found) goes
+    whole to rank 0.  Deterministic: every rank computes the same plan."""
+    import gzip
+    info = []
+    for p in paths:
+        with open(p, "rb") as f:
+            magic = f.read(2)
+            size = os.fstat(f.fileno()).st_size
+            gz = magic == b"\x1f\x8b"
+            last = b"\n"
+            if not gz and size:
+                f.seek(size - 1)
+                last = f.read(1)
+        if gz:
+            with gzip.open(p, "rb") as g:
+                first = g.read(1)
+        else:
+            first = magic[:1]
+        info.append((p, size, gz, first, last))
+    everything_to_rank0 = [[(p, 0, -1) for p in paths]] + [[] for _ in range(world - 1)]
+    firsts = {i[3] for i in info if i[1]}
+    if len(firsts) > 1 or not firsts <= {b"@", b">"} or any(i[4] != b"\n" for i in info[:-1]):
+        return everything_to_rank0
+    shards = [[] for _ in range(world)]
+    whole = [i for i in info if i[2]]
+    load = [0] * world
+    for p, size, gz, first, last in info:
+        if gz or not size:
+            continue
+        cuts = [0]
+        with open(p, "rb") as f:
+            for r in range(1, world):
+                target = max(size * r // world, cuts[-1])
+                pos, win = None, 1 << 20
+                while pos is None and target < size:
+                    f.seek(target)
+                    buf = f.read(win)
+                    if first == b">":
+                        j = buf.find(b"\n>")
+                        pos = target + j + 1 if j >= 0 else None
+                    else:
+                        j = _fastq_record_start(buf)
+                        pos = target + j if j is not None else None
+                    if pos is None:
+                        if target + len(buf) >= size:
+                            break
+                        if win >= (64 << 20):
+                            return everything_to_rank0        # no 4-line record start in 64 MB: not a file to cut blindly
+                        win *= 4
+                cuts.append(pos if pos is not None else size)
+        cuts.append(size)
+        for r in range(world):
+            if cuts[r + 1] > cuts[r]:
+                shards[r].append((p, cuts[r], cuts[r + 1]))
+                load[r] += cuts[r + 1] - cuts[r]
+    for p, size, gz, first, last in sorted(whole, key=lambda i: (-i[1], i[0])):
+        r = min(range(world), key=lambda r: (load[r], r))
+        shards[r].append((p, 0, -1))
+        load[r] += 4 * size
+    return shards
+
+
 def all_gather_entries(entries, group=None):
     """entries: int64 tensor [n, 3] (mixed hash hi, lo, count) of THIS rank, on the device the backend works with.
 

@@ -124,6 +124,17 @@ class KmerTable:
         self.k = self.info()["k"]
         return self
 
+    @classmethod
+    def from_jf_part(cls, path, part, nparts, device=0):
+        """records [n*part/nparts, n*(part+1)/nparts) of a Jellyfish DB: one GPU's shard of it"""
+        self = cls.__new__(cls)
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        self.device = int(device)
+        check(self._L.jasper_table_load_jf_part(path.encode(), self.device, int(part), int(nparts), C.byref(self._h)))
+        self.k = self.info()["k"]
+        return self
+
     def write_jf(self, path, cmdline=()):
         """write the table as a Jellyfish binary/sorted DB (what `jellyfish count -o` produces, src/jasper.sh:177)"""
         args = [a.encode() for a in cmdline]
@@ -145,6 +156,14 @@ class KmerTable:
     def count_files(self, paths):
         arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
         check(self._L.jasper_count_reads_files(self._h, arr, len(paths)))
+
+    def count_file_ranges(self, ranges):
+        """ranges: list of (path, begin, end) byte ranges (end < 0: to the end of the file) -- one GPU's shard of the reads"""
+        n = len(ranges)
+        arr = (C.c_char_p * max(n, 1))(*[r[0].encode() for r in ranges])
+        b = (C.c_int64 * max(n, 1))(*[int(r[1]) for r in ranges])
+        e = (C.c_int64 * max(n, 1))(*[int(r[2]) for r in ranges])
+        check(self._L.jasper_count_reads_file_ranges(self._h, arr, b, e, n))
 
     def last_ingest(self):
         """(text bytes parsed on the GPU, text bytes parsed by the host state machine) of the last count_files call"""

@@ -81,3 +81,68 @@ def test_cli_errors(hip, tmp_path):
     (tmp_path / "a.fa").write_text(">c\nACGT\n")
     p = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-a", "a.fa", "-r", "nope.fq"], cwd=tmp_path, env=env, capture_output=True, text=True)
     assert p.returncode == 1 and "does not exist" in p.stderr
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun_cli(cwd, args, nproc=2):
+    """the multi-GPU form of the driver: one process per GPU under torch.distributed.run; rehearsed here with both ranks on
+    the one GPU of the test box and gloo as the transport (RCCL refuses two ranks on one device)"""
+    env = dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_DIST_BACKEND="gloo", JASPER_AMD_ONE_GPU="1")
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                           "--master-port", str(_free_port()), "-m", "jasper_amd.cli"] + args,
+                          cwd=cwd, env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_cli_two_ranks_matches_jasper_sh(hip, tmp_path):
+    """read files cut into per-rank byte ranges, counts summed by key owner, batch files divided over the ranks, lookups
+    through IPC-mapped owner tables: same artefacts as the real jasper.sh run"""
+    meta = json.load(open(os.path.join(E2E, "meta.json")))
+    for fn in ("r1.fq", "r2.fq"):
+        with open(tmp_path / fn, "wb") as f:
+            f.write(gzip.open(os.path.join(E2E, fn + ".gz")).read())
+    shutil.copy(os.path.join(E2E, "asm.fa"), tmp_path)
+    args = ["-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(meta["k"]), "-t", str(meta["threads"]), "-p", str(meta["passes"]), "-d"]
+    p = _torchrun_cli(tmp_path, args)
+    assert p.returncode == 0, p.stdout + p.stderr
+
+    def check_outputs():
+        assert open(tmp_path / "threshold.txt").read() == open(os.path.join(E2E, "threshold.txt")).read()
+        assert open(tmp_path / "jfhisto25.csv").read() == open(os.path.join(E2E, "jfhisto25.csv")).read()
+        assert fasta_records(tmp_path / "asm.fa.polished.fasta") == fasta_records(os.path.join(E2E, "asm.fa.polished.fasta"))
+        assert open(tmp_path / "asm.fa.fixes.csv", newline="").read() == open(os.path.join(E2E, "asm.fa.fixes.csv"), newline="").read()
+    check_outputs()
+    assert sorted(fn for fn in os.listdir(tmp_path) if re.match(r"jasper\..*\.success$", fn)) == meta["sentinels"]
+    mine = [re.sub(r"^\[[^\]]*\]", "[DATE]", ln) for ln in p.stdout.splitlines() if re.match(r"^\[\w{3} \w{3} \d", ln)]   # (gloo prints its own "[Gloo] ..." lines)
+    strip_q = lambda ls: [re.sub(r"Q value = .*", "Q value =", ln) for ln in ls]
+    assert strip_q(mine) == strip_q(meta["stdout"])                       # only rank 0 talks, same lines as one process
+    assert not os.path.exists(tmp_path / "mer_counts25.jf")               # (documented: no GPU holds the whole table)
+
+    # an existing database is read in record ranges, one per rank: write it with a one-GPU run, wipe, run two ranks again
+    def wipe():
+        for fn in os.listdir(tmp_path):
+            if re.match(r"jasper\..*\.success$", fn) or fn.endswith(".polished.fasta") or fn.endswith(".fixes.csv") or fn.startswith("jfhisto") \
+                    or fn == "threshold.txt" or ".batch." in fn:
+                os.remove(tmp_path / fn)
+    wipe()
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p1 = subprocess.run([sys.executable, "-m", "jasper_amd.cli"] + args, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert p1.returncode == 0 and os.path.getsize(tmp_path / "mer_counts25.jf") > 1000
+    wipe()
+    p2 = _torchrun_cli(tmp_path, args)
+    assert p2.returncode == 0, p2.stdout + p2.stderr
+    assert "Using existing jellyfish database mer_counts25.jf" in p2.stdout
+    check_outputs()
+    # ... and the same through -j
+    wipe()
+    os.rename(tmp_path / "mer_counts25.jf", tmp_path / "db.jf")
+    p3 = _torchrun_cli(tmp_path, ["-j", "db.jf", "-a", "asm.fa", "-k", str(meta["k"]), "-t", str(meta["threads"]), "-p", str(meta["passes"])])
+    assert p3.returncode == 0, p3.stdout + p3.stderr
+    check_outputs()
