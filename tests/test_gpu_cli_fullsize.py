@@ -40,3 +40,34 @@ def test_cli_fullsize_matches_real_reference(hip, tmp_path, name):
     strip = lambda ls: [re.sub(r"Q value = .*", "Q value =", re.sub(r"^\[[^\]]*\]", "[DATE]", ln)) for ln in ls]
     assert strip(p.stdout.splitlines()) == strip(ref["stdout"])
     print("drop-in wall %.1f s vs reference %.1f s on %s" % (wall, ref["reference_wall_seconds"], ref["host"]))
+
+
+def test_cli_fullsize_two_ranks_matches_real_reference(hip, tmp_path):
+    """configs[1] through the multi-GPU form of the driver (2 ranks rehearsed on the one GPU, gloo transport): the 2.9 GB
+    FASTQ is cut into two byte ranges at record boundaries, the counts are summed by key owner, each rank polishes half of
+    the batch files through IPC-mapped owner tables -- same digests as the real reference's run"""
+    import re
+    import socket
+    from jasper_amd import synth
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_cfg2.json")))
+    d = str(tmp_path)
+    nreads, asm_len = synth.write_cli_inputs(d, ref["genome_mb"], ref["seed"])
+    assert nreads == ref["reads"] and asm_len == ref["assembly_bases"]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_DIST_BACKEND="gloo", JASPER_AMD_ONE_GPU="1")
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "jasper_amd.cli", "-r", "reads.fq", "-a", "asm.fa", "-k", str(ref["k"]),
+                        "-t", str(ref["threads"]), "-p", str(ref["passes"])], cwd=d, env=env, capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - t0
+    assert p.returncode == 0, p.stdout + p.stderr
+    got = synth.output_digests(d, k=ref["k"])
+    for key in ("threshold", "jfhisto_sha256", "polished_bases", "polished_fasta_sha256", "fixes_csv_lines", "fixes_csv_sha256"):
+        assert got[key] == ref[key], (key, got[key], ref[key])
+    strip = lambda ls: [re.sub(r"Q value = .*", "Q value =", re.sub(r"^\[[^\]]*\]", "[DATE]", ln)) for ln in ls]
+    mine = [ln for ln in p.stdout.splitlines() if not ln.startswith("[Gloo]")]
+    assert strip(mine) == strip(ref["stdout"])
+    print("2-rank drop-in wall %.1f s (both ranks on one GPU, gloo) vs reference %.1f s" % (wall, ref["reference_wall_seconds"]))

@@ -142,6 +142,41 @@ def test_fit_cuts_an_oversized_table_to_size(KT):
     t.close()
 
 
+def test_counting_file_ranges_adds_up_to_the_whole_file(KT, tmp_path):
+    """jasper_count_reads_file_ranges over the cuts of dist.plan_read_shards == jasper_count_reads_files over the file"""
+    import gzip
+    from jasper_amd import dist as jd
+    k = 37
+    rng = np.random.default_rng(3)
+    genome = synth.make_genome(rng, 80_000)
+    reads = synth.make_reads_stream(rng, genome, 25, 150, 0.003).tobytes().split(b"N")
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"@" * len(r)) for i, r in enumerate(reads) if r)
+    p = tmp_path / "reads.fq"
+    p.write_bytes(fq)
+    fa = tmp_path / "more.fq"
+    fa.write_bytes(fq[: fq.index(b"\n@r5000\n") + 1])
+    whole = KT(k, min_slots=1 << 21)
+    whole.count_files([str(p), str(fa)])
+    for world in (2, 5):
+        t = KT(k, min_slots=1 << 21)
+        for shard in jd.plan_read_shards([str(p), str(fa)], world):
+            assert shard, "every rank gets a piece of files this large"
+            t.count_file_ranges(shard)
+        assert t.info()["occurrences"] == whole.info()["occurrences"] and t.info()["distinct"] == whole.info()["distinct"]
+        assert t.histogram() == whole.histogram()
+        t.close()
+    # a gzip file cannot be cut: read whole by the reader whose range starts at 0, skipped by the others
+    gz = tmp_path / "reads.fq.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(fq)
+    a, b = KT(k, min_slots=1 << 21), KT(k, min_slots=1 << 21)
+    a.count_file_ranges([(str(gz), 0, -1), (str(fa), 0, -1)])
+    b.count_file_ranges([(str(gz), 1000, -1), (str(fa), 0, 0)])
+    assert a.histogram() == whole.histogram() and b.info()["occurrences"] == 0
+    for t in (a, b, whole):
+        t.close()
+
+
 # ---- two processes, IPC-mapped peers -------------------------------------------------------------------------------
 def _free_port():
     s = socket.socket()
