@@ -115,6 +115,9 @@ int jasper_device_free(jasper_table *t, void *d_ptr);
  * counts (key-wise sum), mode 1 sets them (an owner's final counts replace this table's partial ones). */
 int jasper_table_export_packed(jasper_table *t, void *d_dst, uint64_t cap_entries, uint64_t *n_entries, uint32_t part, uint32_t nparts);
 int jasper_table_import_packed(jasper_table *t, const void *d_src, uint64_t n_entries, int mode);
+/* add up to 8 entry lists in ONE sweep over the table (an owner adding what every rank sent it): the lists are in slot order
+ * of same-hash tables, so their c-th parts land in the same band of slots, which stays in cache while all lists update it */
+int jasper_table_import_packed_multi(jasper_table *t, const void *const *d_srcs, const uint64_t *counts, uint32_t n_src);
 /* grow to at least min_slots slots (ranks agree on one geometry before exchanging slot-range partitions) */
 int jasper_table_reserve(jasper_table *t, uint64_t min_slots);
 /* rehash into the smallest slot count that holds the present keys at a load of at most max_load (0.05 .. 0.9); may shrink */
@@ -133,6 +136,13 @@ int jasper_table_fit(jasper_table *t, double max_load);
  *   jasper_table_detach: back to a whole table.  Growing a table detaches it.
  * The owners' tables must not be written while any GPU reads them; that ordering is the caller's (a barrier). */
 int jasper_table_export_owner(jasper_table *t, void *d_dst, uint64_t cap_entries, uint32_t n_owners, uint64_t *counts);
+/* A binary/sorted database written by several GPUs: the file order (pos, key) with `size` = 2^size_log2 is the numeric order
+ * of the key rotated right by size_log2 bits, so cutting the value range of the key's low size_log2 bits into n_ranges equal
+ * parts cuts the file into n_ranges consecutive pieces.  jasper_table_export_file_ranges groups the entries of t by that
+ * range (same layout and conventions as jasper_table_export_owner); after an all_to_all each GPU holds one range, sorts it
+ * and writes it with jasper_table_write_jf_piece (what = 1: records only; 2: the header only; 0: both). */
+int jasper_table_export_file_ranges(jasper_table *t, void *d_dst, uint64_t cap_entries, uint32_t n_ranges, int size_log2, uint64_t *counts);
+int jasper_table_write_jf_piece(jasper_table *t, const char *path, const char *const *cmdline, int n_cmdline, int size_log2, int what);
 int jasper_table_ipc_handle(jasper_table *t, void *out64);
 int jasper_table_attach_ipc(jasper_table *t, const void *handles, uint32_t n, uint32_t self);
 int jasper_table_attach_tables(jasper_table *t, jasper_table *const *shards, uint32_t n, uint32_t self);

@@ -55,9 +55,12 @@ SYMBOLS = {
     "jasper_device_free": (C.c_int, [_P, _P]),
     "jasper_table_export_packed": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32]),
     "jasper_table_import_packed": (C.c_int, [_P, _P, C.c_uint64, C.c_int]),
+    "jasper_table_import_packed_multi": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64), C.c_uint32]),
     "jasper_table_reserve": (C.c_int, [_P, C.c_uint64]),
     "jasper_table_fit": (C.c_int, [_P, C.c_double]),
     "jasper_table_export_owner": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "jasper_table_export_file_ranges": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)]),
+    "jasper_table_write_jf_piece": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int]),
     "jasper_table_ipc_handle": (C.c_int, [_P, _P]),
     "jasper_table_attach_ipc": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
     "jasper_table_attach_tables": (C.c_int, [_P, C.POINTER(_P), C.c_uint32, C.c_uint32]),

@@ -289,7 +289,7 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
     counts by key owner, and every rank polishes its share of the batch files with lookups served from the owners' HBM.
     Rank 0 alone splits, joins, writes the histogram / threshold / sentinels and talks; the stage decisions (which
     sentinels exist) are taken by rank 0 and shared, so that no rank sees a file another one is just creating.
-    Not written in a multi-GPU run: mer_counts$K.jf (no GPU holds the whole table; an existing one, or -j, is read)."""
+    mer_counts$K.jf is written by all GPUs together (dist.write_jf_sharded); an existing one, or -j, is read in record ranges."""
     import torch
     import torch.distributed as tdist
     from . import dist as jdist
@@ -346,9 +346,14 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
                        % (o.jf_db, o.jf_db, e))
     # key-wise sum over the GPUs; the result stays sharded by key owner unless the peers' HBM cannot be mapped
     table = KmerTable(local.k, min_slots=1 << 21, device=o.device)
+    write_db = counted and os.environ.get("JASPER_AMD_NO_JF", "") not in ("1", "true", "yes")
+    db_cmdline = ["count", "-C", "-t", str(o.num_threads), "-s", str(o.jf_size), "-m", str(kmer), "-o", "mer_counts%d.jf" % kmer] + (o.reads.split() if counted else [])
     try:
         jdist.shard_tables(local, table, dev)
         local.close()
+        if write_db:       # :177 `... | tee $JF_DB | ...`: every GPU sorts and writes one consecutive piece of the file
+            jdist.write_jf_sharded(table, "mer_counts%d.jf" % kmer, db_cmdline, dev)
+            _timing("write mer_counts.jf")
         h = jdist.histogram_sharded(table, dev)
     except jdist.ShardAttachError as e:
         if is0:
@@ -356,6 +361,11 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
         table.close()
         table = local
         jdist.merge_tables(table, dev)
+        if write_db:
+            if is0:
+                table.write_jf("mer_counts%d.jf.tmp" % kmer, db_cmdline)
+                os.replace("mer_counts%d.jf.tmp" % kmer, "mer_counts%d.jf" % kmer)
+            bar()
         h = jdist.histogram_merged(table, dev)
     rows = [(m, h[m]) for m in range(1, 10002) if h[m]]
     _timing("sum counts over the GPUs + histogram")

@@ -257,12 +257,24 @@ int jasper_table_export_packed(jasper_table *t, void *d_dst, uint64_t cap_entrie
 int jasper_table_import_packed(jasper_table *t, const void *d_src, uint64_t n_entries, int mode) {
     return t->t.import_packed(d_src, n_entries, mode, g_err);
 }
+int jasper_table_import_packed_multi(jasper_table *t, const void *const *d_srcs, const uint64_t *counts, uint32_t n_src) {
+    if (!d_srcs || !counts) { g_err = "null argument"; return JASPER_ERR; }
+    return t->t.import_packed_multi(d_srcs, counts, n_src, g_err);
+}
 int jasper_table_reserve(jasper_table *t, uint64_t min_slots) { return t->t.reserve(min_slots, g_err); }
 
 int jasper_table_fit(jasper_table *t, double max_load) { return t->t.fit(max_load, g_err); }
 int jasper_table_export_owner(jasper_table *t, void *d_dst, uint64_t cap_entries, uint32_t n_owners, uint64_t *counts) {
     if (!counts) { g_err = "counts is null"; return JASPER_ERR; }
-    return t->t.export_owner(d_dst, cap_entries, n_owners, counts, g_err);
+    return t->t.export_owner(d_dst, cap_entries, n_owners, 0, counts, g_err);
+}
+int jasper_table_export_file_ranges(jasper_table *t, void *d_dst, uint64_t cap_entries, uint32_t n_ranges, int size_log2, uint64_t *counts) {
+    if (!counts || size_log2 < 1) { g_err = "bad argument"; return JASPER_ERR; }
+    return t->t.export_owner(d_dst, cap_entries, n_ranges, size_log2, counts, g_err);
+}
+int jasper_table_write_jf_piece(jasper_table *t, const char *path, const char *const *cmdline, int n_cmdline, int size_log2, int what) {
+    if (!t || !path || n_cmdline < 0 || (n_cmdline && !cmdline) || what < 0 || what > 2 || size_log2 < 1) { g_err = "bad argument"; return JASPER_ERR; }
+    return t->t.write_jf(path, cmdline, n_cmdline, g_err, size_log2, what) ? JASPER_ERR : JASPER_OK;
 }
 int jasper_table_ipc_handle(jasper_table *t, void *out64) { return t->t.ipc_handle(out64, g_err) ? JASPER_ERR : JASPER_OK; }
 int jasper_table_attach_ipc(jasper_table *t, const void *handles, uint32_t n, uint32_t self) {

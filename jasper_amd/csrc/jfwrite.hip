@@ -118,7 +118,7 @@ static std::string json_str(const char *s) {
     return o + "\"";
 }
 
-int Table::write_jf(const char *path, const char *const *cmdline, int n_cmd, std::string &err) {
+int Table::write_jf(const char *path, const char *const *cmdline, int n_cmd, std::string &err, int r_bits, int what) {
     int rc = 0;
     FILE *f = nullptr;
     unsigned long long *d_klo[2] = {nullptr, nullptr}, *d_khi[2] = {nullptr, nullptr}, *d_counter = nullptr;
@@ -128,13 +128,13 @@ int Table::write_jf(const char *path, const char *const *cmdline, int n_cmd, std
     uint8_t *d_fmt = nullptr, *h_fmt = nullptr;
     hipEvent_t ev_fmt[2] = {nullptr, nullptr};
     const int B = d.B;
-    const int r = d.s < B ? d.s : B;                 // rows of the identity matrix = log2(size)
+    const int r = r_bits >= 0 ? (r_bits < B ? r_bits : B) : (d.s < B ? d.s : B);   // rows of the identity matrix = log2(size)
     const int kb = (B + 7) / 8;
     uint64_t n = 0;
     if (hipSetDevice(device) != hipSuccess) { err = "hipSetDevice failed"; return -1; }
     if (materialize(err)) return -1;
     if (read_stats(err)) return -1;
-    {
+    if (what != 2) {
         const uint64_t cap = h_stats[ST_DISTINCT] + 1;
         unsigned long long zero = 0, cnt = 0;
         HIPCHK(hipMalloc((void **)&d_counter, 8));
@@ -191,13 +191,15 @@ int Table::write_jf(const char *path, const char *const *cmdline, int n_cmd, std
         hlen += pad;
         f = fopen(path, "wb");
         if (!f) { err = std::string("cannot create ") + path; rc = -1; goto done; }
-        char digits[16];
-        snprintf(digits, sizeof digits, "%09zu", hlen);
-        if (fwrite(digits, 1, 9, f) != 9 || fwrite(h.data(), 1, h.size(), f) != h.size()) { err = "write error"; rc = -1; goto done; }
-        const char zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (pad && fwrite(zeros, 1, pad, f) != pad) { err = "write error"; rc = -1; goto done; }
+        if (what != 1) {
+            char digits[16];
+            snprintf(digits, sizeof digits, "%09zu", hlen);
+            if (fwrite(digits, 1, 9, f) != 9 || fwrite(h.data(), 1, h.size(), f) != h.size()) { err = "write error"; rc = -1; goto done; }
+            const char zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (pad && fwrite(zeros, 1, pad, f) != pad) { err = "write error"; rc = -1; goto done; }
+        }
     }
-    {
+    if (what != 2) {
         // ---- records: formatted on the device, copied through two pinned buffers; the fwrite of a block overlaps the
         //      formatting + copy of the next one
         const uint64_t BLK = 1u << 22;

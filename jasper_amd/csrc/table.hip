@@ -307,18 +307,26 @@ __global__ __launch_bounds__(256) void export_packed_write_kernel(TableDev T, ul
 
 // ---- owner-sharded table: every entry of the table, grouped by owner_of(hash, nown), in ONE pass over the slots ----
 // Same two atomic-free passes as above with one count array per owner: counts[o * EXP_STRIDE + block].
-__device__ __forceinline__ bool owner_entry_of(const TableDev &T, uint64_t i, uint32_t nown, int sh, ulonglong2 &o, uint32_t &owner) {
+// sort_r > 0: group by the RANGE of the key in the order of a binary/sorted database with `size` 2^sort_r instead (that
+// order is the numeric order of the key rotated right by sort_r bits, jfwrite.hip: range = its top bits = the key's low
+// sort_r bits), so that the groups, each sorted, are consecutive pieces of the file
+__device__ __forceinline__ bool owner_entry_of(const TableDev &T, uint64_t i, uint32_t nown, int sort_r, int sh, ulonglong2 &o, uint32_t &owner) {
     const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * i);
     if (e.x == 0ull) return false;
     const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
     const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
     const u128 h = hash_from((i - off) & T.mask, rem, T.B, T.s);
     if (sh && (e.y >> (64 - sh)) != 0ull) { atomicExch(&T.stats[ST_FATAL], 2ull); return false; }
+    if (sort_r > 0) {
+        const u128 key = unmix(h, T.B);
+        const uint64_t low = sort_r >= 64 ? key.lo : (key.lo & ((1ull << sort_r) - 1ull));
+        owner = (uint32_t)(((low >> (sort_r > 32 ? sort_r - 32 : 0)) * (uint64_t)nown) >> (sort_r > 32 ? 32 : sort_r));
+    } else
     owner = owner_of(h, nown);
     o = make_ulonglong2(h.lo, sh ? (h.hi | (e.y << sh)) : e.y);   // (B <= 64: the whole second word is the count)
     return true;
 }
-__global__ __launch_bounds__(256) void export_owner_count_kernel(TableDev T, uint32_t nown, uint64_t chunk, unsigned long long *__restrict__ counts) {
+__global__ __launch_bounds__(256) void export_owner_count_kernel(TableDev T, uint32_t nown, int sort_r, uint64_t chunk, unsigned long long *__restrict__ counts) {
     __shared__ unsigned int s_w[4][MAX_SHARDS];
     const int sh = packed_count_shift(T.B);
     const uint64_t span = T.mask + 1;
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(256) void export_owner_count_kernel(TableDev T, uin
     for (uint64_t q = lo + threadIdx.x; q < hi; q += blockDim.x) {
         ulonglong2 o;
         uint32_t owner = 0;
-        if (owner_entry_of(T, q, nown, sh, o, owner)) {
+        if (owner_entry_of(T, q, nown, sort_r, sh, o, owner)) {
 #pragma unroll
             for (uint32_t w = 0; w < MAX_SHARDS; ++w) n[w] += owner == w ? 1u : 0u;
         }
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(256) void export_owner_count_kernel(TableDev T, uin
         counts[(size_t)threadIdx.x * EXP_STRIDE + blockIdx.x] =
             (unsigned long long)s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x];
 }
-__global__ __launch_bounds__(256) void export_owner_write_kernel(TableDev T, ulonglong2 *__restrict__ out, uint64_t cap, uint32_t nown, uint64_t chunk,
+__global__ __launch_bounds__(256) void export_owner_write_kernel(TableDev T, ulonglong2 *__restrict__ out, uint64_t cap, uint32_t nown, int sort_r, uint64_t chunk,
                                                                  const unsigned long long *__restrict__ bases) {
     __shared__ unsigned int s_w[4][MAX_SHARDS];
     const int sh = packed_count_shift(T.B);
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(256) void export_owner_write_kernel(TableDev T, ulo
         const uint64_t q = q0 + threadIdx.x;
         ulonglong2 o = make_ulonglong2(0ull, 0ull);
         uint32_t owner = 0;
-        const bool have = q < hi && owner_entry_of(T, q, nown, sh, o, owner);
+        const bool have = q < hi && owner_entry_of(T, q, nown, sort_r, sh, o, owner);
         uint64_t mine = 0;     // ballot of my owner's lanes in this wave
 #pragma unroll
         for (uint32_t w = 0; w < MAX_SHARDS; ++w) {
@@ -420,6 +428,34 @@ __global__ __launch_bounds__(256) void import_packed_kernel(const ulonglong2 *__
             const int r = table_set(T, h, c);
             if (r == 2) ++fresh;
             else if (r == 0) table_spill(T, h, c);   // re-inserted additively after growth: only ever reached for NEW keys
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+}
+
+// The same for up to MAX_SHARDS entry lists at once (an owner adding what every rank sent it).  Each list is in slot order
+// of a table with the same hash, so position c/nchunks of every list falls into the same part of THIS table: block group c
+// takes chunk c of every list, and because blocks are dispatched in index order the slots being updated at any time are a
+// narrow band that stays in L2 / Infinity Cache -- one sweep over the table instead of one per list.
+struct MultiSrc { const ulonglong2 *p[MAX_SHARDS]; unsigned long long n[MAX_SHARDS]; uint32_t n_src; };
+constexpr uint32_t IMP_BPC = 64;      // blocks per chunk
+__global__ __launch_bounds__(256) void import_packed_multi_kernel(MultiSrc S, uint32_t nchunks, TableDev T) {
+    unsigned long long fresh = 0;
+    const int sh = packed_count_shift(T.B);
+    const unsigned long long himask = sh ? ((1ull << sh) - 1ull) : 0ull;
+    const uint32_t c = blockIdx.x / IMP_BPC, j = blockIdx.x % IMP_BPC;
+#pragma unroll 1
+    for (uint32_t s = 0; s < S.n_src; ++s) {
+        const ulonglong2 *__restrict__ in = S.p[s];
+        // (128-bit products: n * c does not fit 64 bits for n ~ 2^32 and c ~ 2^8 only far beyond any real list; plain math is fine)
+        const unsigned long long lo = S.n[s] / nchunks * c + (S.n[s] % nchunks) * c / nchunks;
+        const unsigned long long hi = c + 1 == nchunks ? S.n[s] : S.n[s] / nchunks * (c + 1) + (S.n[s] % nchunks) * (c + 1) / nchunks;
+        for (unsigned long long i = lo + (unsigned long long)j * 256 + threadIdx.x; i < hi; i += (unsigned long long)IMP_BPC * 256) {
+            const ulonglong2 e = in[i];
+            const u128 h = mk(e.y & himask, e.x);
+            const unsigned long long cnt = sh ? (e.y >> sh) : e.y;
+            if (cnt) fresh += table_add_or_spill(T, h, cnt);
         }
     }
     for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
@@ -1011,16 +1047,16 @@ int Table::export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t pa
     return 0;
 }
 
-int Table::export_owner(void *d_dst, uint64_t cap, uint32_t nown, uint64_t *counts_out, std::string &err) {
-    if (nown < 1 || nown > MAX_SHARDS) { err = "export_owner: 1..8 owners"; return -1; }
+int Table::export_owner(void *d_dst, uint64_t cap, uint32_t nown, int sort_r, uint64_t *counts_out, std::string &err) {
+    if (nown < 1 || nown > MAX_SHARDS || sort_r < 0 || sort_r > 60 || sort_r > d.B) { err = "export_owner: 1..8 owners, 0 <= sort_r <= min(60, 2k)"; return -1; }
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
     unsigned long long *d_counts = reinterpret_cast<unsigned long long *>(workspace(WS_COUNT + 2, (size_t)MAX_SHARDS * EXP_STRIDE * 8 + 256, err));
     if (!d_counts) return -1;
     const uint64_t chunk = ((nslots + EXP_BLOCKS - 1) / EXP_BLOCKS + 255) / 256 * 256;
-    hipLaunchKernelGGL(export_owner_count_kernel, dim3(EXP_BLOCKS), dim3(256), 0, stream, d, nown, chunk, d_counts);
+    hipLaunchKernelGGL(export_owner_count_kernel, dim3(EXP_BLOCKS), dim3(256), 0, stream, d, nown, sort_r, chunk, d_counts);
     hipLaunchKernelGGL(export_packed_scan_kernel, dim3(nown), dim3(1024), 0, stream, d_counts);
-    if (cap) hipLaunchKernelGGL(export_owner_write_kernel, dim3(EXP_BLOCKS), dim3(256), 0, stream, d, (ulonglong2 *)d_dst, cap, nown, chunk, d_counts);
+    if (cap) hipLaunchKernelGGL(export_owner_write_kernel, dim3(EXP_BLOCKS), dim3(256), 0, stream, d, (ulonglong2 *)d_dst, cap, nown, sort_r, chunk, d_counts);
     HIPCHK(hipGetLastError());
     unsigned long long got[MAX_SHARDS];
     HIPCHK(hipMemcpy2DAsync(got, 8, d_counts + EXP_BLOCKS, (size_t)EXP_STRIDE * 8, 8, nown, hipMemcpyDeviceToHost, stream));
@@ -1094,6 +1130,29 @@ int Table::attach_tables(Table *const *peers, uint32_t n, uint32_t self, std::st
     }
     d.nshard = n;
     return 0;
+}
+
+int Table::import_packed_multi(const void *const *d_srcs, const uint64_t *counts, uint32_t n_src, std::string &err) {
+    if (n_src < 1 || n_src > MAX_SHARDS) { err = "import_packed_multi: 1..8 lists"; return -1; }
+    histo_cached = false;
+    HIPCHK(hipSetDevice(device));
+    if (materialize(err)) return -1;
+    if (read_stats(err)) return -1;
+    MultiSrc S{};
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_src; ++i) { S.p[i] = (const ulonglong2 *)d_srcs[i]; S.n[i] = counts[i]; total += counts[i]; }
+    S.n_src = n_src;
+    if (!total) return 0;
+    // worst case every entry is a new key; if that could overfill the table, grow first (keys shared between the lists make
+    // this generous -- callers that know better size the table themselves and never get here)
+    if ((double)(h_stats[ST_DISTINCT] + total) > 0.9 * (double)nslots) {
+        if (ensure_capacity(total, err)) return -1;
+    }
+    const uint64_t band = 32ull << 20;                                   // bytes of slots per chunk
+    const uint32_t nchunks = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, nslots * 16 / band));
+    hipLaunchKernelGGL(import_packed_multi_kernel, dim3(nchunks * IMP_BPC), dim3(256), 0, stream, S, nchunks, d);
+    HIPCHK(hipGetLastError());
+    return after_batch(err);
 }
 
 int Table::import_packed(const void *d_src, uint64_t n, int mode, std::string &err) {

@@ -295,18 +295,21 @@ struct Table {
     // falls into partition `part` of `nparts` equal slot ranges; mode 0 = add counts, 1 = set counts
     int export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t part, uint32_t nparts, std::string &err);
     int import_packed(const void *d_src, uint64_t n, int mode, std::string &err);
+    int import_packed_multi(const void *const *d_srcs, const uint64_t *counts, uint32_t n_src, std::string &err);   // add, all lists in one sweep
     int reserve(uint64_t min_slots, std::string &err);
     // Owner-sharded table (table.hip, "shards"): all entries of this table in ONE pass, grouped by owner_of(hash, nown)
     // -- segment o starts at d_dst + o * cap entries, counts_out[o] entries long (may exceed cap: nothing is written past
     // cap, the caller retries with a larger buffer); attach = lookups through this table read shard o's slot array.
-    int export_owner(void *d_dst, uint64_t cap, uint32_t nown, uint64_t *counts_out, std::string &err);
+    int export_owner(void *d_dst, uint64_t cap, uint32_t nown, int sort_r, uint64_t *counts_out, std::string &err);   // sort_r > 0: by file range, see table.hip
     int ipc_handle(void *out64, std::string &err);
     int attach_ipc(const void *handles64, uint32_t n, uint32_t self, std::string &err);
     int attach_tables(Table *const *peers, uint32_t n, uint32_t self, std::string &err);
     void detach_shards();
     void *ipc_mapped[MAX_SHARDS] = {};   // peers' slot arrays opened with hipIpcOpenMemHandle (closed by detach_shards)
     // the table as a Jellyfish binary/sorted database (jfwrite.hip); cmdline goes into the header like jellyfish's own
-    int write_jf(const char *path, const char *const *cmdline, int n_cmd, std::string &err);
+    // r_bits = log2 of the file's `size` (-1: this table's slot count); what: 0 = header + records, 1 = records only (one
+    // sorted piece of a file written by several GPUs), 2 = header only
+    int write_jf(const char *path, const char *const *cmdline, int n_cmd, std::string &err, int r_bits = -1, int what = 0);
     int load_jf_records(const char *path, uint64_t data_offset, uint64_t n_records, int key_len_bits, int counter_len, std::string &err);
 };
 

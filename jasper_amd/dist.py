@@ -313,10 +313,9 @@ def shard_tables(local, shard, device, group=None):
     first = not getattr(shard, "_fitted", False)
     if first:
         shard.reserve(2 * incoming)                    # a guess that never has to grow (sources share keys: generous)
-    for src in range(world):
-        n = int(allc[src][rank])
-        if n:
-            shard.import_packed(recv[src].data_ptr(), n, 0)
+    srcs = [src for src in range(world) if int(allc[src][rank])]
+    if srcs:                                           # all lists in one sweep over the shard (they share its slot order)
+        shard.import_packed_multi([recv[src].data_ptr() for src in srcs], [int(allc[src][rank]) for src in srcs])
     del recv
     if first:                                          # ... cut to size once; later calls reuse the slot array as it is
         shard.fit(0.5)
@@ -355,6 +354,61 @@ def shard_tables(local, shard, device, group=None):
     _sync(device)
     dist.barrier(group=group)
     return incoming
+
+
+def write_jf_sharded(shard, path, cmdline, device, group=None):
+    """`mer_counts$K.jf` from an owner-sharded table (src/jasper.sh:177 `tee $JF_DB`): a binary/sorted file is ordered by
+    the key rotated right by log2(size) bits, so the value range of the key's low bits cut into `world` equal parts gives
+    `world` consecutive pieces of the file.  Every rank groups its shard's entries by piece (one table pass), ONE all_to_all
+    brings each piece together on one GPU, which sorts it and writes `<path>.piece<r>`; rank 0 writes the header and strings
+    the pieces together.  Collective; the file is complete when it returns."""
+    import shutil
+    import torch
+    import torch.distributed as dist
+    from .table import KmerTable
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    k = shard.k
+    size_log2 = min(2 * k, 60, (shard.info()["slots"] * world - 1).bit_length())
+    est = torch.tensor([int(shard.info()["distinct"] / world * 1.1) + (1 << 16)], dtype=torch.int64, device=device)
+    dist.all_reduce(est, op=dist.ReduceOp.MAX, group=group)
+    mx = int(est.item())
+    send = torch.empty((world, mx, 2), dtype=torch.int64, device=device)
+    _sync(device)
+    ct = torch.tensor(shard.export_file_ranges(send.data_ptr(), mx, world, size_log2), dtype=torch.int64, device=device)
+    allc = [torch.zeros_like(ct) for _ in range(world)]
+    dist.all_gather(allc, ct, group=group)
+    allc = torch.stack(allc).cpu()                     # allc[src][piece]
+    if int(allc.max().item()) > mx:                    # (key ends are not as even as hashes: exact sizes when the guess was low)
+        mx = int(allc.max().item())
+        del send
+        send = torch.empty((world, mx, 2), dtype=torch.int64, device=device)
+        _sync(device)
+        shard.export_file_ranges(send.data_ptr(), mx, world, size_log2)
+    _sync(device)
+    recv = _all_to_all_rows(send, group)
+    _sync(device)
+    del send
+    incoming = int(allc[:, rank].sum().item())
+    piece = KmerTable(k, min_slots=max(1 << 16, 2 * incoming), device=shard.device)
+    srcs = [src for src in range(world) if int(allc[src][rank])]
+    if srcs:
+        piece.import_packed_multi([recv[src].data_ptr() for src in srcs], [int(allc[src][rank]) for src in srcs])
+    del recv
+    piece.write_jf_piece("%s.piece%d" % (path, rank), [], size_log2, 1)
+    if rank == 0:
+        piece.write_jf_piece(path + ".tmp", list(cmdline), size_log2, 2)
+    piece.close()
+    _sync(device)
+    dist.barrier(group=group)
+    if rank == 0:
+        with open(path + ".tmp", "ab") as out:
+            for r in range(world):
+                with open("%s.piece%d" % (path, r), "rb") as f:
+                    shutil.copyfileobj(f, out, 16 << 20)
+                os.remove("%s.piece%d" % (path, r))
+        os.replace(path + ".tmp", path)
+    dist.barrier(group=group)
 
 
 def histogram_sharded(shard, device, group=None):

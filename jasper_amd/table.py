@@ -141,6 +141,18 @@ class KmerTable:
         arr = (C.c_char_p * max(len(args), 1))(*args)
         check(self._L.jasper_table_write_jf(self._h, path.encode(), arr, len(args)))
 
+    def write_jf_piece(self, path, cmdline, size_log2, what):
+        """what: 0 = whole file, 1 = sorted records only (one GPU's piece), 2 = header only; `size` of the file = 2^size_log2"""
+        args = [a.encode() for a in cmdline]
+        arr = (C.c_char_p * max(len(args), 1))(*args)
+        check(self._L.jasper_table_write_jf_piece(self._h, path.encode(), arr, len(args), int(size_log2), int(what)))
+
+    def export_file_ranges(self, dev_ptr, cap_entries, n_ranges, size_log2):
+        """entries grouped by their range in the order of a binary/sorted file of size 2^size_log2 (layout as export_owner)"""
+        counts = (C.c_uint64 * int(n_ranges))()
+        check(self._L.jasper_table_export_file_ranges(self._h, C.c_void_p(dev_ptr), int(cap_entries), int(n_ranges), int(size_log2), counts))
+        return [int(c) for c in counts]
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._L.jasper_table_destroy(self._h)
@@ -289,6 +301,13 @@ class KmerTable:
 
     def import_packed(self, dev_ptr, n, mode=0):
         check(self._L.jasper_table_import_packed(self._h, C.c_void_p(dev_ptr), int(n), int(mode)))
+
+    def import_packed_multi(self, dev_ptrs, counts):
+        """add several entry lists (device pointers, entry counts) in one sweep over the table"""
+        n = len(dev_ptrs)
+        ps = (C.c_void_p * n)(*[int(p) for p in dev_ptrs])
+        cs = (C.c_uint64 * n)(*[int(c) for c in counts])
+        check(self._L.jasper_table_import_packed_multi(self._h, ps, cs, n))
 
     def reserve(self, min_slots):
         check(self._L.jasper_table_reserve(self._h, int(min_slots)))

@@ -116,6 +116,10 @@ class FakeTable:
             self.slots *= 2
             self.handle_epoch += 1
 
+    def import_packed_multi(self, ptrs, counts):
+        for p, n in zip(ptrs, counts):
+            self.import_packed(p, n, 0)
+
     def ipc_handle(self):
         return bytes([self.tag, self.handle_epoch % 256]) + bytes(62)
 

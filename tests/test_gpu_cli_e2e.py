@@ -123,7 +123,24 @@ def test_cli_two_ranks_matches_jasper_sh(hip, tmp_path):
     mine = [re.sub(r"^\[[^\]]*\]", "[DATE]", ln) for ln in p.stdout.splitlines() if re.match(r"^\[\w{3} \w{3} \d", ln)]   # (gloo prints its own "[Gloo] ..." lines)
     strip_q = lambda ls: [re.sub(r"Q value = .*", "Q value =", ln) for ln in ls]
     assert strip_q(mine) == strip_q(meta["stdout"])                       # only rank 0 talks, same lines as one process
-    assert not os.path.exists(tmp_path / "mer_counts25.jf")               # (documented: no GPU holds the whole table)
+    # src/jasper.sh:177 leaves the database behind: written by both ranks together, one consecutive sorted piece each.
+    # The reader's ordering rule (test_gpu_jf.py restates it from binary_dumper.hpp) holds across the seam, the content is
+    # what one GPU writes, and the file goes back to the build container for the real jellyfish to read (gpurun_out)
+    sys.path.insert(0, HERE)
+    from test_gpu_jf import _read_jf, _jf_pos
+    from jasper_amd import KmerTable
+    db2 = tmp_path / "mer_counts25.jf"
+    hdr2, recs2 = _read_jf(str(db2))
+    order = [(_jf_pos(hdr2, k), k) for k, _ in recs2]
+    assert order == sorted(order) and len(set(order)) == len(order) and hdr2["size"] == 1 << hdr2["matrix1"]["r"]
+    assert hdr2["cmdline"][:2] == ["count", "-C"] and hdr2["cmdline"][-2:] == ["r1.fq", "r2.fq"]
+    t2 = KmerTable.from_jf(str(db2))
+    assert ["%d %d" % (m, n) for m, n in t2.histo_rows()] == open(os.path.join(E2E, "jfhisto25.csv")).read().split("\n")[:-1]
+    t2.close()
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        shutil.copy(db2, os.path.join(out, "two_rank_mer_counts25.jf"))
+    os.remove(db2)
 
     # an existing database is read in record ranges, one per rank: write it with a one-GPU run, wipe, run two ranks again
     def wipe():

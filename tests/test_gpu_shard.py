@@ -55,7 +55,11 @@ def make_shards(KT, full, n, slots):
     shards = []
     for o in range(n):
         t = KT(full.k, min_slots=slots)
-        t.import_packed(buf[o].data_ptr(), counts[o], 0)
+        if o % 2:
+            t.import_packed(buf[o].data_ptr(), counts[o], 0)
+        else:        # the one-sweep form, the list cut into three uneven pieces (one of them empty)
+            c1, c2 = counts[o] // 5, counts[o] // 2
+            t.import_packed_multi([buf[o].data_ptr(), buf[o][c1:].data_ptr(), buf[o][c2:].data_ptr(), buf[o].data_ptr()], [c1, c2 - c1, counts[o] - c2, 0])
         assert t.info()["slots"] == slots, "the test sizes the shards so that they do not grow"
         assert t.info()["distinct"] == counts[o]
         shards.append(t)

@@ -56,8 +56,7 @@ for o in range(world):
     t = KmerTable(K, min_slots=1 << 21)
     incoming = sum(int(segs[r][o].shape[0]) for r in range(world))
     t.reserve(2 * incoming)
-    for r in range(world):
-        t.import_packed(segs[r][o].data_ptr(), segs[r][o].shape[0], 0)
+    t.import_packed_multi([segs[r][o].data_ptr() for r in range(world)], [segs[r][o].shape[0] for r in range(world)])
     t.fit(0.5)
     shards.append(t)
 print("owner tables: %s keys in 2^%d slots" % ([t.info()["distinct"] for t in shards], shards[0].info()["slots"].bit_length() - 1), flush=True)
@@ -65,6 +64,9 @@ S = shards[0]
 for rep in range(2):
     timed("owner 0: clear + add %d incoming entries" % sum(int(segs[r][0].shape[0]) for r in range(world)),
           lambda: (S.clear(), [S.import_packed(segs[r][0].data_ptr(), segs[r][0].shape[0], 0) for r in range(world)]), [S])
+for rep in range(2):
+    timed("owner 0: clear + add the same in ONE sweep (import_packed_multi)",
+          lambda: (S.clear(), S.import_packed_multi([segs[r][0].data_ptr() for r in range(world)], [segs[r][0].shape[0] for r in range(world)])), [S])
 for rep in range(2):
     h = timed("owner 0: histogram of its shard", lambda: S.histogram(), [S])
 acc = [0] * 10002
