@@ -2,7 +2,7 @@
 sentinel files and log lines; the Jellyfish + per-batch python processes are replaced by the HBM table and the GPU
 polisher.  Lines are cited as src/jasper.sh:N.
 
-    python -m jasper_amd.cli -r 'R1.fq R2.fq' -a asm.fa -k 37 -t 16 -p 2
+    python -m jasper_amd.cli -r 'R1.fq R2.fq' -a asm.fa -k 37 -t 16 -p 2 [--gpus N]
 
 Differences that are deliberate and documented in DESIGN.md:
   * contigs are written to <asm>.polished.fasta in input order (the reference's order is perl-hash random, :220)
@@ -134,6 +134,8 @@ def parse_args(argv):
             sys.exit(0)
         elif key == "--device":                                        # extension: which GPU
             o.device = int(nxt); i += 1
+        elif key == "--gpus":                                          # extension: handled by main() (one process per GPU)
+            i += 1
         else:
             print("Unknown option %s" % key)
             sys.exit(1)
@@ -680,7 +682,22 @@ def run(argv):
 
 
 def main():
-    sys.exit(run(sys.argv[1:]))
+    argv = sys.argv[1:]
+    if "--gpus" in argv and "WORLD_SIZE" not in os.environ:
+        # extension: `--gpus N` = this driver as one process per GPU. Nothing has touched the GPU yet,
+        # so the launcher is simply started as a child with the same arguments.
+        import subprocess
+        i = argv.index("--gpus")
+        try:
+            n = int(argv[i + 1])
+        except (IndexError, ValueError):
+            print("--gpus needs a number")
+            sys.exit(1)
+        if n > 1:
+            sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                                      "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"),
+                                      "-m", "jasper_amd.cli"] + argv))
+    sys.exit(run(argv))
 
 
 if __name__ == "__main__":

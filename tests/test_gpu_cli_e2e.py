@@ -157,9 +157,11 @@ def test_cli_two_ranks_matches_jasper_sh(hip, tmp_path):
     assert p2.returncode == 0, p2.stdout + p2.stderr
     assert "Using existing jellyfish database mer_counts25.jf" in p2.stdout
     check_outputs()
-    # ... and the same through -j
+    # ... and the same through -j, started with the driver's own --gpus flag
     wipe()
     os.rename(tmp_path / "mer_counts25.jf", tmp_path / "db.jf")
-    p3 = _torchrun_cli(tmp_path, ["-j", "db.jf", "-a", "asm.fa", "-k", str(meta["k"]), "-t", str(meta["threads"]), "-p", str(meta["passes"])])
+    env2 = dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_DIST_BACKEND="gloo", JASPER_AMD_ONE_GPU="1", MASTER_PORT=str(_free_port()))
+    p3 = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-j", "db.jf", "-a", "asm.fa", "-k", str(meta["k"]), "-t", str(meta["threads"]),
+                         "-p", str(meta["passes"]), "--gpus", "2"], cwd=tmp_path, env=env2, capture_output=True, text=True, timeout=900)
     assert p3.returncode == 0, p3.stdout + p3.stderr
     check_outputs()
