@@ -1107,6 +1107,16 @@ int Table::attach_ipc(const void *handles64, uint32_t n, uint32_t self, std::str
         }
         ipc_mapped[i] = p;
         d.shard[i] = (const unsigned long long *)p;
+        // a mapping that this GPU cannot actually load from would only show as a page fault inside a polishing kernel
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.device != device) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, device, at.device) != hipSuccess || !can) {
+                err = "GPU " + std::to_string(device) + " has no peer access to GPU " + std::to_string(at.device) + " (shard " + std::to_string(i) + ")";
+                detach_shards();
+                return -1;
+            }
+        }
     }
     d.nshard = n;
     return 0;
