@@ -165,3 +165,23 @@ def test_cli_two_ranks_matches_jasper_sh(hip, tmp_path):
                          "-p", str(meta["passes"]), "--gpus", "2"], cwd=tmp_path, env=env2, capture_output=True, text=True, timeout=900)
     assert p3.returncode == 0, p3.stdout + p3.stderr
     check_outputs()
+
+
+def test_cli_three_ranks(hip, tmp_path):
+    """a rank count that is not a power of two: three byte ranges per read file, three key owners, three file pieces"""
+    meta = json.load(open(os.path.join(E2E, "meta.json")))
+    for fn in ("r1.fq", "r2.fq"):
+        with open(tmp_path / fn, "wb") as f:
+            f.write(gzip.open(os.path.join(E2E, fn + ".gz")).read())
+    shutil.copy(os.path.join(E2E, "asm.fa"), tmp_path)
+    p = _torchrun_cli(tmp_path, ["-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(meta["k"]), "-t", str(meta["threads"]), "-p", str(meta["passes"])], nproc=3)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert open(tmp_path / "threshold.txt").read() == open(os.path.join(E2E, "threshold.txt")).read()
+    assert open(tmp_path / "jfhisto25.csv").read() == open(os.path.join(E2E, "jfhisto25.csv")).read()
+    assert fasta_records(tmp_path / "asm.fa.polished.fasta") == fasta_records(os.path.join(E2E, "asm.fa.polished.fasta"))
+    assert open(tmp_path / "asm.fa.fixes.csv", newline="").read() == open(os.path.join(E2E, "asm.fa.fixes.csv"), newline="").read()
+    sys.path.insert(0, HERE)
+    from test_gpu_jf import _read_jf, _jf_pos
+    hdr, recs = _read_jf(str(tmp_path / "mer_counts25.jf"))
+    order = [(_jf_pos(hdr, k), k) for k, _ in recs]
+    assert order == sorted(order) and len(set(order)) == len(order)
