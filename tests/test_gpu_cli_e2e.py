@@ -185,3 +185,42 @@ def test_cli_three_ranks(hip, tmp_path):
     hdr, recs = _read_jf(str(tmp_path / "mer_counts25.jf"))
     order = [(_jf_pos(hdr, k), k) for k, _ in recs]
     assert order == sorted(order) and len(set(order)) == len(order)
+
+
+def test_cli_two_ranks_degenerate_inputs(hip, tmp_path):
+    """a rank with nothing to count, a rank with no batch file, and the run the reference aborts (no usable threshold):
+    two ranks behave like one process"""
+    rng = __import__("numpy").random.default_rng(4)
+    genome = "".join(rng.choice(list("ACGT"), 3000))
+    (tmp_path / "asm.fa").write_text(">c1\n" + genome + "\n")
+    # one read only: rank 1's byte range of the file is empty; the histogram has a single row -> threshold script exits 1
+    (tmp_path / "one.fq").write_text("@r\n%s\n+\n%s\n" % (genome[100:250], "I" * 150))
+    args = ["-r", "one.fq", "-a", "asm.fa", "-k", "25", "-t", "1", "-p", "1"]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    one = tmp_path / "single"
+    two = tmp_path / "double"
+    for d in (one, two):
+        d.mkdir()
+        for fn in ("asm.fa", "one.fq"):
+            shutil.copy(tmp_path / fn, d)
+    p1 = subprocess.run([sys.executable, "-m", "jasper_amd.cli"] + args, cwd=one, env=env, capture_output=True, text=True, timeout=300)
+    p2 = _torchrun_cli(two, args)
+    assert p1.returncode == 1 and "Local min of kmer counts is smaller than 4" in p1.stderr
+    assert p2.returncode != 0 and "Local min of kmer counts is smaller than 4" in p2.stderr
+    assert open(one / "jfhisto25.csv").read() == open(two / "jfhisto25.csv").read() == "1 126\n"
+    # the golden reads (usable threshold) with an assembly that makes ONE batch file: rank 1 has nothing to polish
+    first = fasta_records(os.path.join(E2E, "asm.fa"))
+    name, seq = sorted(first.items())[0]
+    for d in (one, two):
+        for fn in os.listdir(d):
+            os.remove(d / fn)
+        with open(d / "many.fq", "wb") as f:
+            f.write(gzip.open(os.path.join(E2E, "r1.fq.gz")).read() + gzip.open(os.path.join(E2E, "r2.fq.gz")).read())
+        (d / "asm.fa").write_text("%s\n%s\n" % (name, seq[:3000]))
+    args = ["-r", "many.fq", "-a", "asm.fa", "-k", "25", "-t", "1", "-p", "2"]
+    p1 = subprocess.run([sys.executable, "-m", "jasper_amd.cli"] + args, cwd=one, env=env, capture_output=True, text=True, timeout=300)
+    p2 = _torchrun_cli(two, args)
+    assert p1.returncode == 0 and p2.returncode == 0, p1.stderr + p2.stdout + p2.stderr
+    for fn in ("asm.fa.polished.fasta", "asm.fa.fixes.csv", "threshold.txt", "jfhisto25.csv"):
+        assert open(one / fn, newline="").read() == open(two / fn, newline="").read(), fn
+    assert len([fn for fn in os.listdir(two) if fn.startswith("jasper.") and fn.endswith(".success")]) == 5
