@@ -21,6 +21,10 @@
 #include <vector>
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <unistd.h>
 #include <zlib.h>
@@ -166,13 +170,80 @@ __global__ __launch_bounds__(IG_THREADS) void ig_emit_kernel(const uint8_t *__re
     }
 }
 
+// One gzip file inflated AHEAD of the consumer by its own thread, at most `cap` bytes ahead.  `zcat -f` inflates on one core
+// (~0.3 GB/s of text) while the GPU parses text at 10 GB/s, so gzip input is inflate-bound; the files of one call are
+// independent gzip streams, so all of them are inflated at the same time and the stream the parser sees -- their
+// concatenation, in order -- is unchanged.  Also overlaps inflating with the GPU work on the previous chunk.
+struct GzAhead {
+    static constexpr size_t BLK = 4u << 20;
+    struct Block { std::unique_ptr<char[]> p; size_t n = 0, used = 0; };
+    std::string path, err;
+    size_t cap;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Block> q;
+    size_t queued = 0;
+    bool done = false, failed = false, stop = false;
+    std::thread th;
+    GzAhead(const char *path_, size_t cap_) : path(path_), cap(cap_ < 2 * BLK ? 2 * BLK : cap_) { th = std::thread([this] { run(); }); }
+    ~GzAhead() {
+        { std::lock_guard<std::mutex> l(mu); stop = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    void run() {
+        gzFile g = gzopen(path.c_str(), "rb");
+        if (!g) { std::lock_guard<std::mutex> l(mu); failed = done = true; err = "cannot open " + path; cv.notify_all(); return; }
+        gzbuffer(g, 1u << 20);
+        for (;;) {
+            Block b;
+            b.p.reset(new char[BLK]);
+            const int r = gzread(g, b.p.get(), (unsigned)BLK);
+            std::unique_lock<std::mutex> l(mu);
+            if (r < 0) { failed = done = true; err = "read error in " + path; break; }
+            if (r == 0) { done = true; break; }
+            b.n = (size_t)r;
+            queued += b.n;
+            q.push_back(std::move(b));
+            cv.notify_all();
+            cv.wait(l, [this] { return stop || queued + BLK <= cap; });
+            if (stop) { done = true; break; }
+        }
+        cv.notify_all();
+        gzclose(g);
+    }
+    // up to `want` bytes; 0 at the end of the file, -1 on error
+    long read(char *dst, size_t want) {
+        size_t got = 0;
+        std::unique_lock<std::mutex> l(mu);
+        while (got < want) {
+            cv.wait(l, [this] { return !q.empty() || done; });
+            if (q.empty()) { if (failed) return -1; break; }
+            Block &b = q.front();
+            const size_t m = std::min(want - got, b.n - b.used);
+            l.unlock();
+            memcpy(dst + got, b.p.get() + b.used, m);       // (only the consumer touches the front block)
+            l.lock();
+            b.used += m;
+            got += m;
+            queued -= m;
+            if (b.used == b.n) q.pop_front();
+            cv.notify_all();
+        }
+        return (long)got;
+    }
+};
+
 struct Reader {           // the concatenation of all input files as one byte stream (src/jasper.sh:177 `zcat -f $READS`)
     const char *const *paths;
     int n_paths, cur = 0;
     // optional byte range [begins[i], ends[i]) of plain file i (ends[i] < 0: to the end); a gzip member or a pipe cannot be
     // cut and is read whole when its range starts at 0 and skipped otherwise (multi-GPU read shards)
     const int64_t *begins = nullptr, *ends = nullptr;
-    gzFile g = nullptr;   // gzip members are inflated by zlib ...
+    std::vector<std::unique_ptr<GzAhead>> ahead;   // per path: the inflating thread of a gzip file (started for all of them at once)
+    bool ahead_started = false;
+    GzAhead *ga = nullptr;                         // the current file's, when it is a gzip file
+    gzFile g = nullptr;   // pipes and other non-regular files are read through zlib's pass-through ...
     int fd = -1;          // ... anything else is read as it is (what `zcat -f` does): pread by a few threads, because one
     off_t off = 0, size = 0;   // thread copies out of the page cache at only ~7 GB/s
     std::string err;
@@ -180,8 +251,9 @@ struct Reader {           // the concatenation of all input files as one byte st
     // fills buf with up to want bytes; returns bytes read, 0 at the end of the last file, -1 on error
     long read(char *buf, size_t want) {
         size_t got = 0;
+        if (!ahead_started) start_ahead();
         while (got < want) {
-            if (!g && fd < 0) {
+            if (!g && fd < 0 && !ga) {
                 if (cur >= n_paths) break;
                 fd = open(paths[cur], O_RDONLY);
                 if (fd < 0) { err = std::string("cannot open ") + paths[cur]; return -1; }
@@ -199,9 +271,8 @@ struct Reader {           // the concatenation of all input files as one byte st
                 if (m == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
                     close(fd);
                     fd = -1;
-                    g = gzopen(paths[cur], "rb");
-                    if (!g) { err = std::string("cannot open ") + paths[cur]; return -1; }
-                    gzbuffer(g, 1u << 20);
+                    if (!ahead[cur]) ahead[cur].reset(new GzAhead(paths[cur], ahead_cap));
+                    ga = ahead[cur].get();
                 } else if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {       // pipes etc.: sequential reads through zlib's pass-through
                     close(fd);
                     fd = -1;
@@ -213,7 +284,10 @@ struct Reader {           // the concatenation of all input files as one byte st
                 }
             }
             long r = 0;
-            if (g) {
+            if (ga) {
+                r = ga->read(buf + got, want - got);
+                if (r < 0) { err = ga->err; return -1; }
+            } else if (g) {
                 r = gzread(g, buf + got, (unsigned)std::min<size_t>(want - got, 1u << 30));
                 if (r < 0) { err = std::string("read error in ") + paths[cur]; return -1; }
             } else {
@@ -241,13 +315,41 @@ struct Reader {           // the concatenation of all input files as one byte st
                 }
             }
             if (r == 0) {
-                if (g) { gzclose(g); g = nullptr; } else { close(fd); fd = -1; }
+                if (ga) { ga = nullptr; ahead[cur].reset(); }
+                else if (g) { gzclose(g); g = nullptr; }
+                else { close(fd); fd = -1; }
                 ++cur;
                 continue;
             }
             got += (size_t)r;
         }
         return (long)got;
+    }
+    // every gzip file this reader will read gets its inflating thread now; together they may run ahead by a budget of
+    // JASPER_INGEST_AHEAD_MB (default: a quarter of the machine's memory, at most 16 GiB), shared evenly
+    size_t ahead_cap = 0;
+    void start_ahead() {
+        ahead_started = true;
+        ahead.resize((size_t)n_paths);
+        std::vector<int> gz;
+        for (int i = 0; i < n_paths; ++i) {
+            if (begins && begins[i] != 0) continue;
+            if (ends && ends[i] >= 0 && ends[i] <= (begins ? begins[i] : 0)) continue;
+            unsigned char magic[2] = {0, 0};
+            const int f = open(paths[i], O_RDONLY);
+            if (f < 0) continue;
+            const ssize_t m = pread(f, magic, 2, 0);
+            close(f);
+            if (m == 2 && magic[0] == 0x1f && magic[1] == 0x8b) gz.push_back(i);
+        }
+        if (gz.empty()) return;
+        size_t budget = 16ull << 30;
+        const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+        if (pages > 0 && psz > 0) budget = std::min<size_t>(budget, (size_t)pages * (size_t)psz / 4);
+        if (const char *e = getenv("JASPER_INGEST_AHEAD_MB")) budget = (size_t)strtoull(e, nullptr, 10) << 20;
+        ahead_cap = budget / gz.size();
+        const size_t max_threads = 16;                       // (more files than that: the later ones start when they are reached)
+        for (size_t j = 0; j < gz.size() && j < max_threads; ++j) ahead[(size_t)gz[j]].reset(new GzAhead(paths[gz[j]], ahead_cap));
     }
     ~Reader() { if (g) gzclose(g); if (fd >= 0) close(fd); }
 };

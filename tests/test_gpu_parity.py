@@ -119,6 +119,41 @@ def test_reads_files_formats_and_gzip(KT, O, tmp_path):
     t.close()
 
 
+@pytest.mark.parametrize("ahead_mb", [None, "1"])
+def test_several_gzip_files_inflated_ahead(KT, O, tmp_path, monkeypatch, ahead_mb):
+    """every gzip file of a call is inflated by its own thread, ahead of the parser by a bounded budget (a tiny one here makes
+    the threads block and resume many times); what the parser sees is still ONE stream, the files in order"""
+    k = 25
+    if ahead_mb:
+        monkeypatch.setenv("JASPER_INGEST_AHEAD_MB", ahead_mb)
+    monkeypatch.setenv("JASPER_INGEST_CHUNK", str(1 << 20))
+    rng = np.random.default_rng(8)
+    genome = synth.make_genome(rng, 120_000, repeat_frac=0)
+    stream = synth.make_reads_stream(rng, genome, 200, 150, 0.005).tobytes().decode()
+    reads = [r for r in stream.split("N") if r]
+    cuts = [0, len(reads) // 5, len(reads) // 2, len(reads) * 3 // 4, len(reads)]
+    texts, paths = [], []
+    for j in range(4):
+        txt = "".join("@f%d_%d\n%s\n+\n%s\n" % (j, i, r, "F" * len(r)) for i, r in enumerate(reads[cuts[j]:cuts[j + 1]]))
+        texts.append(txt)
+        p = tmp_path / ("part%d.fq%s" % (j, "" if j == 1 else ".gz"))        # plain file in the middle of the gzip ones
+        if j == 1:
+            p.write_text(txt)
+        else:
+            with gzip.open(p, "wb", compresslevel=1) as f:
+                f.write(txt.encode())
+        paths.append(str(p))
+    assert min(len(x) for x in texts) > 9 << 20                               # every file is longer than the smallest look-ahead (2 x 4 MB)
+    t = KT(k, min_slots=1 << 21)
+    t.count_files(paths)
+    ref = KT(k, min_slots=1 << 21)
+    ref.count_text("".join(texts))
+    assert t.info()["occurrences"] == ref.info()["occurrences"] and t.info()["distinct"] == ref.info()["distinct"]
+    assert t.histogram() == ref.histogram()
+    t.close()
+    ref.close()
+
+
 def test_format_errors(KT):
     from jasper_amd._lib import JasperHipError
     t = KT(21, min_slots=1 << 16)

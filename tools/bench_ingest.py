@@ -30,3 +30,31 @@ for label, env in (("GPU text parser", None), ("GPU text parser (again)", None),
     t0 = time.perf_counter(); t.count_files([fq]); t.sync(); t1 = time.perf_counter()
     print("FASTQ file, %s: %.0f MB in %.1f ms -> %.2f GB/s of text, %.2f Gk-mers/s (file read + PCIe inclusive); parsed on GPU/host: %s"
           % (label, sz / 1e6, (t1 - t0) * 1e3, sz / (t1 - t0) / 1e9, kmers / (t1 - t0) / 1e9, t.last_ingest()), flush=True)
+os.environ.pop("JASPER_INGEST_HOST", None)
+# gzip input: the text split into 4 .gz files (random qualities, so that it compresses like real FASTQ, ~3.5x)
+import gzip, subprocess
+qs = np.frombuffer(b"FFFFFFFF:,#", dtype=np.uint8)
+parts = []
+per = r2.shape[0] // 4
+for j in range(4):
+    p = os.path.join(d, "p%d.fq" % j)
+    rows = r2[j * per:(j + 1) * per]
+    rec = np.empty((rows.shape[0], 4 + 150 + 3 + 150 + 1), dtype=np.uint8)
+    rec[:, 0:4] = np.frombuffer(b"@rd\n", dtype=np.uint8)
+    rec[:, 4:154] = rows
+    rec[:, 154:157] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, 157:307] = rng.choice(qs, (rows.shape[0], 150))
+    rec[:, 307] = 10
+    rec.tofile(p)
+    subprocess.run(["gzip", "-1", "-f", p], check=True)
+    parts.append(p + ".gz")
+gsz = sum(os.path.getsize(p) for p in parts)
+text = 4 * per * 308
+for label, mb in (("one file at a time (JASPER_INGEST_AHEAD_MB=0: 8 MB look-ahead)", "0"), ("all files inflated ahead (default budget)", None)):
+    if mb is None:
+        os.environ.pop("JASPER_INGEST_AHEAD_MB", None)
+    else:
+        os.environ["JASPER_INGEST_AHEAD_MB"] = mb
+    t.clear()
+    t0 = time.perf_counter(); t.count_files(parts); t.sync(); t1 = time.perf_counter()
+    print("4 gzip files (%.0f MB -> %.0f MB of text), %s: %.2f s -> %.2f GB/s of text" % (gsz / 1e6, text / 1e6, label, t1 - t0, text / (t1 - t0) / 1e9), flush=True)
