@@ -502,6 +502,11 @@ int Table::min_log2_slots(int k) {
 
 int Table::init(int k_, uint64_t min_slots, int device_, std::string &err) {
     if (k_ < 1 || k_ > 64) { err = "k must be in [1,64]"; return -1; }
+    if (min_log2_slots(k_) > 34) {
+        // the slot's tag word holds the 2k - s hash bits the slot index does not imply (<= 53): k = 44 would need 2^35 slots
+        err = "k = " + std::to_string(k_) + " is not supported: this table format holds k-mers of up to 43 bases in the HBM of one GPU (DESIGN.md section 3)";
+        return -1;
+    }
     k = k_;
     device = device_;
     HIPCHK(hipSetDevice(device));

@@ -154,6 +154,16 @@ def test_several_gzip_files_inflated_ahead(KT, O, tmp_path, monkeypatch, ahead_m
     ref.close()
 
 
+def test_k_limits(KT):
+    """k up to 43 (the tag word holds 2k - log2(slots) <= 53 hash bits); beyond that a clear refusal, not an allocation failure"""
+    from jasper_amd._lib import JasperHipError
+    for k in (44, 51, 64):
+        with pytest.raises(JasperHipError, match="up to 43 bases"):
+            KT(k, min_slots=1 << 20)
+    with pytest.raises(JasperHipError, match=r"\[1,64\]"):
+        KT(0, min_slots=1 << 20)
+
+
 def test_format_errors(KT):
     from jasper_amd._lib import JasperHipError
     t = KT(21, min_slots=1 << 16)
