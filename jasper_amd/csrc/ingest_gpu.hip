@@ -274,10 +274,11 @@ struct Reader {           // the concatenation of all input files as one byte st
                     if (!ahead[cur]) ahead[cur].reset(new GzAhead(paths[cur], ahead_cap));
                     ga = ahead[cur].get();
                 } else if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {       // pipes etc.: sequential reads through zlib's pass-through
-                    close(fd);
+                    // (on the descriptor already open: closing a FIFO's only reader would break the writer's pipe)
+                    g = gzdopen(fd, "rb");
+                    if (!g) { close(fd); fd = -1; err = std::string("cannot open ") + paths[cur]; return -1; }
                     fd = -1;
-                    g = gzopen(paths[cur], "rb");
-                    if (!g) { err = std::string("cannot open ") + paths[cur]; return -1; }
+                    gzbuffer(g, 1u << 20);
                 } else {
                     off = (off_t)std::min<int64_t>(rb, (int64_t)st.st_size);
                     size = re >= 0 ? (off_t)std::min<int64_t>(re, (int64_t)st.st_size) : st.st_size;
@@ -336,6 +337,8 @@ struct Reader {           // the concatenation of all input files as one byte st
             if (begins && begins[i] != 0) continue;
             if (ends && ends[i] >= 0 && ends[i] <= (begins ? begins[i] : 0)) continue;
             unsigned char magic[2] = {0, 0};
+            struct stat st;
+            if (stat(paths[i], &st) != 0 || !S_ISREG(st.st_mode)) continue;     // (never open a pipe just to look at it)
             const int f = open(paths[i], O_RDONLY);
             if (f < 0) continue;
             const ssize_t m = pread(f, magic, 2, 0);

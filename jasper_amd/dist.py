@@ -69,6 +69,9 @@ def plan_read_shards(paths, world):
     differ between files, a file without a final newline, multi-line FASTQ where no 4-line record start is found) goes
     whole to rank 0.  Deterministic: every rank computes the same plan."""
     import gzip
+    import stat as _stat
+    if any(not _stat.S_ISREG(os.stat(p).st_mode) for p in paths):     # a pipe can be read once, by one reader: not looked at here
+        return [[(p, 0, -1) for p in paths]] + [[] for _ in range(world - 1)]
     info = []
     for p in paths:
         with open(p, "rb") as f:

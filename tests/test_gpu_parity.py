@@ -154,6 +154,37 @@ def test_several_gzip_files_inflated_ahead(KT, O, tmp_path, monkeypatch, ahead_m
     ref.close()
 
 
+def test_reads_from_named_pipes(KT, tmp_path):
+    """`-r <(zcat a.gz)`-style input: a pipe cannot be sized, seeked or looked at twice; plain and gzip content both work"""
+    import threading
+    k = 31
+    rng = np.random.default_rng(12)
+    genome = synth.make_genome(rng, 30_000, repeat_frac=0)
+    reads = [r for r in synth.make_reads_stream(rng, genome, 20, 100, 0.01).tobytes().decode().split("N") if r]
+    txt = "".join("@p%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads))
+    half = txt.index("@p%d\n" % (len(reads) // 2))
+    ref = KT(k, min_slots=1 << 16)
+    ref.count_text(txt)
+    f1, f2 = str(tmp_path / "a.fifo"), str(tmp_path / "b.fifo")
+    os.mkfifo(f1)
+    os.mkfifo(f2)
+
+    def feed(path, data):
+        with open(path, "wb") as f:
+            f.write(data)
+    ws = [threading.Thread(target=feed, args=(f1, txt[:half].encode())), threading.Thread(target=feed, args=(f2, gzip.compress(txt[half:].encode())))]
+    for w in ws:
+        w.start()
+    t = KT(k, min_slots=1 << 16)
+    t.count_files([f1, f2])
+    for w in ws:
+        w.join(timeout=60)
+        assert not w.is_alive()
+    assert t.histogram() == ref.histogram() and t.info()["occurrences"] == ref.info()["occurrences"]
+    t.close()
+    ref.close()
+
+
 def test_k_limits(KT):
     """k up to 43 (the tag word holds 2k - log2(slots) <= 53 hash bits); beyond that a clear refusal, not an allocation failure"""
     from jasper_amd._lib import JasperHipError

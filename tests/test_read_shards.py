@@ -82,3 +82,13 @@ def test_gzip_files_go_whole_to_the_least_loaded_rank(tmp_path):
     sh = jd.plan_read_shards(paths, 2)
     assert sorted(x for r in sh for x in r) == sorted((p, 0, -1) for p in paths)
     assert [p for p, _, _ in sh[0]] == [paths[0]] and sorted(p for p, _, _ in sh[1]) == sorted(paths[1:])
+
+
+def test_pipes_are_not_touched(tmp_path):
+    import os
+    fifo = tmp_path / "r.fifo"
+    os.mkfifo(fifo)
+    plain = tmp_path / "a.fq"
+    plain.write_bytes(b"@a\nACGT\n+\nIIII\n")
+    # (opening the FIFO would block forever here: the plan must come back without looking at it)
+    assert jd.plan_read_shards([str(plain), str(fifo)], 2) == [[(str(plain), 0, -1), (str(fifo), 0, -1)], []]
