@@ -462,6 +462,118 @@ __global__ __launch_bounds__(256) void import_packed_multi_kernel(MultiSrc S, ui
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
 }
 
+// ---- the same into an EMPTY table, without a global atomic: region images in LDS --------------------------------------
+// Global atomics top out at ~17 G entries/s (two or three L2 transactions per entry).  When the table is empty there is
+// nothing to merge with in HBM, so the table can be built the way lds_insert_kernel builds it: one block owns a region of
+// IMPR slots, collects the region's entries in an LDS image and writes the image out once.  Which entries are a region's?
+// The lists are in slot order of same-hash tables, i.e. nearly sorted by destination slot: a histogram of the entries'
+// regions (pass 1) and its prefix sums cut every list into consecutive pieces, one per region, that hold exactly as many
+// entries as the region gets and -- up to the few inversions next to a boundary -- exactly its entries.  An entry that is
+// not the block's (an inversion), or whose probe sequence leaves the region, goes to a deferred list and is added with
+// the global kernel afterwards.  Nothing depends on the lists really being sorted: unsorted input just defers everything.
+constexpr uint32_t IMPR_LOG = 12, IMPR = 1u << IMPR_LOG;                 // 4096 slots = 64 KB of LDS
+__global__ __launch_bounds__(256) void imp_region_hist_kernel(MultiSrc S, TableDev T, uint32_t nreg, unsigned int *__restrict__ hist) {
+    const int sh = packed_count_shift(T.B);
+    const unsigned long long himask = sh ? ((1ull << sh) - 1ull) : 0ull;
+    for (uint32_t s = 0; s < S.n_src; ++s) {
+        const ulonglong2 *__restrict__ in = S.p[s];
+        unsigned int *__restrict__ hs = hist + (size_t)s * (nreg + 1);
+        const unsigned long long n = S.n[s], step = (unsigned long long)gridDim.x * blockDim.x;
+        for (unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x; i0 < n; i0 += step) {
+            const unsigned long long i = i0 + threadIdx.x;
+            uint32_t reg = 0xFFFFFFFFu;
+            if (i < n) {
+                const ulonglong2 e = in[i];
+                reg = (uint32_t)(home_of(mk(e.y & himask, e.x), T.B, T.s) >> IMPR_LOG);
+            }
+            // neighbours in the list fall into the same one or two regions: one atomic per distinct region of the wave
+            uint64_t todo = __ballot(reg != 0xFFFFFFFFu);
+            while (todo) {
+                const int leader = (int)__builtin_ctzll(todo);
+                const uint32_t r = __shfl(reg, leader);
+                const uint64_t same = __ballot(reg == r);
+                if ((threadIdx.x & 63) == leader) atomicAdd(&hs[r], (unsigned int)__popcll(same));
+                todo &= ~same;
+            }
+        }
+    }
+}
+// in-place exclusive scan of each list's nreg counts (block s = list s); entry nreg = the total
+__global__ __launch_bounds__(1024) void imp_region_scan_kernel(unsigned int *__restrict__ hist, uint32_t nreg) {
+    __shared__ unsigned int s_w[16];
+    __shared__ unsigned int s_carry;
+    unsigned int *h = hist + (size_t)blockIdx.x * (nreg + 1);
+    const int t = threadIdx.x;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nreg; base += 1024) {
+        const unsigned int v = base + t < nreg ? h[base + t] : 0u;
+        unsigned int inc = v;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
+        if ((t & 63) == 63) s_w[t >> 6] = inc;
+        __syncthreads();
+        unsigned int wbase = s_carry;
+        for (int w = 0; w < (t >> 6); ++w) wbase += s_w[w];
+        if (base + t < nreg) h[base + t] = wbase + inc - v;
+        __syncthreads();
+        if (t == 1023) s_carry = wbase + inc;
+        __syncthreads();
+    }
+    if (t == 0) h[nreg] = s_carry;
+}
+__global__ __launch_bounds__(256) void lds_import_kernel(MultiSrc S, TableDev T, uint32_t nreg, const unsigned int *__restrict__ bounds,
+                                                         ulonglong2 *__restrict__ deferred, unsigned long long *__restrict__ deferred_n, unsigned long long deferred_cap) {
+    __shared__ unsigned long long s_tag[IMPR];
+    __shared__ unsigned long long s_cnt[IMPR];
+    __shared__ unsigned int s_fresh[4];
+    const uint32_t r = blockIdx.x;
+    const int sh = packed_count_shift(T.B);
+    const unsigned long long himask = sh ? ((1ull << sh) - 1ull) : 0ull;
+    for (uint32_t j = threadIdx.x; j < IMPR; j += 256) { s_tag[j] = 0ull; s_cnt[j] = 0ull; }
+    __syncthreads();
+    unsigned int fresh = 0;
+    for (uint32_t s = 0; s < S.n_src; ++s) {
+        const ulonglong2 *__restrict__ in = S.p[s];
+        const unsigned int *__restrict__ b = bounds + (size_t)s * (nreg + 1);
+        const unsigned int lo = b[r], hi = b[r + 1];
+        for (unsigned int i = lo + threadIdx.x; i < hi; i += 256) {
+            const ulonglong2 e = in[i];
+            const u128 h = mk(e.y & himask, e.x);
+            const unsigned long long c = sh ? (e.y >> sh) : e.y;
+            if (!c) continue;
+            const uint64_t home = home_of(h, T.B, T.s);
+            bool placed = false;
+            if ((uint32_t)(home >> IMPR_LOG) == r) {
+                const uint64_t rem = rem_of(h, T.B, T.s);
+                const uint32_t local = (uint32_t)(home & (IMPR - 1));
+                for (uint32_t off = 0; off < MAXPROBE && local + off < IMPR; ++off) {
+                    const unsigned long long want = tag_of(rem, off);
+                    unsigned long long cur = s_tag[local + off];
+                    if (cur == 0ull) {
+                        cur = atomicCAS(&s_tag[local + off], 0ull, want);
+                        if (cur == 0ull) { ++fresh; cur = want; }
+                    }
+                    if (cur == want) { atomicAdd(&s_cnt[local + off], c); placed = true; break; }
+                }
+            }
+            if (!placed) {        // an inversion of the list order, or a probe sequence that leaves the region
+                const unsigned long long di = atomicAdd(deferred_n, 1ull);
+                if (di < deferred_cap) deferred[di] = e;
+            }
+        }
+    }
+    __syncthreads();
+    ulonglong2 *out = reinterpret_cast<ulonglong2 *>(T.slots) + (size_t)r * IMPR;
+    for (uint32_t j = threadIdx.x; j < IMPR; j += 256) out[j] = make_ulonglong2(s_tag[j], s_cnt[j]);
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0) s_fresh[threadIdx.x >> 6] = fresh;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int f = s_fresh[0] + s_fresh[1] + s_fresh[2] + s_fresh[3];
+        if (f) atomicAdd(&T.stats[ST_DISTINCT], (unsigned long long)f);
+    }
+}
+
 // hipMemsetAsync runs at ~1 TB/s on this stack; 16-B streaming stores reach the HBM write rate
 __global__ __launch_bounds__(256) void zero_kernel(ulonglong2 *__restrict__ p, uint64_t n16) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
@@ -1151,18 +1263,51 @@ int Table::import_packed_multi(const void *const *d_srcs, const uint64_t *counts
     if (n_src < 1 || n_src > MAX_SHARDS) { err = "import_packed_multi: 1..8 lists"; return -1; }
     histo_cached = false;
     HIPCHK(hipSetDevice(device));
-    if (materialize(err)) return -1;
     if (read_stats(err)) return -1;
     MultiSrc S{};
     uint64_t total = 0;
     for (uint32_t i = 0; i < n_src; ++i) { S.p[i] = (const ulonglong2 *)d_srcs[i]; S.n[i] = counts[i]; total += counts[i]; }
     S.n_src = n_src;
-    if (!total) return 0;
+    if (!total) return materialize(err);
     // worst case every entry is a new key; if that could overfill the table, grow first (keys shared between the lists make
     // this generous -- callers that know better size the table themselves and never get here)
     if ((double)(h_stats[ST_DISTINCT] + total) > 0.9 * (double)nslots) {
         if (ensure_capacity(total, err)) return -1;
     }
+    // an empty table is built region by region in LDS (no global atomic); lists of up to 2^32 entries, tables of >= 2 regions
+    bool big = false;
+    for (uint32_t i = 0; i < n_src; ++i) big = big || counts[i] >= 0xFFFFFFFFull;
+    if (h_stats[ST_DISTINCT] == 0 && h_stats[ST_SPILL] == 0 && !big && nslots >= 2 * IMPR && !getenv("JASPER_IMPORT_ATOMIC")) {
+        const uint32_t nreg = (uint32_t)(nslots >> IMPR_LOG);
+        const uint64_t dcap = total / 8 + (1u << 20);
+        const size_t hwords = (size_t)n_src * (nreg + 1);
+        unsigned int *d_ws = reinterpret_cast<unsigned int *>(workspace(WS_COUNT + 2, (hwords + 2) * 4 + 64, err));   // [deferred counter (8 B)][histograms]
+        ulonglong2 *d_def = reinterpret_cast<ulonglong2 *>(workspace(WS_COUNT + 0, dcap * 16 + 64, err));
+        if (!d_ws || !d_def) return -1;
+        unsigned long long *d_defn = reinterpret_cast<unsigned long long *>(d_ws);
+        unsigned int *d_b = d_ws + 2;
+        slots_dirty = false;               // every slot is written below: a lazily cleared table needs no zeroing first
+        HIPCHK(hipMemsetAsync(d_ws, 0, (hwords + 2) * 4, stream));
+        hipLaunchKernelGGL(imp_region_hist_kernel, dim3(2048), dim3(256), 0, stream, S, d, nreg, d_b);
+        hipLaunchKernelGGL(imp_region_scan_kernel, dim3(n_src), dim3(1024), 0, stream, d_b, nreg);
+        hipLaunchKernelGGL(lds_import_kernel, dim3(nreg), dim3(256), 0, stream, S, d, nreg, d_b, d_def, d_defn, (unsigned long long)dcap);
+        HIPCHK(hipGetLastError());
+        unsigned long long n_def = 0;
+        HIPCHK(hipMemcpyAsync(&n_def, d_defn, 8, hipMemcpyDeviceToHost, stream));
+        HIPCHK(jk_stream_wait(stream));
+        if (getenv("JASPER_COUNT_DEBUG")) fprintf(stderr, "[import] %llu entries into %u LDS regions, %llu deferred\n", (unsigned long long)total, nreg, n_def);
+        if (n_def <= dcap) {
+            if (n_def) {
+                hipLaunchKernelGGL(import_packed_kernel, dim3(grid_for(n_def, 256)), dim3(256), 0, stream, d_def, (uint64_t)n_def, d, 0);
+                HIPCHK(hipGetLastError());
+            }
+            return after_batch(err);
+        }
+        // the lists were not in slot order (too many entries outside their piece): start over with the atomic kernel
+        HIPCHK(hipMemsetAsync(d.stats + ST_DISTINCT, 0, sizeof(unsigned long long), stream));
+        if (zero_slots(d.slots, nslots, err)) return -1;
+    }
+    if (materialize(err)) return -1;
     const uint64_t band = 32ull << 20;                                   // bytes of slots per chunk
     const uint32_t nchunks = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, nslots * 16 / band));
     hipLaunchKernelGGL(import_packed_multi_kernel, dim3(nchunks * IMP_BPC), dim3(256), 0, stream, S, nchunks, d);
