@@ -56,3 +56,17 @@ def test_fuzz_hip_vs_oracle(hip, tmp_path):
     import fuzz_vs_reference as F
     for seed in range(5000, 5300):
         _one(seed, KmerTable, polisher, O, G, F, tmp_path)
+
+
+def test_fuzz_reads_through_owner_shards(hip, tmp_path):
+    """the same cases with every read (histogram, lookups, polishing) going through 2..5 owner tables split off the counted
+    one (tools/fuzz_shard.py): an owner-sharded table must be indistinguishable from a whole one"""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    from jasper_amd import KmerTable, polisher
+    from oracle import oracle as O
+    import make_golden as G
+    import fuzz_vs_reference as F
+    from fuzz_shard import sharded_class
+    S = sharded_class(KmerTable)
+    for seed in range(9000, 9060):
+        _one(seed, S, polisher, O, G, F, tmp_path)
