@@ -161,6 +161,9 @@ def main():
                          "it on every GPU; auto = sharded, replicated only if the peers' memory cannot be mapped")
     a = ap.parse_args()
 
+    if os.environ.get("JASPER_BENCH_WATCHDOG"):      # debugging aid: where is every thread, every N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["JASPER_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))

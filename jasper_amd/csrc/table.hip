@@ -599,6 +599,15 @@ __global__ __launch_bounds__(256) void rehash_kernel(TableDev oldT, TableDev new
 // ==================================================================================================
 // host side
 // ==================================================================================================
+// bytes to allocate for a slot array.  An allocation of exactly 2 GiB (2^27 slots) cannot be mapped by another process on
+// this ROCm stack: hipIpcOpenMemHandle never returns (seen with 2 and with 4 processes; 1 GiB, 4 GiB and 8 GiB are fine) --
+// bit 31 of the size is the suspect, so such an array is allocated as 4 GiB.
+static size_t slot_alloc_bytes(uint64_t nslots) {
+    size_t b = (size_t)nslots * 16;
+    if (b & (1ull << 31)) b += 1ull << 31;
+    return b;
+}
+
 static int grid_for(uint64_t work_items, int per_block) {
     uint64_t b = (work_items + per_block - 1) / per_block;
     const uint64_t cap = 256ull * 8;  // 256 CUs x 8 blocks: fills the chip, rest is grid-stride
@@ -634,7 +643,7 @@ int Table::init(int k_, uint64_t min_slots, int device_, std::string &err) {
     d = TableDev{};
     d.s = s; d.B = 2 * k; d.k = k; d.mask = nslots - 1;
     d.spill_cap = 1u << 16;
-    HIPCHK(hipMalloc((void **)&d.slots, nslots * 16));
+    HIPCHK(hipMalloc((void **)&d.slots, slot_alloc_bytes(nslots)));
     HIPCHK(hipMalloc((void **)&d.stats, ST_WORDS * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&d.spill, d.spill_cap * 3 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&d_histo, 2 * HISTO_WORDS * sizeof(unsigned long long)));
@@ -752,7 +761,7 @@ int Table::resize(int new_s, std::string &err) {
     detach_shards();      // the slot array moves and its geometry changes: the owners have to agree and attach again
     if (slots_dirty) {   // logically empty: nothing to rehash, the new slot array stays lazily cleared as well
         unsigned long long *ns = nullptr;
-        HIPCHK(hipMalloc((void **)&ns, (1ull << new_s) * 16));
+        HIPCHK(hipMalloc((void **)&ns, slot_alloc_bytes(1ull << new_s)));
         HIPCHK(jk_stream_wait(stream));
         HIPCHK(hipFree(d.slots));
         d.slots = ns; d.s = new_s; d.mask = (1ull << new_s) - 1; nslots = 1ull << new_s;
@@ -761,7 +770,7 @@ int Table::resize(int new_s, std::string &err) {
     TableDev nt = d;
     nt.s = new_s;
     nt.mask = (1ull << new_s) - 1;
-    HIPCHK(hipMalloc((void **)&nt.slots, (1ull << new_s) * 16));
+    HIPCHK(hipMalloc((void **)&nt.slots, slot_alloc_bytes(1ull << new_s)));
     if (zero_slots(nt.slots, 1ull << new_s, err)) return -1;
     // distinct is recounted by the re-insertion
     HIPCHK(hipMemsetAsync(d.stats + ST_DISTINCT, 0, sizeof(unsigned long long), stream));
@@ -1207,8 +1216,10 @@ int Table::ipc_handle(void *out64, std::string &err) {
 // owner's table must have this table's geometry -- the caller agrees on it before (dist.shard_tables).
 int Table::attach_ipc(const void *handles64, uint32_t n, uint32_t self, std::string &err) {
     if (n < 1 || n > MAX_SHARDS || self >= n) { err = "attach: 1..8 shards, self among them"; return -1; }
+    const bool dbg = getenv("JASPER_SHARD_DEBUG") != nullptr;
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
+    if (dbg) { fprintf(stderr, "[attach %u] waiting for the stream\n", self); fflush(stderr); }
     HIPCHK(jk_stream_wait(stream));
     detach_shards();
     for (uint32_t i = 0; i < n; ++i) {
@@ -1216,7 +1227,9 @@ int Table::attach_ipc(const void *handles64, uint32_t n, uint32_t self, std::str
         hipIpcMemHandle_t h;
         memcpy(&h, (const char *)handles64 + 64 * (size_t)i, 64);
         void *p = nullptr;
+        if (dbg) { fprintf(stderr, "[attach %u] opening shard %u\n", self, i); fflush(stderr); }
         const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (dbg) { fprintf(stderr, "[attach %u] shard %u -> %p (%s)\n", self, i, p, hipGetErrorString(e)); fflush(stderr); }
         if (e != hipSuccess) {
             err = std::string("hipIpcOpenMemHandle (shard ") + std::to_string(i) + "): " + hipGetErrorString(e);
             detach_shards();

@@ -341,11 +341,16 @@ def shard_tables(local, shard, device, group=None):
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine, group=group)
         handles = [bytes(p.cpu().numpy().tobytes()) for p in parts]
-        if ok:
-            try:
-                shard.attach_ipc(handles, rank)
-            except RuntimeError as e:                  # either every rank is attached or none
-                ok, why = 0, str(e)
+        # one rank maps its peers at a time: four processes opening each other's handles at the same moment were seen to
+        # block each other for good (each open is served by the exporting process); (re)attaching is rare, a few barriers
+        # are not
+        for turn in range(world):
+            if turn == rank and ok:
+                try:
+                    shard.attach_ipc(handles, rank)
+                except RuntimeError as e:              # either every rank is attached or none
+                    ok, why = 0, str(e)
+            dist.barrier(group=group)
         okt = torch.tensor([ok], dtype=torch.int64, device=device)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
         if not int(okt.item()):

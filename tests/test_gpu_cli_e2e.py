@@ -98,7 +98,7 @@ def _torchrun_cli(cwd, args, nproc=2):
     env = dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_DIST_BACKEND="gloo", JASPER_AMD_ONE_GPU="1")
     return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                            "--master-port", str(_free_port()), "-m", "jasper_amd.cli"] + args,
-                          cwd=cwd, env=env, capture_output=True, text=True, timeout=900)
+                          cwd=cwd, env=env, capture_output=True, text=True, timeout=240)
 
 
 def test_cli_two_ranks_matches_jasper_sh(hip, tmp_path):
@@ -167,14 +167,15 @@ def test_cli_two_ranks_matches_jasper_sh(hip, tmp_path):
     check_outputs()
 
 
-def test_cli_three_ranks(hip, tmp_path):
-    """a rank count that is not a power of two: three byte ranges per read file, three key owners, three file pieces"""
+@pytest.mark.parametrize("nproc", [3, 4])
+def test_cli_three_ranks(hip, tmp_path, nproc):
+    """rank counts beyond two, one of them not a power of two: that many byte ranges per read file, key owners, file pieces"""
     meta = json.load(open(os.path.join(E2E, "meta.json")))
     for fn in ("r1.fq", "r2.fq"):
         with open(tmp_path / fn, "wb") as f:
             f.write(gzip.open(os.path.join(E2E, fn + ".gz")).read())
     shutil.copy(os.path.join(E2E, "asm.fa"), tmp_path)
-    p = _torchrun_cli(tmp_path, ["-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(meta["k"]), "-t", str(meta["threads"]), "-p", str(meta["passes"])], nproc=3)
+    p = _torchrun_cli(tmp_path, ["-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(meta["k"]), "-t", str(meta["threads"]), "-p", str(meta["passes"])], nproc=nproc)
     assert p.returncode == 0, p.stdout + p.stderr
     assert open(tmp_path / "threshold.txt").read() == open(os.path.join(E2E, "threshold.txt")).read()
     assert open(tmp_path / "jfhisto25.csv").read() == open(os.path.join(E2E, "jfhisto25.csv")).read()
