@@ -266,3 +266,15 @@ def test_two_ranks_one_gpu_ipc_shards(hip):
         assert got == full.seqs                                   # chunk shards through IPC-mapped owners == unsharded run
         assert tuple(r0[5]) == tuple(r1[5]) == full.qv
     t.close()
+
+
+def test_ipc_mapping_of_a_2_gib_slot_array(hip):
+    """hipIpcOpenMemHandle hangs on an allocation of exactly 2^31 bytes on this stack (found rehearsing N=4): a table of 2^27
+    slots must still be mappable by its peers (table.hip: slot_alloc_bytes).  Two processes, a hard time limit."""
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "ipc_probe.py"), "27", "one_gpu"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.count("attached 1 peers of 2^27 slots") == 2 and p.stdout.count("lookup through the sharded view -> [1]") == 2
