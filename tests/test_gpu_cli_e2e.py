@@ -120,7 +120,7 @@ def test_cli_two_ranks_matches_jasper_sh(hip, tmp_path):
         assert open(tmp_path / "asm.fa.fixes.csv", newline="").read() == open(os.path.join(E2E, "asm.fa.fixes.csv"), newline="").read()
     check_outputs()
     assert sorted(fn for fn in os.listdir(tmp_path) if re.match(r"jasper\..*\.success$", fn)) == meta["sentinels"]
-    mine = [re.sub(r"^\[[^\]]*\]", "[DATE]", ln) for ln in p.stdout.splitlines() if re.match(r"^\[\w{3} \w{3} \d", ln)]   # (gloo prints its own "[Gloo] ..." lines)
+    mine = [re.sub(r"^\[[^\]]*\]", "[DATE]", ln) for ln in p.stdout.splitlines() if re.match(r"^\[\w{3} \w{3} +\d", ln)]   # (gloo prints its own "[Gloo] ..." lines)
     strip_q = lambda ls: [re.sub(r"Q value = .*", "Q value =", ln) for ln in ls]
     assert strip_q(mine) == strip_q(meta["stdout"])                       # only rank 0 talks, same lines as one process
     # src/jasper.sh:177 leaves the database behind: written by both ranks together, one consecutive sorted piece each.
