@@ -147,6 +147,9 @@ int jasper_table_ipc_handle(jasper_table *t, void *out64);
 int jasper_table_attach_ipc(jasper_table *t, const void *handles, uint32_t n, uint32_t self);
 int jasper_table_attach_tables(jasper_table *t, jasper_table *const *shards, uint32_t n, uint32_t self);
 int jasper_table_detach(jasper_table *t);
+/* open and close the peers' handles without a table: run from a throw-away process with a time limit before the real
+ * attach (jasper_amd/dist.py), so that a mapping call that never returns costs a killed helper, not a hung GPU process */
+int jasper_ipc_probe(int device, const void *handles, uint32_t n, uint32_t self);
 /* owner of a packed entry's hash among n (host-side restatement of the device function, for tests and routing) */
 uint32_t jasper_owner_of(uint64_t hash_lo, uint64_t hash_hi, uint32_t n);
 

@@ -286,6 +286,27 @@ int jasper_table_attach_tables(jasper_table *t, jasper_table *const *shards, uin
     for (uint32_t i = 0; i < n; ++i) p[i] = shards[i] ? &shards[i]->t : nullptr;
     return t->t.attach_tables(p, n, self, g_err) ? JASPER_ERR : JASPER_OK;
 }
+// Can this process map these slot arrays at all?  Meant to be called from a THROW-AWAY process with a time limit: a mapping
+// call that never returns (seen on this stack for one allocation size) then costs a killed helper, not a hung rank.
+int jasper_ipc_probe(int device, const void *handles, uint32_t n, uint32_t self) {
+    if (!handles || n < 1 || n > MAX_SHARDS || self >= n) { g_err = "probe: 1..8 handles, self among them"; return JASPER_ERR; }
+    CHK(hipSetDevice(device));
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i == self) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)handles + 64 * (size_t)i, 64);
+        void *p = nullptr;
+        CHK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.device != device) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, device, at.device) != hipSuccess || !can) { (void)hipIpcCloseMemHandle(p); g_err = "no peer access"; return JASPER_ERR; }
+        }
+        CHK(hipIpcCloseMemHandle(p));
+    }
+    return JASPER_OK;
+}
+
 int jasper_table_detach(jasper_table *t) {
     if (hipSetDevice(t->t.device) != hipSuccess) { g_err = "hipSetDevice"; return JASPER_ERR; }
     (void)jk_stream_wait(t->t.stream);

@@ -266,6 +266,25 @@ def merge_tables(table, device, group=None):
     return received
 
 
+def _ipc_probe_ok(shard, handles, rank, seconds=None):
+    """Mapping a peer's memory is a call into the driver stack that has been seen never to return (an allocation of exactly
+    2 GiB on ROCm 7.2).  A rank stuck there would hang the whole job, so the same calls are first made by a throw-away
+    process with a time limit; only if that comes back clean does the rank itself attach.  JASPER_AMD_IPC_PROBE=0 skips it."""
+    import subprocess
+    import sys
+    if os.environ.get("JASPER_AMD_IPC_PROBE", "1") in ("0", "no", "false") or not hasattr(shard, "device"):
+        return True
+    seconds = seconds or float(os.environ.get("JASPER_AMD_IPC_PROBE_SECONDS", "60"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    try:
+        p = subprocess.run([sys.executable, "-m", "jasper_amd._ipc_probe", str(shard.device), str(rank), b"".join(bytes(h) for h in handles).hex()],
+                           env=env, timeout=seconds, capture_output=True)
+        return p.returncode == 0
+    except subprocess.TimeoutExpired:
+        return False
+
+
 class ShardAttachError(RuntimeError):
     """the owners' slot arrays could not be mapped into this process (no IPC / no peer access between the GPUs)"""
 
@@ -346,10 +365,13 @@ def shard_tables(local, shard, device, group=None):
         # are not
         for turn in range(world):
             if turn == rank and ok:
-                try:
-                    shard.attach_ipc(handles, rank)
-                except RuntimeError as e:              # either every rank is attached or none
-                    ok, why = 0, str(e)
+                if not _ipc_probe_ok(shard, handles, rank):
+                    ok, why = 0, "a probe process could not map a peer's slot array within its time limit"
+                else:
+                    try:
+                        shard.attach_ipc(handles, rank)
+                    except RuntimeError as e:          # either every rank is attached or none
+                        ok, why = 0, str(e)
             dist.barrier(group=group)
         okt = torch.tensor([ok], dtype=torch.int64, device=device)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)

@@ -278,3 +278,52 @@ def test_ipc_mapping_of_a_2_gib_slot_array(hip):
                        env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
     assert p.stdout.count("attached 1 peers of 2^27 slots") == 2 and p.stdout.count("lookup through the sharded view -> [1]") == 2
+
+
+def _probe_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      JASPER_NO_IPC_PAD="1", JASPER_AMD_IPC_PROBE_SECONDS="15")
+    import time
+    import torch
+    import torch.distributed as dist
+    from jasper_amd import KmerTable, dist as jd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        local = KmerTable(37, min_slots=1 << 21, device=0)
+        local.count_bases(b"ACGTTGCATGCAAGTCCGATAGGCTAACGTTTGACCATGACAGATTACAGGCATCGATCGGATC" if rank == 0 else b"TTGACCATGACAGATTACAGGCATCGATCGGATCAAGGTTCCAAGGTTACGTAGCTAGCTAGGA")
+        shard = KmerTable(37, min_slots=1 << 27, device=0)      # 2^31 bytes, NOT padded (JASPER_NO_IPC_PAD): the size that hangs
+        shard._fitted = True                                     # (keep that size)
+        t0 = time.time()
+        try:
+            jd.shard_tables(local, shard, dev)
+            out = "attached"
+        except jd.ShardAttachError as e:
+            out = "refused: " + str(e)
+        q.put((rank, out, time.time() - t0))
+        dist.barrier()
+        shard.close()
+        local.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not os.environ.get("JASPER_TEST_IPC_HANG"), reason="provokes a hung driver call in a helper process on purpose: on request only (JASPER_TEST_IPC_HANG=1)")
+def test_a_mapping_that_never_returns_is_caught_by_the_probe(hip):
+    """without the padding of slot_alloc_bytes a peer's 2 GiB slot array cannot be mapped -- hipIpcOpenMemHandle never returns.
+    The throw-away probe process takes that hit: both ranks get ShardAttachError together, within the probe's time limit,
+    and can go on (bench.py / cli.py then replicate the table instead)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_probe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=200) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1].startswith("refused: ") and "probe process" in r[1] for r in res), res
+    assert all(r[2] < 120 for r in res), res
