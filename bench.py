@@ -117,33 +117,72 @@ def one_step(torch, dev_index, table, reads, d_chunks, world, timers, shard=None
     return res
 
 
-def cpu_baseline(seed):
-    """the C oracle (a port of the reference's algorithm) on a bounded sample of the same workload, 1 thread"""
+def host_cpu():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return cores, model
+
+
+def cpu_baseline(seed, reads_np, names, seqs, gpu):
+    """The CPU restatement of the reference's algorithm (oracle/jasper_oracle.c, kind "port") on the host cores of this box,
+    divided the way the reference divides its work: counting like `jellyfish count -t N`, chunk records like `xargs -P N`
+    (src/jasper.sh:177,212).  With >= 8 cores it runs the WHOLE workload of the timed steps (the same reads and chunk
+    records, copied out of HBM) and its results must equal the GPU's: histogram, threshold, polished text, number of fix
+    records, QV counters -- the full-size check of the bench's own chunking against the oracle.  With fewer cores a
+    12 Mb sample of the same recipe is timed instead (no comparison)."""
     import numpy as np
     from jasper_amd import synth, polisher
     from oracle import oracle as O
-    rng = np.random.default_rng(seed)
-    G = 12_000_000     # ~270 M k-mer insertions + 3 scans of 12 Mb: roughly 20 s of one host core
-    genome = synth.make_genome(rng, G)
-    reads = synth.make_reads_stream(rng, genome, COVERAGE, READ_LEN, 0.003)
-    asm = synth.make_assembly(rng, genome, err=1e-4, n_every=10_000_000)
+    cores, model = host_cpu()
+    full = cores >= 8 and reads_np is not None
+    if full:
+        reads = reads_np
+        G = sum(len(q) for q in seqs)
+        chunk_names, chunk_seqs = names, [q.decode() for q in seqs]
+    else:
+        rng = np.random.default_rng(seed)
+        G = 12_000_000
+        genome = synth.make_genome(rng, G)
+        reads = synth.make_reads_stream(rng, genome, COVERAGE, READ_LEN, 0.003)
+        asm = synth.make_assembly(rng, genome, err=1e-4, n_every=10_000_000)
+        bs = synth.jasper_batch_size(len(asm), THREADS_FOR_BATCH_RULE)
+        recs = synth.chunk_records("s", len(asm), bs)
+        b = asm.tobytes().decode()
+        chunk_names, chunk_seqs = [r[0] for r in recs], [b[a:e] for _, a, e in recs]
     t0 = time.perf_counter()
-    db = O.OracleDB(K)
-    nk = db.count_bases(reads.tobytes())
+    db = O.OracleDB(K, threads=cores)
+    nk = db.count_bases(reads)
     t1 = time.perf_counter()
     h = db.histo()
-    txt, status = polisher.threshold_from_histo_rows([(m, h[m]) for m in range(1, 10002) if h[m]])
+    rows = [(m, h[m]) for m in range(1, 10002) if h[m]]
+    txt, status = polisher.threshold_from_histo_rows(rows)
     thr = int(txt) if (status == 0 and txt) else 2
-    bs = synth.jasper_batch_size(len(asm), THREADS_FOR_BATCH_RULE)
-    recs = synth.chunk_records("s", len(asm), bs)
-    b = asm.tobytes().decode()
-    db.polish_batch([r[0] for r in recs], [b[a:e] for _, a, e in recs], thr, PASSES)
+    fixed, csv_rows, qv, _ = db.polish_batch(chunk_names, chunk_seqs, thr, PASSES)
     t2 = time.perf_counter()
-    return dict(value=round(len(asm) / 1e6 / (t2 - t0), 4), unit="Mbp/s", cores=1, kind="port",
-                sample="%.1f Mb synthetic genome, 30x 150-bp reads (%d k-mers), k=37, 2 passes; oracle/jasper_oracle.c, 1 thread"
-                       % (G / 1e6, nk),
-                count_Mkmers_per_s=round(nk / 1e6 / (t1 - t0), 3), polish_Mbp_per_s=round(len(asm) / 1e6 / (t2 - t1), 3),
-                seconds=round(t2 - t0, 2))
+    out = dict(value=round(G / 1e6 / (t2 - t0), 4), unit="Mbp/s", cores=cores, cpu=model, kind="port",
+               sample=("the whole workload of a timed step" if full else "12 Mb sample of the same recipe") +
+                      ": %.1f Mb assembly, %dx %d-bp reads (%d k-mers), k=%d, %d passes; oracle/jasper_oracle.c, %d threads "
+                      "(reads divided like jellyfish count -t, chunk records like xargs -P)" % (G / 1e6, COVERAGE, READ_LEN, nk, K, PASSES, cores),
+               count_Mkmers_per_s=round(nk / 1e6 / (t1 - t0), 3), polish_Mbp_per_s=round(G / 1e6 / (t2 - t1), 3),
+               seconds=round(t2 - t0, 2))
+    if full:
+        nfix = sum(r.count("\n") for r in csv_rows)
+        same = dict(histogram=rows == gpu["rows"], threshold=thr == gpu["thr"], qv_counters=tuple(qv) == tuple(gpu["qv"]),
+                    fix_records=nfix == gpu["nfix"], polished_text=all(f.encode() == g for f, g in zip(fixed, gpu["text"])))
+        out["gpu_result_equals_oracle"] = same
+        if not all(same.values()):
+            raise RuntimeError("GPU result differs from the CPU oracle on the bench workload: %r" % (same,))
+    return out
 
 
 def main():
@@ -164,15 +203,28 @@ def main():
     if os.environ.get("JASPER_BENCH_WATCHDOG"):      # debugging aid: where is every thread, every N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["JASPER_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as CHILD processes (one per GPU, RCCL rendezvous on
+        # 127.0.0.1, a free port) and leave with their exit code.  Decided before anything here touches the GPU -- this
+        # process never initialises HIP, and nothing is exec'ed.
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.stderr.write("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`\n" % (a.gpus, a.gpus))
-            sys.exit(2)
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (a.gpus, world))
+        sys.exit(2)
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible; the product has no CPU path\n")
         sys.exit(2)
@@ -275,7 +327,8 @@ def main():
         "metric": "assembly Mbp/s polished + Gk-mers/s counted, k=37",
         "value": round(asm_total / 1e6 / (dt / steps), 3),
         "unit": "Mbp/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+        "n_gpus": world, "rccl_world_size": (dist.get_world_size() if world > 1 else 1), "backend": (a.backend if world > 1 else None),
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%s: %.0f Mb synthetic genome x %d GPU(s) + %dx %d-bp reads, k=%d, %d passes, "
                                "chunked as jasper.sh -t %d (BATCH_SIZE %d)" % ("configs[1] chr21-sized" if a.genome_mb == 47.0 else "custom size", a.genome_mb, world, COVERAGE, READ_LEN, K, PASSES,
@@ -311,10 +364,14 @@ def main():
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
+            gpu = dict(rows=table.histo_rows(), thr=T["thr"], qv=T["qv"], nfix=T["nfix"], text=[bytes(res.seq_view(i)) for i in range(len(seqs))])
+            reads_np = reads.cpu().numpy()
             try:
-                out["cpu_baseline"] = cpu_baseline(a.seed)
-            except Exception as e:  # the baseline is a report, never a reason to lose the measurement
-                out["cpu_baseline"] = {"value": None, "unit": "Mbp/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+                out["cpu_baseline"] = cpu_baseline(a.seed, reads_np, names, seqs, gpu)
+            except RuntimeError:
+                raise               # a result that differs from the oracle voids the measurement
+            except Exception as e:  # anything else: the baseline is a report, never a reason to lose the measurement
+                out["cpu_baseline"] = {"value": None, "unit": "Mbp/s", "cores": host_cpu()[0], "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()           # nobody frees a shard that a peer may still be reading

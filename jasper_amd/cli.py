@@ -694,9 +694,15 @@ def main():
             print("--gpus needs a number")
             sys.exit(1)
         if n > 1:
+            port = os.environ.get("MASTER_PORT")
+            if not port:                      # a free port, so that two runs on one node do not meet
+                import socket
+                sk = socket.socket()
+                sk.bind(("127.0.0.1", 0))
+                port = str(sk.getsockname()[1])
+                sk.close()
             sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-                                      "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"),
-                                      "-m", "jasper_amd.cli"] + argv))
+                                      "--master-addr", "127.0.0.1", "--master-port", port, "-m", "jasper_amd.cli"] + argv))
     sys.exit(run(argv))
 
 

@@ -349,6 +349,8 @@ struct Reader {           // the concatenation of all input files as one byte st
         size_t budget = 16ull << 30;
         const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
         if (pages > 0 && psz > 0) budget = std::min<size_t>(budget, (size_t)pages * (size_t)psz / 4);
+        // one process per GPU on the same host: the ranks share the machine's memory
+        if (const char *w = getenv("WORLD_SIZE")) { const long nw = atol(w); if (nw > 1) budget /= (size_t)nw; }
         if (const char *e = getenv("JASPER_INGEST_AHEAD_MB")) budget = (size_t)strtoull(e, nullptr, 10) << 20;
         ahead_cap = budget / gz.size();
         const size_t max_threads = 16;                       // (more files than that: the later ones start when they are reached)

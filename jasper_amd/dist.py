@@ -277,12 +277,35 @@ def _ipc_probe_ok(shard, handles, rank, seconds=None):
     seconds = seconds or float(os.environ.get("JASPER_AMD_IPC_PROBE_SECONDS", "60"))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    # Popen with bounded waits: if the helper is stuck in an uninterruptible driver call, SIGKILL does not reap it and an
+    # unbounded wait() here would be exactly the hang the probe exists to avoid -- the zombie is abandoned instead.
+    import tempfile
+    errf = tempfile.TemporaryFile()
+    p = subprocess.Popen([sys.executable, "-m", "jasper_amd._ipc_probe", str(shard.device), str(rank), b"".join(bytes(h) for h in handles).hex()],
+                         env=env, stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=errf)
+    why = ""
     try:
-        p = subprocess.run([sys.executable, "-m", "jasper_amd._ipc_probe", str(shard.device), str(rank), b"".join(bytes(h) for h in handles).hex()],
-                           env=env, timeout=seconds, capture_output=True)
-        return p.returncode == 0
+        rc = p.wait(timeout=seconds)
+        ok = rc == 0
+        if not ok:
+            why = "exit %d" % rc
     except subprocess.TimeoutExpired:
-        return False
+        ok = False
+        why = "no answer within %.0f s" % seconds
+        p.kill()
+        try:
+            p.wait(timeout=5)
+        except subprocess.TimeoutExpired:
+            why += " (helper not reaped)"
+    if not ok:
+        try:
+            errf.seek(0)
+            tail = errf.read()[-400:].decode("utf-8", "replace").strip()
+            sys.stderr.write("jasper_amd: IPC probe of rank %d failed: %s%s\n" % (rank, why, (" -- " + tail) if tail else ""))
+        except Exception:
+            pass
+    errf.close()
+    return ok
 
 
 class ShardAttachError(RuntimeError):

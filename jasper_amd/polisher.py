@@ -253,23 +253,23 @@ def main_many(query_paths, k, test, fix, db, thre, num_iter):
 
 
 def threshold_from_histo_rows(rows):
-    """src/jellyfish.py:8-22 on rows (multiplicity, n_distinct).
+    """The solid-k-mer threshold rule of src/jellyfish.py:8-22, on histogram rows (multiplicity, ..., n_distinct).
 
-    Returns the text the script writes to stdout ('' if it prints nothing) and its exit status.
+    The histogram is followed downhill from its first row; the first row whose n_distinct RISES ends the descent, and the
+    threshold is half the multiplicity (rounded down) of the last row of the descent (0 if the descent was the first row
+    alone).  Returns (what the script writes to stdout, its exit status): ("", 1) when that threshold is below 2,
+    ("", 0) when the histogram never rises.
     """
-    count = -1
-    threshold = 0
-    for row in rows:
-        if count == -1:
-            count = int(row[-1])
-        else:
-            if count >= int(row[-1]):
-                count = int(row[-1])
-                threshold = int(int(row[0]) / 2)
-            else:
-                if threshold < 2:
-                    return "", 1
-                return str(threshold), 0
+    it = iter(rows)
+    first = next(it, None)
+    if first is None:
+        return "", 0
+    floor_n, half = int(first[-1]), 0
+    for row in it:
+        n = int(row[-1])
+        if n > floor_n:
+            return ("", 1) if half < 2 else (str(half), 0)
+        floor_n, half = n, int(row[0]) // 2
     return "", 0
 
 

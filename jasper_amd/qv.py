@@ -28,6 +28,9 @@ def _bc_str(x):
 
 def q_value(bad, total, kmer):
     """returns the string jasper.sh logs after 'Q value = ' (src/jasper.sh:239-246 / 249-256)"""
+    if int(total) == 0:
+        # bc: "Divide by zero" -> empty $pgood -> the later bc calls print errors, the (( ... )) test fails -> else branch
+        return "Inf"
     bad = Decimal(int(bad))
     total = Decimal(int(total))
     pgood = Decimal(1) - _trunc(bad / total, 10)                      # scale=10; 1-bad/total

@@ -159,14 +159,7 @@ def torch_reads_stream(gen, genome, nreads, read_len=150, err=0.003, block=1 << 
     return out.reshape(-1)
 
 
-def write_cli_inputs(d, genome_mb=47.0, seed=2, coverage=30, read_len=150, err=0.003):
-    """reads.fq (4-line FASTQ, header "@r", quality 'I') + asm.fa (one contig, 60 columns) in directory d; byte-identical
-    for the same arguments wherever numpy is the same -- the build container runs the REAL reference on them
-    (tests/golden/ref_fullsize.py), the GPU box runs the drop-in, and the outputs are compared by digest."""
-    import os
-    rng = np.random.default_rng(seed)
-    genome = make_genome(rng, int(genome_mb * 1e6))
-    reads = make_reads_stream(rng, genome, coverage, read_len, err).reshape(-1, read_len + 1)[:, :read_len]
+def _write_fastq(path, reads, read_len):
     n = reads.shape[0]
     rec = np.empty((n, 2 * read_len + 7), dtype=np.uint8)
     rec[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
@@ -174,14 +167,73 @@ def write_cli_inputs(d, genome_mb=47.0, seed=2, coverage=30, read_len=150, err=0
     rec[:, 3 + read_len:6 + read_len] = np.frombuffer(b"\n+\n", dtype=np.uint8)
     rec[:, 6 + read_len:6 + 2 * read_len] = ord("I")
     rec[:, 6 + 2 * read_len] = ord("\n")
-    rec.tofile(os.path.join(d, "reads.fq"))
-    asm = make_assembly(rng, genome)
-    a = asm.tobytes()
+    rec.tofile(path)
+    return n
+
+
+def contig_lengths(total, contigs):
+    """deterministic contig sizes: one contig = everything; otherwise weights falling linearly 5 : 1 from the first to
+    the last contig (SURVEY 8d cfg 4: "24 contigs 50-250 Mb"; cfg 3's 7 contigs get the same shape)"""
+    if contigs <= 1:
+        return [int(total)]
+    w = np.linspace(5.0, 1.0, contigs)
+    lens = np.floor(w / w.sum() * total).astype(np.int64)
+    lens[0] += int(total) - int(lens.sum())
+    return [int(x) for x in lens]
+
+
+def write_cli_inputs(d, genome_mb=47.0, seed=2, coverage=30, read_len=150, err=0.003, contigs=1, populations=1, snp=0.001):
+    """reads.fq (4-line FASTQ, header "@r", quality 'I') + asm.fa (60 columns) in directory d; byte-identical for the same
+    arguments wherever numpy is the same -- the build container runs the REAL reference on them
+    (tests/golden/ref_fullsize.py), the GPU box runs the drop-in, and the outputs are compared by digest.
+
+    contigs > 1: the genome is cut into `contigs` records chr1..chrN (contig_lengths), reads never span contigs, every
+    contig's assembly gets its own errors and N-runs (SURVEY 8d cfg 3 / cfg 4 shape).
+    populations > 1: `populations` individuals, each the genome with its own substitutions at rate `snp`, each sequenced
+    at `coverage` into its own file reads_<i>.fq (SURVEY 8d cfg 5 shape: "10 individuals x 30x each carrying 0.1 %
+    private SNPs"); the draft assembly is made from the common genome.
+    Returns (number of reads, assembly bases); the read files are reads.fq, or reads_0.fq .. reads_{P-1}.fq."""
+    import os
+    rng = np.random.default_rng(seed)
+    genome = make_genome(rng, int(genome_mb * 1e6))
+    if contigs <= 1 and populations <= 1:      # (the round-1 inputs: same generator calls in the same order)
+        reads = make_reads_stream(rng, genome, coverage, read_len, err).reshape(-1, read_len + 1)[:, :read_len]
+        n = _write_fastq(os.path.join(d, "reads.fq"), reads, read_len)
+        asm = make_assembly(rng, genome)
+        a = asm.tobytes()
+        with open(os.path.join(d, "asm.fa"), "wb") as f:
+            f.write(b">chr1\n")
+            f.write(b"\n".join(a[i:i + 60] for i in range(0, len(a), 60)))
+            f.write(b"\n")
+        return n, len(asm)
+    lens = contig_lengths(len(genome), contigs)
+    starts = np.concatenate([[0], np.cumsum(lens)]).tolist()
+    n = 0
+    for p in range(populations):
+        g = genome
+        if populations > 1:
+            g = genome.copy()
+            m = rng.random(len(g)) < snp
+            code = np.searchsorted(ACGT, g[m]) % 4
+            g[m] = ACGT[(code + rng.integers(1, 4, int(m.sum()))) % 4]
+        parts = [make_reads_stream(rng, g[starts[c]:starts[c + 1]], coverage, read_len, err).reshape(-1, read_len + 1)[:, :read_len]
+                 for c in range(contigs)]
+        reads = np.concatenate(parts) if len(parts) > 1 else parts[0]
+        n += _write_fastq(os.path.join(d, "reads.fq" if populations <= 1 else "reads_%d.fq" % p), reads, read_len)
+        del reads, parts
+    total = 0
     with open(os.path.join(d, "asm.fa"), "wb") as f:
-        f.write(b">chr1\n")
-        f.write(b"\n".join(a[i:i + 60] for i in range(0, len(a), 60)))
-        f.write(b"\n")
-    return n, len(asm)
+        for c in range(contigs):
+            a = make_assembly(rng, genome[starts[c]:starts[c + 1]]).tobytes()
+            total += len(a)
+            f.write(b">chr%d some description\n" % (c + 1))      # (the reference keeps only the first token of a header)
+            f.write(b"\n".join(a[i:i + 60] for i in range(0, len(a), 60)))
+            f.write(b"\n")
+    return n, total
+
+
+def read_files(populations=1):
+    return ["reads.fq"] if populations <= 1 else ["reads_%d.fq" % p for p in range(populations)]
 
 
 def output_digests(d, asm_name="asm.fa", k=37):

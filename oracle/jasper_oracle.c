@@ -99,6 +99,10 @@ struct jo_db {
     uint64_t cap, used; /* cap is a power of two */
     u128 *keys;         /* key+1 stored, 0 = empty (key+1 never overflows: 2k <= 126 enforced) */
     uint64_t *vals;
+    /* multi-threaded baseline only (jo_mt_*, end of file): the map split into `nshard` maps by key owner, so that the
+     * counting threads never share a map (what `jellyfish count -t N` does with CAS on one array). 0 = plain map. */
+    int nshard;
+    struct jo_db **shard;
 };
 
 static inline uint64_t mix128(u128 x) {
@@ -121,10 +125,18 @@ jo_db *jo_db_new(int k) {
 }
 void jo_db_free(jo_db *db) {
     if (!db) return;
+    for (int i = 0; i < db->nshard; i++) jo_db_free(db->shard[i]);
+    free(db->shard);
     free(db->keys); free(db->vals); free(db);
 }
 int jo_db_k(const jo_db *db) { return db->k; }
-uint64_t jo_db_distinct(const jo_db *db) { return db->used; }
+uint64_t jo_db_distinct(const jo_db *db) {
+    uint64_t n = db->used;
+    for (int i = 0; i < db->nshard; i++) n += db->shard[i]->used;
+    return n;
+}
+/* owner of a key among n maps: hash bits the in-map position does not use */
+static inline int db_owner(u128 key, int n) { return (int)(((mix128(key) >> 40) * (uint64_t)n) >> 24); }
 
 static void db_grow(jo_db *db);
 static inline void db_add(jo_db *db, u128 key, uint64_t by) {
@@ -150,6 +162,7 @@ static void db_grow(jo_db *db) {
     free(ok); free(ov);
 }
 static inline uint64_t db_get(const jo_db *db, u128 key) {
+    if (db->nshard) db = db->shard[db_owner(key, db->nshard)];
     uint64_t mask = db->cap - 1, p = mix128(key) & mask;
     u128 kk = key + 1;
     for (;;) {
@@ -294,8 +307,13 @@ int jo_db_add_kmer(jo_db *db, const char *kmer, uint64_t count) {
     return 0;
 }
 
+static void db_histo_add(const jo_db *db, uint64_t *out);
 void jo_db_histo(const jo_db *db, uint64_t *out) {
     memset(out, 0, 10002 * sizeof(uint64_t));
+    db_histo_add(db, out);
+    for (int i = 0; i < db->nshard; i++) db_histo_add(db->shard[i], out);
+}
+static void db_histo_add(const jo_db *db, uint64_t *out) {
     for (uint64_t i = 0; i < db->cap; i++) {
         if (!db->keys[i]) continue;
         uint64_t c = clamp32(db->vals[i]);
@@ -972,3 +990,149 @@ int jo_polish_batch(const jo_db *db, int k, int n_chunks, const char *const *nam
 }
 
 void jo_free(void *p) { free(p); }
+
+/* ================================================================================================
+ * Multi-threaded driver (bench.py's cpu_baseline on all host cores; tests check it against the plain path).
+ * The algorithm is the restatement above, unchanged; only the work is divided the way the reference divides it:
+ *   counting  = `jellyfish count -t N` (src/jasper.sh:177; JF::sub_commands/count_main.cc:152-184: N threads pull
+ *               pieces of the read stream and add into one table).  Here: every thread rolls the k-mers of its slice of
+ *               the base stream (slices end at a non-ACGT byte, so no window is cut) and files them by key owner; then
+ *               every thread adds the keys it owns into its own map -- same counts, no locks.
+ *   polishing = `xargs -P N` over batch files (src/jasper.sh:212): chunk records are independent, one worker each.
+ * ==============================================================================================*/
+#include <pthread.h>
+
+jo_db *jo_mt_db_new(int k, int nshard) {
+    jo_db *db = jo_db_new(k);
+    if (!db || nshard < 1) { jo_db_free(db); return NULL; }
+    db->shard = (jo_db **)calloc((size_t)nshard, sizeof(jo_db *));
+    for (int i = 0; i < nshard; i++) db->shard[i] = jo_db_new(k);
+    db->nshard = nshard;
+    return db;
+}
+
+typedef struct { u128 *p; size_t n, cap; } kbuf;
+typedef struct {
+    jo_db *db; const char *bases; size_t lo, hi; int T, me; kbuf *out; /* out[T*T]: [producer][owner] */
+    uint64_t added;
+} mt_count_arg;
+
+static void *mt_produce(void *v) {
+    mt_count_arg *a = (mt_count_arg *)v;
+    const int k = a->db->k, T = a->T;
+    const u128 mask = kmask(k);
+    u128 fwd = 0, rc = 0;
+    int filled = 0;
+    kbuf *mine = a->out + (size_t)a->me * T;
+    for (int o = 0; o < T; o++) mine[o].n = 0;
+    a->added = 0;
+    for (size_t i = a->lo; i < a->hi; i++) {
+        int c = base_code((unsigned char)a->bases[i]);
+        if (c < 0) { filled = 0; continue; }
+        fwd = ((fwd << 2) | (u128)c) & mask;
+        rc = (rc >> 2) | ((u128)(3 - c) << (2 * (k - 1)));
+        if (filled < k) filled++;
+        if (filled >= k) {
+            u128 key = fwd < rc ? fwd : rc;
+            kbuf *b = mine + db_owner(key, T);
+            if (b->n == b->cap) { b->cap = b->cap ? b->cap * 2 : 4096; b->p = (u128 *)realloc(b->p, b->cap * sizeof(u128)); }
+            b->p[b->n++] = key;
+            a->added++;
+        }
+    }
+    return NULL;
+}
+static void *mt_consume(void *v) {
+    mt_count_arg *a = (mt_count_arg *)v;
+    jo_db *sh = a->db->shard[a->me];
+    for (int prod = 0; prod < a->T; prod++) {
+        const kbuf *b = a->out + (size_t)prod * a->T + a->me;
+        for (size_t i = 0; i < b->n; i++) db_add(sh, b->p[i], 1);
+    }
+    return NULL;
+}
+
+/* same result as jo_db_count_bases on a plain map; db must come from jo_mt_db_new (threads = its number of shards) */
+uint64_t jo_mt_count_bases(jo_db *db, const char *bases, size_t n) {
+    const int T = db->nshard;
+    if (T < 1) return jo_db_count_bases(db, bases, n);
+    const size_t round_bases = (size_t)T << 22;     /* 4 M bases per thread and round: 64 MB of keys per thread */
+    kbuf *out = (kbuf *)calloc((size_t)T * T, sizeof(kbuf));
+    mt_count_arg *args = (mt_count_arg *)calloc((size_t)T, sizeof(mt_count_arg));
+    pthread_t *th = (pthread_t *)calloc((size_t)T, sizeof(pthread_t));
+    uint64_t added = 0;
+    size_t pos = 0;
+    while (pos < n) {
+        size_t end = pos + round_bases < n ? pos + round_bases : n;
+        while (end < n && base_code((unsigned char)bases[end]) >= 0) end++;     /* rounds and slices end between windows */
+        size_t cut = pos;
+        for (int t = 0; t < T; t++) {
+            size_t hi = t == T - 1 ? end : pos + (end - pos) / T * (size_t)(t + 1);
+            if (hi < cut) hi = cut;
+            while (hi < end && base_code((unsigned char)bases[hi]) >= 0) hi++;
+            args[t] = (mt_count_arg){db, bases, cut, hi, T, t, out, 0};
+            cut = hi;
+        }
+        for (int t = 0; t < T; t++) pthread_create(&th[t], NULL, mt_produce, &args[t]);
+        for (int t = 0; t < T; t++) { pthread_join(th[t], NULL); added += args[t].added; }
+        for (int t = 0; t < T; t++) pthread_create(&th[t], NULL, mt_consume, &args[t]);
+        for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
+        pos = end;
+    }
+    for (size_t i = 0; i < (size_t)T * T; i++) free(out[i].p);
+    free(out); free(args); free(th);
+    return added;
+}
+
+typedef struct {
+    const jo_db *db; int k, n_chunks; const char *const *names; char **seqs; int solid, passes, fix;
+    char **csv;          /* [chunk * passes + pass] */
+    int64_t (*qv)[4]; uint64_t *nlook; int *rc;
+    volatile int *next;
+} mt_polish_arg;
+static void *mt_polish(void *v) {
+    mt_polish_arg *a = (mt_polish_arg *)v;
+    for (;;) {
+        int q = __sync_fetch_and_add(a->next, 1);
+        if (q >= a->n_chunks) break;
+        a->rc[q] = jo_polish_batch(a->db, a->k, 1, a->names + q, a->seqs + q, a->solid, a->passes, a->fix,
+                                   a->csv + (size_t)q * (size_t)(a->passes > 0 ? a->passes : 1), a->qv[q], a->nlook + q);
+    }
+    return NULL;
+}
+/* jo_polish_batch with the chunk records handed to `threads` workers; outputs as jo_polish_batch (rows of a pass in
+ * chunk order, counters summed) */
+int jo_mt_polish_batch(const jo_db *db, int k, int n_chunks, const char *const *names, char **seqs, int solid_thre, int passes,
+                       int fix, char **csv_out, int64_t qv[4], uint64_t *n_lookups, int threads) {
+    if (threads < 1) threads = 1;
+    const size_t P = (size_t)(passes > 0 ? passes : 1), N = (size_t)(n_chunks > 0 ? n_chunks : 1);
+    char **csv = (char **)calloc(N * P, sizeof(char *));
+    int64_t (*q4)[4] = (int64_t (*)[4])calloc(N, sizeof(int64_t[4]));
+    uint64_t *nl = (uint64_t *)calloc(N, sizeof(uint64_t));
+    int *rc = (int *)calloc(N, sizeof(int));
+    volatile int next = 0;
+    mt_polish_arg a = {db, k, n_chunks, names, seqs, solid_thre, passes, fix, csv, q4, nl, rc, &next};
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, mt_polish, &a);
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    int ret = 0;
+    qv[0] = qv[1] = qv[2] = qv[3] = 0;
+    uint64_t looks = 0;
+    for (int q = 0; q < n_chunks; q++) {
+        if (rc[q] && !ret) ret = rc[q];
+        for (int j = 0; j < 4; j++) qv[j] += q4[q][j];
+        looks += nl[q];
+    }
+    for (int p = 0; p < passes; p++) {
+        sbuf all = {0};
+        sb_reserve(&all, 1); all.p[0] = 0;
+        for (int q = 0; q < n_chunks; q++) {
+            char *r = csv[(size_t)q * P + (size_t)p];
+            if (r) { sb_put(&all, r, strlen(r)); free(r); }
+        }
+        if (csv_out) csv_out[p] = all.p; else free(all.p);
+    }
+    if (n_lookups) *n_lookups = looks;
+    free(csv); free(q4); free(nl); free(rc); free(th);
+    return ret;
+}

@@ -70,6 +70,15 @@ int      jo_polish_batch(const jo_db *db, int k, int n_chunks, const char *const
                          char **csv_out, int64_t qv[4], uint64_t *n_lookups);
 void     jo_free(void *p);
 
+/* Multi-threaded driver around the same restatement (bench.py's cpu_baseline on all host cores): the work divided as
+ * `jellyfish count -t N` (src/jasper.sh:177) and `xargs -P N` over batch files (src/jasper.sh:212) divide it.
+ * jo_mt_db_new: a map split into `threads` maps by key owner; jo_db_query / jo_db_histo / jo_db_distinct /
+ * jo_polish_batch work on it, jo_db_next does not. */
+jo_db   *jo_mt_db_new(int k, int threads);
+uint64_t jo_mt_count_bases(jo_db *db, const char *bases, size_t n);
+int      jo_mt_polish_batch(const jo_db *db, int k, int n_chunks, const char *const *names, char **seqs, int solid_thre,
+                            int passes, int fix, char **csv_out, int64_t qv[4], uint64_t *n_lookups, int threads);
+
 #ifdef __cplusplus
 }
 #endif

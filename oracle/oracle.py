@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "libjasper_oracle.so")
 def build(force=False):
     src = os.path.join(_HERE, "jasper_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", _SO, src, "-lm"])
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-pthread", "-o", _SO, src, "-lm"])
     return _SO
 
 
@@ -54,6 +54,12 @@ def lib():
                                       C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_uint64)]
         L.jo_free.argtypes = [C.c_void_p]
+        L.jo_mt_db_new.restype = C.c_void_p
+        L.jo_mt_db_new.argtypes = [C.c_int, C.c_int]
+        L.jo_mt_count_bases.restype = C.c_uint64
+        L.jo_mt_count_bases.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.jo_mt_polish_batch.restype = C.c_int
+        L.jo_mt_polish_batch.argtypes = L.jo_polish_batch.argtypes + [C.c_int]
         L.malloc_copy = None
         _lib = L
     return _lib
@@ -67,9 +73,12 @@ _libc.malloc.argtypes = [C.c_size_t]
 class OracleDB:
     """canonical k-mer -> count map built the way `jellyfish count -C` defines it"""
 
-    def __init__(self, k):
+    def __init__(self, k, threads=0):
+        """threads > 0: the multi-threaded driver (jo_mt_*): counting and polishing divided over that many host threads,
+        the map split by key owner; same results as the plain map"""
         self.k = k
-        self._h = lib().jo_db_new(k)
+        self.threads = threads
+        self._h = lib().jo_mt_db_new(k, threads) if threads > 0 else lib().jo_db_new(k)
         if not self._h:
             raise ValueError("bad k")
 
@@ -81,6 +90,10 @@ class OracleDB:
     def count_bases(self, b):
         if isinstance(b, str):
             b = b.encode()
+        if self.threads > 0:
+            buf = C.c_char_p(b) if isinstance(b, bytes) else None
+            ptr = C.cast(buf, C.c_void_p) if buf is not None else C.c_void_p(b.ctypes.data)      # bytes, or a numpy uint8 array
+            return lib().jo_mt_count_bases(self._h, ptr, len(b))
         return lib().jo_db_count_bases(self._h, b, len(b))
 
     def count_text(self, t):
@@ -131,7 +144,10 @@ class OracleDB:
         csv = (C.c_void_p * max(passes, 1))()
         qv = (C.c_int64 * 4)()
         nl = C.c_uint64(0)
-        rc = lib().jo_polish_batch(self._h, self.k, n, cn, cs, solid_thre, passes, 1 if fix else 0, csv, qv, C.byref(nl))
+        if self.threads > 0:
+            rc = lib().jo_mt_polish_batch(self._h, self.k, n, cn, cs, solid_thre, passes, 1 if fix else 0, csv, qv, C.byref(nl), self.threads)
+        else:
+            rc = lib().jo_polish_batch(self._h, self.k, n, cn, cs, solid_thre, passes, 1 if fix else 0, csv, qv, C.byref(nl))
         out = []
         for i in range(n):
             out.append(C.string_at(cs[i]).decode())

@@ -16,7 +16,8 @@ positions of CSV rows that came out of that branch.
 
 Fixtures are DATA (inputs + reference outputs). No reference source is written anywhere.
 
-usage: python3 tests/golden/make_golden.py [--out tests/golden/cases] [--only NAME]
+usage: python3 tests/golden/make_golden.py [--out tests/golden/cases] [--only NAME | e2e | kats]
+       (mer_kats.json and e2e/ are written next to the --out directory)
 """
 import argparse
 import gzip
@@ -336,6 +337,12 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     specs = case_specs()
+    base = os.path.dirname(os.path.abspath(a.out))      # mer_kats.json and e2e/ live next to the cases directory
+    if a.only in (None, "kats") and os.environ.get("GOLDEN_KATS", "1") == "1":
+        make_mer_kats(os.path.join(base, "mer_kats.json"))
+    if a.only in (None, "e2e") and os.environ.get("GOLDEN_E2E", "1") == "1":
+        m = make_e2e(os.path.join(base, "e2e"))
+        print("e2e exit", m["exit"], m["batches"], m["stdout"])
     for i, (name, spec) in enumerate(specs.items()):
         if a.only and a.only != name:
             continue
@@ -345,8 +352,6 @@ def main():
         print("   ", meta["debug_messages_seen"])
 
 
-if __name__ == "__main__":
-    main()
 
 
 def make_mer_kats(out_path):
@@ -383,8 +388,6 @@ json.dump(out, open(sys.argv[1], "w"), indent=0)
     subprocess.run([sys.executable, "-c", code, out_path], check=True)
 
 
-if __name__ == "__main__" and os.environ.get("GOLDEN_KATS", "1") == "1":
-    make_mer_kats(os.path.join(os.path.dirname(os.path.abspath(__file__)), "mer_kats.json"))
 
 
 def make_e2e(outdir):
@@ -442,8 +445,13 @@ def make_e2e(outdir):
     for fn in ("r1.fq", "r2.fq"):
         with gzip.GzipFile(os.path.join(outdir, fn + ".gz"), "wb", mtime=0) as f:
             f.write(open(os.path.join(run_dir, fn), "rb").read())
-    for fn in ("asm.fa.polished.fasta", "asm.fa.fixes.csv", "jfhisto%d.csv" % k, "threshold.txt"):
+    for fn in ("asm.fa.fixes.csv", "jfhisto%d.csv" % k, "threshold.txt"):
         shutil.copy(os.path.join(run_dir, fn), outdir)
+    # the join step prints contigs in perl's hash order, which changes from run to run: the fixture keeps the records
+    # sorted by name (the tests compare per record anyway), so that regenerating does not dirty it
+    recs = open(os.path.join(run_dir, "asm.fa.polished.fasta")).read().split(">")[1:]
+    with open(os.path.join(outdir, "asm.fa.polished.fasta"), "w") as f:
+        f.write("".join(">" + r for r in sorted(recs)))
     batches = {}
     for bf in sorted(_glob.glob(os.path.join(run_dir, "asm.fa.batch.*.fa"))):
         batches[os.path.basename(bf)] = [ln.strip() for ln in open(bf) if ln.startswith(">")]
@@ -460,6 +468,5 @@ def re_sub_date(line):
     return re.sub(r"^\[[^\]]*\]", "[DATE]", line)
 
 
-if __name__ == "__main__" and os.environ.get("GOLDEN_E2E", "1") == "1":
-    m = make_e2e(os.path.join(os.path.dirname(os.path.abspath(__file__)), "e2e"))
-    print("e2e exit", m["exit"], m["batches"], m["stdout"])
+if __name__ == "__main__":
+    main()

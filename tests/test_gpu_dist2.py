@@ -20,13 +20,18 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo", one_gpu=True):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
     from jasper_amd import KmerTable, synth, dist as jd
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    di = 0 if one_gpu else rank                          # one rank per device when the box has them (backend nccl = RCCL)
+    if backend == "nccl":
+        torch.cuda.set_device(di)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", di))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         k = 37
         rng = np.random.default_rng(42)                     # same workload on every rank
@@ -36,9 +41,9 @@ def _worker(rank, world, port, q):
         nrec = reads.size // 151
         lo, hi = jd.shard_range(nrec, rank, world)          # read shard of this rank
         mine = reads[lo * 151:hi * 151].tobytes()
-        t = KmerTable(k, min_slots=1 << 21, device=0)
+        t = KmerTable(k, min_slots=1 << 21, device=di)
         t.count_bases(mine)
-        dev = torch.device("cuda", 0)
+        dev = torch.device("cuda", di)
         merged = jd.merge_tables(t, dev)
         h = t.histogram()
         assert jd.histogram_merged(t, dev) == h             # owner ranges binned per rank + all_reduce == full scan

@@ -56,6 +56,34 @@ def test_count_histogram_lookup_vs_oracle(KT, O, k, G, seed):
     t.close()
 
 
+def test_encoder_known_answers_through_the_lookup_entry_point(KT):
+    """tests/golden/mer_kats.json = 162 answers of the REAL SWIG `MerDNA(s)` / `.get_canonical()` (lower case, N at various
+    offsets, short and empty strings; JF::swig/mer_dna.i:12-19, JF::include/jellyfish/mer_dna.hpp:525-542).  Through the
+    C-ABI: a table of each k holds every KAT's canonical k-mer exactly as often as it occurs among the KATs, and
+    jasper_lookup of the RAW string s (truncate at the first non-ACGT byte, right-fill with 'A', canonicalise on the GPU)
+    must return that multiplicity -- a wrong bit in the device encoder / reverse complement lands on another key (0)."""
+    import collections
+    import json
+    import os
+    kats = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mer_kats.json")))
+    by_k = collections.defaultdict(list)
+    for e in kats:
+        by_k[e["k"]].append(e)
+    assert len(by_k) >= 2
+    for k, es in sorted(by_k.items()):
+        if k > 43:
+            continue      # the slot format holds k <= 43 (table.hip: min_log2_slots); the oracle checks k = 48, 63 (test_oracle_golden.py)
+        mult = collections.Counter(e["canonical"] for e in es)
+        t = KT(k, min_slots=1 << 12)
+        t.count_bases("N".join(c for c, m in mult.items() for _ in range(m)).encode())
+        assert t.info()["distinct"] == len(mult)
+        got = t.lookup([e["s"] for e in es])
+        assert got == [mult[e["canonical"]] for e in es], (k, [(e["s"], g) for e, g in zip(es, got) if g != mult[e["canonical"]]])
+        # the uncanonicalised mer the binding reports is the same key's other strand (or itself)
+        assert t.lookup([e["mer"] for e in es]) == [mult[e["canonical"]] for e in es]
+        t.close()
+
+
 @pytest.mark.parametrize("k,G,seed,thre,passes", [(37, 300_000, 11, 3, 2), (25, 200_000, 12, 3, 2), (31, 100_000, 13, 4, 3),
                                                     (21, 80_000, 14, 3, 1), (37, 120_000, 15, 5, 4),
                                                     # chunks of 230 kb: later passes find no sync points and cut at clean

@@ -190,13 +190,18 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo", one_gpu=True):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
     from jasper_amd import KmerTable, dist as jd
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    di = 0 if one_gpu else rank                          # one rank per device when the box has them (backend nccl = RCCL)
+    if backend == "nccl":
+        torch.cuda.set_device(di)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", di))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         k = 37
         rng = np.random.default_rng(43)                     # same workload on every rank
@@ -204,9 +209,9 @@ def _worker(rank, world, port, q):
         reads = synth.make_reads_stream(rng, genome, 30, 150, 0.003)
         asm = synth.make_assembly(rng, genome, err=1e-3, n_every=10**9).tobytes().decode()
         nrec = reads.size // 151
-        dev = torch.device("cuda", 0)
-        local = KmerTable(k, min_slots=1 << 21, device=0)
-        shard = KmerTable(k, min_slots=1 << 16, device=0)
+        dev = torch.device("cuda", di)
+        local = KmerTable(k, min_slots=1 << 21, device=di)
+        shard = KmerTable(k, min_slots=1 << 16, device=di)
         out = []
         for step in range(2):                               # second round: other read shards, same shard tables reused
             lo, hi = jd.shard_range(nrec, (rank + step) % world, world)

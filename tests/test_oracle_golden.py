@@ -90,3 +90,24 @@ def test_count_text_errors():
     with pytest.raises(RuntimeError, match="Invalid fastq"):
         db.count_text("@r\nACGTACGT\n+\nIIII\n")
     assert O.OracleDB(21).count_text("") == 0
+
+
+def test_multithreaded_driver_equals_plain_oracle():
+    """oracle.OracleDB(k, threads=N) (bench.py's all-core cpu_baseline: reads divided like `jellyfish count -t N`, chunk
+    records like `xargs -P N`) gives exactly what the plain single-threaded restatement gives"""
+    import numpy as np
+    from jasper_amd import synth
+    rng = np.random.default_rng(9)
+    g = synth.make_genome(rng, 120_000)
+    reads = synth.make_reads_stream(rng, g, 25, 100, 0.004)
+    asm = synth.make_assembly(rng, g, err=1e-3, n_every=50_000, n_len=40).tobytes().decode()
+    for k, threads in ((25, 3), (37, 5)):
+        a, b = O.OracleDB(k), O.OracleDB(k, threads=threads)
+        assert a.count_bases(reads.tobytes()) == b.count_bases(reads)           # bytes and numpy input
+        assert b.count_bases(reads.tobytes()[:5000]) == a.count_bases(reads.tobytes()[:5000])   # a second call adds up
+        assert a.distinct() == b.distinct() and a.histo() == b.histo()
+        recs = synth.chunk_records("c", len(asm), 17_000)
+        names, seqs = [r[0] for r in recs], [asm[x:y] for _, x, y in recs]
+        assert a.polish_batch(names, seqs, 3, 2) == b.polish_batch(names, seqs, 3, 2)
+        qs = [asm[i:i + k] for i in range(0, 3000, 7)] + ["", "ACGTN"]
+        assert [a.query(q) for q in qs] == [b.query(q) for q in qs]
