@@ -83,6 +83,7 @@ def one_step(torch, dev_index, table, reads, d_chunks, world, timers, shard=None
     t1 = time.perf_counter()
     kms, launches = table.count_timing()
     stages, part_launches = table.count_stages()
+    path = table.count_path()
     merged = 0
     if world > 1:
         if shard is not None:    # one all_to_all: owner o ends up with the summed counts of the keys it owns
@@ -108,7 +109,7 @@ def one_step(torch, dev_index, table, reads, d_chunks, world, timers, shard=None
     res = lookup_table.polish_batch_device(d_chunks[0], d_chunks[1], thr, PASSES, fix=True)   # returns when the GPU is done
     t4 = time.perf_counter()
     info = table.info()
-    timers.append(dict(count=t1 - t0, clear=t0b - t0, merge=t2 - t1, histo=t3 - t2, polish=t4 - t3, kernel_ms=kms, launches=launches, stages=stages, part_launches=part_launches,
+    timers.append(dict(count=t1 - t0, clear=t0b - t0, merge=t2 - t1, histo=t3 - t2, polish=t4 - t3, kernel_ms=kms, launches=launches, stages=stages, part_launches=part_launches, path=path,
                        polish_dev=res.seconds, thr=thr, qv=res.qv, nfix=res.n_records, merged=merged,
                        distinct=info["distinct"], occurrences=info["occurrences"], slots=info["slots"], lookups=res.lookups,
                        segments=res.segments, respeculated=res.respeculated,
@@ -176,9 +177,10 @@ def cpu_baseline(seed, reads_np, names, seqs, gpu):
                count_Mkmers_per_s=round(nk / 1e6 / (t1 - t0), 3), polish_Mbp_per_s=round(G / 1e6 / (t2 - t1), 3),
                seconds=round(t2 - t0, 2))
     if full:
-        nfix = sum(r.count("\n") for r in csv_rows)
         same = dict(histogram=rows == gpu["rows"], threshold=thr == gpu["thr"], qv_counters=tuple(qv) == tuple(gpu["qv"]),
-                    fix_records=nfix == gpu["nfix"], polished_text=all(f.encode() == g for f, g in zip(fixed, gpu["text"])))
+                    fix_csv_rows=["Contig Base_coord Original Mutation\r\n" + r for r in csv_rows] == gpu["csv"],
+                    polished_text=all(f.encode() == g for f, g in zip(fixed, gpu["text"])))
+        out["fix_csv_rows"] = sum(r.count("\n") for r in csv_rows)
         out["gpu_result_equals_oracle"] = same
         if not all(same.values()):
             raise RuntimeError("GPU result differs from the CPU oracle on the bench workload: %r" % (same,))
@@ -240,6 +242,7 @@ def main():
             dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     reads, names, seqs, d_chunks, asm_len, bs, nreads = build_workload(torch, dev, rank, world, a.genome_mb, a.seed)
+    from jasper_amd import polisher
     # size hint like jasper.sh: JF_SIZE = FASTQ bytes / 10 (src/jasper.sh:82); FASTQ ~ 2.1 bytes per base
     from jasper_amd import KmerTable, dist as jdist
     sharded = world > 1 and a.table != "replicated"
@@ -351,20 +354,25 @@ def main():
         "qv_counters": list(T["qv"]), "fix_records": T["nfix"], "polish_lookups": T["lookups"],
         "polish_segments": T["segments"], "polish_chunks_redone_unsegmented": T["respeculated"],
         "roofline": {"bound": "hbm",
-                     "kernel": "k-mer counting = part1_kernel + part2_kernel + lds_insert_kernel (even, odd) per piece"
-                               if T["part_launches"] else "count_kernel",
+                     "kernel": {2: "k-mer counting = mz_part + mz_split + mz_count + ent_split + lds_insert (even, odd) per piece (minimizer super-k-mers)",
+                                1: "k-mer counting = part1_kernel + part2_kernel + lds_insert_kernel (even, odd) per piece",
+                                0: "count_kernel"}[T["path"]],
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": int(BYTES_PER_KMER * kmers_rank / launches),
                      "launches_per_step": launches, "partitioned_launches": T["part_launches"],
                      "avg_launch_ms": round(mean("kernel_ms") / launches, 3),
                      "kernel_ms_per_step": {n: round(sum(t["stages"][i] for t in timers) / len(timers), 3)
-                                            for i, n in enumerate(("part1_kernel", "part2_kernel", "lds_insert_kernel_even",
-                                                                   "lds_insert_kernel_odd", "deferred_import3_kernel"))}},
+                                            for i, n in enumerate(KmerTable.STAGE_NAMES[T["path"]])}},
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            gpu = dict(rows=table.histo_rows(), thr=T["thr"], qv=T["qv"], nfix=T["nfix"], text=[bytes(res.seq_view(i)) for i in range(len(seqs))])
+            # the last step's fix records as the rows jasper.py would write (per pass, chunk order), like polisher.polish_batch
+            per_pass = [[] for _ in range(PASSES)]
+            for r in res.records:
+                per_pass[r["pass_"]].append((r["chunk"], r["seqno"], polisher.rows_from_record(names[r["chunk"]], r)))
+            csv_gpu = [polisher.fix_csv_text([row for _, _, rr in sorted(pp, key=lambda x: (x[0], x[1])) for row in rr]) for pp in per_pass]
+            gpu = dict(rows=table.histo_rows(), thr=T["thr"], qv=T["qv"], csv=csv_gpu, text=[bytes(res.seq_view(i)) for i in range(len(seqs))])
             reads_np = reads.cpu().numpy()
             try:
                 out["cpu_baseline"] = cpu_baseline(a.seed, reads_np, names, seqs, gpu)

@@ -182,9 +182,13 @@ void jasper_result_free(jasper_result *r);
 
 /* kernel timing for bench.py: HIP-event time of the last counting call on this table, and its launch count */
 int jasper_last_count_timing(jasper_table *t, double *kernel_ms, uint64_t *launches);
-/* the same split by kernel of the partitioned path: part1, part2, lds_insert (even regions), lds_insert (odd), deferred
- * direct inserts; *partitioned_launches of the counted launches took that path (the others ran count_kernel) */
-int jasper_last_count_stages(jasper_table *t, double stage_ms[5], uint64_t *partitioned_launches);
+/* the same split by kernel stage of the atomic-free counting paths, and which path the last piece took (*path):
+ *   2 = minimizer super-k-mers (count_mz.hip): mz_part, mz_split (count + scan + write), mz_count, ent_split,
+ *       lds_insert (even regions), lds_insert (odd), expand + deferred direct inserts, (unused)
+ *   1 = one record per occurrence (count_part.hip): part1, part2, lds_insert (even), lds_insert (odd), deferred, (unused x3)
+ *   0 = count_kernel (global atomics; small pieces)
+ * *partitioned_launches of the counted launches took path 1 or 2 (the others ran count_kernel) */
+int jasper_last_count_stages(jasper_table *t, double stage_ms[8], uint64_t *partitioned_launches, int *path);
 
 #ifdef __cplusplus
 }

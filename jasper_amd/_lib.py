@@ -83,7 +83,7 @@ SYMBOLS = {
     "jasper_result_retried": (C.c_int, [_P]),
     "jasper_result_free": (None, [_P]),
     "jasper_last_count_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
-    "jasper_last_count_stages": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "jasper_last_count_stages": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
 }
 
 _lib = None

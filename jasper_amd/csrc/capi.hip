@@ -208,9 +208,10 @@ int jasper_last_count_timing(jasper_table *t, double *kernel_ms, uint64_t *launc
     return JASPER_OK;
 }
 
-int jasper_last_count_stages(jasper_table *t, double stage_ms[5], uint64_t *partitioned_launches) {
-    for (int i = 0; i < 5; ++i) stage_ms[i] = t->t.part_stage_ms[i];
+int jasper_last_count_stages(jasper_table *t, double stage_ms[8], uint64_t *partitioned_launches, int *path) {
+    for (int i = 0; i < 8; ++i) stage_ms[i] = t->t.part_stage_ms[i];
     if (partitioned_launches) *partitioned_launches = t->t.count_partitioned_launches;
+    if (path) *path = t->t.count_path;
     return JASPER_OK;
 }
 

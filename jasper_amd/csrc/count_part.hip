@@ -27,6 +27,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace jk {
@@ -39,6 +40,11 @@ namespace jk {
             return -1;                                                                \
         }                                                                             \
     } while (0)
+
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's outstanding GLOBAL stores and loads
+// (s_waitcnt vmcnt(0)) -- here that would make every tile wait for the copy-out of the previous phase to reach memory, and
+// for the prefetch of the next tile, although nothing in the workgroup reads those bytes back.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int PT_THREADS = 1024;
 constexpr int PT_GROUP = 16;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(TH) void part1_kernel(const uint8_t *__restrict__ b
     const int bsh = WIDE && !rec64 ? 64 - G.recbits : 0;                        // hi word's place in the bucket number
     unsigned long long added = 0, fresh = 0;
     for (int i = t; i < nb; i += TH) { s_cur[i] = 0; s_cnt[i] = 0; }
-    __syncthreads();
+    lds_barrier();
     // my 16 bases of the NEXT tile are requested while the current one is processed (one block per CU: nothing else
     // would hide that latency)
     Raw16 raw = load16(bases, (int64_t)(blockIdx.x * (uint64_t)(TH * PT_GROUP)) + (int64_t)t * PT_GROUP, (int64_t)n);
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(TH) void part1_kernel(const uint8_t *__restrict__ b
             s_code[t] = hc;
             s_inv[t] = hiv;
         }
-        __syncthreads();
+        lds_barrier();
         // A. hash my 16 windows, take a rank in the tile's bucket histogram
         const uint32_t w4 = s_code[t], w3 = s_code[t + 1], w2 = s_code[t + 2], w1 = s_code[t + 3];
         const uint64_t ivprev = ((uint64_t)s_inv[t] << 48) | ((uint64_t)s_inv[t + 1] << 32) | ((uint64_t)s_inv[t + 2] << 16) | (uint64_t)s_inv[t + 3];
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(TH) void part1_kernel(const uint8_t *__restrict__ b
                 ++added;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // B. exclusive prefix of the bucket counts (P1_MAXB / TH buckets per thread, wave scan + wave totals)
         {
             constexpr int BPT = P1_MAXB / TH;
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(TH) void part1_kernel(const uint8_t *__restrict__ b
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
             if ((t & 63) == 63) s_wsum[t >> 6] = inc;
-            __syncthreads();
+            lds_barrier();
             unsigned int wbase = 0;
             for (int w = 0; w < (t >> 6); ++w) wbase += s_wsum[w];
             unsigned int ex = wbase + inc - v;
@@ -197,12 +203,12 @@ __global__ __launch_bounds__(TH) void part1_kernel(const uint8_t *__restrict__ b
             for (int u = 0; u < BPT; ++u) { if (t * BPT + u < nb) s_off[t * BPT + u] = ex; ex += vb[u]; }
             if (t == TH - 1) s_off[nb] = wbase + inc;                         // tile total
         }
-        __syncthreads();
+        lds_barrier();
         // C. records into LDS in bucket order
 #pragma unroll
         for (int j = 0; j < PT_GROUP; ++j)
             if (br[j] != 0xFFFFFFFFu) s_stage[s_off[br[j] >> 16] + (br[j] & 0xFFFFu)] = rec[j];
-        __syncthreads();
+        lds_barrier();
         // D. copy out, one bucket per 16 lanes: a tile holds ~16 records per bucket, so a 16-lane group writes one
         //    128-B run of its bucket's slice per round (three LDS reads per bucket instead of a binary search per record)
         {
@@ -219,11 +225,11 @@ __global__ __launch_bounds__(TH) void part1_kernel(const uint8_t *__restrict__ b
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         for (int i = t; i < nb; i += TH) { s_cur[i] += s_cnt[i]; s_cnt[i] = 0; }
         // (the next tile's first barrier orders this against its histogram updates)
     }
-    __syncthreads();
+    lds_barrier();
     for (int i = t; i < nb; i += TH) cnt1[(uint64_t)i * G.nblk1 + blockIdx.x] = s_cur[i] < G.cap1 ? s_cur[i] : G.cap1;
     for (int o = 32; o > 0; o >>= 1) { added += __shfl_xor(added, o); fresh += __shfl_xor(fresh, o); }
     if ((threadIdx.x & 63) == 0) {
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
             }
             if (t == 0) s_pref[nmine] = carry;
         }
-        __syncthreads();
+        lds_barrier();
         const uint32_t total = s_pref[nmine];
         const uint64_t *src0 = out1 + ((uint64_t)b1 * G.nblk1 + blockIdx.x) * G.cap1;      // slice x; slice x + j*nblk2 is j*nblk2*cap1 further
         for (uint32_t tile0 = 0; tile0 < total; tile0 += PT_TILE) {
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
                 const uint32_t b2 = (uint32_t)(rec[j] >> shift2) & (uint32_t)(nb2 - 1);
                 br[j] = (b2 << 16) | (atomicAdd(&s_cnt[b2], 1u) & 0xFFFFu);   // a tile holds 2^14 records
             }
-            __syncthreads();
+            lds_barrier();
             // B. exclusive prefix of the region counts: thread t owns regions 2t and 2t+1 (nb2 <= 2048)
             {
                 const unsigned int v0 = 2 * t < nb2 ? s_cnt[2 * t] : 0u, v1 = 2 * t + 1 < nb2 ? s_cnt[2 * t + 1] : 0u;
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
                 if ((t & 63) == 63) s_wsum[t >> 6] = inc;
-                __syncthreads();
+                lds_barrier();
                 unsigned int wbase = 0;
                 for (int w = 0; w < (t >> 6); ++w) wbase += s_wsum[w];
                 const unsigned int ex = wbase + inc - v;
@@ -319,12 +325,12 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
                 if (2 * t + 1 < nb2) s_off[2 * t + 1] = ex + v0;
                 if (t == PT_THREADS - 1) s_off[nb2] = wbase + inc;
             }
-            __syncthreads();
+            lds_barrier();
             // C. records into LDS in region order
 #pragma unroll
             for (int j = 0; j < PT_GROUP; ++j)
                 if (br[j] != 0xFFFFFFFFu) s_stage[s_off[br[j] >> 16] + (br[j] & 0xFFFFu)] = rec[j];
-            __syncthreads();
+            lds_barrier();
             // D. copy out: `lpb` lanes per region (a tile holds PT_TILE / nb2 records per region on average)
             {
                 const int lpb = nb2 <= 256 ? 64 : 16;
@@ -341,13 +347,13 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             for (int i = t; i < nb2; i += PT_THREADS) { s_cur[i] += s_cnt[i]; s_cnt[i] = 0; }
-            __syncthreads();
+            lds_barrier();
         }
         for (int i = t; i < nb2; i += PT_THREADS)
             cnt2[(((uint64_t)b1 << G.p2) + i) * G.nblk2 + blockIdx.x] = s_cur[i] < G.cap2 ? s_cur[i] : G.cap2;
-        __syncthreads();
+        lds_barrier();
     }
 }
 constexpr size_t P2_LDS = (size_t)PT_TILE * 8 + (size_t)(3 * PT_MAXBUCKETS + 1 + 16 + P2_MAXSL + 1) * 4;
@@ -355,11 +361,16 @@ constexpr size_t P2_LDS = (size_t)PT_TILE * 8 + (size_t)(3 * PT_MAXBUCKETS + 1 +
 // ---- final: region lists -> LDS image of the region -> table ------------------------------------------------------
 // lists: slices  lists[(region * nsl + x) * cap + i], i < cnt[region * nsl + x].  `parity`: regions with (region & 1) == parity.
 constexpr int LDS_HBINS = 1024;        // histogram bins kept in LDS by lds_insert_kernel (higher multiplicities are rare: global atomics)
-__global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *__restrict__ lists, const unsigned int *__restrict__ cnt, uint32_t cap,
+// ENT = false: lists of 8-byte records (count_part.hip: low hash bits, one occurrence each);  ENT = true: lists of 16-byte
+// (hash, count) entries { hash.lo, hash.hi | count << 32 } (count_mz.hip) -- the whole hash is there, the count is added.
+template <bool ENT>
+__global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__restrict__ lists_v, const unsigned int *__restrict__ cnt, uint32_t cap,
                                                                  uint32_t nsl, TableDev T, PartGeom G, uint32_t nregions, uint32_t parity, int fresh_table,
                                                                  unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
                                                                  uint64_t deferred_cap, unsigned long long *__restrict__ histo) {
     extern __shared__ __align__(16) unsigned long long s_img[];    // 2 words per slot: (R + halo) slots
+    using rec_t = typename std::conditional<ENT, ulonglong2, uint64_t>::type;
+    const rec_t *lists = reinterpret_cast<const rec_t *>(lists_v);
     const int t = threadIdx.x;
     const uint32_t R = 1u << G.rbits;
     const uint32_t halo = nregions > 1 ? (uint32_t)RG_HALO : 0u;     // a single region is the whole table: probes wrap inside it
@@ -373,7 +384,7 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *
     unsigned int *s_bins = reinterpret_cast<unsigned int *>(s_img + 2 * (size_t)span);     // LDS_HBINS words, only with histo
     if (histo) {
         for (int i = t; i < LDS_HBINS; i += PT_THREADS) s_bins[i] = 0;
-        __syncthreads();
+        lds_barrier();
     }
     for (uint32_t region = blockIdx.x * 2 + parity; region < nregions; region += gridDim.x * 2) {
         uint32_t total = 0;
@@ -381,11 +392,16 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *
         if (total == 0 && !fresh_table && !histo) continue;                  // block-uniform (a fresh table must still be zeroed here)
         const uint64_t first = (uint64_t)region << G.rbits;        // first slot of the region
         const uint64_t b1 = region >> G.p2;
-        auto insert = [&](uint64_t rec) {
+        auto insert = [&](rec_t recv) {
             // the record holds the low recbits hash bits; the bits above the slot index of this region are implied
             // by the list it is in, so slot and remainder come from the record alone (no 128-bit arithmetic here)
-            const uint64_t rem = rec & rmask;
-            const uint32_t local = (uint32_t)(rec >> rs) & (R - 1);
+            uint64_t rec, inc;
+            u128 hfull = mk(0, 0);
+            if constexpr (ENT) { rec = recv.x; inc = recv.y >> 32; hfull = mk(recv.y & 0xFFFFFFFFull, recv.x); }
+            else { rec = recv; inc = 1ull; }
+            uint64_t rem = rec & rmask;
+            uint32_t local = (uint32_t)(rec >> rs) & (R - 1);
+            if constexpr (ENT) { local = (uint32_t)shr(hfull, rs).lo & (R - 1); }      // (rs may exceed the low word's reach)
             bool done = false;
             for (uint32_t off = 0; off < MAXPROBE && !done; ++off) {
                 uint32_t idx = local + off;
@@ -398,20 +414,28 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *
                     if (cur == 0ull) { ++fresh; cur = want; }
                 }
                 if (cur == want) {
-                    atomicAdd(&s_img[2 * idx + 1], 1ull);      // LDS add
+                    atomicAdd(&s_img[2 * idx + 1], (unsigned long long)inc);      // LDS add
                     done = true;
                 }
             }
-            if (!done) defer_record(T, hash_of(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
+            if (!done) {
+                if constexpr (ENT) {
+                    const unsigned long long di = atomicAdd(deferred_n, 1ull);
+                    if (di < deferred_cap) { deferred[3 * di] = hfull.hi; deferred[3 * di + 1] = hfull.lo; deferred[3 * di + 2] = inc; }
+                    else atomicExch(&T.stats[ST_FATAL], 1ull);
+                } else {
+                    defer_record(T, hash_of(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
+                }
+            }
         };
         // the first 16 records per lane of the region's first slice (a region holds ~16 K, and normally in ONE slice) are
         // requested before the image is set up: one latency instead of four, overlapped with the set-up
         constexpr int PF = 4;
         const uint32_t nrec0 = cnt[(uint64_t)region * nsl];
-        const uint64_t *src0 = lists + (uint64_t)region * nsl * cap;
-        uint64_t pre[PF];
+        const rec_t *src0 = lists + (uint64_t)region * nsl * cap;
+        rec_t pre[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) { const uint32_t i = (uint32_t)u * PT_THREADS + t; pre[u] = i < nrec0 ? src0[i] : 0ull; }
+        for (int u = 0; u < PF; ++u) { const uint32_t i = (uint32_t)u * PT_THREADS + t; pre[u] = i < nrec0 ? src0[i] : rec_t{}; }
         // image in: coalesced 16-B loads (the halo wraps around the end of the table).  On a lazily cleared table the slot
         // memory is garbage except for what this pass has already written: nothing yet in the even launch; in the odd
         // launch the even regions, i.e. this region's own first `halo` slots (its left neighbour's halo) and its own halo.
@@ -422,23 +446,23 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *
             s_img[2 * i] = e.x;
             s_img[2 * i + 1] = e.y;
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int u = 0; u < PF; ++u)
             if ((uint32_t)u * PT_THREADS + t < nrec0) insert(pre[u]);
         for (uint32_t x = 0; x < nsl; ++x) {
             const uint32_t nrec = x == 0 ? nrec0 : cnt[(uint64_t)region * nsl + x];
-            const uint64_t *src = src0 + (uint64_t)x * cap;
+            const rec_t *src = src0 + (uint64_t)x * cap;
             for (uint32_t i0 = x == 0 ? PF * PT_THREADS : 0; i0 < nrec; i0 += 4 * PT_THREADS) {
-                uint64_t recs[4];
+                rec_t recs[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * PT_THREADS + t; recs[u] = i < nrec ? src[i] : 0ull; }   // 4 loads in flight
+                for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * PT_THREADS + t; recs[u] = i < nrec ? src[i] : rec_t{}; }   // 4 loads in flight
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (i0 + u * PT_THREADS + t < nrec) insert(recs[u]);
             }
         }
-        __syncthreads();
+        lds_barrier();
         for (uint32_t i = t; i < span; i += PT_THREADS) {
             const unsigned long long tag = s_img[2 * i], c64 = s_img[2 * i + 1];
             *reinterpret_cast<ulonglong2 *>(T.slots + 2 * ((first + i) & T.mask)) = make_ulonglong2(tag, c64);
@@ -449,7 +473,7 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const uint64_t *
                 else atomicAdd(&histo[b], 1ull);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (histo) {
         for (int i = t; i < LDS_HBINS; i += PT_THREADS)
@@ -520,6 +544,8 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     HIPCHK(hipMemsetAsync(defer_n, 0, 64, stream));
     const uint64_t ntiles = (len + (uint64_t)G.th1 * PT_GROUP - 1) / ((uint64_t)G.th1 * PT_GROUP);
     for (int i = 0; i < 6; ++i) if (!ev_stage_t[i]) HIPCHK(hipEventCreate(&ev_stage_t[i]));
+    part_stage_n = 5;
+    count_path = 1;
     HIPCHK(hipEventRecord(ev_k0, stream));
     HIPCHK(hipEventRecord(ev_stage_t[0], stream));
     static bool attr1_set = false;
@@ -561,13 +587,13 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     const int fresh = slots_dirty ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_insert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_insert_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     for (uint32_t parity = 0; parity < 2; ++parity) {
         if (!(nregions == 1 && parity == 1)) {
             const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
-            hipLaunchKernelGGL(lds_insert_kernel, dim3(nblk), dim3(PT_THREADS), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, parity, fresh, defer_e,
+            hipLaunchKernelGGL(lds_insert_kernel<false>, dim3(nblk), dim3(PT_THREADS), lds, stream, (const void *)lists, lcnt, lcap, nsl, d, G, nregions, parity, fresh, defer_e,
                                defer_n, deferred_cap, histo);
             HIPCHK(hipGetLastError());
         }
@@ -591,6 +617,42 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
         fprintf(stderr, "[count] partitioned piece %llu bases: p1 %d p2 %d rbits %d nblk1 %u nblk2 %u cap1 %u cap2 %u | fullest slice1 %u slice2 %u deferred %llu\n",
                 (unsigned long long)len, G.p1, G.p2, G.rbits, G.nblk1, G.nblk2, G.cap1, G.cap2, mx1, mx2, dn);
     }
+    return 0;
+}
+
+// ---- the entry form, used by count_mz.hip ----------------------------------------------------------------------------
+int Table::insert_entry_lists(const void *lists, const unsigned int *cnt, uint32_t cap, uint32_t nsl, int region_bits_total, int rbits, unsigned long long *defer_e,
+                              unsigned long long *defer_n, uint64_t deferred_cap, hipEvent_t *ev, std::string &err) {
+    PartGeom G{};
+    G.rbits = rbits; G.p1 = region_bits_total; G.p2 = 0; G.recbits = d.B;      // (only rbits is read by the entry form)
+    const uint32_t nregions = 1u << region_bits_total;
+    unsigned long long *histo = histo_request ? d_histo : nullptr;
+    if (histo) HIPCHK(hipMemsetAsync(histo, 0, HISTO_WORDS * sizeof(unsigned long long), stream));
+    const size_t lds = ((size_t)(1u << rbits) + RG_HALO) * 16 + (histo ? LDS_HBINS * 4 : 0);
+    if (slots_dirty && nregions <= 1) { if (materialize(err)) return -1; }
+    const int fresh = slots_dirty ? 1 : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_insert_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    for (uint32_t parity = 0; parity < 2; ++parity) {
+        if (!(nregions == 1 && parity == 1)) {
+            const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
+            hipLaunchKernelGGL(lds_insert_kernel<true>, dim3(nblk), dim3(PT_THREADS), lds, stream, lists, cnt, cap, nsl, d, G, nregions, parity, fresh, defer_e, defer_n,
+                               deferred_cap, histo);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(ev[parity], stream));
+    }
+    slots_dirty = false;
+    return 0;
+}
+
+int Table::finish_deferred(unsigned long long *defer_e, unsigned long long *defer_n, uint64_t deferred_cap, std::string &err) {
+    unsigned long long *histo = histo_request ? d_histo : nullptr;
+    hipLaunchKernelGGL(import3_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, deferred_cap, d, histo ? histo + 10002 : nullptr);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -831,11 +831,19 @@ int Table::launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from
     // to the table (host-staged 64 MiB pieces stay on the direct kernel and are PCIe-bound anyway)
     // break-even measured on MI355X: direct ~18 Gk-mers/s; partitioned ~55 Gk-mers/s for the two list passes plus one
     // streaming pass over the table (32 B/slot, 16 B/slot when the table is still lazily cleared)
-    if (len >= (slots_dirty ? nslots / 6 : nslots / 4) && partition_geometry(len, geom)) {
-        ++count_partitioned_launches;
-        return launch_count_partitioned(d_piece, len, emit_from, geom, err);
+    if (len >= (slots_dirty ? nslots / 6 : nslots / 4)) {
+        alignas(16) char mzgeom[128];
+        if (minimizer_geometry(len, mzgeom)) {
+            ++count_partitioned_launches;
+            return launch_count_minimizer(d_piece, len, emit_from, mzgeom, err);
+        }
+        if (partition_geometry(len, geom)) {
+            ++count_partitioned_launches;
+            return launch_count_partitioned(d_piece, len, emit_from, geom, err);
+        }
     }
     histo_request = false;
+    count_path = 0;
     if (materialize(err)) return -1;
     const uint64_t ntiles = (len + CT_TILE - 1) / CT_TILE;
     HIPCHK(hipEventRecord(ev_k0, stream));
@@ -940,7 +948,7 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
         if (h_stats[ST_OCCURRENCES] > occ_before)
             dup_ratio = (double)(h_stats[ST_DISTINCT] - distinct_before) / (double)(h_stats[ST_OCCURRENCES] - occ_before);
         if (part_stage_pending) {
-            for (int i = 0; i < 5; ++i) { float m = 0; if (hipEventElapsedTime(&m, ev_stage_t[i], ev_stage_t[i + 1]) == hipSuccess) part_stage_ms[i] += m; }
+            for (int i = 0; i < part_stage_n; ++i) { float m = 0; if (hipEventElapsedTime(&m, ev_stage_t[i], ev_stage_t[i + 1]) == hipSuccess) part_stage_ms[i] += m; }
             part_stage_pending = false;
         }
         if (getenv("JASPER_COUNT_DEBUG"))

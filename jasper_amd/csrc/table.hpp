@@ -241,8 +241,21 @@ struct Table {
     bool partition_geometry(uint64_t piece_bases, void *geom_out) const;
     int launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, const void *geom, std::string &err);
     uint64_t count_partitioned_launches = 0;
-    hipEvent_t ev_stage_t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries of the partitioned path
-    double part_stage_ms[5] = {0, 0, 0, 0, 0};                                          // part1, part2, lds even, lds odd, deferred
+    // minimizer super-k-mer path, count_mz.hip; `geom` is an opaque MzGeom
+    bool minimizer_geometry(uint64_t piece_bases, void *geom_out) const;
+    int launch_count_minimizer(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, const void *geom, std::string &err);
+    // region lists of 16-byte (hash, count) entries -> LDS images -> table (the entry form of lds_insert_kernel, count_part.hip);
+    // records the two stage events ev[0], ev[1] after the even and the odd launch
+    int insert_entry_lists(const void *lists, const unsigned int *cnt, uint32_t cap, uint32_t nsl, int region_bits_total, int rbits, unsigned long long *defer_e,
+                           unsigned long long *defer_n, uint64_t deferred_cap, hipEvent_t *ev, std::string &err);
+    int finish_deferred(unsigned long long *defer_e, unsigned long long *defer_n, uint64_t deferred_cap, std::string &err);   // deferred list -> direct path
+    static constexpr int N_STAGES = 8;
+    hipEvent_t ev_stage_t[N_STAGES + 1] = {};   // stage boundaries of the last partitioned / minimizer piece
+    // count_part.hip: part1, part2, lds even, lds odd, deferred;  count_mz.hip: mz_part, mz_split (count+scan+write), mz_count, ent_split,
+    // lds even, lds odd, expand + deferred
+    double part_stage_ms[N_STAGES] = {};
+    int part_stage_n = 5;          // stages the last piece recorded
+    int count_path = 0;            // path of the last piece: 0 direct kernel, 1 count_part.hip, 2 count_mz.hip
     bool part_stage_pending = false;
     // Multiplicity histogram taken for free while lds_insert_kernel writes the final region images back: valid when one
     // partitioned piece counted the whole input into an empty table and nothing had to take the deferred (direct) path.
@@ -255,7 +268,7 @@ struct Table {
     uint64_t size_hint = 0;   // caller's expected number of distinct k-mers (`jellyfish count -s`); 0 = none given
     // grow-only device workspace reused by the polisher across calls (hipMalloc of GBs costs far more than the kernels)
     struct WsBuf { void *p = nullptr; size_t bytes = 0; };
-    static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_INGEST = 44, WS_SLOTS = 50;
+    static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_INGEST = 44, WS_MZ = 50, WS_SLOTS = 54;
     WsBuf ws[WS_SLOTS];   // 0..WS_POLISH_MAX-1: polisher (polish_host.hip, in allocation order); WS_COUNT..+3: partitioned counting
     void *workspace(int id, size_t bytes, std::string &err);
 

@@ -202,12 +202,25 @@ class KmerTable:
         check(self._L.jasper_last_count_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    STAGE_NAMES = {2: ("mz_part_kernel", "mz_split_kernels", "mz_count_kernel", "ent_split_kernel", "lds_insert_kernel_even", "lds_insert_kernel_odd",
+                       "expand_and_deferred_kernels"),
+                   1: ("part1_kernel", "part2_kernel", "lds_insert_kernel_even", "lds_insert_kernel_odd", "deferred_import3_kernel"),
+                   0: ()}
+
     def count_stages(self):
-        """(ms per kernel of the partitioned counting path [part1, part2, lds even, lds odd, deferred], launches that took it)"""
-        ms = (C.c_double * 5)()
+        """(ms per kernel stage of the atomic-free counting path the last piece took, launches that took such a path);
+        count_path() names the path, STAGE_NAMES[path] the stages"""
+        ms = (C.c_double * 8)()
         n = C.c_uint64(0)
-        check(self._L.jasper_last_count_stages(self._h, ms, C.byref(n)))
-        return list(ms), n.value
+        path = C.c_int(0)
+        check(self._L.jasper_last_count_stages(self._h, ms, C.byref(n), C.byref(path)))
+        self._count_path = path.value
+        return list(ms)[:len(self.STAGE_NAMES.get(path.value, ()))] or list(ms)[:5], n.value
+
+    def count_path(self):
+        """2 = minimizer super-k-mers, 1 = one record per occurrence, 0 = count_kernel (after count_stages())"""
+        self.count_stages()
+        return self._count_path
 
     def clear(self):
         check(self._L.jasper_table_clear(self._h))

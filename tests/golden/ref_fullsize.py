@@ -11,7 +11,8 @@ usage: python3 tests/golden/ref_fullsize.py [genome_mb] [threads] [k] [passes] [
          cfg 3 (7 contigs, 40x)      140  16 37 2 3 fullsize_cfg3 40 7
          cfg 3 at 1/4 scale          35   16 37 2 3 fullsize_cfg3_quarter 40 7
          cfg 4 shape, 1/64 scale     48.4 64 37 2 4 fullsize_cfg4_scaled 30 24   (24 contigs, several chunks each, many batch files)
-         cfg 5 shape, scaled         10   16 37 4 5 fullsize_cfg5_scaled 10 3 10 (10 read sets with private SNPs, 4 passes)"""
+         cfg 5 shape, scaled         4    16 37 4 5 fullsize_cfg5_scaled 30 3 10 (10 read sets with private SNPs, 4 passes)
+         the same, too thin          10   16 37 4 5 fullsize_cfg5_lowcov 10 3 10 (first local minimum < 4: the reference aborts)"""
 import json, os, shutil, subprocess, sys, tempfile, time
 
 HERE = os.path.dirname(os.path.abspath(__file__))

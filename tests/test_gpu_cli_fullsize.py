@@ -1,12 +1,28 @@
-"""GPU: the drop-in at BASELINE configs[1] size against the REAL reference.
+"""GPU: the drop-in at BASELINE configs[0..4] shape against the REAL reference.
 
-tests/golden/fullsize_cfg2.json holds what the unmodified reference (bash src/jasper.sh, Jellyfish 2.3.0, jasper.py; 107 s on
-the 8 vCPU of the build container) produced for the 47 Mb / 30x / k=37 / 2-pass synthetic input of
-jasper_amd.synth.write_cli_inputs(seed 2): digests of the polished FASTA (records sorted by name), of fixes.csv, of the
-histogram file, and the threshold.  The same input is regenerated here (deterministic numpy), `python -m jasper_amd.cli`
-runs with the same flags, and every digest must be identical."""
+tests/golden/fullsize_*.json hold what the unmodified reference (bash src/jasper.sh, Jellyfish 2.3.0, jasper.py, on the 8
+vCPU of the build container; tests/golden/ref_fullsize.py) produced for the deterministic synthetic inputs of
+jasper_amd.synth.write_cli_inputs: digests of the polished FASTA (records sorted by name), of fixes.csv, of the histogram
+file, the threshold and the log lines.  The same input is regenerated here (numpy), `python -m jasper_amd.cli` runs with
+the same flags -- as one process, or as two ranks (the multi-GPU form of the driver) -- and every digest must be identical.
+
+  fullsize_cfg1          configs[0]: 4.6 Mb, 30x, k=25, 1 pass, -t 8
+  fullsize_cfg2          configs[1]: 47 Mb, 30x, k=37, 2 passes, -t 8      (also as two ranks)
+  fullsize_cfg2_t16      configs[1] chunked as -t 16 (the chunking bench.py uses)
+  fullsize_cfg3_quarter  configs[2] shape at 1/4 scale: 35 Mb in 7 contigs, 40x, two ranks (read shards + table merge)
+  fullsize_cfg4_scaled   configs[3] shape at 1/64 scale: 48.4 Mb in 24 contigs of 0.7-3.4 Mb, 30x, -t 64 -> BATCH_SIZE below the
+                         contig sizes: several chunk records per contig, ~70 batch files (src/jasper.sh:132-139,155-156)
+  fullsize_cfg5_scaled   configs[4] shape, scaled: 4 Mb in 3 contigs, 10 read sets (individuals with 0.1 % private SNPs) x 30x,
+                         4 passes (the rolling-threshold path sees 300x counts, src/jasper.py:80-93)
+  fullsize_cfg5_lowcov   the same shape with 10 x 10x on 10 Mb: the private-SNP k-mers put the histogram's first local minimum
+                         below 4 and the REFERENCE aborts ("Local min of kmer counts is smaller than 4", src/jasper.sh:200-202) --
+                         the drop-in must abort the same way, with the same log lines
+  on request (JASPER_TEST_BIG=1): fullsize_cfg3 = configs[2] exactly (140 Mb, 7 contigs, 40x: 11.5 GB of FASTQ, two ranks)
+                         and fullsize_cfg3like (140 Mb, one contig, 30x)"""
 import json
 import os
+import re
+import socket
 import subprocess
 import sys
 import time
@@ -15,59 +31,78 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIG = bool(os.environ.get("JASPER_TEST_BIG"))
+_inputs = {}
 
 
-# the 140 Mb case (11 GB of FASTQ) runs only on request: JASPER_TEST_BIG=1
-@pytest.mark.parametrize("name", ["fullsize_cfg1", "fullsize_cfg2"] + (["fullsize_cfg3like"] if os.environ.get("JASPER_TEST_BIG") else []))
-def test_cli_fullsize_matches_real_reference(hip, tmp_path, name):
-    """cfg1 = BASELINE configs[0] (4.6 Mb, k=25, 1 pass: the reference's own CPU-runnable case), cfg2 = configs[1]"""
+def _ref(name):
+    return json.load(open(os.path.join(ROOT, "tests", "golden", name + ".json")))
+
+
+def _input_dir(ref, tmp_path_factory):
+    """the inputs of one shape are generated once per session and linked into every run directory"""
     from jasper_amd import synth
-    ref = json.load(open(os.path.join(ROOT, "tests", "golden", name + ".json")))
-    d = str(tmp_path)
-    nreads, asm_len = synth.write_cli_inputs(d, ref["genome_mb"], ref["seed"])
-    assert nreads == ref["reads"] and asm_len == ref["assembly_bases"]
+    key = (ref["genome_mb"], ref["seed"], ref.get("coverage", 30), ref.get("contigs", 1), ref.get("populations", 1))
+    if key not in _inputs:
+        d = str(tmp_path_factory.mktemp("inputs"))
+        nreads, asm_len = synth.write_cli_inputs(d, ref["genome_mb"], ref["seed"], coverage=key[2], contigs=key[3], populations=key[4])
+        assert nreads == ref["reads"] and asm_len == ref["assembly_bases"]
+        _inputs[key] = d
+    return _inputs[key]
+
+
+def _run(ref, tmp_path_factory, ranks):
+    from jasper_amd import synth
+    src = _input_dir(ref, tmp_path_factory)
+    d = str(tmp_path_factory.mktemp("run"))
+    files = synth.read_files(ref.get("populations", 1))
+    for fn in files + ["asm.fa"]:
+        os.symlink(os.path.join(src, fn), os.path.join(d, fn))
+    args = ["-r", " ".join(files), "-a", "asm.fa", "-k", str(ref["k"]), "-t", str(ref["threads"]), "-p", str(ref["passes"])]
     env = dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_NO_JF="1")
+    if ranks == 1:
+        cmd = [sys.executable, "-m", "jasper_amd.cli"] + args
+    else:
+        # the multi-GPU form of the driver, rehearsed on the one GPU of the test box with gloo as the transport (with two
+        # GPUs, tests/test_gpu_nccl.py runs the same driver over RCCL)
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env.update(JASPER_AMD_DIST_BACKEND="gloo", JASPER_AMD_ONE_GPU="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "-m", "jasper_amd.cli"] + args
     t0 = time.perf_counter()
-    p = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-r", "reads.fq", "-a", "asm.fa", "-k", str(ref["k"]), "-t", str(ref["threads"]),
-                        "-p", str(ref["passes"])], cwd=d, env=env, capture_output=True, text=True, timeout=900)
+    p = subprocess.run(cmd, cwd=d, env=env, capture_output=True, text=True, timeout=900)
     wall = time.perf_counter() - t0
+    strip = lambda ls: [re.sub(r"Q value = .*", "Q value =", re.sub(r"^\[[^\]]*\]", "[DATE]", ln)) for ln in ls]
+    mine = [ln for ln in p.stdout.splitlines() if re.match(r"^\[\w{3} \w{3} +\d", ln)]      # (gloo prints its own, sometimes interleaved, lines)
+    if ref["exit"] != 0:
+        # the reference gave up on this input (src/jasper.sh:35-39: message on stderr, exit 1): so must the drop-in, at the same point
+        assert p.returncode != 0, p.stdout + p.stderr
+        assert strip(mine) == strip(ref["stdout"])
+        assert "Local min of kmer counts is smaller than 4" in p.stderr
+        assert not os.path.exists(os.path.join(d, "asm.fa.polished.fasta"))
+        return
     assert p.returncode == 0, p.stdout + p.stderr
     got = synth.output_digests(d, k=ref["k"])
     for key in ("threshold", "jfhisto_sha256", "polished_bases", "polished_fasta_sha256", "fixes_csv_lines", "fixes_csv_sha256"):
         assert got[key] == ref[key], (key, got[key], ref[key])
     # same log lines (dates and Q digits aside: bc is missing in the build container, so the reference printed "Inf")
-    import re
-    strip = lambda ls: [re.sub(r"Q value = .*", "Q value =", re.sub(r"^\[[^\]]*\]", "[DATE]", ln)) for ln in ls]
-    assert strip(p.stdout.splitlines()) == strip(ref["stdout"])
-    print("drop-in wall %.1f s vs reference %.1f s on %s" % (wall, ref["reference_wall_seconds"], ref["host"]))
-
-
-def test_cli_fullsize_two_ranks_matches_real_reference(hip, tmp_path):
-    """configs[1] through the multi-GPU form of the driver (2 ranks rehearsed on the one GPU, gloo transport): the 2.9 GB
-    FASTQ is cut into two byte ranges at record boundaries, the counts are summed by key owner, each rank polishes half of
-    the batch files through IPC-mapped owner tables -- same digests as the real reference's run"""
-    import re
-    import socket
-    from jasper_amd import synth
-    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_cfg2.json")))
-    d = str(tmp_path)
-    nreads, asm_len = synth.write_cli_inputs(d, ref["genome_mb"], ref["seed"])
-    assert nreads == ref["reads"] and asm_len == ref["assembly_bases"]
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_DIST_BACKEND="gloo", JASPER_AMD_ONE_GPU="1", JASPER_AMD_NO_JF="1")
-    t0 = time.perf_counter()
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), "-m", "jasper_amd.cli", "-r", "reads.fq", "-a", "asm.fa", "-k", str(ref["k"]),
-                        "-t", str(ref["threads"]), "-p", str(ref["passes"])], cwd=d, env=env, capture_output=True, text=True, timeout=900)
-    wall = time.perf_counter() - t0
-    assert p.returncode == 0, p.stdout + p.stderr
-    got = synth.output_digests(d, k=ref["k"])
-    for key in ("threshold", "jfhisto_sha256", "polished_bases", "polished_fasta_sha256", "fixes_csv_lines", "fixes_csv_sha256"):
-        assert got[key] == ref[key], (key, got[key], ref[key])
-    strip = lambda ls: [re.sub(r"Q value = .*", "Q value =", re.sub(r"^\[[^\]]*\]", "[DATE]", ln)) for ln in ls]
-    mine = [ln for ln in p.stdout.splitlines() if re.match(r"^\[\w{3} \w{3} +\d", ln)]      # (gloo prints its own, sometimes interleaved, lines)
     assert strip(mine) == strip(ref["stdout"])
-    print("2-rank drop-in wall %.1f s (both ranks on one GPU, gloo) vs reference %.1f s" % (wall, ref["reference_wall_seconds"]))
+    print("%d-rank drop-in wall %.1f s vs reference %.1f s on %s" % (ranks, wall, ref["reference_wall_seconds"], ref["host"]))
+    for fn in os.listdir(d):          # (GBs of intermediates per case)
+        if not os.path.islink(os.path.join(d, fn)):
+            os.remove(os.path.join(d, fn))
+
+
+CASES = [("fullsize_cfg1", 1), ("fullsize_cfg2", 1), ("fullsize_cfg2_t16", 1), ("fullsize_cfg2", 2),
+         ("fullsize_cfg3_quarter", 2), ("fullsize_cfg3_quarter", 1), ("fullsize_cfg4_scaled", 1), ("fullsize_cfg4_scaled", 2),
+         ("fullsize_cfg5_scaled", 1), ("fullsize_cfg5_scaled", 2), ("fullsize_cfg5_lowcov", 1)]
+if BIG:
+    CASES += [("fullsize_cfg3", 2), ("fullsize_cfg3like", 1)]
+
+
+@pytest.mark.parametrize("name,ranks", CASES)
+def test_cli_fullsize_matches_real_reference(hip, tmp_path_factory, name, ranks):
+    _run(_ref(name), tmp_path_factory, ranks)

@@ -452,10 +452,11 @@ def test_histogram_fused_into_counting_pass_equals_table_scan(KT):
     t.close()
 
 
-@pytest.mark.parametrize("k", [21, 27, 31, 32, 33, 35, 37])
-def test_partitioned_counting_equals_direct_counting(KT, k):
-    """the atomic-free partitioned path (part1 -> part2 -> lds_insert, count_part.hip) and the direct insert kernel
-    must build the same table for every k the partitioned path accepts (one- and two-word k-mers)"""
+@pytest.mark.parametrize("k", [15, 21, 25, 27, 31, 32, 33, 35, 37, 41])
+def test_atomic_free_counting_paths_equal_direct_counting(KT, k):
+    """the three ways a table is filled must build the same table for every k they accept (one- and two-word k-mers):
+    minimizer super-k-mers (count_mz.hip: mz_part -> mz_split -> mz_count -> ent_split -> lds_insert), one record per
+    occurrence (count_part.hip: part1 -> part2 -> lds_insert; k <= 37) and the direct insert kernel (global atomics)"""
     import torch
     G = 1_500_000
     dev = torch.device("cuda", 0)
@@ -463,11 +464,26 @@ def test_partitioned_counting_equals_direct_counting(KT, k):
     genome = synth.torch_genome(gen, G, dev)
     nreads = G * 30 // 150
     reads = synth.torch_reads_stream(gen, genome, nreads, 150, 0.004)
+    # low-complexity stretches: long runs of one minimizer (records cut at nmax), and a read of all-N
+    reads[1000:1600] = ord("A")
+    reads[5000:5400] = torch.tensor(list(b"ACACACACACACACACACAC" * 20), dtype=torch.uint8, device=dev)
+    reads[9000:9300] = ord("N")
     torch.cuda.synchronize()
     slots = int(1.25 * nreads * 150 * 2.1 / 10)
-    tp = KT(k, min_slots=slots)
-    tp.count_bases_device(reads.data_ptr(), reads.numel())
-    assert tp.count_stages()[1] >= 1, "partitioned path not taken"
+    os.environ["JASPER_COUNT_PATH"] = "2"
+    try:
+        tm = KT(k, min_slots=slots)
+        tm.count_bases_device(reads.data_ptr(), reads.numel())
+    finally:
+        del os.environ["JASPER_COUNT_PATH"]
+    if k <= 37:      # (k >= 38 needs >= 2^(2k-53) slots: this input is then small against the table and takes the direct kernel)
+        assert tm.count_stages()[1] >= 1 and tm.count_path() == 2, "minimizer path not taken"
+    tables = [tm]
+    if k <= 37:
+        tp = KT(k, min_slots=slots)
+        tp.count_bases_device(reads.data_ptr(), reads.numel())
+        assert tp.count_stages()[1] >= 1 and tp.count_path() == 1, "partitioned path not taken"
+        tables.append(tp)
     os.environ["JASPER_COUNT_DIRECT"] = "1"
     try:
         td = KT(k, min_slots=slots)
@@ -475,13 +491,28 @@ def test_partitioned_counting_equals_direct_counting(KT, k):
         assert td.count_stages()[1] == 0
     finally:
         del os.environ["JASPER_COUNT_DIRECT"]
-    ip, idr = tp.info(), td.info()
-    assert ip["occurrences"] == idr["occurrences"] == nreads * (150 - k + 1) and ip["distinct"] == idr["distinct"]
-    assert tp.histogram() == td.histogram()
+    idr = td.info()
     g = genome[:200_000].cpu().numpy().tobytes().decode()
-    qs = [g[i:i + k] for i in range(0, len(g) - k, 997)] + ["A" * k, "ACGT" * 16]
-    assert tp.lookup(qs) == td.lookup(qs)
-    tp.close()
+    qs = [g[i:i + k] for i in range(0, len(g) - k, 997)] + ["A" * k, "ACGT" * 16, "AC" * 32]
+    hd, ld = td.histogram(), td.lookup(qs)
+    for tp in tables:
+        ip = tp.info()
+        assert ip["occurrences"] == idr["occurrences"] and ip["distinct"] == idr["distinct"], (tp.count_path(), ip, idr)
+        assert tp.histogram() == hd, tp.count_path()
+        assert tp.lookup(qs) == ld
+        tp.close()
+    # a second call adds to the table that is already there (images loaded, not started from zeros)
+    for path in ("1", "2"):
+        os.environ["JASPER_COUNT_PATH"] = path
+        try:
+            t2 = KT(k, min_slots=slots)
+            half = (reads.numel() // 2) // 151 * 151
+            t2.count_bases_device(reads.data_ptr(), half)
+            t2.count_bases_device(reads.data_ptr() + half, reads.numel() - half)
+        finally:
+            del os.environ["JASPER_COUNT_PATH"]
+        assert t2.info()["distinct"] == idr["distinct"] and t2.histogram() == hd and t2.lookup(qs) == ld
+        t2.close()
     td.close()
 
 
