@@ -637,7 +637,7 @@ bool Table::minimizer_geometry(uint64_t piece_bases, void *geom_out) const {
     // instructions against 4.4 G for part1 + part2 + lds_insert together) and is slower (26 ms against 17 ms for cfg 2), so it
     // is kept as the second, parity-tested way to fill a table and as the starting point of a bucket-addressed table.
     const int mode = getenv("JASPER_COUNT_PATH") ? atoi(getenv("JASPER_COUNT_PATH")) : 1;
-    if (mode != 2 || getenv("JASPER_COUNT_DIRECT")) return false;
+    if (mode != 2 || getenv("JASPER_COUNT_DIRECT") || d.ext) return false;
     if (piece_bases < (8u << 20) || piece_bases >= (1ull << 32)) return false;
     const int B = d.B, s = d.s;
     if (k < 15 || k > 43 || s < 16) return false;

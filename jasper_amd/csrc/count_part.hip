@@ -501,6 +501,7 @@ static uint32_t list_cap(double avg) { return (uint32_t)std::min<double>(4.0e9, 
 bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     PartGeom &G = *reinterpret_cast<PartGeom *>(geom_out);
     if (getenv("JASPER_COUNT_DIRECT")) return false;
+    if (d.ext) return false;                              // wide remainders: the LDS images hold tags only
     if (piece_bases < (8u << 20)) return false;          // small pieces: the direct kernel is already latency-hidden
     const int B = d.B, s = d.s;
     const int need_p1 = B > 64 ? B - 64 : 0;              // records are 8 bytes

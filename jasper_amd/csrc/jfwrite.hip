@@ -53,10 +53,7 @@ __global__ __launch_bounds__(256) void export_rotated_kernel(TableDev T, int r, 
         base = __shfl(base, leader);
         if (!have) continue;
         const unsigned long long idx = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-        const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
-        const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
-        const uint64_t home = (i - off) & T.mask;
-        const u128 key = unmix(hash_from(home, rem, B, T.s), B);
+        const u128 key = unmix(slot_hash(T, i, e.x), B);
         const u128 K = r == 0 || r == B ? key : bor(shl(band(key, maskbits(r)), B - r), shr(key, r));
         if (idx < cap) {
             klo[idx] = K.lo;

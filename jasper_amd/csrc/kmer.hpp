@@ -193,4 +193,13 @@ JK_HD uint64_t rem_of(u128 h, int B, int s) { return band(h, maskbits(B - s)).lo
 JK_HD uint64_t tag_of(uint64_t rem, uint32_t off) { return OCC | (rem << OFFBITS) | off; }
 JK_HD u128 hash_from(uint64_t home, uint64_t rem, int B, int s) { return bor(shl(mk(0, home), B - s), mk(0, rem)); }
 
+// Wide remainders.  The tag word has room for 63 - OFFBITS = 53 remainder bits.  When the slot index leaves more than that
+// (B - s > 53: k >= 38 unless the table is huge, every k >= 44) the LOW 64 remainder bits live in a second array, one word
+// per slot ("ext"), and the tag keeps the bits above them (B - s - 64 <= 53 for every k <= 64 once s >= 11).  Same role as
+// Jellyfish's variable-width key field, which may straddle words (JF::include/jellyfish/large_hash_array.hpp:509-597).
+JK_HD bool wide_rem(int B, int s) { return B - s > 63 - OFFBITS; }
+JK_HD uint64_t tag_rem_of(u128 h, int B, int s) { const u128 r = band(h, maskbits(B - s)); return wide_rem(B, s) ? r.hi : r.lo; }
+JK_HD uint64_t ext_of(u128 h, int B, int s) { return band(h, maskbits(B - s)).lo; }
+JK_HD u128 hash_from_wide(uint64_t home, uint64_t tag_rem, uint64_t ext, int B, int s) { return bor(shl(mk(0, home), B - s), mk(tag_rem, ext)); }
+
 }  // namespace jk

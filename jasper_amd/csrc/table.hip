@@ -197,10 +197,7 @@ __global__ __launch_bounds__(256) void export_kernel(TableDev T, unsigned long l
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < nslots; i += (uint64_t)gridDim.x * blockDim.x) {
         const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * i);
         if (e.x == 0ull) continue;
-        const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
-        const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
-        const uint64_t home = (i - off) & T.mask;
-        const u128 h = hash_from(home, rem, T.B, T.s);
+        const u128 h = slot_hash(T, i, e.x);
         const unsigned long long idx = atomicAdd(counter, 1ull);
         if (idx < cap) {
             entries[3 * idx + 0] = h.hi;
@@ -238,10 +235,7 @@ __host__ __device__ __forceinline__ uint32_t part_of(u128 h, int B, uint32_t npa
 __device__ __forceinline__ bool packed_entry_of(const TableDev &T, uint64_t i, uint32_t part, uint32_t nparts, int sh, ulonglong2 &o) {
     const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * i);
     if (e.x == 0ull) return false;
-    const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
-    const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
-    const uint64_t home = (i - off) & T.mask;
-    const u128 h = hash_from(home, rem, T.B, T.s);
+    const u128 h = slot_hash(T, i, e.x);
     if (nparts > 1 && part_of(h, T.B, nparts) != part) return false;
     if (sh && (e.y >> (64 - sh)) != 0ull) { atomicExch(&T.stats[ST_FATAL], 2ull); return false; }   // count does not fit the packing
     o = make_ulonglong2(h.lo, sh ? (h.hi | (e.y << sh)) : e.y);   // (B <= 64: the whole second word is the count)
@@ -313,9 +307,7 @@ __global__ __launch_bounds__(256) void export_packed_write_kernel(TableDev T, ul
 __device__ __forceinline__ bool owner_entry_of(const TableDev &T, uint64_t i, uint32_t nown, int sort_r, int sh, ulonglong2 &o, uint32_t &owner) {
     const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * i);
     if (e.x == 0ull) return false;
-    const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
-    const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
-    const u128 h = hash_from((i - off) & T.mask, rem, T.B, T.s);
+    const u128 h = slot_hash(T, i, e.x);
     if (sh && (e.y >> (64 - sh)) != 0ull) { atomicExch(&T.stats[ST_FATAL], 2ull); return false; }
     if (sort_r > 0) {
         const u128 key = unmix(h, T.B);
@@ -393,6 +385,7 @@ __global__ __launch_bounds__(256) void export_owner_write_kernel(TableDev T, ulo
 
 // insert-or-assign: the key's count becomes `val` (used when an owner's final counts replace a rank's partial ones)
 __device__ __forceinline__ int table_set(const TableDev &T, u128 h, unsigned long long val) {
+    if (T.ext) return table_put_wide(T, h, val, true);
     const uint64_t home = home_of(h, T.B, T.s);
     const uint64_t rem = rem_of(h, T.B, T.s);
     for (uint32_t off = 0; off < MAXPROBE; ++off) {
@@ -587,10 +580,7 @@ __global__ __launch_bounds__(256) void rehash_kernel(TableDev oldT, TableDev new
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < nslots; i += (uint64_t)gridDim.x * blockDim.x) {
         const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(oldT.slots + 2 * i);
         if (e.x == 0ull) continue;
-        const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
-        const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
-        const uint64_t home = (i - off) & oldT.mask;
-        fresh += table_add_or_spill(newT, hash_from(home, rem, oldT.B, oldT.s), e.y);
+        fresh += table_add_or_spill(newT, slot_hash(oldT, i, e.x), e.y);
     }
     for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&newT.stats[ST_DISTINCT], fresh);
@@ -617,17 +607,13 @@ static int grid_for(uint64_t work_items, int per_block) {
 }
 
 int Table::min_log2_slots(int k) {
-    int need = 2 * k - (63 - OFFBITS);  // B - s <= 63 - OFFBITS
+    // the tag holds 63 - OFFBITS remainder bits, the ext word of a wide table (kmer.hpp: wide_rem) 64 more: B - s <= 117
+    int need = 2 * k - (63 - OFFBITS) - 64;
     return std::max(need, 10);
 }
 
 int Table::init(int k_, uint64_t min_slots, int device_, std::string &err) {
     if (k_ < 1 || k_ > 64) { err = "k must be in [1,64]"; return -1; }
-    if (min_log2_slots(k_) > 34) {
-        // the slot's tag word holds the 2k - s hash bits the slot index does not imply (<= 53): k = 44 would need 2^35 slots
-        err = "k = " + std::to_string(k_) + " is not supported: this table format holds k-mers of up to 43 bases in the HBM of one GPU (DESIGN.md section 3)";
-        return -1;
-    }
     k = k_;
     device = device_;
     HIPCHK(hipSetDevice(device));
@@ -644,6 +630,7 @@ int Table::init(int k_, uint64_t min_slots, int device_, std::string &err) {
     d.s = s; d.B = 2 * k; d.k = k; d.mask = nslots - 1;
     d.spill_cap = 1u << 16;
     HIPCHK(hipMalloc((void **)&d.slots, slot_alloc_bytes(nslots)));
+    if (wide_rem(d.B, d.s)) HIPCHK(hipMalloc((void **)&d.ext, (size_t)nslots * 8));      // (never read before the slot's count is non-zero: not zeroed)
     HIPCHK(hipMalloc((void **)&d.stats, ST_WORDS * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&d.spill, d.spill_cap * 3 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&d_histo, 2 * HISTO_WORDS * sizeof(unsigned long long)));
@@ -686,6 +673,7 @@ void Table::destroy() {
         if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]);
     }
     if (d.slots) (void)hipFree(d.slots);
+    if (d.ext) (void)hipFree(d.ext);
     if (d.stats) (void)hipFree(d.stats);
     if (d.spill) (void)hipFree(d.spill);
     if (d_histo) (void)hipFree(d_histo);
@@ -748,6 +736,7 @@ int Table::fit(double max_load, std::string &err) {
     if (read_stats(err)) return -1;
     if (!(max_load > 0.05 && max_load <= 0.9)) { err = "fit: load must be in (0.05, 0.9]"; return -1; }
     int ns = min_log2_slots(k);
+    if (!d.ext) ns = std::max(ns, std::min(d.s, d.B - (63 - OFFBITS)));      // a table with whole remainders in its tags keeps them (shards)
     while ((double)h_stats[ST_DISTINCT] > max_load * (double)(1ull << ns) && ns < d.B) ++ns;
     if (ns == d.s) return 0;
     histo_cached = false;
@@ -759,17 +748,21 @@ int Table::fit(double max_load, std::string &err) {
 int Table::resize(int new_s, std::string &err) {
     if (new_s == d.s) return 0;
     detach_shards();      // the slot array moves and its geometry changes: the owners have to agree and attach again
+    unsigned long long *new_ext = nullptr;      // the new geometry may or may not need the second remainder word
+    if (wide_rem(d.B, new_s)) HIPCHK(hipMalloc((void **)&new_ext, (size_t)(1ull << new_s) * 8));
     if (slots_dirty) {   // logically empty: nothing to rehash, the new slot array stays lazily cleared as well
         unsigned long long *ns = nullptr;
         HIPCHK(hipMalloc((void **)&ns, slot_alloc_bytes(1ull << new_s)));
         HIPCHK(jk_stream_wait(stream));
         HIPCHK(hipFree(d.slots));
-        d.slots = ns; d.s = new_s; d.mask = (1ull << new_s) - 1; nslots = 1ull << new_s;
+        if (d.ext) HIPCHK(hipFree(d.ext));
+        d.slots = ns; d.ext = new_ext; d.s = new_s; d.mask = (1ull << new_s) - 1; nslots = 1ull << new_s;
         return 0;
     }
     TableDev nt = d;
     nt.s = new_s;
     nt.mask = (1ull << new_s) - 1;
+    nt.ext = new_ext;
     HIPCHK(hipMalloc((void **)&nt.slots, slot_alloc_bytes(1ull << new_s)));
     if (zero_slots(nt.slots, 1ull << new_s, err)) return -1;
     // distinct is recounted by the re-insertion
@@ -778,6 +771,7 @@ int Table::resize(int new_s, std::string &err) {
     HIPCHK(hipGetLastError());
     HIPCHK(jk_stream_wait(stream));
     HIPCHK(hipFree(d.slots));
+    if (d.ext) HIPCHK(hipFree(d.ext));
     d = nt;
     nslots = 1ull << new_s;
     return 0;
@@ -1045,10 +1039,7 @@ __global__ __launch_bounds__(256) void histo_part_kernel(TableDev T, uint32_t pa
         const uint64_t i = (first + q) & T.mask;
         const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * i);
         if (e.x == 0ull || e.y == 0ull) continue;
-        const uint32_t off = (uint32_t)(e.x & (MAXPROBE - 1));
-        const uint64_t rem = (e.x & ~OCC) >> OFFBITS;
-        const uint64_t home = (i - off) & T.mask;
-        if (nparts > 1 && part_of(hash_from(home, rem, T.B, T.s), T.B, nparts) != part) continue;
+        if (nparts > 1 && part_of(slot_hash(T, i, e.x), T.B, nparts) != part) continue;
         const uint32_t c = clamp32(e.y);
         atomicAdd(&bins[c > 10001u ? 10001u : c], 1u);
     }
@@ -1159,7 +1150,18 @@ void Table::part_span(uint32_t part, uint32_t nparts, uint64_t &first, uint64_t 
     span = std::min<uint64_t>(nslots, last_excl - first + MAXPROBE);
 }
 
+static const char *WIDE_NO_EXCHANGE = "the multi-GPU table exchange packs a key and its count into 16 bytes and holds k <= 48, and a table that other GPUs "
+                                      "read keeps whole remainders in its tags (k <= 43, at least 2^(2k-53) slots): run a larger k on one GPU";
+// A table that peers read (shards) or that is built region by region from entry lists keeps the whole remainder in the tag
+// word: grow it to the smallest such geometry if it is not there yet (2^(2k-53) slots; k <= 43 fits one GPU)
+int Table::ensure_narrow(std::string &err) {
+    if (!d.ext) return 0;
+    const int need = d.B - (63 - OFFBITS);
+    if (need > 34) { err = WIDE_NO_EXCHANGE; return -1; }
+    return resize(std::max(need, d.s), err);
+}
 int Table::export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t part, uint32_t nparts, std::string &err) {
+    if (d.B > 96) { err = WIDE_NO_EXCHANGE; return -1; }
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
     uint64_t first = 0, span = nslots;
@@ -1183,6 +1185,7 @@ int Table::export_packed(void *d_dst, uint64_t cap, uint64_t *n_out, uint32_t pa
 
 int Table::export_owner(void *d_dst, uint64_t cap, uint32_t nown, int sort_r, uint64_t *counts_out, std::string &err) {
     if (nown < 1 || nown > MAX_SHARDS || sort_r < 0 || sort_r > 60 || sort_r > d.B) { err = "export_owner: 1..8 owners, 0 <= sort_r <= min(60, 2k)"; return -1; }
+    if (d.B > 96) { err = WIDE_NO_EXCHANGE; return -1; }
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
     unsigned long long *d_counts = reinterpret_cast<unsigned long long *>(workspace(WS_COUNT + 2, (size_t)MAX_SHARDS * EXP_STRIDE * 8 + 256, err));
@@ -1212,6 +1215,7 @@ void Table::detach_shards() {
 
 int Table::ipc_handle(void *out64, std::string &err) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C-ABI hands IPC handles over as 64 bytes");
+    if (ensure_narrow(err)) return -1;
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
     hipIpcMemHandle_t h;
@@ -1224,6 +1228,7 @@ int Table::ipc_handle(void *out64, std::string &err) {
 // owner's table must have this table's geometry -- the caller agrees on it before (dist.shard_tables).
 int Table::attach_ipc(const void *handles64, uint32_t n, uint32_t self, std::string &err) {
     if (n < 1 || n > MAX_SHARDS || self >= n) { err = "attach: 1..8 shards, self among them"; return -1; }
+    if (ensure_narrow(err)) return -1;
     const bool dbg = getenv("JASPER_SHARD_DEBUG") != nullptr;
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
@@ -1264,6 +1269,8 @@ int Table::attach_ipc(const void *handles64, uint32_t n, uint32_t self, std::str
 // one allocation)
 int Table::attach_tables(Table *const *peers, uint32_t n, uint32_t self, std::string &err) {
     if (n < 1 || n > MAX_SHARDS || self >= n) { err = "attach: 1..8 shards, self among them"; return -1; }
+    if (ensure_narrow(err)) return -1;
+    for (uint32_t i = 0; i < n; ++i) if (peers[i] && peers[i] != this && peers[i]->ensure_narrow(err)) return -1;
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;
     detach_shards();
@@ -1281,6 +1288,8 @@ int Table::attach_tables(Table *const *peers, uint32_t n, uint32_t self, std::st
 }
 
 int Table::import_packed_multi(const void *const *d_srcs, const uint64_t *counts, uint32_t n_src, std::string &err) {
+    if (d.B > 96) { err = WIDE_NO_EXCHANGE; return -1; }
+    if (ensure_narrow(err)) return -1;
     if (n_src < 1 || n_src > MAX_SHARDS) { err = "import_packed_multi: 1..8 lists"; return -1; }
     histo_cached = false;
     HIPCHK(hipSetDevice(device));
@@ -1337,6 +1346,7 @@ int Table::import_packed_multi(const void *const *d_srcs, const uint64_t *counts
 }
 
 int Table::import_packed(const void *d_src, uint64_t n, int mode, std::string &err) {
+    if (d.B > 96) { err = WIDE_NO_EXCHANGE; return -1; }
     histo_cached = false;
     HIPCHK(hipSetDevice(device));
     if (materialize(err)) return -1;

@@ -27,7 +27,65 @@ struct TableDev {
     // table is whole and `slots` is read.  Insertions always go to `slots`.
     const unsigned long long *shard[MAX_SHARDS];
     uint32_t nshard;
+    // wide remainders (kmer.hpp: wide_rem): the low 64 remainder bits of slot i are ext[i]; null when the tag holds the whole
+    // remainder.  A slot's ext word is valid once its count is non-zero: the claimant writes tag (CAS), ext, then adds its count.
+    unsigned long long *ext;
 };
+
+// the hash of the key stored in slot i (tag != 0)
+__device__ __forceinline__ u128 slot_hash(const TableDev &T, uint64_t i, unsigned long long tag) {
+    const uint32_t off = (uint32_t)(tag & (MAXPROBE - 1));
+    const uint64_t rem = (tag & ~OCC) >> OFFBITS;
+    const uint64_t home = (i - off) & T.mask;
+    if (T.ext) return hash_from_wide(home, rem, T.ext[i], T.B, T.s);
+    return hash_from(home, rem, T.B, T.s);
+}
+// Insert-or-add / insert-or-assign for a wide table.  A claimant writes tag (compare-and-swap), ext, then its count (release);
+// a lane that meets a matching tag whose count is still zero cannot tell yet whether that is its own key.  It must not wait in
+// place: the claimant may be a lane of the SAME wave whose side of the branch has not run yet.  So the loop below leaves only
+// when every lane of the wave is done -- each trip is then complete for all lanes before the next one starts -- and the
+// undecided lane simply looks at the same slot again on the next trip (a bounded number of times; then it reports 0 and the
+// caller spills the insertion, to be re-inserted later).  assign: the count is set to `val` instead of being added to.
+__device__ __forceinline__ int table_put_wide(const TableDev &T, u128 h, unsigned long long val, bool assign) {
+    const uint64_t home = home_of(h, T.B, T.s);
+    const uint64_t rem = tag_rem_of(h, T.B, T.s);
+    const unsigned long long ext = ext_of(h, T.B, T.s);
+    int result = -1;
+    uint32_t off = 0, waited = 0;
+    for (;;) {
+        if (result < 0) {
+            const uint64_t slot = (home + off) & T.mask;
+            const unsigned long long want = tag_of(rem, off);
+            unsigned long long *p = T.slots + 2 * slot;
+            unsigned long long cur = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == 0ull) {
+                cur = atomicCAS(p, 0ull, want);
+                if (cur == 0ull) {
+                    __hip_atomic_store(T.ext + slot, ext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p + 1, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // (the claimant is the only writer until the count is non-zero)
+                    result = 2;
+                }
+            }
+            if (result < 0) {
+                bool next = true;
+                if (cur == want) {
+                    const unsigned long long c = __hip_atomic_load(p + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (c == 0ull) {                       // claimed, key not complete yet: same slot again on the next trip
+                        next = false;
+                        if (++waited > (1u << 16)) result = 0;
+                    } else if (__hip_atomic_load(T.ext + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ext) {
+                        if (assign) __hip_atomic_store(p + 1, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else __hip_atomic_fetch_add(p + 1, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        result = 1;
+                    }
+                }
+                if (result < 0 && next && ++off >= MAXPROBE) result = 0;
+            }
+        }
+        if (__ballot(result < 0) == 0ull) break;
+    }
+    return result;
+}
 
 // The owner of a key among n shards: a second mix of the hash, so that the keys of one owner are spread evenly over the
 // slots of its table whatever the table size is.
@@ -52,6 +110,7 @@ enum { ST_DISTINCT = 0, ST_SPILL = 1, ST_OCCURRENCES = 2, ST_FATAL = 3, ST_WORDS
 // existed, 2 if this call claimed a new slot (callers batch the distinct-key counter: one same-address atomic
 // per new key would serialise the whole chip on a single L2 channel).
 __device__ __forceinline__ int table_add(const TableDev &T, u128 h, unsigned long long inc) {
+    if (T.ext) return table_put_wide(T, h, inc, false);
     const uint64_t home = home_of(h, T.B, T.s);
     const uint64_t rem = rem_of(h, T.B, T.s);
     for (uint32_t off = 0; off < MAXPROBE; ++off) {
@@ -80,6 +139,7 @@ __device__ __forceinline__ int table_add(const TableDev &T, u128 h, unsigned lon
 // same as table_add, but the tag of the home slot has already been loaded (`cur0`): lets a thread keep several
 // first probes in flight before resolving them
 __device__ __forceinline__ int table_add_prefetched(const TableDev &T, u128 h, unsigned long long inc, unsigned long long cur0) {
+    if (T.ext) return table_add(T, h, inc);      // (wide tables: the prefetched tag alone does not decide anything)
     const uint64_t home = home_of(h, T.B, T.s);
     const uint64_t rem = rem_of(h, T.B, T.s);
     for (uint32_t off = 0; off < MAXPROBE; ++off) {
@@ -130,12 +190,14 @@ __device__ __forceinline__ unsigned table_add_or_spill(const TableDev &T, u128 h
 // exact 64-bit count of the key whose mixed hash is h, or 0
 __device__ __forceinline__ unsigned long long table_get(const TableDev &T, u128 h) {
     const uint64_t home = home_of(h, T.B, T.s);
-    const uint64_t rem = rem_of(h, T.B, T.s);
+    const uint64_t rem = tag_rem_of(h, T.B, T.s);
     const unsigned long long *S = read_slots(T, h);
+    const bool wide = T.ext != nullptr;          // (a wide table is never sharded: attach refuses it)
+    const unsigned long long ext = wide ? ext_of(h, T.B, T.s) : 0ull;
     for (uint32_t off = 0; off < MAXPROBE; ++off) {
         const uint64_t slot = (home + off) & T.mask;
         const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(S + 2 * slot);  // tag + count, one 16-B load
-        if (e.x == tag_of(rem, off)) return e.y;
+        if (e.x == tag_of(rem, off) && (!wide || T.ext[slot] == ext)) return e.y;
         if (e.x == 0ull) return 0ull;
     }
     return 0ull;
@@ -143,6 +205,7 @@ __device__ __forceinline__ unsigned long long table_get(const TableDev &T, u128 
 
 // the same with the home slot already loaded (callers put several home-slot loads in flight before resolving them)
 __device__ __forceinline__ unsigned long long table_get_prefetched(const TableDev &T, u128 h, ulonglong2 e0) {
+    if (T.ext) return table_get(T, h);
     const uint64_t home = home_of(h, T.B, T.s);
     const uint64_t rem = rem_of(h, T.B, T.s);
     if (e0.x == tag_of(rem, 0)) return e0.y;
@@ -287,6 +350,7 @@ struct Table {
     int ensure_capacity(uint64_t upcoming_kmers, std::string &err);
     int grow(int new_s, std::string &err);            // rehash into 2^new_s slots if that is more than now
     int resize(int new_s, std::string &err);
+    int ensure_narrow(std::string &err);             // whole remainders in the tags (what shards and region-wise imports need)
     int fit(double max_load, std::string &err);
     int after_batch(std::string &err);                // spill / fatal / growth handling
     int count_device(const uint8_t *d_bases, uint64_t n, std::string &err);

@@ -174,6 +174,9 @@ def case_specs():
     add("simple_k37", k=37, passes=2, thre=5, rl=150, cov=40, err=0.002, fmt="fq", build=b_simple)
     add("simple_k17_p1", k=17, passes=1, thre=4, rl=80, cov=40, err=0.002, fmt="fa", build=b_simple)
     add("simple_k31_p3", k=31, passes=3, thre=5, rl=120, cov=40, err=0.002, fmt="fa_multiline", build=b_simple)
+    # k beyond 43: keys of more than 86 bits (jasper.sh -k takes any k, src/jasper.sh:89-92)
+    add("simple_k45", k=45, passes=2, thre=4, rl=150, cov=40, err=0.002, fmt="fq", build=b_simple)
+    add("simple_k63", k=63, passes=2, thre=3, rl=150, cov=50, err=0.001, fmt="fq", build=b_simple)
 
     # 2. homopolymer indels
     def b_homo(rng, k):

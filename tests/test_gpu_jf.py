@@ -135,3 +135,48 @@ def test_write_jf_small_k_and_empty(hip, tmp_path):
         assert t2.histogram() == t.histogram()
         t.close()
         t2.close()
+
+
+@pytest.mark.parametrize("k", [45, 51, 63, 64])
+def test_write_and_load_jf_wide_k(hip, tmp_path, k):
+    """k > 43: keys of up to 128 bits (key bytes = ceil(2k/8) up to 16): the file obeys the reader's (pos, key) order, holds
+    the same (k-mer, count) set as a Python restatement of `jellyfish count -C`, and loads back into an identical table.
+    The files are kept under gpurun_out/ so that the real jellyfish 2.3.0 can read them in the build container
+    (tests/golden/check_jf_writer.py)."""
+    import collections
+    import numpy as np
+    from jasper_amd import KmerTable, synth
+    rng = np.random.default_rng(k)
+    genome = synth.make_genome(rng, 4000, repeat_frac=0)
+    reads = synth.make_reads_stream(rng, genome, 8, 130, 0.002).tobytes().decode()
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    want = collections.Counter()
+    for r in reads.split("N"):
+        for i in range(len(r) - k + 1):
+            f = rc = 0
+            for ch in r[i:i + k]:
+                f = (f << 2) | code[ch]
+            for ch in reversed(r[i:i + k]):
+                rc = (rc << 2) | (3 - code[ch])
+            want[min(f, rc)] += 1
+    t = KmerTable(k, min_slots=1 << 12)
+    t.count_bases(reads.encode())
+    p = str(tmp_path / ("k%d.jf" % k))
+    t.write_jf(p, ["count", "-C", "-m", str(k)])
+    hdr, recs = _read_jf(p)
+    assert hdr["key_len"] == 2 * k
+    assert dict(recs) == dict(want) and len(recs) == len(want)
+    order = [(_jf_pos(hdr, key), key) for key, _ in recs]
+    assert order == sorted(order)
+    t2 = KmerTable.from_jf(p)
+    assert t2.k == k and t2.histogram() == t.histogram() and t2.info()["distinct"] == len(want)
+    g = genome.tobytes().decode()
+    qs = [g[i:i + k] for i in range(0, len(g) - k, 53)]
+    assert t2.lookup(qs) == t.lookup(qs) and sum(t.lookup(qs)) > 0
+    out = os.path.join(ROOT, "gpurun_out", "jf_wide")
+    os.makedirs(out, exist_ok=True)
+    shutil.copy(p, os.path.join(out, "k%d.jf" % k))
+    with open(os.path.join(out, "k%d.reads.fa" % k), "w") as f:
+        f.write("".join(">r%d\n%s\n" % (i, r) for i, r in enumerate(reads.split("N")) if r))
+    t.close()
+    t2.close()

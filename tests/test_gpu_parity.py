@@ -37,7 +37,11 @@ def histo_rows(h):
 
 
 @pytest.mark.parametrize("k,G,seed", [(37, 1_200_000, 1), (25, 150_000, 2), (31, 60_000, 3), (32, 60_000, 4), (33, 60_000, 5),
-                                       (15, 30_000, 6), (41, 50_000, 7)])
+                                       (15, 30_000, 6), (41, 50_000, 7),
+                                       # k >= 38 in a table of few slots: the remainder does not fit the tag word and its low 64
+                                       # bits live in the second array (kmer.hpp: wide_rem); `jasper.sh -k` takes any k
+                                       # (src/jasper.sh:89-92, JF::include/jellyfish/mer_dna.hpp:660-669)
+                                       (38, 60_000, 8), (45, 60_000, 9), (51, 400_000, 10), (63, 60_000, 11)])
 def test_count_histogram_lookup_vs_oracle(KT, O, k, G, seed):
     genome, reads, asm = workload(seed, G, k)
     t = KT(k, min_slots=1 << 16)          # far too small on purpose: exercises growth / rehash between launches
@@ -56,6 +60,51 @@ def test_count_histogram_lookup_vs_oracle(KT, O, k, G, seed):
     t.close()
 
 
+def test_k64_counts_against_python_integers(KT):
+    """k = 64 is the widest k-mer the 128-bit arithmetic holds (the C oracle stops at 63): counts of a small read set against
+    a dictionary of Python integers -- 2-bit codes, first base in the top pair, canonical = min(mer, revcomp)
+    (JF::include/jellyfish/mer_dna.hpp:38-55,428-431,525-542)"""
+    import collections
+    k = 64
+    rng = np.random.default_rng(64)
+    genome = synth.make_genome(rng, 3000, repeat_frac=0)
+    reads = synth.make_reads_stream(rng, genome, 12, 120, 0.002).tobytes().decode()
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    want = collections.Counter()
+    mask = (1 << (2 * k)) - 1
+    for r in reads.split("N"):
+        for i in range(len(r) - k + 1):
+            f = 0
+            for ch in r[i:i + k]:
+                f = (f << 2) | code[ch]
+            rc = 0
+            for ch in reversed(r[i:i + k]):
+                rc = (rc << 2) | (3 - code[ch])
+            want[min(f, rc) & mask] += 1
+    t = KT(k, min_slots=1 << 12)
+    t.count_bases(reads.encode())
+    info = t.info()
+    assert info["occurrences"] == sum(want.values()) and info["distinct"] == len(want)
+    h = t.histogram()
+    hw = collections.Counter(want.values())
+    assert all(h[m] == hw.get(m, 0) for m in range(1, 200))
+    g = genome.tobytes().decode()
+    qs = [g[i:i + k] for i in range(0, len(g) - k, 37)] + ["A" * k, g[:k - 1], g[7:7 + k].lower()]
+
+    def cnt(q):
+        q = q.upper()
+        q = (q + "A" * k)[:k] if all(c in code for c in q) else None
+        f = 0
+        for ch in q:
+            f = (f << 2) | code[ch]
+        rc = 0
+        for ch in reversed(q):
+            rc = (rc << 2) | (3 - code[ch])
+        return want.get(min(f, rc), 0)
+    assert t.lookup(qs) == [cnt(q) for q in qs]
+    t.close()
+
+
 def test_encoder_known_answers_through_the_lookup_entry_point(KT):
     """tests/golden/mer_kats.json = 162 answers of the REAL SWIG `MerDNA(s)` / `.get_canonical()` (lower case, N at various
     offsets, short and empty strings; JF::swig/mer_dna.i:12-19, JF::include/jellyfish/mer_dna.hpp:525-542).  Through the
@@ -71,8 +120,6 @@ def test_encoder_known_answers_through_the_lookup_entry_point(KT):
         by_k[e["k"]].append(e)
     assert len(by_k) >= 2
     for k, es in sorted(by_k.items()):
-        if k > 43:
-            continue      # the slot format holds k <= 43 (table.hip: min_log2_slots); the oracle checks k = 48, 63 (test_oracle_golden.py)
         mult = collections.Counter(e["canonical"] for e in es)
         t = KT(k, min_slots=1 << 12)
         t.count_bases("N".join(c for c, m in mult.items() for _ in range(m)).encode())
@@ -86,6 +133,7 @@ def test_encoder_known_answers_through_the_lookup_entry_point(KT):
 
 @pytest.mark.parametrize("k,G,seed,thre,passes", [(37, 300_000, 11, 3, 2), (25, 200_000, 12, 3, 2), (31, 100_000, 13, 4, 3),
                                                     (21, 80_000, 14, 3, 1), (37, 120_000, 15, 5, 4),
+                                                    (45, 200_000, 18, 3, 2), (63, 150_000, 19, 2, 2),      # wide remainders
                                                     # chunks of 230 kb: later passes find no sync points and cut at clean
                                                     # zones instead (segments chained through their arrival positions)
                                                     (37, 1_600_000, 16, 3, 2), (25, 1_200_000, 17, 3, 3)])
@@ -214,13 +262,21 @@ def test_reads_from_named_pipes(KT, tmp_path):
 
 
 def test_k_limits(KT):
-    """k up to 43 (the tag word holds 2k - log2(slots) <= 53 hash bits); beyond that a clear refusal, not an allocation failure"""
+    """every k of `jasper.sh -k` up to 64 (two 64-bit words, JF::include/jellyfish/mer_dna.hpp:660-669 has no limit of its own);
+    a table of few slots keeps the remainder bits the tag word cannot hold in its second array and moves to tags alone
+    when it has grown enough (kmer.hpp: wide_rem); tables that other GPUs read need whole remainders in the tags: k <= 43"""
     from jasper_amd._lib import JasperHipError
     for k in (44, 51, 64):
-        with pytest.raises(JasperHipError, match="up to 43 bases"):
-            KT(k, min_slots=1 << 20)
+        t = KT(k, min_slots=1 << 12)
+        t.count_bases(b"ACGTTGCATGCAAGTCCGATAGGCTAACGTTTGACCATGACAGATTACAGGATCCATTGACCGTAAGGCTTAACGTA" * 2)
+        assert t.info()["occurrences"] == 2 * 77 - k + 1
+        with pytest.raises(JasperHipError, match="k <= 43"):
+            t.ipc_handle()
+        t.close()
     with pytest.raises(JasperHipError, match=r"\[1,64\]"):
         KT(0, min_slots=1 << 20)
+    with pytest.raises(JasperHipError, match=r"\[1,64\]"):
+        KT(65, min_slots=1 << 20)
 
 
 def test_format_errors(KT):
