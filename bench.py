@@ -365,6 +365,16 @@ def main():
                      "kernel_ms_per_step": {n: round(sum(t["stages"][i] for t in timers) / len(timers), 3)
                                             for i, n in enumerate(KmerTable.STAGE_NAMES[T["path"]])}},
     }
+    # the polishing phase against the dense model of SURVEY 8d: every base read once per scan with one 16-byte slot probe
+    # ((P+1) scans x 17 B) plus one byte of output.  The walk itself is sparse (it looks at ~0.06 slots per base and scan),
+    # so this figure says how the phase compares with a dense formulation at the HBM roofline, not how full the memory pipe is.
+    polish_bytes = asm_len * ((PASSES + 1) * 17 + 1)
+    pol_s = mean("polish_dev")
+    out["roofline_polish"] = {"bound": "hbm", "kernel": "scan_batch + classify + find_sync (pass 0), seg_walk x %d, seg_stitch, rescan" % (PASSES + 1),
+                              "achieved": round(polish_bytes / pol_s / 1e9, 1) if pol_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(polish_bytes / pol_s / 1e9 / HBM_PEAK_GBS, 4) if pol_s > 0 else 0.0,
+                              "algorithmic_bytes_per_step": int(polish_bytes), "device_ms": round(pol_s * 1e3, 3),
+                              "lookups_per_base_and_scan": round(T["lookups"] / max(asm_len * (PASSES + 1), 1), 4), "traffic": None}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             # the last step's fix records as the rows jasper.py would write (per pass, chunk order), like polisher.polish_batch

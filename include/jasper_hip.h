@@ -190,6 +190,12 @@ int jasper_last_count_timing(jasper_table *t, double *kernel_ms, uint64_t *launc
  * *partitioned_launches of the counted launches took path 1 or 2 (the others ran count_kernel) */
 int jasper_last_count_stages(jasper_table *t, double stage_ms[8], uint64_t *partitioned_launches, int *path);
 
+/* Host only (no GPU touched): one gzip file inflated by `threads` threads into out_path (or nowhere when out_path is null),
+ * the way jasper_count_reads_files reads a large .gz -- the role of `zcat -f` in src/jasper.sh:177.  chunk_bytes = compressed
+ * bytes per unit of work (0: default 4 MiB).  *n_out = inflated bytes; *parallel = 1 when the many-thread reader handled the
+ * file, 0 when it declined (small file, not a regular gzip file) and zlib's reader was used. */
+int jasper_inflate_file(const char *path, int threads, uint64_t chunk_bytes, const char *out_path, uint64_t *n_out, int *parallel);
+
 #ifdef __cplusplus
 }
 #endif

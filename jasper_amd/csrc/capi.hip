@@ -3,6 +3,8 @@
 #include "ingest.hpp"
 #include "polish_host.hpp"
 #include "table.hpp"
+#include "pgunzip.hpp"
+#include <zlib.h>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -289,6 +291,42 @@ int jasper_table_attach_tables(jasper_table *t, jasper_table *const *shards, uin
 }
 // Can this process map these slot arrays at all?  Meant to be called from a THROW-AWAY process with a time limit: a mapping
 // call that never returns (seen on this stack for one allocation size) then costs a killed helper, not a hung rank.
+int jasper_inflate_file(const char *path, int threads, uint64_t chunk_bytes, const char *out_path, uint64_t *n_out, int *parallel) {
+    if (!path) { g_err = "bad arguments"; return JASPER_ERR; }
+    FILE *f = nullptr;
+    if (out_path) { f = fopen(out_path, "wb"); if (!f) { g_err = std::string("cannot write ") + out_path; return JASPER_ERR; } }
+    uint64_t total = 0;
+    int par = 0, rc = JASPER_OK;
+    size_t fsz = 0;
+    { struct stat st; if (stat(path, &st) == 0) fsz = (size_t)st.st_size; }
+    jk::ParallelGunzip pg(path, threads, chunk_bytes ? (size_t)chunk_bytes : jk::ParallelGunzip::chunk_for(fsz, threads));
+    if (threads >= 2 && pg.open()) {
+        par = 1;
+        std::vector<std::vector<uint8_t>> pieces;
+        while (pg.next(pieces))
+            for (auto &pc : pieces) { total += pc.size(); if (f && !pc.empty() && fwrite(pc.data(), 1, pc.size(), f) != pc.size()) { g_err = "write error"; rc = JASPER_ERR; } }
+        if (!pg.error().empty()) { g_err = pg.error(); rc = JASPER_ERR; }
+    } else {
+        gzFile g = gzopen(path, "rb");
+        if (!g) { g_err = std::string("cannot open ") + path; rc = JASPER_ERR; }
+        else {
+            std::vector<char> buf(4u << 20);
+            for (;;) {
+                const int r = gzread(g, buf.data(), (unsigned)buf.size());
+                if (r < 0) { g_err = std::string("read error in ") + path; rc = JASPER_ERR; break; }
+                if (r == 0) break;
+                total += (uint64_t)r;
+                if (f && fwrite(buf.data(), 1, (size_t)r, f) != (size_t)r) { g_err = "write error"; rc = JASPER_ERR; break; }
+            }
+            gzclose(g);
+        }
+    }
+    if (f) fclose(f);
+    if (n_out) *n_out = total;
+    if (parallel) *parallel = par;
+    return rc;
+}
+
 int jasper_ipc_probe(int device, const void *handles, uint32_t n, uint32_t self) {
     if (!handles || n < 1 || n > MAX_SHARDS || self >= n) { g_err = "probe: 1..8 handles, self among them"; return JASPER_ERR; }
     CHK(hipSetDevice(device));

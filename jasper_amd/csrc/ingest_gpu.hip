@@ -14,6 +14,7 @@
 // DOS line ends and malformed input, and which then keeps the rest of the stream.  FASTA needs no such assumption: a line
 // is a header iff it starts with '>'.
 #include "ingest.hpp"
+#include "pgunzip.hpp"
 #include "table.hpp"
 #include <cstdio>
 #include <cstring>
@@ -176,22 +177,57 @@ __global__ __launch_bounds__(IG_THREADS) void ig_emit_kernel(const uint8_t *__re
 // concatenation, in order -- is unchanged.  Also overlaps inflating with the GPU work on the previous chunk.
 struct GzAhead {
     static constexpr size_t BLK = 4u << 20;
-    struct Block { std::unique_ptr<char[]> p; size_t n = 0, used = 0; };
+    struct Block {
+        std::unique_ptr<char[]> p; std::vector<uint8_t> v; size_t n = 0, used = 0;      // storage: p (zlib path) or v (parallel path)
+        const char *data() const { return p ? p.get() : reinterpret_cast<const char *>(v.data()); }
+    };
     std::string path, err;
     size_t cap;
+    // threads for THIS file's inflation (1 = the plain zlib reader): see Reader::start_ahead
+    int gz_threads = 1;
     std::mutex mu;
     std::condition_variable cv;
     std::deque<Block> q;
     size_t queued = 0;
     bool done = false, failed = false, stop = false;
     std::thread th;
-    GzAhead(const char *path_, size_t cap_) : path(path_), cap(cap_ < 2 * BLK ? 2 * BLK : cap_) { th = std::thread([this] { run(); }); }
+    GzAhead(const char *path_, size_t cap_, int gz_threads_ = 1) : path(path_), cap(cap_ < 2 * BLK ? 2 * BLK : cap_), gz_threads(gz_threads_) { th = std::thread([this] { run(); }); }
     ~GzAhead() {
         { std::lock_guard<std::mutex> l(mu); stop = true; }
         cv.notify_all();
         if (th.joinable()) th.join();
     }
+    // a large regular gzip file: many threads (pgunzip.hpp); true when it was read to its end or failed, false when the
+    // file is not for that reader (small, not a regular file) and zlib's reader takes over from the first byte
+    bool run_parallel() {
+        if (gz_threads < 2) return false;
+        struct stat st;
+        if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return false;
+        ParallelGunzip pg(path.c_str(), gz_threads, ParallelGunzip::chunk_for((size_t)st.st_size, gz_threads));
+        if (!pg.open()) return false;
+        std::vector<std::vector<uint8_t>> pieces;
+        while (pg.next(pieces)) {
+            for (auto &pc : pieces) {
+                if (pc.empty()) continue;
+                Block b;
+                b.n = pc.size();
+                b.v = std::move(pc);
+                std::unique_lock<std::mutex> l(mu);
+                queued += b.n;
+                q.push_back(std::move(b));
+                cv.notify_all();
+                cv.wait(l, [this] { return stop || queued + BLK <= cap || q.size() <= 1; });
+                if (stop) { done = true; cv.notify_all(); return true; }
+            }
+        }
+        std::lock_guard<std::mutex> l(mu);
+        if (!pg.error().empty()) { failed = true; err = pg.error(); }
+        done = true;
+        cv.notify_all();
+        return true;
+    }
     void run() {
+        if (run_parallel()) return;
         gzFile g = gzopen(path.c_str(), "rb");
         if (!g) { std::lock_guard<std::mutex> l(mu); failed = done = true; err = "cannot open " + path; cv.notify_all(); return; }
         gzbuffer(g, 1u << 20);
@@ -222,7 +258,7 @@ struct GzAhead {
             Block &b = q.front();
             const size_t m = std::min(want - got, b.n - b.used);
             l.unlock();
-            memcpy(dst + got, b.p.get() + b.used, m);       // (only the consumer touches the front block)
+            memcpy(dst + got, b.data() + b.used, m);       // (only the consumer touches the front block)
             l.lock();
             b.used += m;
             got += m;
@@ -271,7 +307,7 @@ struct Reader {           // the concatenation of all input files as one byte st
                 if (m == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
                     close(fd);
                     fd = -1;
-                    if (!ahead[cur]) ahead[cur].reset(new GzAhead(paths[cur], ahead_cap));
+                    if (!ahead[cur]) ahead[cur].reset(new GzAhead(paths[cur], ahead_cap, gz_threads));
                     ga = ahead[cur].get();
                 } else if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {       // pipes etc.: sequential reads through zlib's pass-through
                     // (on the descriptor already open: closing a FIFO's only reader would break the writer's pipe)
@@ -329,6 +365,7 @@ struct Reader {           // the concatenation of all input files as one byte st
     // every gzip file this reader will read gets its inflating thread now; together they may run ahead by a budget of
     // JASPER_INGEST_AHEAD_MB (default: a quarter of the machine's memory, at most 16 GiB), shared evenly
     size_t ahead_cap = 0;
+    int gz_threads = 1;
     void start_ahead() {
         ahead_started = true;
         ahead.resize((size_t)n_paths);
@@ -354,7 +391,18 @@ struct Reader {           // the concatenation of all input files as one byte st
         if (const char *e = getenv("JASPER_INGEST_AHEAD_MB")) budget = (size_t)strtoull(e, nullptr, 10) << 20;
         ahead_cap = budget / gz.size();
         const size_t max_threads = 16;                       // (more files than that: the later ones start when they are reached)
-        for (size_t j = 0; j < gz.size() && j < max_threads; ++j) ahead[(size_t)gz[j]].reset(new GzAhead(paths[gz[j]], ahead_cap));
+        // threads that inflate ONE file (pgunzip.hpp): JASPER_INGEST_GZ_THREADS, else the host's threads divided by the ranks of
+        // the job and by the gzip files inflated at the same time (at most 48; below 2 the plain zlib reader is used)
+        {
+            long hw = (long)std::thread::hardware_concurrency();
+            if (const char *w = getenv("WORLD_SIZE")) { const long nw = atol(w); if (nw > 1) hw /= nw; }
+            hw /= (long)std::min(gz.size(), max_threads);
+            gz_threads = (int)std::max<long>(1, std::min<long>(48, hw));
+            if (const char *e = getenv("JASPER_INGEST_GZ_THREADS")) gz_threads = std::max(1, atoi(e));
+        }
+        // a wave of the parallel reader holds ~40 MB of text per thread: the read-ahead budget must have room for two of them
+        ahead_cap = std::max<size_t>(ahead_cap, (size_t)gz_threads * (96u << 20));
+        for (size_t j = 0; j < gz.size() && j < max_threads; ++j) ahead[(size_t)gz[j]].reset(new GzAhead(paths[gz[j]], ahead_cap, gz_threads));
     }
     ~Reader() { if (g) gzclose(g); if (fd >= 0) close(fd); }
 };

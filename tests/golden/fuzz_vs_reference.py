@@ -26,7 +26,9 @@ from oracle import oracle as O  # noqa: E402
 
 def random_case(seed):
     rng = np.random.default_rng(seed)
-    k = int(rng.choice([15, 17, 20, 21, 24, 25, 28, 31, 33, 36, 37, 41]))
+    # JASPER_FUZZ_WIDE_K=1: keys of more than 86 bits as well (the default list keeps the cases of the recorded seed ranges)
+    ks = [15, 17, 20, 21, 24, 25, 28, 31, 33, 36, 37, 41] + ([38, 45, 51, 57, 63] if os.environ.get("JASPER_FUZZ_WIDE_K") else [])
+    k = int(rng.choice(ks))
     rl = int(max(k + 10, rng.choice([60, 80, 100, 150])))
     L = int(rng.integers(300, 5000))
     t = G.rand_seq(rng, L)

@@ -70,3 +70,19 @@ def test_fuzz_reads_through_owner_shards(hip, tmp_path):
     S = sharded_class(KmerTable)
     for seed in range(9000, 9060):
         _one(seed, S, polisher, O, G, F, tmp_path)
+
+
+def test_fuzz_wide_k(hip, tmp_path, monkeypatch):
+    """the same generator with k in {38, 45, 51, 57, 63} mixed in (tables of few slots: remainders wider than the tag word);
+    the oracle was checked against the real reference on these k too (tests/golden/fuzz_vs_reference.py with
+    JASPER_FUZZ_WIDE_K=1: 750 cases, 0 failing)"""
+    monkeypatch.setenv("JASPER_FUZZ_WIDE_K", "1")
+    from jasper_amd import KmerTable, polisher
+    from oracle import oracle as O
+    import make_golden as G
+    import fuzz_vs_reference as F
+    wide = 0
+    for seed in range(12000, 12120):
+        wide += F.random_case(seed)[1]["k"] >= 38
+        _one(seed, KmerTable, polisher, O, G, F, tmp_path)
+    assert wide >= 20

@@ -195,6 +195,32 @@ def test_reads_files_formats_and_gzip(KT, O, tmp_path):
     t.close()
 
 
+def test_one_large_gzip_file_inflated_by_many_threads(KT, O, tmp_path, monkeypatch):
+    """a .gz large enough for the many-thread reader (pgunzip.hpp: cut at block boundaries found by search, each piece inflated
+    twice with two made-up windows, stitched in order) gives the same table as the text itself; with one thread the plain
+    zlib reader does"""
+    k = 31
+    rng = np.random.default_rng(55)
+    genome = synth.make_genome(rng, 400_000)
+    stream = synth.make_reads_stream(rng, genome, 40, 120, 0.004).tobytes().decode()
+    reads = [r for r in stream.split("N") if r]
+    q = "FFFFFFFFF:,F#"
+    idx = rng.integers(0, len(q), (len(reads), 120))
+    fq = "".join("@SIM:%d:%d 1:N:0\n%s\n+\n%s\n" % (i // 997, i % 997, r, "".join(q[j] for j in idx[i])) for i, r in enumerate(reads))
+    p = tmp_path / "big.fq.gz"
+    with gzip.open(p, "wb", compresslevel=6) as f:
+        f.write(fq.encode())
+    assert os.path.getsize(p) > 8 << 20
+    db = O.OracleDB(k)
+    db.count_text(fq)
+    for threads in ("6", "1"):
+        monkeypatch.setenv("JASPER_INGEST_GZ_THREADS", threads)
+        t = KT(k, min_slots=1 << 20)
+        t.count_files([str(p)])
+        assert t.histogram() == db.histo() and t.info()["distinct"] == db.distinct()
+        t.close()
+
+
 @pytest.mark.parametrize("ahead_mb", [None, "1"])
 def test_several_gzip_files_inflated_ahead(KT, O, tmp_path, monkeypatch, ahead_mb):
     """every gzip file of a call is inflated by its own thread, ahead of the parser by a bounded budget (a tiny one here makes

@@ -58,3 +58,32 @@ for label, mb in (("one file at a time (JASPER_INGEST_AHEAD_MB=0: 8 MB look-ahea
     t.clear()
     t0 = time.perf_counter(); t.count_files(parts); t.sync(); t1 = time.perf_counter()
     print("4 gzip files (%.0f MB -> %.0f MB of text), %s: %.2f s -> %.2f GB/s of text" % (gsz / 1e6, text / 1e6, label, t1 - t0, text / (t1 - t0) / 1e9), flush=True)
+# ONE large gzip file (what a real read set looks like: R1.fastq.gz, R2.fastq.gz): inflated by many threads (pgunzip.hpp)
+big = os.path.join(d, "big.fq")
+with open(big, "wb") as f:
+    for rep in range(3):
+        for p in parts:
+            f.write(gzip.open(p).read())
+subprocess.run(["gzip", "-6", "-f", big], check=True)
+big += ".gz"
+bsz = os.path.getsize(big)
+btext = 3 * text
+import ctypes as C
+from jasper_amd import _lib
+L = _lib.lib()
+for thr in (1, 8, 16, 32, 48, 64):
+    n = C.c_uint64(0); par = C.c_int(0)
+    t0 = time.perf_counter()
+    rc = L.jasper_inflate_file(big.encode(), thr, 0, None, C.byref(n), C.byref(par))
+    t1 = time.perf_counter()
+    print("one gzip file (%.0f MB -> %.0f MB of text), inflate only, %2d threads (%s): %.2f s -> %.2f GB/s of text"
+          % (bsz / 1e6, n.value / 1e6, thr, "parallel" if par.value else "zlib", t1 - t0, n.value / (t1 - t0) / 1e9), flush=True)
+for thr in ("1", None):
+    if thr:
+        os.environ["JASPER_INGEST_GZ_THREADS"] = thr
+    else:
+        os.environ.pop("JASPER_INGEST_GZ_THREADS", None)
+    t.clear()
+    t0 = time.perf_counter(); t.count_files([big]); t.sync(); t1 = time.perf_counter()
+    print("one gzip file -> table, %s: %.2f s -> %.2f GB/s of text, %.2f Gk-mers/s"
+          % ("zlib reader (JASPER_INGEST_GZ_THREADS=1)" if thr else "default threads", t1 - t0, btext / (t1 - t0) / 1e9, 3 * 4 * per * 114 / (t1 - t0) / 1e9), flush=True)
