@@ -145,6 +145,8 @@ def cpu_baseline(seed, reads_np, names, seqs, gpu):
     from jasper_amd import synth, polisher
     from oracle import oracle as O
     cores, model = host_cpu()
+    host_cores = cores
+    cores = min(cores, 64)       # the counting threads hand keys over through threads x threads buffers: more than 64 only adds overhead
     full = cores >= 8 and reads_np is not None
     if full:
         reads = reads_np
@@ -170,7 +172,7 @@ def cpu_baseline(seed, reads_np, names, seqs, gpu):
     thr = int(txt) if (status == 0 and txt) else 2
     fixed, csv_rows, qv, _ = db.polish_batch(chunk_names, chunk_seqs, thr, PASSES)
     t2 = time.perf_counter()
-    out = dict(value=round(G / 1e6 / (t2 - t0), 4), unit="Mbp/s", cores=cores, cpu=model, kind="port",
+    out = dict(value=round(G / 1e6 / (t2 - t0), 4), unit="Mbp/s", cores=cores, host_threads_available=host_cores, cpu=model, kind="port",
                sample=("the whole workload of a timed step" if full else "12 Mb sample of the same recipe") +
                       ": %.1f Mb assembly, %dx %d-bp reads (%d k-mers), k=%d, %d passes; oracle/jasper_oracle.c, %d threads "
                       "(reads divided like jellyfish count -t, chunk records like xargs -P)" % (G / 1e6, COVERAGE, READ_LEN, nk, K, PASSES, cores),
