@@ -360,21 +360,29 @@ __global__ __launch_bounds__(256) void mz_scan2_kernel(unsigned int *__restrict_
     if (blockIdx.x == 0 && t == 0) startF[(uint64_t)nc << G.pf] = s_base[nc];
 }
 
-// ---- C: records in fine-bucket order -> LDS hash table -> (hash, count) entries ----------------------------------------------
+// ---- C: records in fine-bucket order -> unique records -> LDS k-mer table -> (hash, count) entries -------------------------------
 // An entry is 16 bytes: { hash.lo, hash.hi | count << 32 }  (hash.hi < 2^22 for k <= 43, count <= 2^32-1).
 // The records of ALL fine buckets lie back to back (mz_split), so a block simply takes its 1/nblkC of that array -- a few
-// hundred consecutive buckets -- and streams it through its table in rounds of MC_TH records; the table is emitted and
-// emptied whenever enough slots have been claimed.  Nothing depends on where a bucket ends: a bucket cut by a flush (or by
-// the end of a block's share) leaves some of its keys as two entries, and entries are partial counts anyway.  No queue, no
-// per-bucket barriers, and the next round's records are in flight while this round is inserted.
-// What bounds the insert itself is the rate of RANDOM LDS accesses (~0.75 clk per lane and access per CU, bank conflicts
-// included; the same figure lds_insert_kernel shows), so a k-mer costs one 16-byte slot read and one 32-bit add where its key
-// is already there, and the table is flushed at a load of ~0.55 so that this is the common case.
+// hundred consecutive buckets -- and streams it in rounds of MC_TH records.  Nothing depends on where a bucket ends: a bucket
+// cut by a flush (or by the end of a block's share) leaves some of its keys as two entries, and entries are partial counts.
+//
+// What bounds this kernel is integer issue (rolling both strands of a two-word k-mer, the canonical choice and the table's
+// 2 x 64-bit-multiply hash are ~100 issue slots per k-mer; an LDS insert whose probe loop runs as long as the slowest of 64
+// lanes costs more than that again -- DESIGN.md 4.2), so the k-mers are not touched until the RECORDS have been made unique:
+// a super-k-mer that lies inside a read is cut out of the genome by its minimizers, not by the read, so every read that
+// covers the place yields the same 16 bytes (or their reverse complement: records are stored in the smaller orientation) --
+// ~20 copies at 30x coverage; only the records at the two ends of a read and those with a read error are on their own.
+//   round:  one record per lane -> canonical orientation -> record table RT (LDS, 512 slots: 16-byte key, 32-bit copies)
+//   flush (RT has MC_RT_FLUSH unique records, or the input ends):  every unique record's k-mers are rolled out ONCE, hashed,
+//           and added to the k-mer table KT (LDS, 4096 slots) with the record's number of copies; KT leaves as entries.
 constexpr int MC_TH = 512;
-constexpr int MC_SLOTS = 4096;                 // LDS table, 16 bytes per slot
-constexpr int MC_STEPS = 10;                   // slot reads per k-mer at most; then it leaves as a (hash, 1) entry
+constexpr int MC_SLOTS = 4096;                 // KT: 16 bytes per slot
+constexpr int MC_KTBITS = 12;
+constexpr int MC_STEPS = 10;                   // KT slot reads per k-mer at most; then it leaves as a (hash, copies) entry
 constexpr int MC_PIECE = 8;                    // k-mers a lane rolls out of a record in one go
-constexpr int MC_FLUSH_AT = 1600;              // claimed slots that trigger a flush at the end of a round
+constexpr int MC_RT = 512;                     // RT slots
+constexpr int MC_RT_FLUSH = 280;               // unique records that trigger a flush at the end of a round
+constexpr int MC_RT_STEPS = 24;                // RT slot reads per record at most; then the record waits for the next flush
 constexpr int MC_MAXE = 256;                   // hash-coarse lists (pe1 <= 8)
 
 // bits [sh, sh+32) of the hash (hhi : hlo), 1 <= sh
@@ -386,15 +394,16 @@ template <bool WIDE>
 __global__ __launch_bounds__(MC_TH) void mz_count_kernel(const ulonglong2 *__restrict__ lists, const unsigned int *__restrict__ total_ptr, TableDev T, MzGeom G,
                                                           ulonglong2 *__restrict__ outC, unsigned int *__restrict__ cntC, unsigned long long *__restrict__ deferred,
                                                           unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
-    // slot = { w0 = hash.lo, w1 = (hash.hi + 1) << 32 | count } ; w1 == 0: empty.  A slot is claimed by a compare-and-swap on
-    // w1 (which also counts the claimant), w0 follows with a plain store; a lane that meets the slot in between sees w0 == 0,
-    // takes it for another key and moves on -- the key then sits in two slots, i.e. leaves as two entries (partial counts).
-    __shared__ __align__(16) unsigned long long s_tab[2 * MC_SLOTS];
-    __shared__ __align__(16) ulonglong2 s_rec[MC_TH];
-    __shared__ unsigned short s_work[MC_TH * 4];               // (record << 2) | piece ; a record has at most 32 / MC_PIECE pieces
+    // KT slot = { w0 = hash.lo, w1 = (hash.hi + 1) << 32 | count } ; w1 == 0: empty.  A slot is claimed by a compare-and-swap
+    // on w1 (which also counts the claimant), w0 follows with a plain store; a lane that meets the slot in between sees
+    // w0 == 0 and looks again.  RT slot = { r0 = record.lo, r1 = record.hi + 1 } claimed through r1 the same way.
+    __shared__ __align__(16) unsigned long long s_kt[2 * MC_SLOTS];
+    __shared__ __align__(16) unsigned long long s_rt[2 * MC_RT];
+    __shared__ unsigned int s_rtc[MC_RT];                      // copies of the record in RT slot i
+    __shared__ unsigned short s_work[MC_RT * 4];               // (RT slot << 2) | piece
     __shared__ unsigned int s_cur[MC_MAXE];
     __shared__ unsigned int s_w[MC_TH / 64];
-    __shared__ unsigned int s_total, s_claims;
+    __shared__ unsigned int s_total, s_claims, s_pending;
     const int t = threadIdx.x;
     const int k = T.k, B = T.B;
     const int ne = 1 << G.pe1;
@@ -404,10 +413,12 @@ __global__ __launch_bounds__(MC_TH) void mz_count_kernel(const ulonglong2 *__res
     const int hshift = WIDE ? 64 - hb : 0;
     const int rcins_w = 2 * (k - 1) - 64, rcins_n = 2 * (k - 1);
     const uint64_t lomask = (!WIDE && 2 * k < 64) ? ((1ull << (2 * k)) - 1ull) : ~0ull;
-    const int e1sh = B - G.pe1, idxsh = B - 12;
+    const int e1sh = B - G.pe1, idxsh = B - MC_KTBITS;
     for (int i = t; i < ne; i += MC_TH) s_cur[i] = 0;
-    for (int i = t; i < 2 * MC_SLOTS; i += MC_TH) s_tab[i] = 0ull;
-    if (t == 0) s_claims = 0;
+    for (int i = t; i < 2 * MC_SLOTS; i += MC_TH) s_kt[i] = 0ull;
+    for (int i = t; i < 2 * MC_RT; i += MC_TH) s_rt[i] = 0ull;
+    for (int i = t; i < MC_RT; i += MC_TH) s_rtc[i] = 0u;
+    if (t == 0) { s_claims = 0; s_pending = 0; }
     // an entry leaves through my slice of the list its top hash bits select, or through the deferred list when that is full
     auto emit_entry = [&](uint64_t hhi, uint64_t hlo, unsigned long long cnt) {
         const uint32_t e1 = top_bits(hhi, hlo, e1sh);                // top pe1 hash bits
@@ -419,126 +430,177 @@ __global__ __launch_bounds__(MC_TH) void mz_count_kernel(const ulonglong2 *__res
             else atomicExch(&T.stats[ST_FATAL], 1ull);
         }
     };
+    // the k-mers i0 .. i1-1 of a record, each added `copies` times to KT
+    auto roll_out = [&](ulonglong2 rr, int i0, int i1, unsigned int copies) {
+        const int nk = (int)(rr.x & 31ull) + 1;
+        const u128 V = mz_bases(rr);
+        const u128 rest = shr(V, 2 * (nk - i1));                   // the bases up to the end of my last k-mer
+        const u128 fwd = band(shr(rest, 2 * (i1 - 1 - i0)), kmask);
+        const u128 rc = revcomp(fwd, k);
+        uint64_t fl = fwd.lo, fh = fwd.hi, rl = rc.lo, rh = rc.hi;
+        const uint32_t tail = (uint32_t)rest.lo;                   // the (i1 - 1 - i0) <= 7 bases after my first k-mer are its low bits
+        for (int i = i0; i < i1; ++i) {
+            if (i > i0) {
+                const uint64_t cj = (tail >> (2 * (i1 - 1 - i))) & 3u;
+                if (WIDE) {
+                    fh = ((fh << 2) | (fl >> 62)) & himask;
+                    fl = (fl << 2) | cj;
+                    rl = (rl >> 2) | (rh << 62);
+                    rh = (rh >> 2) | ((3ull - cj) << rcins_w);
+                } else {
+                    fl = ((fl << 2) | cj) & lomask;
+                    rl = (rl >> 2) | ((3ull - cj) << rcins_n);
+                }
+            }
+            uint64_t hhi, hlo;
+            if (WIDE) {
+                const bool take_rc = rh < fh || (rh == fh && rl < fl);
+                const uint64_t mh = take_rc ? rh : fh, ml = take_rc ? rl : fl;
+                uint64_t mid;
+                hlo = mix64_mid(ml, mid);
+                hhi = (mh ^ (mid >> hshift)) & himask;
+            } else {
+                const u128 h = mix(mk(0, rl < fl ? rl : fl), B);
+                hhi = 0; hlo = h.lo;
+            }
+            // KT: home = top 12 hash bits; MC_STEPS bounds probes and second looks together, so nothing here can spin
+            const uint32_t want_hi = (uint32_t)hhi + 1u;
+            uint32_t idx = top_bits(hhi, hlo, idxsh) & (MC_SLOTS - 1);
+            bool done = false;
+            if (hlo != 0ull) {                                   // (w0 == 0 is what a slot shows before its key is written)
+#pragma unroll 1
+                for (int st = 0; st < MC_STEPS; ++st) {
+                    const ulonglong2 sl = *reinterpret_cast<const ulonglong2 *>(&s_kt[2 * idx]);
+                    if (sl.y == 0ull) {
+                        if (atomicCAS(&s_kt[2 * idx + 1], 0ull, ((unsigned long long)want_hi << 32) | copies) == 0ull) {     // claims the slot with my copies
+                            s_kt[2 * idx] = hlo;
+                            done = true;
+                            break;
+                        }
+                        continue;                                // somebody else has just claimed it: look again
+                    }
+                    if ((uint32_t)(sl.y >> 32) == want_hi) {
+                        if (sl.x == hlo) {
+                            atomicAdd(reinterpret_cast<unsigned int *>(&s_kt[2 * idx + 1]), copies);      // the count is the low half of w1
+                            done = true;
+                            break;
+                        }
+                        if (sl.x == 0ull) continue;              // claimed, key not visible yet: look again
+                    }
+                    idx = (idx + 1) & (MC_SLOTS - 1);
+                }
+            }
+            if (!done) emit_entry(hhi, hlo, copies);
+        }
+    };
+    unsigned long long dbg_rolled = 0, dbg_unique = 0;
     const uint64_t total = *total_ptr;
     const uint64_t lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
     ulonglong2 rec_next = make_ulonglong2(0ull, 0ull);
     if (lo + t < hi) rec_next = lists[lo + t];
-    for (uint64_t r0 = lo; r0 < hi; r0 += MC_TH) {
-        // a round of MC_TH records: their pieces of MC_PIECE k-mers are listed in s_work (block prefix sum of the piece counts)
-        const ulonglong2 rec = rec_next;
-        const bool have = r0 + t < hi;
+    __syncthreads();
+    for (uint64_t r0 = lo; r0 < hi || r0 == lo; r0 += MC_TH) {
+        // ---- a round: my record, in its smaller orientation, into RT
+        ulonglong2 rec = rec_next;
+        bool have = r0 + t < hi;
         rec_next = make_ulonglong2(0ull, 0ull);
-        if (r0 + MC_TH + t < hi) rec_next = lists[r0 + MC_TH + t];       // in flight while this round is inserted
-        const unsigned int np = have ? (((unsigned int)(rec.x & 31ull) + 1u) + MC_PIECE - 1) / MC_PIECE : 0u;
-        s_rec[t] = rec;
-        unsigned int inc = np;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
-        if ((t & 63) == 63) s_w[t >> 6] = inc;
-        __syncthreads();
-        {
-            unsigned int wbase = 0;
-            for (int w = 0; w < (t >> 6); ++w) wbase += s_w[w];
-            const unsigned int o = wbase + inc - np;
-            for (unsigned int q = 0; q < np; ++q) s_work[o + q] = (unsigned short)((t << 2) | q);
-            if (t == MC_TH - 1) s_total = wbase + inc;
+        if (r0 + MC_TH + t < hi) rec_next = lists[r0 + MC_TH + t];       // in flight while this round is worked on
+        if (have) {
+            const int nk = (int)(rec.x & 31ull) + 1;
+            const int L = k - 1 + nk;
+            const u128 V = mz_bases(rec);
+            const u128 R = revcomp(V, L);
+            if (lt(R, V)) {
+                const u128 nr = bor(shl(R, MZ_VSH), mk(0, rec.x & ((1ull << MZ_VSH) - 1ull)));
+                rec = make_ulonglong2(nr.lo, nr.hi);
+            }
         }
-        __syncthreads();
-        const unsigned int nwork = s_total;
-        unsigned int claims = 0;
-        unsigned long long dummy = 0;
-        for (unsigned int wi = t; wi < nwork; wi += MC_TH) {
-            const unsigned int w = s_work[wi];
-            const ulonglong2 rr = s_rec[w >> 2];
-            const int piece = (int)(w & 3u);
-            const int nk = (int)(rr.x & 31ull) + 1;
-            const int i0 = piece * MC_PIECE;
-            const int i1 = i0 + MC_PIECE < nk ? i0 + MC_PIECE : nk;
-            const u128 V = mz_bases(rr);
-            const u128 rest = shr(V, 2 * (nk - i1));               // the bases up to the end of my last k-mer
-            const u128 fwd = band(shr(rest, 2 * (i1 - 1 - i0)), kmask);
-            const u128 rc = revcomp(fwd, k);
-            uint64_t fl = fwd.lo, fh = fwd.hi, rl = rc.lo, rh = rc.hi;
-            const uint32_t tail = (uint32_t)rest.lo;               // the (i1 - 1 - i0) <= 7 bases after my first k-mer are its low bits
-            for (int i = i0; i < i1; ++i) {
-                if (i > i0) {
-                    const uint64_t cj = (tail >> (2 * (i1 - 1 - i))) & 3u;
-                    if (WIDE) {
-                        fh = ((fh << 2) | (fl >> 62)) & himask;
-                        fl = (fl << 2) | cj;
-                        rl = (rl >> 2) | (rh << 62);
-                        rh = (rh >> 2) | ((3ull - cj) << rcins_w);
-                    } else {
-                        fl = ((fl << 2) | cj) & lomask;
-                        rl = (rl >> 2) | ((3ull - cj) << rcins_n);
-                    }
-                }
-                uint64_t hhi, hlo;
-                if (WIDE) {
-                    const bool take_rc = rh < fh || (rh == fh && rl < fl);
-                    const uint64_t mh = take_rc ? rh : fh, ml = take_rc ? rl : fl;
-                    uint64_t mid;
-                    hlo = mix64_mid(ml, mid);
-                    hhi = (mh ^ (mid >> hshift)) & himask;
-                } else {
-                    const u128 h = mix(mk(0, rl < fl ? rl : fl), B);
-                    hhi = 0; hlo = h.lo;
-                }
-                // insert: home = top 12 hash bits.  The occurrences of a k-mer sit next to each other in the stream (same bucket, same
-                // few reads), so several lanes meet the same new key within a few cycles: one of them claims the slot, the others
-                // see its w1 before its w0.  They look at the same slot again (the claimant's store is already queued behind its
-                // compare-and-swap) instead of taking it for another key and claiming a second one; MC_STEPS bounds probes and
-                // second looks together, so nothing here can spin.
-                const uint32_t want_hi = (uint32_t)hhi + 1u;
-                uint32_t idx = top_bits(hhi, hlo, idxsh) & (MC_SLOTS - 1);
-                bool done = false;
-                if (G.exp == 1) { dummy ^= hlo ^ hhi; done = true; }
-                else if (hlo != 0ull) {                          // (w0 == 0 is what a slot shows before its key is written)
+        bool pending = have;
+        for (;;) {      // (normally one trip; more only when RT was full: every flush empties it, so the records left over get in)
+            unsigned int claims = 0;
+            if (pending) {
+                uint32_t x = (uint32_t)rec.x ^ (uint32_t)(rec.x >> 32) ^ (uint32_t)rec.y ^ (uint32_t)(rec.y >> 32);
+                x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u;
+                uint32_t idx = (x >> 16) & (MC_RT - 1);
+                const unsigned long long want1 = rec.y + 1ull;
 #pragma unroll 1
-                    for (int st = 0; st < MC_STEPS; ++st) {
-                        const ulonglong2 sl = *reinterpret_cast<const ulonglong2 *>(&s_tab[2 * idx]);
-                        if (sl.y == 0ull) {
-                            if (atomicCAS(&s_tab[2 * idx + 1], 0ull, ((unsigned long long)want_hi << 32) | 1ull) == 0ull) {     // claims the slot and counts me
-                                s_tab[2 * idx] = hlo;
-                                ++claims;
-                                done = true;
-                                break;
-                            }
-                            continue;                            // somebody else has just claimed it: look again
+                for (int st = 0; st < MC_RT_STEPS; ++st) {
+                    const ulonglong2 sl = *reinterpret_cast<const ulonglong2 *>(&s_rt[2 * idx]);
+                    if (sl.y == 0ull) {
+                        if (atomicCAS(&s_rt[2 * idx + 1], 0ull, want1) == 0ull) {       // claimed through the high word (+1: never 0)
+                            s_rt[2 * idx] = rec.x;
+                            atomicAdd(&s_rtc[idx], 1u);
+                            ++claims;
+                            pending = false;
+                            break;
                         }
-                        if ((uint32_t)(sl.y >> 32) == want_hi) {
-                            if (sl.x == hlo) {
-                                atomicAdd(reinterpret_cast<unsigned int *>(&s_tab[2 * idx + 1]), 1u);      // the count is the low half of w1
-                                done = true;
-                                break;
-                            }
-                            if (sl.x == 0ull) continue;          // claimed, key not visible yet: look again
-                        }
-                        idx = (idx + 1) & (MC_SLOTS - 1);
+                        continue;
+                    }
+                    if (sl.y == want1) {
+                        if (sl.x == rec.x) { atomicAdd(&s_rtc[idx], 1u); pending = false; break; }
+                        if (sl.x == 0ull) continue;              // claimed just now, low word not visible yet (or really another record: MC_RT_STEPS bounds the looking)
+                    }
+                    idx = (idx + 1) & (MC_RT - 1);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) claims += __shfl_xor(claims, o);
+            if ((t & 63) == 0 && claims) atomicAdd(&s_claims, claims);
+            if (__ballot(pending) != 0ull && (t & 63) == 0) atomicOr(&s_pending, 1u);
+            __syncthreads();
+            const bool last_round = r0 + MC_TH >= hi;
+            const bool flush = s_claims >= (unsigned)MC_RT_FLUSH || s_pending != 0u || last_round;
+            if (!flush) break;                                      // (the same answer in every thread)
+            // ---- flush: unique records -> pieces of MC_PIECE k-mers (block prefix sum of the piece counts) -> KT -> entries
+            {
+                ulonglong2 ur = make_ulonglong2(0ull, 0ull);
+                if (t < MC_RT) ur = *reinterpret_cast<const ulonglong2 *>(&s_rt[2 * t]);         // RT slot t
+                const unsigned int np = ur.y != 0ull ? (((unsigned int)(ur.x & 31ull) + 1u) + MC_PIECE - 1) / MC_PIECE : 0u;
+                unsigned int inc = np;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
+                if ((t & 63) == 63) s_w[t >> 6] = inc;
+                __syncthreads();
+                unsigned int wbase = 0;
+                for (int w = 0; w < (t >> 6); ++w) wbase += s_w[w];
+                const unsigned int o = wbase + inc - np;
+                for (unsigned int q = 0; q < np; ++q) s_work[o + q] = (unsigned short)((t << 2) | q);
+                if (t == MC_TH - 1) s_total = wbase + inc;
+                __syncthreads();
+                const unsigned int nwork = s_total;
+                for (unsigned int wi = t; wi < nwork; wi += MC_TH) {
+                    const unsigned int w = s_work[wi];
+                    const unsigned int slot = w >> 2;
+                    const ulonglong2 sl = *reinterpret_cast<const ulonglong2 *>(&s_rt[2 * slot]);
+                    const ulonglong2 rr = make_ulonglong2(sl.x, sl.y - 1ull);
+                    const int nk = (int)(rr.x & 31ull) + 1;
+                    const int i0 = (int)(w & 3u) * MC_PIECE;
+                    roll_out(rr, i0, i0 + MC_PIECE < nk ? i0 + MC_PIECE : nk, s_rtc[slot]);
+                    dbg_rolled += (unsigned long long)((i0 + MC_PIECE < nk ? i0 + MC_PIECE : nk) - i0);
+                    dbg_unique += (w & 3u) == 0u;
+                }
+                __syncthreads();
+                for (int i = t; i < MC_SLOTS; i += MC_TH) {
+                    const ulonglong2 sl = *reinterpret_cast<const ulonglong2 *>(&s_kt[2 * i]);
+                    if (sl.y != 0ull) {
+                        emit_entry((sl.y >> 32) - 1ull, sl.x, sl.y & 0xFFFFFFFFull);
+                        *reinterpret_cast<ulonglong2 *>(&s_kt[2 * i]) = make_ulonglong2(0ull, 0ull);
                     }
                 }
-                if (!done) emit_entry(hhi, hlo, 1ull);
+                if (t < MC_RT) { *reinterpret_cast<ulonglong2 *>(&s_rt[2 * t]) = make_ulonglong2(0ull, 0ull); s_rtc[t] = 0u; }
+                if (t == 0) { s_claims = 0; s_pending = 0; }
+                __syncthreads();
             }
+            if (__syncthreads_or(pending ? 1 : 0) == 0) break;      // records that found RT full go into the empty one now
         }
-        if (G.exp == 1 && dummy == 0x123456789ull) atomicAdd(&s_claims, 1u);      // (keeps the experiment's hashing alive)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) claims += __shfl_xor(claims, o);
-        if ((t & 63) == 0 && claims) atomicAdd(&s_claims, claims);
-        __syncthreads();
-        if (s_claims >= (unsigned)MC_FLUSH_AT || r0 + MC_TH >= hi) {           // (the same answer in every thread)
-            for (int i = t; i < MC_SLOTS; i += MC_TH) {
-                const ulonglong2 sl = *reinterpret_cast<const ulonglong2 *>(&s_tab[2 * i]);
-                if (sl.y != 0ull) {
-                    if (G.exp != 2) emit_entry((sl.y >> 32) - 1ull, sl.x, sl.y & 0xFFFFFFFFull);
-                    *reinterpret_cast<ulonglong2 *>(&s_tab[2 * i]) = make_ulonglong2(0ull, 0ull);
-                }
-            }
-            __syncthreads();
-            if (t == 0) s_claims = 0;
-        }
+        if (r0 + MC_TH >= hi) break;
     }
     __syncthreads();
     for (int i = t; i < ne; i += MC_TH) cntC[(uint64_t)i * G.nblkC + blockIdx.x] = s_cur[i] < G.capC ? s_cur[i] : G.capC;
+    if (G.exp == 9) {     // (tuning: how many k-mers were rolled out, how many unique records)
+        for (int o = 32; o > 0; o >>= 1) { dbg_rolled += __shfl_xor(dbg_rolled, o); dbg_unique += __shfl_xor(dbg_unique, o); }
+        if ((t & 63) == 0) { atomicAdd(&T.stats[5], dbg_rolled); atomicAdd(&T.stats[6], dbg_unique); }
+    }
 }
 
 // ---- entry list -> 2^pe2 region lists -------------------------------------------------------------------------------------
@@ -741,6 +803,11 @@ int Table::launch_count_minimizer(const uint8_t *d_piece, uint64_t len, uint64_t
         HIPCHK(jk_stream_wait(stream));
         unsigned long long dn[2] = {0, 0};
         HIPCHK(hipMemcpy(dn, defer_n, 16, hipMemcpyDeviceToHost));
+        if (G.exp == 9) {
+            unsigned long long st[ST_WORDS];
+            HIPCHK(hipMemcpy(st, d.stats, sizeof st, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[count] mz_count: %llu unique records flushed, %llu k-mers rolled out (cumulative)\n", st[6], st[5]);
+        }
         std::vector<unsigned int> hc(n_cntA + 2 * n_cntP + NF + 1 + n_cntC + n_cntE);
         HIPCHK(hipMemcpy(hc.data(), cur, hc.size() * 4, hipMemcpyDeviceToHost));
         unsigned int mxA = 0, mxC = 0, mxE = 0, mxF = 0;
