@@ -698,7 +698,9 @@ bool Table::minimizer_geometry(uint64_t piece_bases, void *geom_out) const {
     // path moves 7x fewer bytes but executes MORE vector instructions than count_part.hip (mz_count alone 5.1 G wave
     // instructions against 4.4 G for part1 + part2 + lds_insert together) and is slower (26 ms against 17 ms for cfg 2), so it
     // is kept as the second, parity-tested way to fill a table and as the starting point of a bucket-addressed table.
-    const int mode = getenv("JASPER_COUNT_PATH") ? atoi(getenv("JASPER_COUNT_PATH")) : 1;
+    // For 38 <= k <= 43 count_part.hip cannot run (its level-1 record holds 64 hash bits below 10 bucket bits) and this path is
+    // the atomic-free one: ~50 Gk-mers/s against ~18 of the direct kernel.
+    const int mode = getenv("JASPER_COUNT_PATH") ? atoi(getenv("JASPER_COUNT_PATH")) : (k >= 38 ? 2 : 1);
     if (mode != 2 || getenv("JASPER_COUNT_DIRECT") || d.ext) return false;
     if (piece_bases < (8u << 20) || piece_bases >= (1ull << 32)) return false;
     const int B = d.B, s = d.s;

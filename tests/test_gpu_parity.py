@@ -598,6 +598,38 @@ def test_atomic_free_counting_paths_equal_direct_counting(KT, k):
     td.close()
 
 
+def test_k41_takes_the_minimizer_path_and_equals_direct_counting(KT):
+    """38 <= k <= 43: keys of up to 86 bits do not fit count_part.hip's 8-byte records; with whole remainders in the tags
+    (2^29 slots at k = 41) an input of that size is counted through minimizer super-k-mers by default"""
+    import torch
+    k = 41
+    G = 3_600_000
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(4100)
+    genome = synth.torch_genome(gen, G, dev)
+    nreads = G * 30 // 150
+    reads = synth.torch_reads_stream(gen, genome, nreads, 150, 0.004)
+    torch.cuda.synchronize()
+    tm = KT(k, min_slots=1 << 29)
+    tm.count_bases_device(reads.data_ptr(), reads.numel())
+    assert tm.count_stages()[1] >= 1 and tm.count_path() == 2, "minimizer path not taken"
+    os.environ["JASPER_COUNT_DIRECT"] = "1"
+    try:
+        td = KT(k, min_slots=1 << 29)
+        td.count_bases_device(reads.data_ptr(), reads.numel())
+        assert td.count_stages()[1] == 0
+    finally:
+        del os.environ["JASPER_COUNT_DIRECT"]
+    im, idr = tm.info(), td.info()
+    assert im["occurrences"] == idr["occurrences"] == nreads * (150 - k + 1) and im["distinct"] == idr["distinct"]
+    assert tm.histogram() == td.histogram()
+    g = genome[:100_000].cpu().numpy().tobytes().decode()
+    qs = [g[i:i + k] for i in range(0, len(g) - k, 499)]
+    assert tm.lookup(qs) == td.lookup(qs)
+    tm.close()
+    td.close()
+
+
 def _ingest_cases():
     rng = np.random.default_rng(77)
     genome = synth.make_genome(rng, 30000, repeat_frac=0)
