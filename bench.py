@@ -322,12 +322,20 @@ def main():
     # HBM bytes of the counting pipeline per launch, from the PMC passes committed with the same build (rocprofv3 cannot
     # collect FETCH_SIZE / WRITE_SIZE inside this process); null when that file is absent
     traffic, traffic_src = None, None
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "round1", "bench_hbm_counters.json")))
-        traffic = int(pj["counting_pipeline"]["hbm_bytes_per_step"] / launches)
-        traffic_src = "profiles/round1/bench_hbm_counters.json (FETCH_SIZE+WRITE_SIZE, separate rocprofv3 --pmc passes, per step / launches)"
-    except Exception:
-        pass
+    for rnd in ("round2", "round1"):
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", rnd, "bench_hbm_counters.json")))
+            cp = pj["counting_pipeline"]
+            if "hbm_bytes_per_step_corrected" in cp:
+                traffic = int(cp["hbm_bytes_per_step_corrected"] / launches)
+                traffic_src = ("profiles/%s/bench_hbm_counters.json: 2 x FETCH_SIZE + WRITE_SIZE per step / launches (separate rocprofv3 --pmc passes; "
+                               "FETCH_SIZE doubled because gfx950 reports half of the bytes of wide coalesced streaming reads, MI355X_MICROARCH.md)" % rnd)
+            else:
+                traffic = int(cp["hbm_bytes_per_step"] / launches)
+                traffic_src = "profiles/%s/bench_hbm_counters.json (FETCH_SIZE+WRITE_SIZE as reported, separate rocprofv3 --pmc passes, per step / launches)" % rnd
+            break
+        except Exception:
+            continue
     out = {
         "metric": "assembly Mbp/s polished + Gk-mers/s counted, k=37",
         "value": round(asm_total / 1e6 / (dt / steps), 3),
