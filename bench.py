@@ -402,8 +402,10 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Mbp/s", "cores": host_cpu()[0], "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     if world > 1:
-        barrier()           # nobody frees a shard that a peer may still be reading
+        barrier()           # nobody unmaps or frees a shard that a peer may still be reading
         if shard is not None:
+            shard.detach()  # every rank lets go of its peers' memory, and only then is any of it freed
+            barrier()
             shard.close()
         dist.barrier()
         dist.destroy_process_group()

@@ -190,6 +190,11 @@ int jasper_last_count_timing(jasper_table *t, double *kernel_ms, uint64_t *launc
  * *partitioned_launches of the counted launches took path 1 or 2 (the others ran count_kernel) */
 int jasper_last_count_stages(jasper_table *t, double stage_ms[8], uint64_t *partitioned_launches, int *path);
 
+/* A slot array whose IPC handle was given out (jasper_table_ipc_handle) and that the table has outgrown since is kept until
+ * this call: the owners make it after they have all attached to the new arrays (jasper_amd/dist.py: shard_tables), so that
+ * nothing a peer may still have mapped is ever freed under it.  jasper_table_destroy releases them too. */
+int jasper_table_release_retired(jasper_table *t);
+
 /* Host only (no GPU touched): one gzip file inflated by `threads` threads into out_path (or nowhere when out_path is null),
  * the way jasper_count_reads_files reads a large .gz -- the role of `zcat -f` in src/jasper.sh:177.  chunk_bytes = compressed
  * bytes per unit of work (0: default 4 MiB).  *n_out = inflated bytes; *parallel = 1 when the many-thread reader handled the

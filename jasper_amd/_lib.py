@@ -66,6 +66,7 @@ SYMBOLS = {
     "jasper_table_attach_tables": (C.c_int, [_P, C.POINTER(_P), C.c_uint32, C.c_uint32]),
     "jasper_table_detach": (C.c_int, [_P]),
     "jasper_ipc_probe": (C.c_int, [C.c_int, _P, C.c_uint32, C.c_uint32]),
+    "jasper_table_release_retired": (C.c_int, [_P]),
     "jasper_inflate_file": (C.c_int, [C.c_char_p, C.c_int, C.c_uint64, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "jasper_owner_of": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_uint32]),
     "jasper_polish_batch": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),

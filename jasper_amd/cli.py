@@ -306,6 +306,23 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
     def decide(cond):
         return bool(jdist.all_reduce_ints([1 if (is0 and cond()) else 0], device=dev)[0])
 
+    def together(work, msg):
+        """a stage that every rank runs on its own share: a rank that fails (an exception, or the reference's own sys.exit(1))
+        must not leave the others waiting in the next collective -- the outcome is agreed, and either all ranks go on or all
+        leave with the message jasper.sh prints for that stage (only rank 0 talks)"""
+        failed, why, out = 0, "", None
+        try:
+            out = work()
+        except SystemExit as e:
+            failed = 1 if e.code not in (0, None) else 0
+        except BaseException as e:                      # noqa: BLE001 -- whatever it was, the others must hear of it
+            failed, why = 1, "%s: %s" % (type(e).__name__, e)
+        if why:
+            sys.stderr.write("jasper_amd: rank %d: %s\n" % (rank, why))
+        if jdist.all_reduce_ints([failed], device=dev)[0]:
+            error_exit(msg)
+        return out
+
     if decide(lambda: not os.path.exists("jasper.split.success")):      # :152-159
         if is0:
             log("Splitting query into batches for parallel execution")
@@ -332,20 +349,21 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
             log("Using existing jellyfish database %s" % jf_file)
             if is0 and os.path.exists("jasper.no_cat.success"):
                 os.remove("jasper.no_cat.success")
-            local = KmerTable.from_jf_part(jf_file, rank, world, device=o.device)
+            local = together(lambda: KmerTable.from_jf_part(jf_file, rank, world, device=o.device),
+                             "Computing mer counts histogram from %s failed, please make sure that %s is a valid Jellyfish mer counts file" % (jf_file, jf_file))
         else:
             _timing("split")
             log("Creating jellyfish database mer_counts%d.jf" % kmer)
-            local = KmerTable(kmer, min_slots=max(1 << 20, int(1.25 * o.jf_size / world)), device=o.device)
-            local.count_file_ranges(jdist.plan_read_shards(reads, world)[rank])
+            def count_my_ranges():
+                t = KmerTable(kmer, min_slots=max(1 << 20, int(1.25 * o.jf_size / world)), device=o.device)
+                t.count_file_ranges(jdist.plan_read_shards(reads, world)[rank])
+                return t
+            local = together(count_my_ranges, "Computing mer counts histogram from mer_counts%d.jf failed, please make sure that mer_counts%d.jf is a valid Jellyfish mer counts file" % (kmer, kmer))
             _timing("count reads (file ranges -> local table)")
             counted = True
     else:
-        try:
-            local = KmerTable.from_jf_part(o.jf_db, rank, world, device=o.device)
-        except Exception as e:
-            error_exit("Computing mer counts histogram from %s failed, please make sure that %s is a valid Jellyfish mer counts file (%s)"
-                       % (o.jf_db, o.jf_db, e))
+        local = together(lambda: KmerTable.from_jf_part(o.jf_db, rank, world, device=o.device),
+                         "Computing mer counts histogram from %s failed, please make sure that %s is a valid Jellyfish mer counts file" % (o.jf_db, o.jf_db))
     # key-wise sum over the GPUs; the result stays sharded by key owner unless the peers' HBM cannot be mapped
     table = KmerTable(local.k, min_slots=1 << 21, device=o.device)
     write_db = counted and os.environ.get("JASPER_AMD_NO_JF", "") not in ("1", "true", "yes")
@@ -360,6 +378,8 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
     except jdist.ShardAttachError as e:
         if is0:
             sys.stderr.write("jasper_amd: %s -- replicating the merged table on every GPU instead\n" % e)
+        table.detach()          # (whatever was mapped is unmapped on every rank before anybody frees its slot array)
+        bar()
         table.close()
         table = local
         jdist.merge_tables(table, dev)
@@ -411,15 +431,18 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
                 for bf in group:
                     os.replace("_iter%d_%s.fixed.fa.tmp" % (last_it, bf), "_iter%d_%s.fixed.fa" % (last_it, bf))
                 del group[:]
-        for bf, ow in zip(batch_files, owner):
-            if ow != rank:
-                continue
-            group.append(bf)
-            group_bytes += os.path.getsize(bf)
-            if group_bytes > (1 << 30):
-                flush_group()
-                group_bytes = 0
-        flush_group()
+        def polish_my_batches():
+            nonlocal group_bytes
+            for bf, ow in zip(batch_files, owner):
+                if ow != rank:
+                    continue
+                group.append(bf)
+                group_bytes += os.path.getsize(bf)
+                if group_bytes > (1 << 30):
+                    flush_group()
+                    group_bytes = 0
+            flush_group()
+        together(polish_my_batches, "Polishing failed")                          # :215
         bar()
         if is0:
             if os.path.exists("jasper.join.success"):
@@ -437,7 +460,9 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
         _qv_block(passes, kmer)
     _timing("join + QV")
     log("Polished sequence is in %s.polished.fasta" % qfn)
-    bar()                       # nobody frees a shard that a peer may still be reading
+    bar()                       # nobody unmaps or frees a shard that a peer may still be reading ...
+    table.detach()              # ... every rank lets go of its peers' memory ...
+    bar()                       # ... and only then is any of it freed
     table.close()
     bar()
     tdist.destroy_process_group()

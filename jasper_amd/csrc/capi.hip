@@ -291,6 +291,11 @@ int jasper_table_attach_tables(jasper_table *t, jasper_table *const *shards, uin
 }
 // Can this process map these slot arrays at all?  Meant to be called from a THROW-AWAY process with a time limit: a mapping
 // call that never returns (seen on this stack for one allocation size) then costs a killed helper, not a hung rank.
+int jasper_table_release_retired(jasper_table *t) {
+    t->t.release_retired();
+    return JASPER_OK;
+}
+
 int jasper_inflate_file(const char *path, int threads, uint64_t chunk_bytes, const char *out_path, uint64_t *n_out, int *parallel) {
     if (!path) { g_err = "bad arguments"; return JASPER_ERR; }
     FILE *f = nullptr;

@@ -125,18 +125,54 @@ int parse_files(const char *const *paths, int n_paths, FastxParser &parser, std:
     return rc;
 }
 
-static bool json_int(const std::string &j, const char *key, long &out) {
-    const std::string pat = std::string("\"") + key + "\"";
-    size_t p = j.find(pat);
-    if (p == std::string::npos) return false;
-    p = j.find(':', p + pat.size());
-    if (p == std::string::npos) return false;
-    ++p;
-    while (p < j.size() && (j[p] == ' ' || j[p] == '\t' || j[p] == '\n')) ++p;
-    char *end = nullptr;
-    out = strtol(j.c_str() + p, &end, 10);
-    return end != j.c_str() + p;
-}
+
+// The header is a JSON object (JF::include/jellyfish/generic_file_header.hpp:88-111) that also carries strings the user
+// controls (cmdline, pwd, exe_path, hostname): it is walked token by token, and only TOP-LEVEL members count -- a path or an
+// argument that contains "key_len" or "binary/sorted" must not be taken for the member of that name.
+namespace {
+struct JsonTop {
+    const std::string &j;
+    size_t p = 0;
+    explicit JsonTop(const std::string &s) : j(s) {}
+    void ws() { while (p < j.size() && (j[p] == ' ' || j[p] == '\n' || j[p] == '\t' || j[p] == '\r')) ++p; }
+    bool str(std::string &out) {
+        if (p >= j.size() || j[p] != '"') return false;
+        ++p;
+        out.clear();
+        while (p < j.size() && j[p] != '"') {
+            if (j[p] == '\\') { if (p + 1 >= j.size()) return false; out.push_back(j[p + 1]); p += 2; }
+            else out.push_back(j[p++]);
+        }
+        if (p >= j.size()) return false;
+        ++p;
+        return true;
+    }
+    // skips any value; scalars are returned as text in `scalar` (strings unquoted)
+    bool value(std::string &scalar) {
+        ws();
+        scalar.clear();
+        if (p >= j.size()) return false;
+        if (j[p] == '"') return str(scalar);
+        if (j[p] == '{' || j[p] == '[') {
+            const char open = j[p], close = open == '{' ? '}' : ']';
+            ++p;
+            for (;;) {
+                ws();
+                if (p >= j.size()) return false;
+                if (j[p] == close) { ++p; return true; }
+                if (j[p] == ',') { ++p; continue; }
+                std::string tmp;
+                if (open == '{') { if (!str(tmp)) return false; ws(); if (p >= j.size() || j[p] != ':') return false; ++p; }
+                if (!value(tmp)) return false;
+            }
+        }
+        const size_t a = p;
+        while (p < j.size() && j[p] != ',' && j[p] != '}' && j[p] != ']' && j[p] != ' ' && j[p] != '\n' && j[p] != '\t' && j[p] != '\r') ++p;
+        scalar = j.substr(a, p - a);
+        return p > a;
+    }
+};
+}  // namespace
 
 int jf_read_header(const char *path, JfHeader &h, std::string &err) {
     FILE *f = fopen(path, "rb");
@@ -145,22 +181,46 @@ int jf_read_header(const char *path, JfHeader &h, std::string &err) {
     if (fread(digits, 1, 9, f) != 9) { fclose(f); err = "Unsupported format"; return -3; }
     for (int i = 0; i < 9; ++i) if (digits[i] < '0' || digits[i] > '9') { fclose(f); err = "Unsupported format"; return -3; }
     const long hlen = strtol(digits, nullptr, 10);
-    std::string j((size_t)hlen, '\0');
-    if (hlen <= 0 || fread(&j[0], 1, (size_t)hlen, f) != (size_t)hlen) { fclose(f); err = "Unsupported format"; return -3; }
     fseek(f, 0, SEEK_END);
     const long fsize = ftell(f);
+    if (hlen <= 0 || 9 + hlen > fsize) { fclose(f); err = "Unsupported format"; return -3; }      // (checked before anything of that size is allocated)
+    fseek(f, 9, SEEK_SET);
+    std::string j((size_t)hlen, '\0');
+    if (fread(&j[0], 1, (size_t)hlen, f) != (size_t)hlen) { fclose(f); err = "Unsupported format"; return -3; }
     fclose(f);
-    if (j.find("\"binary/sorted\"") == std::string::npos) { err = "Unsupported format"; return -3; }           // JF::swig/mer_file.i:34
-    long kl = 0, cl = 0;
-    if (!json_int(j, "key_len", kl) || !json_int(j, "counter_len", cl) || kl <= 0 || kl > 128 || (kl & 1) || cl <= 0 || cl > 8) {
-        err = "Unsupported format"; return -3;
+    std::string format, key_len, counter_len, canonical;
+    {
+        JsonTop t(j);
+        t.ws();
+        if (t.p >= j.size() || j[t.p] != '{') { err = "Unsupported format"; return -3; }
+        ++t.p;
+        for (;;) {
+            t.ws();
+            if (t.p >= j.size()) { err = "Unsupported format"; return -3; }
+            if (j[t.p] == '}') break;
+            if (j[t.p] == ',') { ++t.p; continue; }
+            std::string name, val;
+            if (!t.str(name)) { err = "Unsupported format"; return -3; }
+            t.ws();
+            if (t.p >= j.size() || j[t.p] != ':') { err = "Unsupported format"; return -3; }
+            ++t.p;
+            if (!t.value(val)) { err = "Unsupported format"; return -3; }
+            if (name == "format") format = val;
+            else if (name == "key_len") key_len = val;
+            else if (name == "counter_len") counter_len = val;
+            else if (name == "canonical") canonical = val;
+        }
     }
+    if (format != "binary/sorted") { err = "Unsupported format"; return -3; }           // JF::swig/mer_file.i:34
+    char *e1 = nullptr, *e2 = nullptr;
+    const long kl = strtol(key_len.c_str(), &e1, 10), cl = strtol(counter_len.c_str(), &e2, 10);
+    if (key_len.empty() || counter_len.empty() || *e1 || *e2 || kl <= 0 || kl > 128 || (kl & 1) || cl <= 0 || cl > 8) { err = "Unsupported format"; return -3; }
     h.key_len = (int)kl;
     h.counter_len = (int)cl;
-    h.canonical = j.find("\"canonical\":true") != std::string::npos || j.find("\"canonical\" : true") != std::string::npos ||
-                  j.find("\"canonical\": true") != std::string::npos;
+    h.canonical = canonical == "true";
     h.data_offset = 9 + (uint64_t)hlen;
     const uint64_t rec = (uint64_t)((kl + 7) / 8) + (uint64_t)cl;
+    if (((uint64_t)fsize - h.data_offset) % rec != 0) { err = "Unsupported format"; return -3; }      // a whole number of records
     h.n_records = ((uint64_t)fsize - h.data_offset) / rec;
     return 0;
 }

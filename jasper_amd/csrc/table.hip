@@ -672,6 +672,7 @@ void Table::destroy() {
         if (h_stage[i]) (void)hipHostFree(h_stage[i]);
         if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]);
     }
+    release_retired();
     if (d.slots) (void)hipFree(d.slots);
     if (d.ext) (void)hipFree(d.ext);
     if (d.stats) (void)hipFree(d.stats);
@@ -754,7 +755,8 @@ int Table::resize(int new_s, std::string &err) {
         unsigned long long *ns = nullptr;
         HIPCHK(hipMalloc((void **)&ns, slot_alloc_bytes(1ull << new_s)));
         HIPCHK(jk_stream_wait(stream));
-        HIPCHK(hipFree(d.slots));
+        if (exported && n_retired < 8) { retired[n_retired++] = d.slots; exported = false; }
+        else HIPCHK(hipFree(d.slots));
         if (d.ext) HIPCHK(hipFree(d.ext));
         d.slots = ns; d.ext = new_ext; d.s = new_s; d.mask = (1ull << new_s) - 1; nslots = 1ull << new_s;
         return 0;
@@ -770,7 +772,8 @@ int Table::resize(int new_s, std::string &err) {
     hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, stream, d, nt);
     HIPCHK(hipGetLastError());
     HIPCHK(jk_stream_wait(stream));
-    HIPCHK(hipFree(d.slots));
+    if (exported && n_retired < 8) { retired[n_retired++] = d.slots; exported = false; }      // peers may still have it mapped
+    else HIPCHK(hipFree(d.slots));
     if (d.ext) HIPCHK(hipFree(d.ext));
     d = nt;
     nslots = 1ull << new_s;
@@ -1221,7 +1224,13 @@ int Table::ipc_handle(void *out64, std::string &err) {
     hipIpcMemHandle_t h;
     HIPCHK(hipIpcGetMemHandle(&h, d.slots));
     memcpy(out64, &h, 64);
+    exported = true;
     return 0;
+}
+
+void Table::release_retired() {
+    for (int i = 0; i < n_retired; ++i) if (retired[i]) (void)hipFree(retired[i]);
+    n_retired = 0;
 }
 
 // handles64: n handles of 64 bytes, one per owner in owner order (entry `self` is ignored: that is this table).  Every

@@ -382,6 +382,12 @@ struct Table {
     int attach_ipc(const void *handles64, uint32_t n, uint32_t self, std::string &err);
     int attach_tables(Table *const *peers, uint32_t n, uint32_t self, std::string &err);
     void detach_shards();
+    // A slot array whose IPC handle has been given out may still be mapped by peers when this table outgrows it: it is not
+    // freed then but retired, until the ranks have attached to the new one and said so (release_retired), or the table goes
+    bool exported = false;
+    void *retired[8] = {};
+    int n_retired = 0;
+    void release_retired();
     void *ipc_mapped[MAX_SHARDS] = {};   // peers' slot arrays opened with hipIpcOpenMemHandle (closed by detach_shards)
     // the table as a Jellyfish binary/sorted database (jfwrite.hip); cmdline goes into the header like jellyfish's own
     // r_bits = log2 of the file's `size` (-1: this table's slot count); what: 0 = header + records, 1 = records only (one

@@ -406,6 +406,10 @@ def shard_tables(local, shard, device, group=None):
     # 4. nobody reads a shard before every owner has finished writing its own
     _sync(device)
     dist.barrier(group=group)
+    # every rank is attached to the present slot arrays (or still to the unchanged ones): arrays that were outgrown after
+    # their handles had been given out can go now
+    if hasattr(shard, "release_retired"):
+        shard.release_retired()
     return incoming
 
 

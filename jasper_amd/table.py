@@ -352,6 +352,11 @@ class KmerTable:
         check(self._L.jasper_table_attach_tables(self._h, arr, len(shards), int(self_index)))
         self._shard_refs = list(shards)      # keep the owners alive while their slot arrays are read through this table
 
+    def release_retired(self):
+        """free slot arrays this table has outgrown after their IPC handles were given out (call once every owner has attached
+        to the new ones)"""
+        check(self._L.jasper_table_release_retired(self._h))
+
     def detach(self):
         check(self._L.jasper_table_detach(self._h))
         self._shard_refs = None

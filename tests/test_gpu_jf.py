@@ -42,6 +42,36 @@ def test_load_jf_errors(hip, tmp_path):
     p.write_bytes(b"not a jellyfish file at all")
     with pytest.raises(JasperHipError, match="Unsupported format"):
         KmerTable.from_jf(str(p))
+    # the header is JSON with strings the user controls (cmdline, pwd): only its TOP-LEVEL members count
+    import json
+    c = Case("simple_k25")
+    raw = open(os.path.join(c.dir, "db.jf"), "rb").read()
+    hlen = int(raw[:9])
+    hdr = json.loads(raw[9:9 + hlen].rstrip(b"\0"))
+    body = raw[9 + hlen:]
+
+    def write(path, h, data):
+        j = json.dumps(h).encode()
+        j += b"\0" * ((-(9 + len(j))) % 8)
+        path.write_bytes(b"%09d" % len(j) + j + data)
+    tricky = {"cmdline": ["count", "-o", '"key_len":10,"format":"text/sorted","counter_len":9'], "pwd": '/tmp/"canonical":false'}
+    tricky.update({k: v for k, v in hdr.items() if k not in ("cmdline", "pwd")})
+    write(p, tricky, body)
+    t = KmerTable.from_jf(str(p))
+    d = c.dump()
+    kmers = sorted(d)[:500]
+    assert t.k == c.k and t.lookup(kmers) == [d[x] for x in kmers]
+    t.close()
+    other = dict(hdr, format="text/sorted")
+    write(p, other, body)
+    with pytest.raises(JasperHipError, match="Unsupported format"):
+        KmerTable.from_jf(str(p))
+    write(p, hdr, body[:-3])                      # not a whole number of records
+    with pytest.raises(JasperHipError, match="Unsupported format"):
+        KmerTable.from_jf(str(p))
+    p.write_bytes(b"999999999{}")                 # a header length beyond the file
+    with pytest.raises(JasperHipError, match="Unsupported format"):
+        KmerTable.from_jf(str(p))
 
 
 def test_cli_with_jf_database(hip, tmp_path):
