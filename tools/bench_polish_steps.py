@@ -16,7 +16,9 @@ t = KmerTable(B.K, min_slots=max(1 << 21, int(1.25 * jf_size)))
 t.count_bases_device(reads.data_ptr(), reads.numel())
 txt, status = polisher.threshold_from_histo_rows(t.histo_rows())
 thr = int(txt)
+res = None
 for r in range(reps):
+    res = None          # (a result that is still alive is brought to the host before the table's arenas are reused)
     t0 = time.perf_counter()
     res = t.polish_batch_device(d_chunks[0], d_chunks[1], thr, B.PASSES, fix=True)
     t1 = time.perf_counter()
