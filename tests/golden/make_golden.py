@@ -346,6 +346,8 @@ def main():
     if a.only in (None, "e2e") and os.environ.get("GOLDEN_E2E", "1") == "1":
         m = make_e2e(os.path.join(base, "e2e"))
         print("e2e exit", m["exit"], m["batches"], m["stdout"])
+        m = make_e2e(os.path.join(base, "e2e_k45"), k=45, seed=78, rl=150)
+        print("e2e_k45 exit", m["exit"], m["batches"], m["stdout"])
     for i, (name, spec) in enumerate(specs.items()):
         if a.only and a.only != name:
             continue
@@ -393,12 +395,12 @@ json.dump(out, open(sys.argv[1], "w"), indent=0)
 
 
 
-def make_e2e(outdir):
-    """one run of the REAL src/jasper.sh (bash + perl + jellyfish + jasper.py) -> tests/golden/e2e/*.
+def make_e2e(outdir, k=25, seed=77, rl=100):
+    """one run of the REAL src/jasper.sh (bash + perl + jellyfish + jasper.py) -> tests/golden/e2e/* (k = 25) and
+    tests/golden/e2e_k45/* (k = 45: keys of 90 bits through the whole driver, incl. mer_counts45.jf).
     QV lines are not captured: `bc` is not installed in the build container."""
     import glob as _glob
-    rng = np.random.default_rng(77)
-    k = 25
+    rng = np.random.default_rng(seed)
     contigs = [("ctgA some description", rand_seq(rng, 9000)), ("ctgB", rand_seq(rng, 5000)), ("ctgC:x", rand_seq(rng, 2500))]
     truth = {n.split()[0]: s for n, s in contigs}
     asm = {}
@@ -407,7 +409,7 @@ def make_e2e(outdir):
         plan = [(int(p), ["sub", "ins", "del"][int(rng.integers(0, 3))], None) for p in sorted(rng.choice(L - 200, max(3, L // 700), replace=False) + 100)]
         plan = [(p, kd, {"sub": 1 + int(rng.integers(0, 3)), "ins": "ACGT"[int(rng.integers(0, 4))], "del": 1}[kd]) for p, kd, _ in plan]
         asm[n] = mutate(rng, s, plan)
-    reads = sample_reads(rng, [(s, 1.0) for s in truth.values()], 40, 100, 0.002)
+    reads = sample_reads(rng, [(s, 1.0) for s in truth.values()], 40, rl, 0.002)
     work = tempfile.mkdtemp(prefix="golden_e2e_")
     half = len(reads) // 2
     write_reads(os.path.join(work, "r1.fq"), reads[:half], "fq", rng)

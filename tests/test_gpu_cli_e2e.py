@@ -27,8 +27,12 @@ def fasta_records(path):
     return d
 
 
-def test_cli_matches_jasper_sh(hip, tmp_path):
+@pytest.mark.parametrize("fixture", ["e2e", "e2e_k45"])
+def test_cli_matches_jasper_sh(hip, tmp_path, fixture):
+    """e2e: k = 25; e2e_k45: k = 45 -- keys of 90 bits through the whole driver, mer_counts45.jf written and reused"""
+    E2E = os.path.join(HERE, "golden", fixture)
     meta = json.load(open(os.path.join(E2E, "meta.json")))
+    K = meta["k"]
     for fn in ("r1.fq", "r2.fq"):
         with open(tmp_path / fn, "wb") as f:
             f.write(gzip.open(os.path.join(E2E, fn + ".gz")).read())
@@ -40,7 +44,7 @@ def test_cli_matches_jasper_sh(hip, tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     # artefacts of src/jasper.sh
     assert open(tmp_path / "threshold.txt").read() == open(os.path.join(E2E, "threshold.txt")).read()
-    assert open(tmp_path / "jfhisto25.csv").read() == open(os.path.join(E2E, "jfhisto25.csv")).read()
+    assert open(tmp_path / ("jfhisto%d.csv" % K)).read() == open(os.path.join(E2E, "jfhisto%d.csv" % K)).read()
     # contig order in the reference is perl-hash order: compare per record
     assert fasta_records(tmp_path / "asm.fa.polished.fasta") == fasta_records(os.path.join(E2E, "asm.fa.polished.fasta"))
     assert open(tmp_path / "asm.fa.fixes.csv", newline="").read() == open(os.path.join(E2E, "asm.fa.fixes.csv"), newline="").read()
@@ -56,20 +60,20 @@ def test_cli_matches_jasper_sh(hip, tmp_path):
     strip_q = lambda ls: [re.sub(r"Q value = .*", "Q value =", ln) for ln in ls]
     assert strip_q(mine) == strip_q(meta["stdout"])
     # src/jasper.sh:177 leaves the database behind (`tee $JF_DB`); ours is a Jellyfish binary/sorted file too
-    assert os.path.getsize(tmp_path / "mer_counts25.jf") > 1000
+    assert os.path.getsize(tmp_path / ("mer_counts%d.jf" % K)) > 1000
     # a second run in the same directory resumes from the sentinels and leaves the result untouched
-    p2 = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", "25", "-t", "4", "-p", "2"],
+    p2 = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(K), "-t", "4", "-p", "2"],
                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
     assert p2.returncode == 0
     # ... and a run without the sentinels reuses the database (:171-173) and arrives at the same result
     for fn in os.listdir(tmp_path):
         if re.match(r"jasper\..*\.success$", fn) or fn.endswith(".polished.fasta") or fn.endswith(".fixes.csv") or fn.startswith("jfhisto"):
             os.remove(tmp_path / fn)
-    p3 = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", "25", "-t", str(meta["threads"]), "-p", "2"],
+    p3 = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(K), "-t", str(meta["threads"]), "-p", "2"],
                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
     assert p3.returncode == 0, p3.stdout + p3.stderr
-    assert "Using existing jellyfish database mer_counts25.jf" in p3.stdout
-    assert open(tmp_path / "jfhisto25.csv").read() == open(os.path.join(E2E, "jfhisto25.csv")).read()
+    assert "Using existing jellyfish database mer_counts%d.jf" % K in p3.stdout
+    assert open(tmp_path / ("jfhisto%d.csv" % K)).read() == open(os.path.join(E2E, "jfhisto%d.csv" % K)).read()
     assert open(tmp_path / "asm.fa.fixes.csv", newline="").read() == open(os.path.join(E2E, "asm.fa.fixes.csv"), newline="").read()
     assert fasta_records(tmp_path / "asm.fa.polished.fasta") == fasta_records(os.path.join(E2E, "asm.fa.polished.fasta"))
 
