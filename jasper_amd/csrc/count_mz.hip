@@ -668,6 +668,111 @@ __global__ __launch_bounds__(ES_TH) void ent_split_kernel(const ulonglong2 *__re
     for (int i = t; i < n2; i += ES_TH) cntE[((((uint64_t)e1 << G.pe2) + i) * G.nsubE) + x] = s_cur[i] < G.capE ? s_cur[i] : G.capE;
 }
 
+// ---- both second-level splits, with the copy-out staged through LDS ---------------------------------------------------------
+// Writing every 16-byte record straight to its list (the kernels above) leaves each of the block's up-to-1024 open 128-byte
+// lines to be filled by eight visits spread over the whole run of the block, and with ~2000 workgroups resident that is far
+// more open lines than the L2s hold: the lines leave half filled (the write pass of mz_split took 4.7x its count pass for the
+// same reads).  Here a tile of ST_TILE records is first ordered by key inside LDS (rank from a returning LDS atomic, offsets
+// from a block scan -- part2_kernel's scheme), and lane t then writes all the tile's records of key t one after the other:
+// a list's line is filled by consecutive stores within a few hundred cycles.
+// KIND 0: super-k-mer records, key = fine bucket field, destination = exact positions (baseP, from the count pass);
+// KIND 1: (hash, count) entries, key = next pe2 hash bits, destination = the block's slice of each region list (capE, deferred list).
+constexpr int ST_TH = 1024, ST_TILE = 4096;
+template <int KIND>
+__global__ __launch_bounds__(ST_TH) void split16_kernel(const ulonglong2 *__restrict__ src_lists, const unsigned int *__restrict__ src_cnt, TableDev T, MzGeom G,
+                                                         const unsigned int *__restrict__ baseP, ulonglong2 *__restrict__ out, unsigned int *__restrict__ out_cnt,
+                                                         unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
+    __shared__ __align__(16) ulonglong2 s_stage[ST_TILE];
+    __shared__ unsigned int s_cnt[1024], s_off[1024], s_cur[1024];
+    __shared__ unsigned int s_pref[SP_MAXSL + 1];
+    __shared__ unsigned int s_w[ST_TH / 64];
+    const int t = threadIdx.x;
+    const uint32_t bkt = blockIdx.y, x = blockIdx.x;             // coarse bucket (KIND 0) / hash-coarse list (KIND 1), sub-block
+    const int nkeys = 1 << (KIND == 0 ? G.pf : G.pe2);
+    const uint32_t kmask = (uint32_t)nkeys - 1u;
+    const uint32_t nsrc = KIND == 0 ? G.nblkA : G.nblkC, nsub = KIND == 0 ? G.nsubP : G.nsubE, scap = KIND == 0 ? G.capA : G.capC;
+    const int sh = T.B - G.pe1 - G.pe2;
+    const uint64_t row = ((uint64_t)bkt * nsub + x) << G.pf;     // (KIND 0)
+    if (t < nkeys) { s_cur[t] = KIND == 0 ? baseP[row + t] : 0u; s_cnt[t] = 0u; }
+    const uint32_t nmine = (nsrc - x + nsub - 1) / nsub;          // slices x, x+nsub, ... as ONE list
+    if (t < 64) {
+        unsigned int carry = 0;
+        for (uint32_t j0 = 0; j0 < nmine; j0 += 64) {
+            const uint32_t j = j0 + t;
+            const unsigned int v = j < nmine ? src_cnt[(uint64_t)bkt * nsrc + x + (uint64_t)j * nsub] : 0u;
+            unsigned int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if (t >= o) inc += u; }
+            if (j < nmine) s_pref[j] = carry + inc - v;
+            carry += __shfl(inc, 63);
+        }
+        if (t == 0) s_pref[nmine] = carry;
+    }
+    __syncthreads();
+    const uint32_t total = s_pref[nmine];
+    const ulonglong2 *src0 = src_lists + ((uint64_t)bkt * nsrc + x) * scap;
+    uint32_t sl[4] = {0, 0, 0, 0};
+    for (uint32_t i0 = 0; i0 < total; i0 += ST_TILE) {
+        ulonglong2 r[4];
+        uint32_t kr[4];                                           // key << 16 | rank in the tile ; 0xFFFFFFFF = nothing
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * ST_TH + t;
+            kr[u] = 0xFFFFFFFFu;
+            r[u] = make_ulonglong2(0ull, 0ull);
+            if (i < total) {
+                while (s_pref[sl[u] + 1] <= i) ++sl[u];
+                r[u] = src0[(uint64_t)sl[u] * nsub * scap + (i - s_pref[sl[u]])];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + (uint32_t)u * ST_TH + t >= total) continue;
+            const uint32_t key = KIND == 0 ? ((uint32_t)(r[u].x >> 5) & kmask) : (top_bits(r[u].y & 0xFFFFFFFFull, r[u].x, sh) & kmask);
+            kr[u] = (key << 16) | (atomicAdd(&s_cnt[key], 1u) & 0xFFFFu);
+        }
+        __syncthreads();
+        {   // exclusive prefix of the key counts: thread t owns key t
+            const unsigned int v = t < nkeys ? s_cnt[t] : 0u;
+            unsigned int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
+            if ((t & 63) == 63) s_w[t >> 6] = inc;
+            __syncthreads();
+            unsigned int wbase = 0;
+            for (int w = 0; w < (t >> 6); ++w) wbase += s_w[w];
+            if (t < nkeys) s_off[t] = wbase + inc - v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (kr[u] != 0xFFFFFFFFu) s_stage[s_off[kr[u] >> 16] + (kr[u] & 0xFFFFu)] = r[u];
+        __syncthreads();
+        if (t < nkeys) {                                          // lane t: the tile's records of key t, one after the other
+            const unsigned int cnt = s_cnt[t], off = s_off[t], cur = s_cur[t];
+            if (KIND == 0) {
+                for (unsigned int q = 0; q < cnt; ++q) out[cur + q] = s_stage[off + q];
+            } else {
+                const uint64_t region = ((uint64_t)bkt << G.pe2) + (uint32_t)t;
+                ulonglong2 *dst = out + (region * nsub + x) * G.capE;
+                for (unsigned int q = 0; q < cnt; ++q) {
+                    const ulonglong2 e = s_stage[off + q];
+                    if (cur + q < G.capE) dst[cur + q] = e;
+                    else {
+                        const unsigned long long di = atomicAdd(deferred_n, 1ull);
+                        if (di < deferred_cap) { deferred[3 * di] = e.y & 0xFFFFFFFFull; deferred[3 * di + 1] = e.x; deferred[3 * di + 2] = e.y >> 32; }
+                        else atomicExch(&T.stats[ST_FATAL], 1ull);
+                    }
+                }
+            }
+            s_cur[t] = cur + cnt;
+            s_cnt[t] = 0u;
+        }
+        __syncthreads();
+    }
+    if (KIND == 1 && t < nkeys) out_cnt[((((uint64_t)bkt << G.pe2) + (uint32_t)t) * nsub) + x] = s_cur[t] < G.capE ? s_cur[t] : G.capE;
+}
+
 // ---- records that overflowed a slice of mz_part: every k-mer through the direct path --------------------------------------
 __global__ __launch_bounds__(256) void mz_expand_kernel(const ulonglong2 *__restrict__ ovf, const unsigned long long *__restrict__ ovf_n, uint64_t cap, TableDev T,
                                                          unsigned long long *__restrict__ histo_incomplete) {
@@ -781,14 +886,16 @@ int Table::launch_count_minimizer(const uint8_t *d_piece, uint64_t len, uint64_t
     hipLaunchKernelGGL(mz_split_kernel<0>, dim3(G.nsubP, nc), dim3(256), 0, stream, bufX, cntA, G, cntP, baseP, bufY);
     hipLaunchKernelGGL(mz_scan1_kernel, dim3(nc), dim3(256), 0, stream, cntP, baseP, ctot, G);
     hipLaunchKernelGGL(mz_scan2_kernel, dim3(64), dim3(256), 0, stream, baseP, ctot, startF, G);
-    hipLaunchKernelGGL(mz_split_kernel<1>, dim3(G.nsubP, nc), dim3(256), 0, stream, bufX, cntA, G, cntP, baseP, bufY);
+    if (getenv("JASPER_MZ_DIRECT_SPLIT")) hipLaunchKernelGGL(mz_split_kernel<1>, dim3(G.nsubP, nc), dim3(256), 0, stream, bufX, cntA, G, cntP, baseP, bufY);
+    else hipLaunchKernelGGL(split16_kernel<0>, dim3(G.nsubP, nc), dim3(ST_TH), 0, stream, bufX, cntA, d, G, baseP, bufY, (unsigned int *)nullptr, defer_e, defer_n, deferred_cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_stage_t[2], stream));
     if (k > 32) hipLaunchKernelGGL(mz_count_kernel<true>, dim3(G.nblkC), dim3(MC_TH), 0, stream, bufY, startF + NF, d, G, bufX, cntC, defer_e, defer_n, deferred_cap);
     else hipLaunchKernelGGL(mz_count_kernel<false>, dim3(G.nblkC), dim3(MC_TH), 0, stream, bufY, startF + NF, d, G, bufX, cntC, defer_e, defer_n, deferred_cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_stage_t[3], stream));
-    hipLaunchKernelGGL(ent_split_kernel, dim3(G.nsubE, ne1), dim3(ES_TH), 0, stream, bufX, cntC, d, G, bufY, cntE, defer_e, defer_n, deferred_cap);
+    if (getenv("JASPER_MZ_DIRECT_SPLIT")) hipLaunchKernelGGL(ent_split_kernel, dim3(G.nsubE, ne1), dim3(ES_TH), 0, stream, bufX, cntC, d, G, bufY, cntE, defer_e, defer_n, deferred_cap);
+    else hipLaunchKernelGGL(split16_kernel<1>, dim3(G.nsubE, ne1), dim3(ST_TH), 0, stream, bufX, cntC, d, G, (const unsigned int *)nullptr, bufY, cntE, defer_e, defer_n, deferred_cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_stage_t[4], stream));
     if (insert_entry_lists(bufY, cntE, G.capE, G.nsubE, G.pe1 + G.pe2, G.rbits, defer_e, defer_n, deferred_cap, &ev_stage_t[5], err)) return -1;   // records ev 5, 6
