@@ -598,6 +598,57 @@ def test_atomic_free_counting_paths_equal_direct_counting(KT, k):
     td.close()
 
 
+def test_minimizer_path_overflowing_slices_take_the_direct_path(KT, capfd):
+    """count_mz.hip sizes its lists from estimates: records that find their slice full are rolled out by mz_expand_kernel,
+    entries that find theirs full go to the deferred list -- both through the direct (atomic) path after the last region
+    image is written.  With the capacities cut (JASPER_MZ_TEST_CAPS) thousands of each overflow; the table must not differ."""
+    import torch
+    k = 31
+    G = 1_500_000
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(777)
+    genome = synth.torch_genome(gen, G, dev)
+    nreads = G * 30 // 150
+    reads = synth.torch_reads_stream(gen, genome, nreads, 150, 0.004)
+    torch.cuda.synchronize()
+    slots = int(1.25 * nreads * 150 * 2.1 / 10)
+    import re
+
+    def run(caps):
+        os.environ.update(JASPER_COUNT_PATH="2", JASPER_COUNT_DEBUG="2")
+        if caps:
+            os.environ["JASPER_MZ_TEST_CAPS"] = caps
+        try:
+            t = KT(k, min_slots=slots)
+            t.count_bases_device(reads.data_ptr(), reads.numel())
+            assert t.count_path() == 2
+        finally:
+            for v in ("JASPER_COUNT_PATH", "JASPER_MZ_TEST_CAPS", "JASPER_COUNT_DEBUG"):
+                os.environ.pop(v, None)
+        return t, capfd.readouterr().err
+    # how full the slices get with the normal capacities, then capacities 30 % below that
+    t0, log = run(None)
+    t0.close()
+    m = re.search(r"fullest sliceA (\d+) / (\d+).*fullest sliceC (\d+) / (\d+), sliceE (\d+) / (\d+)", log)
+    assert m, log[-600:]
+    f = [0.7 * int(m.group(i)) / int(m.group(i + 1)) for i in (1, 3, 5)]
+    tm, log = run("%.4f:%.4f:%.4f" % tuple(f))
+    m = re.search(r"deferred (\d+), overflow records (\d+)", log)
+    assert m and int(m.group(1)) > 10 and int(m.group(2)) > 10, "the capacities were not cut far enough to overflow: " + log[-400:]
+    os.environ["JASPER_COUNT_DIRECT"] = "1"
+    try:
+        td = KT(k, min_slots=slots)
+        td.count_bases_device(reads.data_ptr(), reads.numel())
+    finally:
+        del os.environ["JASPER_COUNT_DIRECT"]
+    assert tm.info() == td.info() and tm.histogram() == td.histogram()
+    g = genome[:100_000].cpu().numpy().tobytes().decode()
+    qs = [g[i:i + k] for i in range(0, len(g) - k, 499)]
+    assert tm.lookup(qs) == td.lookup(qs)
+    tm.close()
+    td.close()
+
+
 def test_k41_takes_the_minimizer_path_and_equals_direct_counting(KT):
     """38 <= k <= 43: keys of up to 86 bits do not fit count_part.hip's 8-byte records; with whole remainders in the tags
     (2^29 slots at k = 41) an input of that size is counted through minimizer super-k-mers by default"""
