@@ -806,7 +806,7 @@ bool Table::minimizer_geometry(uint64_t piece_bases, void *geom_out) const {
     // For 38 <= k <= 43 count_part.hip cannot run (its level-1 record holds 64 hash bits below 10 bucket bits) and this path is
     // the atomic-free one: ~50 Gk-mers/s against ~18 of the direct kernel.
     const int mode = getenv("JASPER_COUNT_PATH") ? atoi(getenv("JASPER_COUNT_PATH")) : (k >= 38 ? 2 : 1);
-    if (mode != 2 || getenv("JASPER_COUNT_DIRECT") || d.ext) return false;
+    if (mode != 2 || getenv("JASPER_COUNT_DIRECT") || d.ext || mz_off) return false;
     if (piece_bases < (8u << 20) || piece_bases >= (1ull << 32)) return false;
     const int B = d.B, s = d.s;
     if (k < 15 || k > 43 || s < 16) return false;

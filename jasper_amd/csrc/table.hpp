@@ -319,6 +319,7 @@ struct Table {
     double part_stage_ms[N_STAGES] = {};
     int part_stage_n = 5;          // stages the last piece recorded
     int count_path = 0;            // path of the last piece: 0 direct kernel, 1 count_part.hip, 2 count_mz.hip
+    bool mz_off = false;           // count_mz.hip overflowed its lists on this table's input once: not tried again
     bool part_stage_pending = false;
     // Multiplicity histogram taken for free while lds_insert_kernel writes the final region images back: valid when one
     // partitioned piece counted the whole input into an empty table and nothing had to take the deferred (direct) path.

@@ -621,7 +621,7 @@ def test_minimizer_path_overflowing_slices_take_the_direct_path(KT, capfd):
         try:
             t = KT(k, min_slots=slots)
             t.count_bases_device(reads.data_ptr(), reads.numel())
-            assert t.count_path() == 2
+            assert t.count_path() == 2 or (caps and caps.startswith("0.02"))
         finally:
             for v in ("JASPER_COUNT_PATH", "JASPER_MZ_TEST_CAPS", "JASPER_COUNT_DEBUG"):
                 os.environ.pop(v, None)
@@ -646,6 +646,11 @@ def test_minimizer_path_overflowing_slices_take_the_direct_path(KT, capfd):
     qs = [g[i:i + k] for i in range(0, len(g) - k, 499)]
     assert tm.lookup(qs) == td.lookup(qs)
     tm.close()
+    # capacities far too small even for the fallbacks: the call notices, empties the table and starts over on the other path
+    tr, log = run("0.02:0.02:0.02")
+    assert "restarting without it" in log
+    assert tr.info() == td.info() and tr.histogram() == td.histogram()
+    tr.close()
     td.close()
 
 
