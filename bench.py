@@ -364,7 +364,7 @@ def main():
         "qv_counters": list(T["qv"]), "fix_records": T["nfix"], "polish_lookups": T["lookups"],
         "polish_segments": T["segments"], "polish_chunks_redone_unsegmented": T["respeculated"],
         "roofline": {"bound": "hbm",
-                     "kernel": {2: "k-mer counting = mz_part + mz_split + mz_count + ent_split + lds_insert (even, odd) per piece (minimizer super-k-mers)",
+                     "kernel": {2: "k-mer counting = mz_part + mz_split + mz_count + split16 (entries) + lds_insert (even, odd) per piece (minimizer super-k-mers)",
                                 1: "k-mer counting = part1_kernel + part2_kernel + lds_insert_kernel (even, odd) per piece",
                                 0: "count_kernel"}[T["path"]],
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -183,7 +183,7 @@ void jasper_result_free(jasper_result *r);
 /* kernel timing for bench.py: HIP-event time of the last counting call on this table, and its launch count */
 int jasper_last_count_timing(jasper_table *t, double *kernel_ms, uint64_t *launches);
 /* the same split by kernel stage of the atomic-free counting paths, and which path the last piece took (*path):
- *   2 = minimizer super-k-mers (count_mz.hip): mz_part, mz_split (count + scan + write), mz_count, ent_split,
+ *   2 = minimizer super-k-mers (count_mz.hip): mz_part, mz_split (count + scan + write), mz_count, split16 (entries),
  *       lds_insert (even regions), lds_insert (odd), expand + deferred direct inserts, (unused)
  *   1 = one record per occurrence (count_part.hip): part1, part2, lds_insert (even), lds_insert (odd), deferred, (unused x3)
  *   0 = count_kernel (global atomics; small pieces)

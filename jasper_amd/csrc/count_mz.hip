@@ -1,29 +1,34 @@
 // count_mz.hip -- counting through minimizer super-k-mers: fewer, fatter records through the partition passes.
 //
-// count_part.hip moves one 8-byte record per k-mer OCCURRENCE through two LDS-sorted partition passes; all three of its
-// kernels are bound by on-chip work per record, so the lever is fewer records.  Consecutive k-mers of a
-// read share their canonical minimizer (the smallest hashed canonical m-mer inside the k-mer) for ~10 positions; such a
-// run -- a super-k-mer -- is ONE 16-byte record holding its k-1+n bases 2-bit packed, and all its k-mers go to the same
-// minimizer bucket whatever the strand they were read from.  The pipeline:
+// count_part.hip moves one 8-byte record per k-mer OCCURRENCE through two LDS-sorted partition passes.  Consecutive k-mers of a
+// read share their canonical minimizer (the smallest hashed canonical m-mer inside the k-mer) for ~12 positions; such a run --
+// a super-k-mer -- is ONE 16-byte record holding its k-1+n bases 2-bit packed, and all its k-mers go to the same minimizer
+// bucket whatever the strand they were read from.  The pipeline:
 //
 //   mz_part_kernel     bases -> hashed canonical m-mers (LDS) -> sliding minimum over the W = k-m+1 m-mers of each k-mer ->
 //                      runs of equal bucket -> super-k-mer records, written straight into the block's own slice of each of
 //                      the 2^pc coarse bucket lists (cursor = LDS atomic; 256 open 128-B lines per block stay in L2).
-//   mz_split_*         coarse list -> 2^pf fine lists (count pass, one-block scan, write pass: exact sizes, no slack).
-//   mz_count_kernel    one workgroup per fine bucket (~16 K k-mer occurrences, ~2.4 K distinct): every k-mer of every
-//                      record is rolled out, hashed with the table's mix() and added to a 4096-slot LDS hash table
-//                      (LDS compare-and-swap / add); the table is then emitted as (hash, count) ENTRIES -- ~7x fewer than
-//                      occurrences at 30x coverage -- into the block's slice of each of 2^pe1 lists by top hash bits.
-//                      A k-mer that finds no room in LDS leaves as a (hash, 1) entry: entries are partial counts, the
-//                      next stage adds them up, so a crowded bucket costs compression, never counts.
-//   ent_split_kernel   entry list -> 2^pe2 region lists (region = 2^rbits consecutive table slots, as in count_part.hip).
+//   mz_split_count_kernel, mz_scan1/2, split16_kernel<0>
+//                      coarse list -> 2^pf fine lists: count pass, scan, write pass (exact sizes, all records back to back;
+//                      the write pass orders a tile by key inside LDS so that a list's line is filled by consecutive stores).
+//   mz_count_kernel    a workgroup streams its share of that array: records are made UNIQUE in an LDS table first (a super-k-mer
+//                      inside a read is cut out by the genome's minimizers, so every read covering the place yields the same
+//                      16 bytes: 34 % of the records are left at 30x), then each unique record's k-mers are rolled out once,
+//                      hashed with the table's mix() and added with the record's copies to an LDS k-mer table, which leaves as
+//                      (hash, count) ENTRIES into the block's slice of each of 2^pe1 lists by top hash bits.  A k-mer that
+//                      finds no room leaves as an entry of its own: entries are partial counts, the next stage adds them up.
+//   split16_kernel<1>  entry list -> 2^pe2 region lists (region = 2^rbits consecutive table slots, as in count_part.hip).
 //   lds_insert_kernel  (count_part.hip, entry form) region image in LDS <- entries, image written back, fused histogram.
 //   Anything that overflows a slice goes to the deferred list (entries) or is expanded by mz_expand_kernel (records) and
-//   takes the direct atomic path after the last image has been written.
+//   takes the direct atomic path after the last image has been written; a call that overflows even those starts over on the
+//   other counting path (Table::count_device).
 //
 // The table layout, tags and probe order are untouched: lookups, histogram, export, growth and the polisher do not know
 // which path filled the table.  Semantics preserved: JF::include/jellyfish/mer_iterator.hpp:53-81 (which windows are
 // counted, canonical = min(mer, revcomp)), JF::include/jellyfish/large_hash_array.hpp:291 (add 1 per occurrence).
+// Where it stands: 19.8 ms for cfg 2 against 17.1 ms of count_part.hip (counting is bound by integer issue, not
+// by the bytes this path saves), so k <= 37 keeps count_part.hip; 38 <= k <= 43, which count_part.hip cannot take, count here
+// by default at 2.6x the rate of the direct kernel.
 #include "table.hpp"
 #include <algorithm>
 #include <cmath>
@@ -253,9 +258,10 @@ __global__ __launch_bounds__(MZ_TH) void mz_part_kernel(const uint8_t *__restric
 // grid (nsubP, 2^pc): block (x, c) reads slices x, x+nsubP, ... of coarse list c.  WRITE = 0: counts per fine key;
 // WRITE = 1: records to base[..] + running cursor.
 constexpr int SP_MAXSL = 512;            // slices a split block reads as one concatenated list
-template <int WRITE>
-__global__ __launch_bounds__(256) void mz_split_kernel(const ulonglong2 *__restrict__ outA, const unsigned int *__restrict__ cntA, MzGeom G,
-                                                        unsigned int *__restrict__ cntP, const unsigned int *__restrict__ baseP, ulonglong2 *__restrict__ out2) {
+// count pass: grid (nsubP, 2^pc): block (x, c) reads slices x, x+nsubP, ... of coarse list c as ONE list (prefix of their
+// lengths in LDS, so that all loads of the loop are independent) and counts its records per fine key
+__global__ __launch_bounds__(256) void mz_split_count_kernel(const ulonglong2 *__restrict__ outA, const unsigned int *__restrict__ cntA, MzGeom G,
+                                                              unsigned int *__restrict__ cntP) {
     __shared__ unsigned int s_cur[1024];
     __shared__ unsigned int s_pref[SP_MAXSL + 1];
     const int t = threadIdx.x;
@@ -263,8 +269,7 @@ __global__ __launch_bounds__(256) void mz_split_kernel(const ulonglong2 *__restr
     const int nf = 1 << G.pf;
     const uint32_t fmask = (uint32_t)nf - 1u;
     const uint64_t row = ((uint64_t)c * G.nsubP + x) << G.pf;
-    for (int i = t; i < nf; i += 256) s_cur[i] = WRITE ? baseP[row + i] : 0u;
-    // my slices x, x+nsubP, ... as ONE list: prefix of their lengths (all loads of the loop below are then independent)
+    for (int i = t; i < nf; i += 256) s_cur[i] = 0u;
     const uint32_t nmine = (G.nblkA - x + G.nsubP - 1) / G.nsubP;
     if (t < 64) {
         unsigned int carry = 0;
@@ -284,30 +289,24 @@ __global__ __launch_bounds__(256) void mz_split_kernel(const ulonglong2 *__restr
     const ulonglong2 *src0 = outA + ((uint64_t)c * G.nblkA + x) * G.capA;      // slice x; slice x + j*nsubP is j*nsubP*capA further
     uint32_t sl[4] = {0, 0, 0, 0};
     for (uint32_t i0 = 0; i0 < total; i0 += 4 * 256) {
-        ulonglong2 r[4];
+        unsigned long long lo[4];
         bool have[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = i0 + (uint32_t)u * 256 + t;
             have[u] = i < total;
-            r[u] = make_ulonglong2(0ull, 0ull);
+            lo[u] = 0ull;
             if (have[u]) {
                 while (s_pref[sl[u] + 1] <= i) ++sl[u];
-                r[u] = src0[(uint64_t)sl[u] * G.nsubP * G.capA + (i - s_pref[sl[u]])];
+                lo[u] = src0[(uint64_t)sl[u] * G.nsubP * G.capA + (i - s_pref[sl[u]])].x;
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (!have[u]) continue;
-            const uint32_t f = (uint32_t)(r[u].x >> 5) & fmask;
-            if (WRITE) out2[atomicAdd(&s_cur[f], 1u)] = r[u];
-            else atomicAdd(&s_cur[f], 1u);
-        }
+        for (int u = 0; u < 4; ++u)
+            if (have[u]) atomicAdd(&s_cur[(uint32_t)(lo[u] >> 5) & fmask], 1u);
     }
-    if (!WRITE) {
-        __syncthreads();
-        for (int i = t; i < nf; i += 256) cntP[row + i] = s_cur[i];
-    }
+    __syncthreads();
+    for (int i = t; i < nf; i += 256) cntP[row + i] = s_cur[i];
 }
 // Exclusive scan of cntP in the order (coarse, fine, sub-block) -> baseP (same indexing as cntP) and the fine lists'
 // boundaries startF[F], F = coarse << pf | fine, startF[NF] = total.  mz_scan1: one block per coarse bucket scans its
@@ -603,78 +602,14 @@ __global__ __launch_bounds__(MC_TH) void mz_count_kernel(const ulonglong2 *__res
     }
 }
 
-// ---- entry list -> 2^pe2 region lists -------------------------------------------------------------------------------------
-// grid (nsubE, 2^pe1): block (x, e1) reads slices x, x+nsubE, ... of entry list e1 and appends to ITS slice of each of the
-// list's 2^pe2 region lists; cursors are LDS atomics, the <= 1024 open lines of a block are combined in L2.
-constexpr int ES_TH = 1024;
-__global__ __launch_bounds__(ES_TH) void ent_split_kernel(const ulonglong2 *__restrict__ outC, const unsigned int *__restrict__ cntC, TableDev T, MzGeom G,
-                                                           ulonglong2 *__restrict__ outE, unsigned int *__restrict__ cntE, unsigned long long *__restrict__ deferred,
-                                                           unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
-    __shared__ unsigned int s_cur[1024];
-    __shared__ unsigned int s_pref[SP_MAXSL + 1];
-    const int t = threadIdx.x;
-    const uint32_t e1 = blockIdx.y, x = blockIdx.x;
-    const int n2 = 1 << G.pe2;
-    const int sh = T.B - G.pe1 - G.pe2;
-    for (int i = t; i < n2; i += ES_TH) s_cur[i] = 0;
-    const uint32_t nmine = (G.nblkC - x + G.nsubE - 1) / G.nsubE;                 // slices x, x+nsubE, ... as one list
-    if (t < 64) {
-        unsigned int carry = 0;
-        for (uint32_t j0 = 0; j0 < nmine; j0 += 64) {
-            const uint32_t j = j0 + t;
-            const unsigned int v = j < nmine ? cntC[(uint64_t)e1 * G.nblkC + x + (uint64_t)j * G.nsubE] : 0u;
-            unsigned int inc = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if (t >= o) inc += u; }
-            if (j < nmine) s_pref[j] = carry + inc - v;
-            carry += __shfl(inc, 63);
-        }
-        if (t == 0) s_pref[nmine] = carry;
-    }
-    __syncthreads();
-    const uint32_t total = s_pref[nmine];
-    const ulonglong2 *src0 = outC + ((uint64_t)e1 * G.nblkC + x) * G.capC;
-    uint32_t sl[4] = {0, 0, 0, 0};
-    for (uint32_t i0 = 0; i0 < total; i0 += 4 * ES_TH) {
-        ulonglong2 r[4];
-        bool have[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = i0 + (uint32_t)u * ES_TH + t;
-            have[u] = i < total;
-            r[u] = make_ulonglong2(0ull, 0ull);
-            if (have[u]) {
-                while (s_pref[sl[u] + 1] <= i) ++sl[u];
-                r[u] = src0[(uint64_t)sl[u] * G.nsubE * G.capC + (i - s_pref[sl[u]])];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (!have[u]) continue;
-            const ulonglong2 e = r[u];
-            const uint64_t hhi = e.y & 0xFFFFFFFFull;
-            const uint32_t e2 = top_bits(hhi, e.x, sh) & (uint32_t)(n2 - 1);
-            const unsigned int pos = atomicAdd(&s_cur[e2], 1u);
-            const uint64_t region = ((uint64_t)e1 << G.pe2) + e2;
-            if (pos < G.capE) outE[(region * G.nsubE + x) * G.capE + pos] = e;
-            else {
-                const unsigned long long di = atomicAdd(deferred_n, 1ull);
-                if (di < deferred_cap) { deferred[3 * di] = hhi; deferred[3 * di + 1] = e.x; deferred[3 * di + 2] = e.y >> 32; }
-                else atomicExch(&T.stats[ST_FATAL], 1ull);
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = t; i < n2; i += ES_TH) cntE[((((uint64_t)e1 << G.pe2) + i) * G.nsubE) + x] = s_cur[i] < G.capE ? s_cur[i] : G.capE;
-}
-
 // ---- both second-level splits, with the copy-out staged through LDS ---------------------------------------------------------
-// Writing every 16-byte record straight to its list (the kernels above) leaves each of the block's up-to-1024 open 128-byte
-// lines to be filled by eight visits spread over the whole run of the block, and with ~2000 workgroups resident that is far
-// more open lines than the L2s hold: the lines leave half filled (the write pass of mz_split took 4.7x its count pass for the
-// same reads).  Here a tile of ST_TILE records is first ordered by key inside LDS (rank from a returning LDS atomic, offsets
+// Writing every 16-byte record straight to its list (as mz_part can: 256 lists) leaves each of the block's up-to-1024 open
+// 128-byte lines to be filled by eight visits spread over the whole run of the block, and with ~2000 workgroups resident that
+// is far more open lines than the L2s hold: the lines leave half filled (such a write pass took 1.7 ms where this one takes
+// 1.1, the entry split 2.3 instead of 1.7).  Here a tile of ST_TILE records is first ordered by key inside LDS (rank from a returning LDS atomic, offsets
 // from a block scan -- part2_kernel's scheme), and lane t then writes all the tile's records of key t one after the other:
 // a list's line is filled by consecutive stores within a few hundred cycles.
+// grid (nsub, lists): block (x, b) reads slices x, x+nsub, ... of list b as one concatenated list.
 // KIND 0: super-k-mer records, key = fine bucket field, destination = exact positions (baseP, from the count pass);
 // KIND 1: (hash, count) entries, key = next pe2 hash bits, destination = the block's slice of each region list (capE, deferred list).
 constexpr int ST_TH = 1024, ST_TILE = 4096;
@@ -891,19 +826,17 @@ int Table::launch_count_minimizer(const uint8_t *d_piece, uint64_t len, uint64_t
 #undef JK_A
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_stage_t[1], stream));
-    hipLaunchKernelGGL(mz_split_kernel<0>, dim3(G.nsubP, nc), dim3(256), 0, stream, bufX, cntA, G, cntP, baseP, bufY);
+    hipLaunchKernelGGL(mz_split_count_kernel, dim3(G.nsubP, nc), dim3(256), 0, stream, bufX, cntA, G, cntP);
     hipLaunchKernelGGL(mz_scan1_kernel, dim3(nc), dim3(256), 0, stream, cntP, baseP, ctot, G);
     hipLaunchKernelGGL(mz_scan2_kernel, dim3(64), dim3(256), 0, stream, baseP, ctot, startF, G);
-    if (getenv("JASPER_MZ_DIRECT_SPLIT")) hipLaunchKernelGGL(mz_split_kernel<1>, dim3(G.nsubP, nc), dim3(256), 0, stream, bufX, cntA, G, cntP, baseP, bufY);
-    else hipLaunchKernelGGL(split16_kernel<0>, dim3(G.nsubP, nc), dim3(ST_TH), 0, stream, bufX, cntA, d, G, baseP, bufY, (unsigned int *)nullptr, defer_e, defer_n, deferred_cap);
+    hipLaunchKernelGGL(split16_kernel<0>, dim3(G.nsubP, nc), dim3(ST_TH), 0, stream, bufX, cntA, d, G, baseP, bufY, (unsigned int *)nullptr, defer_e, defer_n, deferred_cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_stage_t[2], stream));
     if (k > 32) hipLaunchKernelGGL(mz_count_kernel<true>, dim3(G.nblkC), dim3(MC_TH), 0, stream, bufY, startF + NF, d, G, bufX, cntC, defer_e, defer_n, deferred_cap);
     else hipLaunchKernelGGL(mz_count_kernel<false>, dim3(G.nblkC), dim3(MC_TH), 0, stream, bufY, startF + NF, d, G, bufX, cntC, defer_e, defer_n, deferred_cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_stage_t[3], stream));
-    if (getenv("JASPER_MZ_DIRECT_SPLIT")) hipLaunchKernelGGL(ent_split_kernel, dim3(G.nsubE, ne1), dim3(ES_TH), 0, stream, bufX, cntC, d, G, bufY, cntE, defer_e, defer_n, deferred_cap);
-    else hipLaunchKernelGGL(split16_kernel<1>, dim3(G.nsubE, ne1), dim3(ST_TH), 0, stream, bufX, cntC, d, G, (const unsigned int *)nullptr, bufY, cntE, defer_e, defer_n, deferred_cap);
+    hipLaunchKernelGGL(split16_kernel<1>, dim3(G.nsubE, ne1), dim3(ST_TH), 0, stream, bufX, cntC, d, G, (const unsigned int *)nullptr, bufY, cntE, defer_e, defer_n, deferred_cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_stage_t[4], stream));
     if (insert_entry_lists(bufY, cntE, G.capE, G.nsubE, G.pe1 + G.pe2, G.rbits, defer_e, defer_n, deferred_cap, &ev_stage_t[5], err)) return -1;   // records ev 5, 6

@@ -314,7 +314,7 @@ struct Table {
     int finish_deferred(unsigned long long *defer_e, unsigned long long *defer_n, uint64_t deferred_cap, std::string &err);   // deferred list -> direct path
     static constexpr int N_STAGES = 8;
     hipEvent_t ev_stage_t[N_STAGES + 1] = {};   // stage boundaries of the last partitioned / minimizer piece
-    // count_part.hip: part1, part2, lds even, lds odd, deferred;  count_mz.hip: mz_part, mz_split (count+scan+write), mz_count, ent_split,
+    // count_part.hip: part1, part2, lds even, lds odd, deferred;  count_mz.hip: mz_part, mz_split (count+scan+write), mz_count, split16 (entries),
     // lds even, lds odd, expand + deferred
     double part_stage_ms[N_STAGES] = {};
     int part_stage_n = 5;          // stages the last piece recorded

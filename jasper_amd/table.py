@@ -202,7 +202,7 @@ class KmerTable:
         check(self._L.jasper_last_count_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
-    STAGE_NAMES = {2: ("mz_part_kernel", "mz_split_kernels", "mz_count_kernel", "ent_split_kernel", "lds_insert_kernel_even", "lds_insert_kernel_odd",
+    STAGE_NAMES = {2: ("mz_part_kernel", "mz_split_kernels", "mz_count_kernel", "split16_entries_kernel", "lds_insert_kernel_even", "lds_insert_kernel_odd",
                        "expand_and_deferred_kernels"),
                    1: ("part1_kernel", "part2_kernel", "lds_insert_kernel_even", "lds_insert_kernel_odd", "deferred_import3_kernel"),
                    0: ()}
