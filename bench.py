@@ -322,7 +322,7 @@ def main():
     # HBM bytes of the counting pipeline per launch, from the PMC passes committed with the same build (rocprofv3 cannot
     # collect FETCH_SIZE / WRITE_SIZE inside this process); null when that file is absent
     traffic, traffic_src = None, None
-    for rnd in ("round2", "round1"):
+    for rnd in (("round2", "round1") if (world == 1 and a.genome_mb == 47.0) else ()):      # (the committed counters are those of the N=1 configs[1] run)
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", rnd, "bench_hbm_counters.json")))
             cp = pj["counting_pipeline"]
