@@ -247,10 +247,14 @@ constexpr size_t p1_lds(int th) { return (size_t)th * PT_GROUP * 8 + (size_t)(3 
 // loaded it, with wave-level "match any" ballots to share the cursor atomics: ~100 instructions per record, and every
 // store instruction touched ~64 different lines -- the kernel was instruction-bound at 2.3 TB/s.)
 constexpr int P2_MAXSL = 512;          // level-1 slices per bucket (= nblk1 <= 512)
+// OWN (the multi-GPU exchange, count_exchange below): a bucket is split 2^p2 * nown ways, by (owner_of(hash), next p2
+// hash bits), and the lists are laid out owner-major -- list ((o * 2^p1 + b1) << p2) + b2 -- so that everything owner o
+// is to receive is ONE contiguous block of out2 / cnt2: the region lists of o's own table, ready for lds_insert_kernel.
+template <bool OWN>
 __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__restrict__ out1, const unsigned int *__restrict__ cnt1, TableDev T,
                                                             PartGeom G, uint64_t *__restrict__ out2, unsigned int *__restrict__ cnt2,
                                                             unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
-                                                            uint64_t deferred_cap) {
+                                                            uint64_t deferred_cap, uint32_t nown) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_raw);                               // PT_TILE records
     unsigned int *s_cur = reinterpret_cast<unsigned int *>(s_raw + (size_t)PT_TILE * 8);   // PT_MAXBUCKETS slice cursors (per b1)
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
     unsigned int *s_wsum = s_off + PT_MAXBUCKETS + 1;                                      // 16 wave totals
     unsigned int *s_pref = s_wsum + 16;                                                    // P2_MAXSL+1 prefix of my slices' lengths
     const int t = threadIdx.x;
-    const int nb2 = 1 << G.p2;
+    const int nb2 = OWN ? (int)(nown << G.p2) : 1 << G.p2;
     const int shift2 = G.recbits - G.p2;               // the p2 bits right below the level-1 bucket bits
     const uint32_t nmine = (G.nblk1 - blockIdx.x + G.nblk2 - 1) / G.nblk2;                 // slices x, x+nblk2, ... < nblk1
     for (uint32_t b1 = blockIdx.y; b1 < (1u << G.p1); b1 += gridDim.y) {
@@ -305,7 +309,11 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
 #pragma unroll
             for (int j = 0; j < PT_GROUP; ++j) {
                 if (br[j] == 0xFFFFFFFFu) continue;
-                const uint32_t b2 = (uint32_t)(rec[j] >> shift2) & (uint32_t)(nb2 - 1);
+                uint32_t b2;
+                if constexpr (OWN) {
+                    b2 = G.p2 ? (uint32_t)(rec[j] >> shift2) & ((1u << G.p2) - 1u) : 0u;
+                    b2 |= owner_of(hash_of(b1, rec[j], G.recbits), nown) << G.p2;
+                } else b2 = (uint32_t)(rec[j] >> shift2) & (uint32_t)(nb2 - 1);
                 br[j] = (b2 << 16) | (atomicAdd(&s_cnt[b2], 1u) & 0xFFFFu);   // a tile holds 2^14 records
             }
             lds_barrier();
@@ -337,7 +345,8 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
                 const int g = t / lpb, r = t % lpb;
                 for (int b2 = g; b2 < nb2; b2 += PT_THREADS / lpb) {
                     const unsigned int off = s_off[b2], cnt = s_cnt[b2], cur = s_cur[b2];
-                    const uint64_t region = ((uint64_t)b1 << G.p2) + (uint64_t)b2;
+                    const uint64_t region = OWN ? ((((uint64_t)(b2 >> G.p2) << G.p1) + b1) << G.p2) + (uint64_t)(b2 & ((1 << G.p2) - 1))
+                                                : ((uint64_t)b1 << G.p2) + (uint64_t)b2;
                     uint64_t *dst = out2 + (region * G.nblk2 + blockIdx.x) * G.cap2;
                     for (unsigned int q = r; q < cnt; q += lpb) {
                         const unsigned int pos = cur + q;
@@ -351,8 +360,10 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
             for (int i = t; i < nb2; i += PT_THREADS) { s_cur[i] += s_cnt[i]; s_cnt[i] = 0; }
             lds_barrier();
         }
-        for (int i = t; i < nb2; i += PT_THREADS)
-            cnt2[(((uint64_t)b1 << G.p2) + i) * G.nblk2 + blockIdx.x] = s_cur[i] < G.cap2 ? s_cur[i] : G.cap2;
+        for (int i = t; i < nb2; i += PT_THREADS) {
+            const uint64_t region = OWN ? ((((uint64_t)(i >> G.p2) << G.p1) + b1) << G.p2) + (uint64_t)(i & ((1 << G.p2) - 1)) : ((uint64_t)b1 << G.p2) + (uint64_t)i;
+            cnt2[region * G.nblk2 + blockIdx.x] = s_cur[i] < G.cap2 ? s_cur[i] : G.cap2;
+        }
         lds_barrier();
     }
 }
@@ -363,11 +374,16 @@ constexpr size_t P2_LDS = (size_t)PT_TILE * 8 + (size_t)(3 * PT_MAXBUCKETS + 1 +
 constexpr int LDS_HBINS = 1024;        // histogram bins kept in LDS by lds_insert_kernel (higher multiplicities are rare: global atomics)
 // ENT = false: lists of 8-byte records (count_part.hip: low hash bits, one occurrence each);  ENT = true: lists of 16-byte
 // (hash, count) entries { hash.lo, hash.hi | count << 32 } (count_mz.hip) -- the whole hash is there, the count is added.
-template <bool ENT>
+// MULTI (count_exchange below): the region's slices come from nsrc senders, each of which laid out ITS lists of all my
+// regions as one block -- slice x of region r = sender x / (nsl/nsrc), its slice x % (nsl/nsrc): list index
+// ((sender * nregions + r) * (nsl/nsrc) + that).  The slices are short (1/nsrc of a region's records each), so they are
+// read as ONE concatenated list (prefix of their lengths in LDS) to keep every lane busy.
+constexpr int LI_MAXSL = 64;           // slices per region in the MULTI form
+template <bool ENT, bool MULTI = false>
 __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__restrict__ lists_v, const unsigned int *__restrict__ cnt, uint32_t cap,
                                                                  uint32_t nsl, TableDev T, PartGeom G, uint32_t nregions, uint32_t parity, int fresh_table,
                                                                  unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
-                                                                 uint64_t deferred_cap, unsigned long long *__restrict__ histo) {
+                                                                 uint64_t deferred_cap, unsigned long long *__restrict__ histo, uint32_t nsrc) {
     extern __shared__ __align__(16) unsigned long long s_img[];    // 2 words per slot: (R + halo) slots
     using rec_t = typename std::conditional<ENT, ulonglong2, uint64_t>::type;
     const rec_t *lists = reinterpret_cast<const rec_t *>(lists_v);
@@ -386,10 +402,24 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__re
         for (int i = t; i < LDS_HBINS; i += PT_THREADS) s_bins[i] = 0;
         lds_barrier();
     }
+    unsigned int *s_pref = s_bins + LDS_HBINS;                     // MULTI (LI_MAXSL + 1 words): exclusive prefix of the region's slice lengths
+    const uint32_t per_src = MULTI ? nsl / nsrc : nsl;
+    auto slice_of = [&](uint32_t region, uint32_t x) -> uint64_t {
+        if constexpr (MULTI) return ((uint64_t)(x / per_src) * nregions + region) * per_src + x % per_src;
+        else return (uint64_t)region * nsl + x;
+    };
     for (uint32_t region = blockIdx.x * 2 + parity; region < nregions; region += gridDim.x * 2) {
         uint32_t total = 0;
-        for (uint32_t x = 0; x < nsl; ++x) total += cnt[(uint64_t)region * nsl + x];
+        for (uint32_t x = 0; x < nsl; ++x) total += cnt[slice_of(region, x)];
         if (total == 0 && !fresh_table && !histo) continue;                  // block-uniform (a fresh table must still be zeroed here)
+        if constexpr (MULTI) {
+            if (t == 0) {
+                unsigned int run = 0;
+                for (uint32_t x = 0; x < nsl; ++x) { s_pref[x] = run; run += cnt[slice_of(region, x)]; }
+                s_pref[nsl] = run;
+            }
+            // (the barrier after the image set-up below orders this before the first use)
+        }
         const uint64_t first = (uint64_t)region << G.rbits;        // first slot of the region
         const uint64_t b1 = region >> G.p2;
         auto insert = [&](rec_t recv) {
@@ -431,7 +461,7 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__re
         // the first 16 records per lane of the region's first slice (a region holds ~16 K, and normally in ONE slice) are
         // requested before the image is set up: one latency instead of four, overlapped with the set-up
         constexpr int PF = 4;
-        const uint32_t nrec0 = cnt[(uint64_t)region * nsl];
+        const uint32_t nrec0 = MULTI ? 0u : cnt[(uint64_t)region * nsl];
         const rec_t *src0 = lists + (uint64_t)region * nsl * cap;
         rec_t pre[PF];
 #pragma unroll
@@ -450,6 +480,24 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__re
 #pragma unroll
         for (int u = 0; u < PF; ++u)
             if ((uint32_t)u * PT_THREADS + t < nrec0) insert(pre[u]);
+        if constexpr (MULTI) {
+            for (uint32_t i0 = 0; i0 < total; i0 += 4 * PT_THREADS) {
+                rec_t recs[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t i = i0 + u * PT_THREADS + t;
+                    recs[u] = rec_t{};
+                    if (i < total) {
+                        uint32_t x = 0;
+                        while (s_pref[x + 1] <= i) ++x;                           // (a handful of slices)
+                        recs[u] = lists[slice_of(region, x) * cap + (i - s_pref[x])];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * PT_THREADS + t < total) insert(recs[u]);
+            }
+        } else
         for (uint32_t x = 0; x < nsl; ++x) {
             const uint32_t nrec = x == 0 ? nrec0 : cnt[(uint64_t)region * nsl + x];
             const rec_t *src = src0 + (uint64_t)x * cap;
@@ -502,7 +550,7 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     PartGeom &G = *reinterpret_cast<PartGeom *>(geom_out);
     if (getenv("JASPER_COUNT_DIRECT")) return false;
     if (d.ext) return false;                              // wide remainders: the LDS images hold tags only
-    if (piece_bases < (8u << 20)) return false;          // small pieces: the direct kernel is already latency-hidden
+    if (piece_bases < (getenv("JASPER_PART_TEST_SMALL") ? 1024u : (8u << 20))) return false;   // small pieces: the direct kernel is already latency-hidden (the env switch: tests)
     const int B = d.B, s = d.s;
     const int need_p1 = B > 64 ? B - 64 : 0;              // records are 8 bytes
     int p1 = std::max(need_p1, (s - RG_MAXBITS + 1) / 2);
@@ -570,10 +618,10 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
         dim3 grid(G.nblk2, std::min<uint32_t>(nb1, 2048));
         static bool attr2_set = false;
         if (!attr2_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr2_set = true;
         }
-        hipLaunchKernelGGL(part2_kernel, grid, dim3(PT_THREADS), P2_LDS, stream, out1, cnt1, d, G, out2, cnt2, defer_e, defer_n, deferred_cap);
+        hipLaunchKernelGGL(part2_kernel<false>, grid, dim3(PT_THREADS), P2_LDS, stream, out1, cnt1, d, G, out2, cnt2, defer_e, defer_n, deferred_cap, 1u);
         HIPCHK(hipGetLastError());
         lists = out2; lcnt = cnt2; lcap = G.cap2; nsl = G.nblk2;
     }
@@ -595,7 +643,7 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
         if (!(nregions == 1 && parity == 1)) {
             const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
             hipLaunchKernelGGL(lds_insert_kernel<false>, dim3(nblk), dim3(PT_THREADS), lds, stream, (const void *)lists, lcnt, lcap, nsl, d, G, nregions, parity, fresh, defer_e,
-                               defer_n, deferred_cap, histo);
+                               defer_n, deferred_cap, histo, 1u);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(ev_stage_t[3 + parity], stream));
@@ -641,7 +689,7 @@ int Table::insert_entry_lists(const void *lists, const unsigned int *cnt, uint32
         if (!(nregions == 1 && parity == 1)) {
             const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
             hipLaunchKernelGGL(lds_insert_kernel<true>, dim3(nblk), dim3(PT_THREADS), lds, stream, lists, cnt, cap, nsl, d, G, nregions, parity, fresh, defer_e, defer_n,
-                               deferred_cap, histo);
+                               deferred_cap, histo, 1u);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(ev[parity], stream));
@@ -654,6 +702,166 @@ int Table::finish_deferred(unsigned long long *defer_e, unsigned long long *defe
     unsigned long long *histo = histo_request ? d_histo : nullptr;
     hipLaunchKernelGGL(import3_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, deferred_cap, d, histo ? histo + 10002 : nullptr);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ==================================================================================================
+// count_exchange: the partition pipeline as the multi-GPU exchange (role: JF::jellyfish/merge_files.cc:44-96 -- there
+// every process counts into a table of its own and the tables are merged; here no rank ever builds a table of its own reads).
+//   every rank    xchg_partition   part1 -> part2<OWN>: its reads become region lists, grouped by the OWNER of the key;
+//                                  what owner o is to get is one contiguous block of the send buffers (records + slice counts)
+//   the caller    one all_to_all of the blocks (8 B per k-mer occurrence + slack), dist.count_sharded
+//   every owner   xchg_insert      lds_insert<MULTI> x 2 straight into its shard, fused histogram, deferred records
+// All ranks must derive the same geometry: from the shard geometry (one for all owners), the number of owners and
+// piece_max = the longest piece any rank partitions in this round.
+static bool xchg_geometry(const Table &t, uint64_t piece_max, uint32_t nown, PartGeom &G) {
+    if (nown < 2 || nown > MAX_SHARDS) return false;
+    alignas(16) char raw[64];
+    if (!t.partition_geometry(piece_max, raw)) return false;
+    G = *reinterpret_cast<const PartGeom *>(raw);
+    if (((uint64_t)nown << G.p2) > (uint64_t)PT_MAXBUCKETS) return false;       // (a third pass would be needed: not built)
+    if (G.th1 != 1024) return false;
+    const uint32_t nb1 = 1u << G.p1;
+    G.nblk2 = nb1 >= 256 ? 1u : std::min<uint32_t>(G.nblk1, 8u);
+    if (nown * G.nblk2 > (uint32_t)LI_MAXSL) return false;
+    G.cap2 = list_cap((double)piece_max / ((double)nb1 * (double)((uint64_t)nown << G.p2) * (double)G.nblk2));
+    return true;
+}
+
+int Table::xchg_plan(uint64_t piece_max, uint32_t nown, uint64_t out[8], std::string &err) {
+    (void)err;
+    PartGeom G;
+    if (!xchg_geometry(*this, piece_max, nown, G)) return 1;
+    const uint64_t lists_per_owner = (uint64_t)1 << (G.p1 + G.p2);
+    out[0] = lists_per_owner * G.nblk2 * G.cap2;               // records (8 B) per owner block
+    out[1] = lists_per_owner * G.nblk2;                        // slice counts (4 B) per owner block
+    out[2] = std::max<uint64_t>(1u << 16, piece_max / 16);     // deferred entries (24 B) a rank may produce
+    out[3] = (uint64_t)G.p1; out[4] = (uint64_t)G.p2; out[5] = (uint64_t)G.rbits; out[6] = G.nblk2; out[7] = G.cap2;
+    return 0;
+}
+
+// d_defer: 64-byte header (word 0 = number of entries) + defer_cap entries of 3 words (hash.hi, hash.lo, 1)
+int Table::xchg_partition(const uint8_t *d_bases, uint64_t n, uint64_t pos, uint64_t end, uint64_t piece_max, uint32_t nown, void *d_send, void *d_send_cnt,
+                          void *d_defer, uint64_t defer_cap, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    PartGeom G;
+    if (!xchg_geometry(*this, piece_max, nown, G)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
+    if (end > n) end = n;
+    const uint32_t nb1 = 1u << G.p1;
+    const uint64_t lists = ((uint64_t)nown << (G.p1 + G.p2));
+    unsigned long long *defer_n = (unsigned long long *)d_defer, *defer_e = defer_n + 8;
+    HIPCHK(hipMemsetAsync(defer_n, 0, 64, stream));
+    for (int i = 0; i <= N_STAGES; ++i) if (!ev_stage_t[i]) HIPCHK(hipEventCreate(&ev_stage_t[i]));
+    count_path = 3;
+    part_stage_n = 5;
+    HIPCHK(hipEventRecord(ev_stage_t[0], stream));
+    if (pos >= end) {                                          // nothing of mine in this round: empty lists
+        HIPCHK(hipMemsetAsync(d_send_cnt, 0, lists * G.nblk2 * 4, stream));
+        HIPCHK(hipEventRecord(ev_stage_t[1], stream));
+        HIPCHK(hipEventRecord(ev_stage_t[2], stream));
+        return 0;
+    }
+    const uint64_t halo = (uint64_t)(k - 1);
+    const uint64_t misalign = reinterpret_cast<uintptr_t>(d_bases) & 15;
+    uint64_t start = pos >= halo ? pos - halo : 0;
+    const uint64_t a = (start + misalign) & 15;
+    start = start >= a ? start - a : 0;
+    const uint64_t len = end - start, emit_from = pos - start;
+    if (end - pos > piece_max) { err = "count exchange: piece longer than the agreed maximum"; return -1; }
+    const size_t n_cnt1 = (size_t)nb1 * G.nblk1;
+    uint64_t *out1 = (uint64_t *)workspace(WS_COUNT + 0, n_cnt1 * G.cap1 * 8, err);
+    unsigned int *cnt1 = (unsigned int *)workspace(WS_COUNT + 2, (n_cnt1 + 4) * 4, err);
+    if (!out1 || !cnt1) return -2;
+    const uint64_t ntiles = (len + (uint64_t)PT_TILE - 1) / (uint64_t)PT_TILE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    if (k > 32) hipLaunchKernelGGL((part1_kernel<true, 1024>), dim3(G.nblk1), dim3(1024), p1_lds(1024), stream, d_bases + start, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, defer_cap);
+    else hipLaunchKernelGGL((part1_kernel<false, 1024>), dim3(G.nblk1), dim3(1024), p1_lds(1024), stream, d_bases + start, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, defer_cap);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ev_stage_t[1], stream));
+    hipLaunchKernelGGL(part2_kernel<true>, dim3(G.nblk2, std::min<uint32_t>(nb1, 2048)), dim3(PT_THREADS), P2_LDS, stream, out1, cnt1, d, G, (uint64_t *)d_send,
+                       (unsigned int *)d_send_cnt, defer_e, defer_n, defer_cap, nown);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ev_stage_t[2], stream));
+    return 0;
+}
+
+// deferred records of ALL ranks (they are rare): the ones this rank owns go in through the direct path
+__global__ __launch_bounds__(256) void import3_owned_kernel(const unsigned long long *__restrict__ entries, uint64_t n, TableDev T, uint32_t nown, uint32_t self,
+                                                            unsigned long long *__restrict__ histo_incomplete) {
+    unsigned long long fresh = 0;
+    bool any = false;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const u128 h = mk(entries[3 * i], entries[3 * i + 1]);
+        if (owner_of(h, nown) != self) continue;
+        any = true;
+        fresh += table_add_or_spill(T, h, entries[3 * i + 2]);
+    }
+    if (any && histo_incomplete) *histo_incomplete = 1ull;       // counts changed after the fused histogram
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+}
+
+// d_recv / d_recv_cnt: block src = what rank src's xchg_partition put into ITS block `self`.  whole_input: these lists are
+// everything that goes into this (empty) shard -> the multiplicity histogram is taken on the way out.
+int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piece_max, uint32_t nown, uint32_t self, const void *d_defer_all, uint64_t n_defer_all,
+                       int whole_input, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    PartGeom G;
+    if (!xchg_geometry(*this, piece_max, nown, G)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
+    if (read_stats(err)) return -1;
+    const uint32_t nregions = 1u << (G.p1 + G.p2);
+    const bool empty = h_stats[ST_DISTINCT] == 0;
+    histo_cached = false;
+    unsigned long long *histo = whole_input && empty ? d_histo : nullptr;
+    if (histo) HIPCHK(hipMemsetAsync(histo, 0, HISTO_WORDS * sizeof(unsigned long long), stream));
+    const size_t lds = ((size_t)(1u << G.rbits) + RG_HALO) * 16 + LDS_HBINS * 4 + (LI_MAXSL + 1) * 4;
+    if (slots_dirty && nregions <= 1) { if (materialize(err)) return -1; }
+    const int fresh = slots_dirty ? 1 : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_insert_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    // this rank's own deferred list lives in the caller's buffer; the kernel's own overflow (probe beyond the halo) goes to a list of its own
+    const uint64_t own_cap = std::max<uint64_t>(1u << 16, piece_max / 16);
+    unsigned long long *defer = (unsigned long long *)workspace(WS_COUNT + 3, own_cap * 24 + 64, err);
+    if (!defer) return -2;
+    unsigned long long *defer_n = defer, *defer_e = defer + 8;
+    HIPCHK(hipMemsetAsync(defer_n, 0, 64, stream));
+    HIPCHK(hipEventRecord(ev_stage_t[3], stream));
+    for (uint32_t parity = 0; parity < 2; ++parity) {
+        if (!(nregions == 1 && parity == 1)) {
+            const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
+            hipLaunchKernelGGL((lds_insert_kernel<false, true>), dim3(nblk), dim3(PT_THREADS), lds, stream, d_recv, (const unsigned int *)d_recv_cnt, G.cap2, nown * G.nblk2, d, G,
+                               nregions, parity, fresh, defer_e, defer_n, own_cap, histo, nown);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(ev_stage_t[4 + parity], stream));
+    }
+    slots_dirty = false;
+    hipLaunchKernelGGL(import3_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, own_cap, d, histo ? histo + 10002 : nullptr);
+    HIPCHK(hipGetLastError());
+    if (n_defer_all) {
+        hipLaunchKernelGGL(import3_owned_kernel, dim3(256), dim3(256), 0, stream, (const unsigned long long *)d_defer_all, n_defer_all, d, nown, self, histo ? histo + 10002 : nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(ev_stage_t[6], stream));
+    const int rc = after_batch(err);                           // (waits; spilled insertions / growth as on the other paths)
+    if (rc) return rc;
+    histo_cached = histo != nullptr;
+    const int pairs[5][2] = {{0, 1}, {1, 2}, {3, 4}, {4, 5}, {5, 6}};
+    for (int i = 0; i < 5; ++i) {
+        float m = 0;
+        if (hipEventElapsedTime(&m, ev_stage_t[pairs[i][0]], ev_stage_t[pairs[i][1]]) == hipSuccess) { part_stage_ms[i] += m; count_kernel_ms += m; }
+    }
+    count_launches += 1;
+    ++count_partitioned_launches;
     return 0;
 }
 

@@ -379,6 +379,12 @@ struct Table {
     // -- segment o starts at d_dst + o * cap entries, counts_out[o] entries long (may exceed cap: nothing is written past
     // cap, the caller retries with a larger buffer); attach = lookups through this table read shard o's slot array.
     int export_owner(void *d_dst, uint64_t cap, uint32_t nown, int sort_r, uint64_t *counts_out, std::string &err);   // sort_r > 0: by file range, see table.hip
+    // counting as a multi-GPU exchange of region lists (count_part.hip, "count_exchange")
+    int xchg_plan(uint64_t piece_max, uint32_t nown, uint64_t out[8], std::string &err);     // 0: available, 1: not for this table / size
+    int xchg_partition(const uint8_t *d_bases, uint64_t n, uint64_t pos, uint64_t end, uint64_t piece_max, uint32_t nown, void *d_send, void *d_send_cnt, void *d_defer,
+                       uint64_t defer_cap, std::string &err);
+    int xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piece_max, uint32_t nown, uint32_t self, const void *d_defer_all, uint64_t n_defer_all,
+                    int whole_input, std::string &err);
     int ipc_handle(void *out64, std::string &err);
     int attach_ipc(const void *handles64, uint32_t n, uint32_t self, std::string &err);
     int attach_tables(Table *const *peers, uint32_t n, uint32_t self, std::string &err);

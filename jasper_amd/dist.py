@@ -365,6 +365,17 @@ def shard_tables(local, shard, device, group=None):
     if first:                                          # ... cut to size once; later calls reuse the slot array as it is
         shard.fit(0.5)
         shard._fitted = True
+    _attach_shards(shard, device, group)
+    return incoming
+
+
+def _attach_shards(shard, device, group=None):
+    """the owners' shards are written: one geometry for all, every rank maps every owner's slot array (again, if any moved),
+    and nobody reads before everybody has finished writing.  Collective."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     # 3. one geometry for all owners, then (re)attach if any slot array moved
     slots = torch.tensor([shard.info()["slots"]], dtype=torch.int64, device=device)
     dist.all_reduce(slots, op=dist.ReduceOp.MAX, group=group)
@@ -410,7 +421,104 @@ def shard_tables(local, shard, device, group=None):
     # their handles had been given out can go now
     if hasattr(shard, "release_retired"):
         shard.release_retired()
-    return incoming
+
+
+def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None, clear=False):
+    """Count this rank's reads (text bases in HBM, as for KmerTable.count_bases_device) into the OWNER-SHARDED table without a
+    table per GPU: every rank turns its reads into region lists grouped by the owner of the key (two partition passes of the
+    atomic-free counting path), ONE all_to_all moves every list to its owner (8 bytes per k-mer occurrence), and the owner
+    inserts what arrived straight into `shard` (include/jasper_hip.h: jasper_count_exchange_*).  Compared with counting into a
+    local table and shard_tables(): no local insert, no export pass, no add pass, and no memory for a local table.
+
+    Collective.  `shard` should be sized for the keys it will own (min_slots / reserve) -- it grows if it must.  Counts are
+    ADDED to what the shard holds; clear=True empties it first (at a point where no peer can still be reading it).  Returns None (collectively, nothing done) when the table / input size / k has no exchange
+    geometry -- count into a local table and call shard_tables() then -- else a dict with the rounds and bytes moved.
+    Afterwards lookups through `shard` read the owner's HBM (own or peer's), as after shard_tables()."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        raise RuntimeError("count_sharded needs an initialised process group of more than one rank")
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    was_empty = clear or shard.info()["distinct"] == 0
+    agree = torch.tensor([int(n_bases), shard.info()["slots"], 0 if was_empty else 1], dtype=torch.int64, device=device)
+    dist.all_reduce(agree, op=dist.ReduceOp.MAX, group=group)
+    n_max, slots, any_filled = (int(v) for v in agree.tolist())
+    # (every rank is here: none of them still reads the shards of the last step through its peer mappings)
+    if clear:
+        shard.clear()
+    if n_max == 0:
+        _attach_shards(shard, device, group)
+        return dict(rounds=0, wire_bytes=0, deferred=0)
+    shard.reserve(slots)
+    piece = min(n_max, int(piece_limit or os.environ.get("JASPER_AMD_EXCHANGE_PIECE", 1 << 31)))
+    rounds = (n_max + piece - 1) // piece
+    plan = shard.exchange_plan(piece, world)
+    okt = torch.tensor([1 if plan is not None else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
+    if not int(okt.item()):
+        return None
+    wire = 0
+    n_deferred = 0
+    for rnd in range(rounds):
+        if rnd:                                         # a shard that grew in the last round changes the geometry for all
+            st = torch.tensor([shard.info()["slots"]], dtype=torch.int64, device=device)
+            dist.all_reduce(st, op=dist.ReduceOp.MAX, group=group)
+            shard.reserve(int(st.item()))
+            plan = shard.exchange_plan(piece, world)
+            okt = torch.tensor([1 if plan is not None else 0], dtype=torch.int64, device=device)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
+            if not int(okt.item()):
+                raise RuntimeError("count_sharded: the shards outgrew the exchange geometry between rounds")
+        nrec, ncnt, dcap = plan["records_per_owner"], plan["counts_per_owner"], plan["deferred_cap"]
+        # (libjasper_hip works on its own stream: torch memory must be idle before it is handed over -- empty(), never zeros())
+        send = torch.empty((world, nrec), dtype=torch.int64, device=device)
+        send_cnt = torch.empty((world, ncnt), dtype=torch.int32, device=device)
+        deferred = torch.empty(8 + 3 * dcap, dtype=torch.int64, device=device)
+        _sync(device)
+        pos = min(rnd * piece, int(n_bases))
+        end = min(pos + piece, int(n_bases))
+        ok, why = 1, ""
+        try:
+            shard.exchange_partition(d_bases, n_bases, pos, end, piece, world, send.data_ptr(), send_cnt.data_ptr(), deferred.data_ptr(), dcap)
+            shard.sync()
+        except RuntimeError as e:
+            ok, why = 0, str(e)
+        mine = int(deferred[0].item()) if ok else 0
+        if mine > dcap:
+            ok, why = 0, "too many records found no room in their lists (%d): pass a larger size hint" % mine
+        nd = torch.tensor([mine, 1 - ok], dtype=torch.int64, device=device)
+        parts = [torch.zeros_like(nd) for _ in range(world)]
+        dist.all_gather(parts, nd, group=group)
+        parts = [p.tolist() for p in parts]
+        if any(p[1] for p in parts):
+            raise RuntimeError("count_sharded: partitioning failed on some rank" + (": " + why if why else ""))
+        recv = _all_to_all_rows(send, group)
+        recv_cnt = _all_to_all_rows(send_cnt, group)
+        wire += (world - 1) * (nrec * 8 + ncnt * 4)
+        d_all, n_all = None, 0
+        mx = max(p[0] for p in parts)
+        if mx:                                          # rare: the deferred entries of all ranks go to everybody, owners pick theirs
+            pad = deferred[8:8 + 3 * mx].contiguous()
+            allp = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(allp, pad, group=group)
+            d_all = torch.cat([allp[src][:3 * parts[src][0]] for src in range(world)]).contiguous()
+            n_all = sum(p[0] for p in parts)
+            n_deferred += n_all
+        _sync(device)
+        del send, send_cnt
+        try:
+            shard.exchange_insert(recv.data_ptr(), recv_cnt.data_ptr(), piece, world, rank, d_all.data_ptr() if n_all else 0, n_all,
+                                  whole_input=(rounds == 1 and not any_filled))
+        except RuntimeError as e:
+            ok, why = 0, str(e)
+        okt = torch.tensor([ok], dtype=torch.int64, device=device)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
+        if not int(okt.item()):
+            raise RuntimeError("count_sharded: inserting the received lists failed on some rank" + (": " + why if why else ""))
+        del recv, recv_cnt, deferred, d_all
+    _attach_shards(shard, device, group)
+    return dict(rounds=rounds, wire_bytes=wire, deferred=n_deferred, plan=plan)
 
 
 def write_jf_sharded(shard, path, cmdline, device, group=None):

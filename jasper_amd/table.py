@@ -205,6 +205,7 @@ class KmerTable:
     STAGE_NAMES = {2: ("mz_part_kernel", "mz_split_kernels", "mz_count_kernel", "split16_entries_kernel", "lds_insert_kernel_even", "lds_insert_kernel_odd",
                        "expand_and_deferred_kernels"),
                    1: ("part1_kernel", "part2_kernel", "lds_insert_kernel_even", "lds_insert_kernel_odd", "deferred_import3_kernel"),
+                   3: ("part1_kernel", "part2_by_owner_kernel", "lds_insert_kernel_even", "lds_insert_kernel_odd", "deferred_import3_kernels"),
                    0: ()}
 
     def count_stages(self):
@@ -218,7 +219,7 @@ class KmerTable:
         return list(ms)[:len(self.STAGE_NAMES.get(path.value, ()))] or list(ms)[:5], n.value
 
     def count_path(self):
-        """2 = minimizer super-k-mers, 1 = one record per occurrence, 0 = count_kernel (after count_stages())"""
+        """3 = region lists exchanged between GPUs, 2 = minimizer super-k-mers, 1 = one record per occurrence, 0 = count_kernel"""
         self.count_stages()
         return self._count_path
 
@@ -327,6 +328,25 @@ class KmerTable:
 
     def fit(self, max_load=0.5):
         check(self._L.jasper_table_fit(self._h, float(max_load)))
+
+    # ---- counting as an exchange of region lists (include/jasper_hip.h, jasper_count_exchange_*) -------
+    def exchange_plan(self, piece_max, n_owners):
+        """None when this table / piece size / k has no exchange geometry, else a dict of buffer sizes"""
+        out = (C.c_uint64 * 8)()
+        rc = self._L.jasper_count_exchange_plan(self._h, int(piece_max), int(n_owners), out)
+        if rc == 1:
+            return None
+        check(rc)
+        names = ("records_per_owner", "counts_per_owner", "deferred_cap", "p1", "p2", "region_bits", "slices", "slice_cap")
+        return dict(zip(names, (int(v) for v in out)))
+
+    def exchange_partition(self, d_bases, n, pos, end, piece_max, n_owners, d_send, d_send_counts, d_deferred, deferred_cap):
+        check(self._L.jasper_count_exchange_partition(self._h, C.c_void_p(d_bases), int(n), int(pos), int(end), int(piece_max), int(n_owners), C.c_void_p(d_send),
+                                                      C.c_void_p(d_send_counts), C.c_void_p(d_deferred), int(deferred_cap)))
+
+    def exchange_insert(self, d_recv, d_recv_counts, piece_max, n_owners, self_index, d_deferred_all=0, n_deferred_all=0, whole_input=False):
+        check(self._L.jasper_count_exchange_insert(self._h, C.c_void_p(d_recv), C.c_void_p(d_recv_counts), int(piece_max), int(n_owners), int(self_index),
+                                                   C.c_void_p(d_deferred_all or None), int(n_deferred_all), 1 if whole_input else 0))
 
     # ---- owner-sharded table (include/jasper_hip.h, "Owner-sharded table") ----------------------------
     def export_owner(self, dev_ptr, cap_entries, n_owners):

@@ -1,0 +1,256 @@
+"""GPU: counting on several GPUs as an exchange of region lists (include/jasper_hip.h: jasper_count_exchange_*,
+jasper_amd.dist.count_sharded; role of JF::jellyfish/merge_files.cc:44-96 without per-process tables).  Every rank partitions
+its reads into region lists grouped by the owner of the key, one all_to_all moves the lists, the owners insert them into their
+shards.  Checked bit-exact against ONE table that counted all reads:
+  * one process playing n ranks on the one GPU (the all_to_all is a torch.stack): k on both hash paths, n = 2, 3, 4, 8, tables
+    with and without a second-level split, one round and several, reads with a k-mer heavy enough to overflow its list;
+  * two processes on the one GPU (dist.count_sharded with gloo as the transport, IPC-mapped shards): histogram, distinct keys
+    and polishing through the shards == the unsharded run.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from jasper_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def KT(hip):
+    from jasper_amd import KmerTable
+    return KmerTable
+
+
+def read_sets(seed, G, n, heavy=0):
+    """n read sets (records of 150 bases + newline, as synth.make_reads_stream writes them) over one genome"""
+    rng = np.random.default_rng(seed)
+    genome = synth.make_genome(rng, G)
+    reads = synth.make_reads_stream(rng, genome, 30, 150, 0.003)
+    nrec = reads.size // 151
+    sets = []
+    for r in range(n):
+        lo, hi = r * nrec // n, (r + 1) * nrec // n
+        b = reads[lo * 151:hi * 151].tobytes()
+        if heavy and r == n - 1:      # one k-mer (poly-A) with far more occurrences than any list slice has room for
+            b += (b"A" * 150 + b"\n") * heavy
+        sets.append(b)
+    asm = synth.make_assembly(rng, genome, err=1e-3, n_every=max(G // 3, 1000), n_len=60).tobytes().decode()
+    return sets, asm
+
+
+def exchange_in_process(KT, k, n, sets, slots, piece=None):
+    """what dist.count_sharded does, with the ranks played one after the other; returns the n shards and statistics"""
+    import torch
+    shards = [KT(k, min_slots=slots) for _ in range(n)]
+    dev = [torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda() for b in sets]
+    n_max = max(len(b) for b in sets)
+    piece = piece or n_max
+    rounds = (n_max + piece - 1) // piece
+    plan = shards[0].exchange_plan(piece, n)
+    assert plan is not None, "the test sizes tables and inputs so that the exchange geometry exists"
+    nrec, ncnt, dcap = plan["records_per_owner"], plan["counts_per_owner"], plan["deferred_cap"]
+    deferred_total = 0
+    for rnd in range(rounds):
+        send = [torch.empty((n, nrec), dtype=torch.int64, device="cuda") for _ in range(n)]
+        cnt = [torch.empty((n, ncnt), dtype=torch.int32, device="cuda") for _ in range(n)]
+        dfr = [torch.empty(8 + 3 * dcap, dtype=torch.int64, device="cuda") for _ in range(n)]
+        torch.cuda.synchronize()
+        for r in range(n):
+            pos = min(rnd * piece, len(sets[r]))
+            end = min(pos + piece, len(sets[r]))
+            shards[r].exchange_partition(dev[r].data_ptr(), len(sets[r]), pos, end, piece, n, send[r].data_ptr(), cnt[r].data_ptr(), dfr[r].data_ptr(), dcap)
+            shards[r].sync()
+        nd = [int(d[0].item()) for d in dfr]
+        assert max(nd) <= dcap
+        d_all = torch.cat([d[8:8 + 3 * m] for d, m in zip(dfr, nd)]).contiguous() if sum(nd) else None
+        deferred_total += sum(nd)
+        for o in range(n):
+            recv = torch.stack([send[r][o] for r in range(n)]).contiguous()
+            rcnt = torch.stack([cnt[r][o] for r in range(n)]).contiguous()
+            assert int(rcnt.max().item()) <= plan["slice_cap"]
+            torch.cuda.synchronize()
+            shards[o].exchange_insert(recv.data_ptr(), rcnt.data_ptr(), piece, n, o, d_all.data_ptr() if d_all is not None else 0, sum(nd), whole_input=(rounds == 1))
+    return shards, plan, deferred_total
+
+
+CASES = [  # k, ranks, log2 slots per shard, genome, rounds, heavy reads
+    (37, 2, 21, 300_000, 1, 0),       # p1 = 10 (records are 64 bits), no second-level bits: lists split by owner only
+    (37, 8, 21, 300_000, 1, 0),
+    (37, 4, 25, 300_000, 1, 0),       # second-level bits AND owners in one pass
+    (25, 3, 21, 300_000, 1, 0),       # one-word k-mers, an odd number of owners
+    (25, 2, 21, 300_000, 3, 0),       # several rounds: later rounds add to a filled shard
+    (31, 4, 22, 200_000, 1, 400),    # a list overflows: deferred records travel to their owner
+    (21, 8, 20, 100_000, 2, 0),
+]
+
+
+@pytest.mark.parametrize("k,n,ls,G,rounds,heavy", CASES)
+def test_exchange_of_region_lists_equals_one_table(KT, monkeypatch, k, n, ls, G, rounds, heavy):
+    monkeypatch.setenv("JASPER_PART_TEST_SMALL", "1")
+    sets, asm = read_sets(1000 + k + n, G, n, heavy)
+    full = KT(k, min_slots=1 << 22)
+    full.count_bases(b"".join(sets))
+    n_max = max(len(b) for b in sets)
+    piece = None if rounds == 1 else (n_max + rounds - 1) // rounds
+    shards, plan, deferred = exchange_in_process(KT, k, n, sets, 1 << ls, piece)
+    if heavy:
+        assert deferred > 0, "the heavy k-mer was meant to overflow its list"
+    assert all(t.info()["slots"] == 1 << ls for t in shards), "the test sizes the shards so that they do not grow"
+    assert sum(t.info()["distinct"] for t in shards) == full.info()["distinct"]          # a disjoint cover
+    assert sum(t.info()["occurrences"] for t in shards) == full.info()["occurrences"]
+    acc = [0] * 10002
+    for t in shards:
+        if rounds == 1 and not deferred:
+            assert t.histogram_is_fused()
+        acc = [a + b for a, b in zip(acc, t.histogram())]
+    assert acc == full.histogram()
+    for o, t in enumerate(shards):
+        t.attach_tables(shards, o)
+    rng = np.random.default_rng(6)
+    pos = rng.integers(0, len(asm) - k, 20_000)
+    qs = [asm[p:p + k] for p in pos] + ["A" * k, "T" * k]
+    want = full.lookup(qs)
+    assert sum(1 for c in want if c) > 10_000
+    for t in (shards[0], shards[-1]):
+        assert t.lookup(qs) == want
+    recs = synth.chunk_records("c", len(asm), 30_000)
+    chunks = [asm[a:b] for _, a, b in recs]
+    ref = full.polish_batch(chunks, 3, 2)
+    got = shards[n // 2].polish_batch(chunks, 3, 2)
+    assert got.seqs == ref.seqs and got.qv == ref.qv and got.records == ref.records
+    # every owner holds its own keys only
+    shards[0].detach()
+    own = shards[0].lookup(qs)
+    assert all(c == w or c == 0 for c, w in zip(own, want)) and own != want
+    for t in shards + [full]:
+        t.close()
+
+
+def test_no_exchange_geometry_is_reported_not_raised(KT):
+    t = KT(37, min_slots=1 << 21)
+    assert t.exchange_plan(1 << 16, 2) is None          # a piece too small to be worth the passes
+    w = KT(51, min_slots=1 << 21)
+    assert w.exchange_plan(1 << 26, 2) is None          # wide remainders: direct kernel only
+    assert t.exchange_plan(1 << 26, 1) is None
+    t.close()
+    w.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q, backend="gloo", one_gpu=True):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), JASPER_PART_TEST_SMALL="1")
+    import torch
+    import torch.distributed as dist
+    from jasper_amd import KmerTable, dist as jd
+    di = 0 if one_gpu else rank
+    if backend == "nccl":
+        torch.cuda.set_device(di)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", di))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        k = 37
+        rng = np.random.default_rng(43)                     # same workload on every rank
+        genome = synth.make_genome(rng, 150_000)
+        reads = synth.make_reads_stream(rng, genome, 30, 150, 0.003)
+        asm = synth.make_assembly(rng, genome, err=1e-3, n_every=10**9).tobytes().decode()
+        nrec = reads.size // 151
+        dev = torch.device("cuda", di)
+        shard = KmerTable(k, min_slots=1 << 21, device=di)
+        out = []
+        for step in range(3):                               # other read shards each step; step 2 in two rounds, adding to step 1's counts
+            lo, hi = jd.shard_range(nrec, (rank + step) % world, world)
+            mine = torch.from_numpy(reads[lo * 151:hi * 151].copy()).to(dev)
+            torch.cuda.synchronize(dev)
+            info = jd.count_sharded(shard, mine.data_ptr(), mine.numel(), dev, clear=(step < 2), piece_limit=(None if step < 2 else 1_200_000))
+            assert info is not None
+            h = jd.histogram_sharded(shard, dev)
+            bs = 20_000
+            recs = synth.chunk_records("c", len(asm), bs)
+            owner = jd.assign_chunks([b - a for _, a, b in recs], world)
+            my = [i for i, o in enumerate(owner) if o == rank]
+            res = shard.polish_batch([asm[recs[i][1]:recs[i][2]] for i in my], 3 if step < 2 else 6, 2)
+            qv = jd.all_reduce_ints(list(res.qv), device=dev)
+            out.append((h, shard.info()["distinct"], info["rounds"], my, res.seqs, qv, shard.info()["slots"], shard.count_path()))
+            dist.barrier()                                  # (peers may still be reading my shard)
+        q.put((rank, out))
+        dist.barrier()
+        shard.detach()
+        dist.barrier()
+        shard.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_count_sharded(hip):
+    import torch.multiprocessing as mp
+    from jasper_amd import KmerTable
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in ps], key=lambda x: x[0])
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    k = 37
+    rng = np.random.default_rng(43)
+    genome = synth.make_genome(rng, 150_000)
+    reads = synth.make_reads_stream(rng, genome, 30, 150, 0.003)
+    asm = synth.make_assembly(rng, genome, err=1e-3, n_every=10**9).tobytes().decode()
+    t = KmerTable(k, min_slots=1 << 21, device=0)
+    t.count_bases(reads.tobytes())
+    recs = synth.chunk_records("c", len(asm), 20_000)
+    for step in range(3):
+        if step == 2:
+            t.count_bases(reads.tobytes())                        # the third step added the reads once more
+        h = t.histogram()
+        full = t.polish_batch([asm[a:b] for _, a, b in recs], 3 if step < 2 else 6, 2)
+        r0, r1 = res[0][1][step], res[1][1][step]
+        assert r0[0] == h and r1[0] == h                          # owners' histograms summed == whole table's
+        assert r0[1] + r1[1] == t.info()["distinct"]              # the owners' key sets are a disjoint cover
+        assert r0[2] == r1[2] == (1 if step < 2 else 2)
+        assert r0[6] == r1[6]                                     # one geometry
+        assert r0[7] == r1[7] == 3                                # the exchange path counted
+        got = [None] * len(recs)
+        for r in (r0, r1):
+            for i, s in zip(r[3], r[4]):
+                got[i] = s
+        assert got == full.seqs                                   # chunk shards through IPC-mapped owners == unsharded run
+        assert tuple(r0[5]) == tuple(r1[5]) == full.qv
+    t.close()
+
+
+needs2 = pytest.mark.skipif("__import__('torch').cuda.device_count() < 2", reason="one rank per device over RCCL needs two GPUs")
+
+
+@needs2
+def test_two_ranks_two_gpus_count_sharded_over_rccl(hip):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, "nccl", False)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in ps], key=lambda x: x[0])
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1][0][0] == res[1][1][0][0]                     # (content is pinned by the one-GPU test above; here the transport runs)
+    assert res[0][1][0][7] == 3
