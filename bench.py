@@ -71,27 +71,45 @@ def build_workload(torch, dev, rank, world, genome_mb, seed):
     return reads, names, seqs, (d_asm, offs), len(asm), bs, hi - lo
 
 
-def one_step(torch, dev_index, table, reads, d_chunks, world, timers, shard=None):
-    """shard: this rank's owner table when the merged table is kept key-sharded over the GPUs (N>1), else None"""
+def one_step(torch, dev_index, local, reads, d_chunks, world, timers, shard=None):
+    """local: {"table": this rank's own table or None, "make": creates it, "exchange": try the exchange of region lists};
+    shard: this rank's owner table when the merged table is kept key-sharded over the GPUs (N>1), else None"""
     from jasper_amd import polisher, dist as jdist
     t0 = time.perf_counter()
-    table.clear()          # a step starts from an empty table (zeroing 16 B/slot is part of the timed path)
-    table.sync()
-    t0b = time.perf_counter()
-    table.count_bases_device(reads.data_ptr(), reads.numel())
-    table.sync()
-    t1 = time.perf_counter()
+    xinfo = None
+    if shard is not None and local["exchange"]:
+        # no table per GPU at all: reads -> region lists grouped by owner -> ONE all_to_all -> owners insert into their shards
+        # (the shard is emptied inside, once no peer can still be reading it: part of the timed path like clear() below)
+        xinfo = jdist.count_sharded(shard, reads.data_ptr(), reads.numel(), torch.device("cuda", dev_index), clear=True)
+        if xinfo is None:        # (decided by all ranks together) this table / input has no exchange geometry
+            local["exchange"] = False
+    if xinfo is not None:
+        t0b = t0
+        t1 = t2 = time.perf_counter()
+        table = shard
+        merged = xinfo["wire_bytes"]
+    else:
+        if local["table"] is None:
+            local["table"] = local["make"]()
+        table = local["table"]
+        table.clear()          # a step starts from an empty table (zeroing 16 B/slot is part of the timed path)
+        table.sync()
+        t0b = time.perf_counter()
+        table.count_bases_device(reads.data_ptr(), reads.numel())
+        table.sync()
+        t1 = time.perf_counter()
     kms, launches = table.count_timing()
     stages, part_launches = table.count_stages()
     path = table.count_path()
-    merged = 0
-    if world > 1:
-        if shard is not None:    # one all_to_all: owner o ends up with the summed counts of the keys it owns
-            merged = jdist.shard_tables(table, shard, torch.device("cuda", dev_index))
-        else:                    # reduce-scatter + all-gather: the merged table on every GPU
-            merged = jdist.merge_tables(table, torch.device("cuda", dev_index))
-            table.sync()
-    t2 = time.perf_counter()
+    if xinfo is None:
+        merged = 0
+        if world > 1:
+            if shard is not None:    # one all_to_all: owner o ends up with the summed counts of the keys it owns
+                merged = jdist.shard_tables(table, shard, torch.device("cuda", dev_index))
+            else:                    # reduce-scatter + all-gather: the merged table on every GPU
+                merged = jdist.merge_tables(table, torch.device("cuda", dev_index))
+                table.sync()
+        t2 = time.perf_counter()
     if world > 1:      # every rank bins the keys it owns, the bins are summed over ranks
         if shard is not None:
             h = jdist.histogram_sharded(shard, torch.device("cuda", dev_index))
@@ -110,6 +128,7 @@ def one_step(torch, dev_index, table, reads, d_chunks, world, timers, shard=None
     t4 = time.perf_counter()
     info = table.info()
     timers.append(dict(count=t1 - t0, clear=t0b - t0, merge=t2 - t1, histo=t3 - t2, polish=t4 - t3, kernel_ms=kms, launches=launches, stages=stages, part_launches=part_launches, path=path,
+                       exchange=xinfo,
                        polish_dev=res.seconds, thr=thr, qv=res.qv, nfix=res.n_records, merged=merged,
                        distinct=info["distinct"], occurrences=info["occurrences"], slots=info["slots"], lookups=res.lookups,
                        segments=res.segments, respeculated=res.respeculated,
@@ -199,6 +218,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: all ranks share GPU 0")
+    ap.add_argument("--count", choices=("auto", "exchange", "local"), default="auto",
+                    help="N>1 with a sharded table: 'exchange' = reads become region lists grouped by key owner, one all_to_all, owners "
+                         "insert (no table per GPU); 'local' = count into a table per GPU, then sum by owner; auto = exchange when the "
+                         "table has a geometry for it")
     ap.add_argument("--table", choices=("auto", "sharded", "replicated"), default="auto",
                     help="N>1: keep the merged table key-sharded over the GPUs (lookups read the owner's HBM over xGMI) or replicate "
                          "it on every GPU; auto = sharded, replicated only if the peers' memory cannot be mapped")
@@ -251,8 +274,13 @@ def main():
     # (a sharded run's local table only ever holds this rank's read shard; a replicated one holds everything)
     jf_size = int(nreads * (1 if sharded else world) * READ_LEN * 2.1 / 10)
     min_slots = max(1 << 21, int(1.25 * jf_size))
-    table = KmerTable(K, min_slots=min_slots, device=local)   # allocated once, like the reference's -s sized hash
-    shard = KmerTable(K, min_slots=1 << 21, device=local) if sharded else None   # grows to its size in the first warm-up step
+    exchange = sharded and a.count != "local"
+    loc = {"table": None, "exchange": exchange, "make": lambda: KmerTable(K, min_slots=min_slots, device=local)}
+    if not exchange:
+        loc["table"] = loc["make"]()        # allocated once, like the reference's -s sized hash
+    # the owner's shard: with the exchange it is the only table and is sized like the reference's -s hash for the keys it will own
+    # (1/N of an N times larger genome); behind local tables it grows to its size in the first warm-up step
+    shard = KmerTable(K, min_slots=(min_slots if exchange else 1 << 21), device=local) if sharded else None
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -265,7 +293,7 @@ def main():
     def step():
         nonlocal shard
         try:
-            return one_step(torch, local, table, reads, d_chunks, world, timers, shard)
+            return one_step(torch, local, loc, reads, d_chunks, world, timers, shard)
         except jdist.ShardAttachError as e:     # raised on every rank together
             if a.table == "sharded":
                 raise
@@ -273,15 +301,20 @@ def main():
                 sys.stderr.write("bench.py: %s -- replicating the merged table instead\n" % e)
             shard.close()
             shard = None
-            table.reserve(max(1 << 21, int(1.25 * nreads * world * READ_LEN * 2.1 / 10)))
-            return one_step(torch, local, table, reads, d_chunks, world, timers, None)
+            loc["exchange"] = False
+            if loc["table"] is None:
+                loc["table"] = loc["make"]()
+            loc["table"].reserve(max(1 << 21, int(1.25 * nreads * world * READ_LEN * 2.1 / 10)))
+            return one_step(torch, local, loc, reads, d_chunks, world, timers, None)
 
     for i in range(a.warmup):
         step()
-        if i == 0 and shard is not None:
+        if i == 0 and shard is not None and loc["table"] is not None:
             # the size hint (FASTQ bytes / 10, as jasper.sh passes to `jellyfish count -s`) is low for a read shard of an
             # N times larger genome, and growing on demand overshoots: settle the local table at load <= 1/2 once
-            table.fit(0.5)
+            loc["table"].fit(0.5)
+    if a.count == "exchange" and sharded and not loc["exchange"]:
+        raise RuntimeError("--count exchange: this table / input size has no exchange geometry")
     timers.clear()
     barrier()
     t0 = time.perf_counter()
@@ -295,7 +328,7 @@ def main():
     host_ms = []
     for _ in range(3):
         th = time.perf_counter()
-        res_h = (shard if shard is not None else table).polish_batch(seqs, timers[-1]["thr"], PASSES, fix=True)
+        res_h = (shard if shard is not None else loc["table"]).polish_batch(seqs, timers[-1]["thr"], PASSES, fix=True)
         host_ms.append((time.perf_counter() - th) * 1e3)
     same_text = all(bytes(res.seq_view(i)) == bytes(res_h.seq_view(i)) for i in range(len(seqs)))
     if not same_text or res.qv != res_h.qv or res.n_records != res_h.n_records:
@@ -349,6 +382,8 @@ def main():
                    "chunks_per_gpu": len(seqs), "reads_per_gpu": nreads, "table_slots": T["slots"], "distinct_kmers": T["distinct"],
                    "threshold": T["thr"],
                    "parallelism": "single GPU" if world == 1 else
+                                  ("read shards + chunk shards; reads partitioned into region lists by key owner, ONE all_to_all of the lists (8 B per k-mer "
+                                   "occurrence), owners insert into their shards -- no table per GPU") if (shard is not None and T["exchange"]) else
                                   "read shards + chunk shards; counts summed by key owner in one all_to_all over RCCL" if shard is not None else
                                   "read shards + chunk shards; table merge (reduce-scatter + all-gather by key range) over RCCL",
                    "table": "whole" if world == 1 else
@@ -357,6 +392,7 @@ def main():
         "kmers_counted_Gk_per_s": round(kmers_rank * world / mean("count") / 1e9, 3),
         "polish_only_Mbp_per_s": round(asm_total / 1e6 / mean("polish"), 3),
         "phase_ms": {k: round(mean(k) * 1e3, 2) for k in ("clear", "count", "merge", "histo", "polish")},
+        "count_exchange": T["exchange"],      # N>1: rounds, bytes this rank put on the wire per step, list geometry (null: tables per GPU, summed by owner)
         "polish_device_ms": round(mean("polish_dev") * 1e3, 2),
         "io": "reads and chunk records resident in HBM; polished text left in HBM; fix records, histogram and QV counters on the host",
         "polish_host_io_ms": round(min(host_ms), 2),
@@ -364,7 +400,8 @@ def main():
         "qv_counters": list(T["qv"]), "fix_records": T["nfix"], "polish_lookups": T["lookups"],
         "polish_segments": T["segments"], "polish_chunks_redone_unsegmented": T["respeculated"],
         "roofline": {"bound": "hbm",
-                     "kernel": {2: "k-mer counting = mz_part + mz_split + mz_count + split16 (entries) + lds_insert (even, odd) per piece (minimizer super-k-mers)",
+                     "kernel": {3: "k-mer counting = part1_kernel + part2_kernel<by owner> on the sender, lds_insert_kernel (even, odd) on the owner, per round",
+                                2: "k-mer counting = mz_part + mz_split + mz_count + split16 (entries) + lds_insert (even, odd) per piece (minimizer super-k-mers)",
                                 1: "k-mer counting = part1_kernel + part2_kernel + lds_insert_kernel (even, odd) per piece",
                                 0: "count_kernel"}[T["path"]],
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -392,7 +429,7 @@ def main():
             for r in res.records:
                 per_pass[r["pass_"]].append((r["chunk"], r["seqno"], polisher.rows_from_record(names[r["chunk"]], r)))
             csv_gpu = [polisher.fix_csv_text([row for _, _, rr in sorted(pp, key=lambda x: (x[0], x[1])) for row in rr]) for pp in per_pass]
-            gpu = dict(rows=table.histo_rows(), thr=T["thr"], qv=T["qv"], csv=csv_gpu, text=[bytes(res.seq_view(i)) for i in range(len(seqs))])
+            gpu = dict(rows=loc["table"].histo_rows(), thr=T["thr"], qv=T["qv"], csv=csv_gpu, text=[bytes(res.seq_view(i)) for i in range(len(seqs))])
             reads_np = reads.cpu().numpy()
             try:
                 out["cpu_baseline"] = cpu_baseline(a.seed, reads_np, names, seqs, gpu)

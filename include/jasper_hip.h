@@ -140,25 +140,32 @@ int jasper_table_export_owner(jasper_table *t, void *d_dst, uint64_t cap_entries
  * src/jasper.sh:177, and of JF::jellyfish/merge_files.cc:44-96): the reads of every GPU go through the two partition passes
  * of the atomic-free counting path; the second pass also groups by owner, so what owner o is to receive is one contiguous
  * block of the send buffers -- the region lists of o's own table.  After ONE all_to_all of those blocks (8 bytes per k-mer
- * occurrence) every owner inserts what it received straight into its shard `t`.  All ranks call with the same piece_max (the
- * longest piece [pos, end) any of them partitions in this round) and shard tables of one geometry.
+ * occurrence plus the slack of the lists) every owner inserts what it received straight into its shard `t`.  All ranks call
+ * with shard tables of one geometry and the same piece_max (the longest piece [pos, end) any of them scans in this round)
+ * and records_max (the most records any rank's scan returned; 0 = not known, piece_max stands in: the lists, and with them
+ * the bytes that travel, are then sized for the worst case).
  *   jasper_count_exchange_plan      out8 = { records (8 B) per owner block, slice counts (4 B) per owner block, deferred entries
  *                                   (24 B) to provide room for, p1, p2, region bits, slices per list, slice capacity };
  *                                   returns 1 (not an error) when this table / piece size / k has no such geometry: count into a
  *                                   table per GPU and use jasper_table_export_owner instead.
- *   jasper_count_exchange_partition bases [pos, end) of d_bases (n bytes, text bases as for jasper_count_bases_device; the k-1
- *                                   bases before pos are read as context) -> d_send (n_owners blocks of records), d_send_counts
- *                                   (n_owners blocks of counts), d_deferred (64-byte header, word 0 = entries; then entries of 3
- *                                   words hash.hi, hash.lo, increment: the few records that found no room in their list).
+ *   jasper_count_exchange_scan      first pass over bases [pos, end) of d_bases (n bytes, text bases as for
+ *                                   jasper_count_bases_device; the k-1 bases before pos are read as context) into lists kept
+ *                                   inside t; *records = k-mer occurrences found.  d_deferred: 64-byte header (word 0 =
+ *                                   entries), then entries of 3 words hash.hi, hash.lo, increment -- the few records that found
+ *                                   no room in their list, here or in the next call.  Returns when the pass is done.
+ *   jasper_count_exchange_partition second pass: the lists of the scan -> d_send (n_owners blocks of records), d_send_counts
+ *                                   (n_owners blocks of counts); asynchronous like the counting calls (jasper_table_sync).
  *   jasper_count_exchange_insert    d_recv / d_recv_counts: block s = what rank s put into its block `self`; d_deferred_all: the
  *                                   deferred entries of ALL ranks back to back (the ones owned by `self` are added);
  *                                   whole_input != 0: these lists are all that goes into the (empty) shard, so the multiplicity
  *                                   histogram is taken on the way (jasper_histogram_is_fused). */
-int jasper_count_exchange_plan(jasper_table *t, uint64_t piece_max, uint32_t n_owners, uint64_t *out8);
-int jasper_count_exchange_partition(jasper_table *t, const void *d_bases, uint64_t n, uint64_t pos, uint64_t end, uint64_t piece_max, uint32_t n_owners, void *d_send,
-                                    void *d_send_counts, void *d_deferred, uint64_t deferred_cap);
-int jasper_count_exchange_insert(jasper_table *t, const void *d_recv, const void *d_recv_counts, uint64_t piece_max, uint32_t n_owners, uint32_t self,
-                                 const void *d_deferred_all, uint64_t n_deferred_all, int whole_input);
+int jasper_count_exchange_plan(jasper_table *t, uint64_t piece_max, uint64_t records_max, uint32_t n_owners, uint64_t *out8);
+int jasper_count_exchange_scan(jasper_table *t, const void *d_bases, uint64_t n, uint64_t pos, uint64_t end, uint64_t piece_max, uint32_t n_owners, void *d_deferred,
+                               uint64_t deferred_cap, uint64_t *records);
+int jasper_count_exchange_partition(jasper_table *t, uint64_t piece_max, uint64_t records_max, uint32_t n_owners, void *d_send, void *d_send_counts, void *d_deferred,
+                                    uint64_t deferred_cap);
+int jasper_count_exchange_insert(jasper_table *t, const void *d_recv, const void *d_recv_counts, uint64_t piece_max, uint64_t records_max, uint32_t n_owners,
+                                 uint32_t self, const void *d_deferred_all, uint64_t n_deferred_all, int whole_input);
 /* A binary/sorted database written by several GPUs: the file order (pos, key) with `size` = 2^size_log2 is the numeric order
  * of the key rotated right by size_log2 bits, so cutting the value range of the key's low size_log2 bits into n_ranges equal
  * parts cuts the file into n_ranges consecutive pieces.  jasper_table_export_file_ranges groups the entries of t by that

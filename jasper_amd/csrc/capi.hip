@@ -271,20 +271,26 @@ int jasper_table_export_owner(jasper_table *t, void *d_dst, uint64_t cap_entries
     if (!counts) { g_err = "counts is null"; return JASPER_ERR; }
     return t->t.export_owner(d_dst, cap_entries, n_owners, 0, counts, g_err);
 }
-int jasper_count_exchange_plan(jasper_table *t, uint64_t piece_max, uint32_t n_owners, uint64_t *out8) {
+int jasper_count_exchange_plan(jasper_table *t, uint64_t piece_max, uint64_t records_max, uint32_t n_owners, uint64_t *out8) {
     if (!t || !out8) { g_err = "bad argument"; return JASPER_ERR; }
-    const int rc = t->t.xchg_plan(piece_max, n_owners, out8, g_err);
+    const int rc = t->t.xchg_plan(piece_max, records_max, n_owners, out8, g_err);
     return rc == 0 ? JASPER_OK : rc == 1 ? 1 : JASPER_ERR;
 }
-int jasper_count_exchange_partition(jasper_table *t, const void *d_bases, uint64_t n, uint64_t pos, uint64_t end, uint64_t piece_max, uint32_t n_owners, void *d_send,
-                                    void *d_send_counts, void *d_deferred, uint64_t deferred_cap) {
-    if (!t || !d_send || !d_send_counts || !d_deferred || (n && !d_bases)) { g_err = "bad argument"; return JASPER_ERR; }
-    return t->t.xchg_partition((const uint8_t *)d_bases, n, pos, end, piece_max, n_owners, d_send, d_send_counts, d_deferred, deferred_cap, g_err) ? JASPER_ERR : JASPER_OK;
+int jasper_count_exchange_scan(jasper_table *t, const void *d_bases, uint64_t n, uint64_t pos, uint64_t end, uint64_t piece_max, uint32_t n_owners, void *d_deferred,
+                               uint64_t deferred_cap, uint64_t *records) {
+    if (!t || !d_deferred || !records || (n && !d_bases)) { g_err = "bad argument"; return JASPER_ERR; }
+    if (pos == 0) t->t.reset_timing();                       // (the first round of a call: stage times are per call, like the other count entry points)
+    return t->t.xchg_scan((const uint8_t *)d_bases, n, pos, end, piece_max, n_owners, d_deferred, deferred_cap, records, g_err) ? JASPER_ERR : JASPER_OK;
 }
-int jasper_count_exchange_insert(jasper_table *t, const void *d_recv, const void *d_recv_counts, uint64_t piece_max, uint32_t n_owners, uint32_t self,
-                                 const void *d_deferred_all, uint64_t n_deferred_all, int whole_input) {
+int jasper_count_exchange_partition(jasper_table *t, uint64_t piece_max, uint64_t records_max, uint32_t n_owners, void *d_send, void *d_send_counts, void *d_deferred,
+                                    uint64_t deferred_cap) {
+    if (!t || !d_send || !d_send_counts || !d_deferred) { g_err = "bad argument"; return JASPER_ERR; }
+    return t->t.xchg_partition(piece_max, records_max, n_owners, d_send, d_send_counts, d_deferred, deferred_cap, g_err) ? JASPER_ERR : JASPER_OK;
+}
+int jasper_count_exchange_insert(jasper_table *t, const void *d_recv, const void *d_recv_counts, uint64_t piece_max, uint64_t records_max, uint32_t n_owners,
+                                 uint32_t self, const void *d_deferred_all, uint64_t n_deferred_all, int whole_input) {
     if (!t || !d_recv || !d_recv_counts || self >= n_owners || (n_deferred_all && !d_deferred_all)) { g_err = "bad argument"; return JASPER_ERR; }
-    return t->t.xchg_insert(d_recv, d_recv_counts, piece_max, n_owners, self, d_deferred_all, n_deferred_all, whole_input, g_err) ? JASPER_ERR : JASPER_OK;
+    return t->t.xchg_insert(d_recv, d_recv_counts, piece_max, records_max, n_owners, self, d_deferred_all, n_deferred_all, whole_input, g_err) ? JASPER_ERR : JASPER_OK;
 }
 int jasper_table_export_file_ranges(jasper_table *t, void *d_dst, uint64_t cap_entries, uint32_t n_ranges, int size_log2, uint64_t *counts) {
     if (!counts || size_log2 < 1) { g_err = "bad argument"; return JASPER_ERR; }

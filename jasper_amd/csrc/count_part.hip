@@ -708,13 +708,20 @@ int Table::finish_deferred(unsigned long long *defer_e, unsigned long long *defe
 // ==================================================================================================
 // count_exchange: the partition pipeline as the multi-GPU exchange (role: JF::jellyfish/merge_files.cc:44-96 -- there
 // every process counts into a table of its own and the tables are merged; here no rank ever builds a table of its own reads).
-//   every rank    xchg_partition   part1 -> part2<OWN>: its reads become region lists, grouped by the OWNER of the key;
+//   every rank    xchg_scan        part1: its reads become level-1 lists (in its workspace); returns how many records
+//                 xchg_partition   part2<OWN>: the level-1 lists become region lists grouped by the OWNER of the key;
 //                                  what owner o is to get is one contiguous block of the send buffers (records + slice counts)
 //   the caller    one all_to_all of the blocks (8 B per k-mer occurrence + slack), dist.count_sharded
 //   every owner   xchg_insert      lds_insert<MULTI> x 2 straight into its shard, fused histogram, deferred records
-// All ranks must derive the same geometry: from the shard geometry (one for all owners), the number of owners and
-// piece_max = the longest piece any rank partitions in this round.
-static bool xchg_geometry(const Table &t, uint64_t piece_max, uint32_t nown, PartGeom &G) {
+// All ranks must derive the same geometry: from the shard geometry (one for all owners), the number of owners, piece_max =
+// the longest piece any rank scans in this round, and records_max = the most records any rank's scan produced (0: not known,
+// piece_max stands in).  The slack of the send lists is what travels, so they are sized from the records actually there, not
+// with the 1.25x of the local lists: mean + 6 sigma, where a list's fill is a sum over the distinct keys hashed into it of
+// their multiplicities in this sender's reads -- variance = mean x (1 + multiplicity).  The multiplicity is estimated from the
+// table the caller sized for the keys (about a third full): records / (keys all shards were sized for).  A list that still
+// overflows (a k-mer far more frequent than the rest, or a table sized far too large) spends the deferred list, as everywhere.
+static uint32_t xchg_cap(double avg, double mult) { return (uint32_t)std::min<double>(4.0e9, avg + 6.0 * std::sqrt(avg * (1.0 + mult)) + 16.0); }
+static bool xchg_geometry(const Table &t, uint64_t piece_max, uint64_t records_max, uint32_t nown, PartGeom &G) {
     if (nown < 2 || nown > MAX_SHARDS) return false;
     alignas(16) char raw[64];
     if (!t.partition_geometry(piece_max, raw)) return false;
@@ -724,14 +731,19 @@ static bool xchg_geometry(const Table &t, uint64_t piece_max, uint32_t nown, Par
     const uint32_t nb1 = 1u << G.p1;
     G.nblk2 = nb1 >= 256 ? 1u : std::min<uint32_t>(G.nblk1, 8u);
     if (nown * G.nblk2 > (uint32_t)LI_MAXSL) return false;
-    G.cap2 = list_cap((double)piece_max / ((double)nb1 * (double)((uint64_t)nown << G.p2) * (double)G.nblk2));
+    const double lists = (double)nb1 * (double)((uint64_t)nown << G.p2) * (double)G.nblk2;
+    if (records_max) {
+        const double rec = (double)std::min(records_max, piece_max);
+        const double keys = std::max(1.0, std::min(rec, 0.35 * (double)t.nslots * (double)nown));
+        G.cap2 = xchg_cap(rec / lists, rec / keys);
+    } else G.cap2 = list_cap((double)piece_max / lists);
     return true;
 }
 
-int Table::xchg_plan(uint64_t piece_max, uint32_t nown, uint64_t out[8], std::string &err) {
+int Table::xchg_plan(uint64_t piece_max, uint64_t records_max, uint32_t nown, uint64_t out[8], std::string &err) {
     (void)err;
     PartGeom G;
-    if (!xchg_geometry(*this, piece_max, nown, G)) return 1;
+    if (!xchg_geometry(*this, piece_max, records_max, nown, G)) return 1;
     const uint64_t lists_per_owner = (uint64_t)1 << (G.p1 + G.p2);
     out[0] = lists_per_owner * G.nblk2 * G.cap2;               // records (8 B) per owner block
     out[1] = lists_per_owner * G.nblk2;                        // slice counts (4 B) per owner block
@@ -741,49 +753,71 @@ int Table::xchg_plan(uint64_t piece_max, uint32_t nown, uint64_t out[8], std::st
 }
 
 // d_defer: 64-byte header (word 0 = number of entries) + defer_cap entries of 3 words (hash.hi, hash.lo, 1)
-int Table::xchg_partition(const uint8_t *d_bases, uint64_t n, uint64_t pos, uint64_t end, uint64_t piece_max, uint32_t nown, void *d_send, void *d_send_cnt,
-                          void *d_defer, uint64_t defer_cap, std::string &err) {
+int Table::xchg_scan(const uint8_t *d_bases, uint64_t n, uint64_t pos, uint64_t end, uint64_t piece_max, uint32_t nown, void *d_defer, uint64_t defer_cap,
+                     uint64_t *records, std::string &err) {
     HIPCHK(hipSetDevice(device));
     PartGeom G;
-    if (!xchg_geometry(*this, piece_max, nown, G)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
+    if (!xchg_geometry(*this, piece_max, 0, nown, G)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
     if (end > n) end = n;
     const uint32_t nb1 = 1u << G.p1;
-    const uint64_t lists = ((uint64_t)nown << (G.p1 + G.p2));
     unsigned long long *defer_n = (unsigned long long *)d_defer, *defer_e = defer_n + 8;
     HIPCHK(hipMemsetAsync(defer_n, 0, 64, stream));
     for (int i = 0; i <= N_STAGES; ++i) if (!ev_stage_t[i]) HIPCHK(hipEventCreate(&ev_stage_t[i]));
     count_path = 3;
     part_stage_n = 5;
+    if (read_stats(err)) return -1;
+    const uint64_t occ_before = h_stats[ST_OCCURRENCES];
     HIPCHK(hipEventRecord(ev_stage_t[0], stream));
+    xchg_partitioned = true;
+    const size_t n_cnt1 = (size_t)nb1 * G.nblk1;
+    uint64_t *out1 = (uint64_t *)workspace(WS_COUNT + 0, n_cnt1 * G.cap1 * 8, err);
+    unsigned int *cnt1 = (unsigned int *)workspace(WS_COUNT + 2, (n_cnt1 + 4) * 4, err);
+    if (!out1 || !cnt1) return -2;
     if (pos >= end) {                                          // nothing of mine in this round: empty lists
-        HIPCHK(hipMemsetAsync(d_send_cnt, 0, lists * G.nblk2 * 4, stream));
+        HIPCHK(hipMemsetAsync(cnt1, 0, n_cnt1 * 4, stream));
         HIPCHK(hipEventRecord(ev_stage_t[1], stream));
-        HIPCHK(hipEventRecord(ev_stage_t[2], stream));
+        if (records) *records = 0;
         return 0;
     }
+    if (end - pos > piece_max) { err = "count exchange: piece longer than the agreed maximum"; return -1; }
     const uint64_t halo = (uint64_t)(k - 1);
     const uint64_t misalign = reinterpret_cast<uintptr_t>(d_bases) & 15;
     uint64_t start = pos >= halo ? pos - halo : 0;
     const uint64_t a = (start + misalign) & 15;
     start = start >= a ? start - a : 0;
     const uint64_t len = end - start, emit_from = pos - start;
-    if (end - pos > piece_max) { err = "count exchange: piece longer than the agreed maximum"; return -1; }
-    const size_t n_cnt1 = (size_t)nb1 * G.nblk1;
-    uint64_t *out1 = (uint64_t *)workspace(WS_COUNT + 0, n_cnt1 * G.cap1 * 8, err);
-    unsigned int *cnt1 = (unsigned int *)workspace(WS_COUNT + 2, (n_cnt1 + 4) * 4, err);
-    if (!out1 || !cnt1) return -2;
     const uint64_t ntiles = (len + (uint64_t)PT_TILE - 1) / (uint64_t)PT_TILE;
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     if (k > 32) hipLaunchKernelGGL((part1_kernel<true, 1024>), dim3(G.nblk1), dim3(1024), p1_lds(1024), stream, d_bases + start, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, defer_cap);
     else hipLaunchKernelGGL((part1_kernel<false, 1024>), dim3(G.nblk1), dim3(1024), p1_lds(1024), stream, d_bases + start, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, defer_cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_stage_t[1], stream));
+    if (read_stats(err)) return -1;                            // (waits for the kernel)
+    if (records) *records = h_stats[ST_OCCURRENCES] - occ_before;
+    return 0;
+}
+
+int Table::xchg_partition(uint64_t piece_max, uint64_t records_max, uint32_t nown, void *d_send, void *d_send_cnt, void *d_defer, uint64_t defer_cap, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    PartGeom G;
+    if (!xchg_geometry(*this, piece_max, records_max, nown, G)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
+    if (!xchg_partitioned) { err = "count exchange: partition without a scan before it"; return -1; }
+    const uint32_t nb1 = 1u << G.p1;
+    unsigned long long *defer_n = (unsigned long long *)d_defer, *defer_e = defer_n + 8;
+    const size_t n_cnt1 = (size_t)nb1 * G.nblk1;
+    uint64_t *out1 = (uint64_t *)workspace(WS_COUNT + 0, n_cnt1 * G.cap1 * 8, err);       // (what the scan filled: same sizes, nothing is reallocated)
+    unsigned int *cnt1 = (unsigned int *)workspace(WS_COUNT + 2, (n_cnt1 + 4) * 4, err);
+    if (!out1 || !cnt1) return -2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
     hipLaunchKernelGGL(part2_kernel<true>, dim3(G.nblk2, std::min<uint32_t>(nb1, 2048)), dim3(PT_THREADS), P2_LDS, stream, out1, cnt1, d, G, (uint64_t *)d_send,
                        (unsigned int *)d_send_cnt, defer_e, defer_n, defer_cap, nown);
     HIPCHK(hipGetLastError());
@@ -809,11 +843,11 @@ __global__ __launch_bounds__(256) void import3_owned_kernel(const unsigned long 
 
 // d_recv / d_recv_cnt: block src = what rank src's xchg_partition put into ITS block `self`.  whole_input: these lists are
 // everything that goes into this (empty) shard -> the multiplicity histogram is taken on the way out.
-int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piece_max, uint32_t nown, uint32_t self, const void *d_defer_all, uint64_t n_defer_all,
-                       int whole_input, std::string &err) {
+int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piece_max, uint64_t records_max, uint32_t nown, uint32_t self, const void *d_defer_all,
+                       uint64_t n_defer_all, int whole_input, std::string &err) {
     HIPCHK(hipSetDevice(device));
     PartGeom G;
-    if (!xchg_geometry(*this, piece_max, nown, G)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
+    if (!xchg_geometry(*this, piece_max, records_max, nown, G)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
     if (read_stats(err)) return -1;
     const uint32_t nregions = 1u << (G.p1 + G.p2);
     const bool empty = h_stats[ST_DISTINCT] == 0;
@@ -834,6 +868,9 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
     if (!defer) return -2;
     unsigned long long *defer_n = defer, *defer_e = defer + 8;
     HIPCHK(hipMemsetAsync(defer_n, 0, 64, stream));
+    for (int i = 0; i <= N_STAGES; ++i) if (!ev_stage_t[i]) HIPCHK(hipEventCreate(&ev_stage_t[i]));
+    count_path = 3;
+    part_stage_n = 5;
     HIPCHK(hipEventRecord(ev_stage_t[3], stream));
     for (uint32_t parity = 0; parity < 2; ++parity) {
         if (!(nregions == 1 && parity == 1)) {
@@ -856,10 +893,12 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
     if (rc) return rc;
     histo_cached = histo != nullptr;
     const int pairs[5][2] = {{0, 1}, {1, 2}, {3, 4}, {4, 5}, {5, 6}};
-    for (int i = 0; i < 5; ++i) {
+    for (int i = xchg_partitioned ? 0 : 2; i < 5; ++i) {       // (a shard that only received: no sender stages of its own)
         float m = 0;
         if (hipEventElapsedTime(&m, ev_stage_t[pairs[i][0]], ev_stage_t[pairs[i][1]]) == hipSuccess) { part_stage_ms[i] += m; count_kernel_ms += m; }
+        else (void)hipGetLastError();
     }
+    xchg_partitioned = false;
     count_launches += 1;
     ++count_partitioned_launches;
     return 0;

@@ -470,17 +470,29 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
             dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
             if not int(okt.item()):
                 raise RuntimeError("count_sharded: the shards outgrew the exchange geometry between rounds")
-        nrec, ncnt, dcap = plan["records_per_owner"], plan["counts_per_owner"], plan["deferred_cap"]
+        dcap = plan["deferred_cap"]
         # (libjasper_hip works on its own stream: torch memory must be idle before it is handed over -- empty(), never zeros())
-        send = torch.empty((world, nrec), dtype=torch.int64, device=device)
-        send_cnt = torch.empty((world, ncnt), dtype=torch.int32, device=device)
         deferred = torch.empty(8 + 3 * dcap, dtype=torch.int64, device=device)
         _sync(device)
         pos = min(rnd * piece, int(n_bases))
         end = min(pos + piece, int(n_bases))
-        ok, why = 1, ""
-        try:
-            shard.exchange_partition(d_bases, n_bases, pos, end, piece, world, send.data_ptr(), send_cnt.data_ptr(), deferred.data_ptr(), dcap)
+        ok, why, found = 1, "", 0
+        try:                                            # first pass: my reads -> level-1 lists inside the library; how many records?
+            found = shard.exchange_scan(d_bases, n_bases, pos, end, piece, world, deferred.data_ptr(), dcap)
+        except RuntimeError as e:
+            ok, why = 0, str(e)
+        agree = torch.tensor([found, 1 - ok], dtype=torch.int64, device=device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MAX, group=group)
+        if int(agree[1].item()):
+            raise RuntimeError("count_sharded: the first partition pass failed on some rank" + (": " + why if why else ""))
+        records_max = max(int(agree[0].item()), 1)      # the send lists are sized from the records that are really there
+        plan = shard.exchange_plan(piece, world, records_max)
+        nrec, ncnt = plan["records_per_owner"], plan["counts_per_owner"]
+        send = torch.empty((world, nrec), dtype=torch.int64, device=device)
+        send_cnt = torch.empty((world, ncnt), dtype=torch.int32, device=device)
+        _sync(device)
+        try:                                            # second pass: level-1 lists -> region lists grouped by owner
+            shard.exchange_partition(piece, records_max, world, send.data_ptr(), send_cnt.data_ptr(), deferred.data_ptr(), dcap)
             shard.sync()
         except RuntimeError as e:
             ok, why = 0, str(e)
@@ -508,7 +520,7 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
         _sync(device)
         del send, send_cnt
         try:
-            shard.exchange_insert(recv.data_ptr(), recv_cnt.data_ptr(), piece, world, rank, d_all.data_ptr() if n_all else 0, n_all,
+            shard.exchange_insert(recv.data_ptr(), recv_cnt.data_ptr(), piece, records_max, world, rank, d_all.data_ptr() if n_all else 0, n_all,
                                   whole_input=(rounds == 1 and not any_filled))
         except RuntimeError as e:
             ok, why = 0, str(e)
@@ -518,7 +530,7 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
             raise RuntimeError("count_sharded: inserting the received lists failed on some rank" + (": " + why if why else ""))
         del recv, recv_cnt, deferred, d_all
     _attach_shards(shard, device, group)
-    return dict(rounds=rounds, wire_bytes=wire, deferred=n_deferred, plan=plan)
+    return dict(rounds=rounds, wire_bytes=wire, deferred=n_deferred, plan=plan, records_max=records_max)
 
 
 def write_jf_sharded(shard, path, cmdline, device, group=None):

@@ -330,23 +330,30 @@ class KmerTable:
         check(self._L.jasper_table_fit(self._h, float(max_load)))
 
     # ---- counting as an exchange of region lists (include/jasper_hip.h, jasper_count_exchange_*) -------
-    def exchange_plan(self, piece_max, n_owners):
+    def exchange_plan(self, piece_max, n_owners, records_max=0):
         """None when this table / piece size / k has no exchange geometry, else a dict of buffer sizes"""
         out = (C.c_uint64 * 8)()
-        rc = self._L.jasper_count_exchange_plan(self._h, int(piece_max), int(n_owners), out)
+        rc = self._L.jasper_count_exchange_plan(self._h, int(piece_max), int(records_max), int(n_owners), out)
         if rc == 1:
             return None
         check(rc)
         names = ("records_per_owner", "counts_per_owner", "deferred_cap", "p1", "p2", "region_bits", "slices", "slice_cap")
         return dict(zip(names, (int(v) for v in out)))
 
-    def exchange_partition(self, d_bases, n, pos, end, piece_max, n_owners, d_send, d_send_counts, d_deferred, deferred_cap):
-        check(self._L.jasper_count_exchange_partition(self._h, C.c_void_p(d_bases), int(n), int(pos), int(end), int(piece_max), int(n_owners), C.c_void_p(d_send),
-                                                      C.c_void_p(d_send_counts), C.c_void_p(d_deferred), int(deferred_cap)))
+    def exchange_scan(self, d_bases, n, pos, end, piece_max, n_owners, d_deferred, deferred_cap):
+        """first pass (returns when it is done): the number of k-mer occurrences found in [pos, end)"""
+        rec = C.c_uint64(0)
+        check(self._L.jasper_count_exchange_scan(self._h, C.c_void_p(d_bases), int(n), int(pos), int(end), int(piece_max), int(n_owners), C.c_void_p(d_deferred),
+                                                 int(deferred_cap), C.byref(rec)))
+        return rec.value
 
-    def exchange_insert(self, d_recv, d_recv_counts, piece_max, n_owners, self_index, d_deferred_all=0, n_deferred_all=0, whole_input=False):
-        check(self._L.jasper_count_exchange_insert(self._h, C.c_void_p(d_recv), C.c_void_p(d_recv_counts), int(piece_max), int(n_owners), int(self_index),
-                                                   C.c_void_p(d_deferred_all or None), int(n_deferred_all), 1 if whole_input else 0))
+    def exchange_partition(self, piece_max, records_max, n_owners, d_send, d_send_counts, d_deferred, deferred_cap):
+        check(self._L.jasper_count_exchange_partition(self._h, int(piece_max), int(records_max), int(n_owners), C.c_void_p(d_send), C.c_void_p(d_send_counts),
+                                                      C.c_void_p(d_deferred), int(deferred_cap)))
+
+    def exchange_insert(self, d_recv, d_recv_counts, piece_max, records_max, n_owners, self_index, d_deferred_all=0, n_deferred_all=0, whole_input=False):
+        check(self._L.jasper_count_exchange_insert(self._h, C.c_void_p(d_recv), C.c_void_p(d_recv_counts), int(piece_max), int(records_max), int(n_owners),
+                                                   int(self_index), C.c_void_p(d_deferred_all or None), int(n_deferred_all), 1 if whole_input else 0))
 
     # ---- owner-sharded table (include/jasper_hip.h, "Owner-sharded table") ----------------------------
     def export_owner(self, dev_ptr, cap_entries, n_owners):

@@ -51,22 +51,31 @@ def exchange_in_process(KT, k, n, sets, slots, piece=None):
     n_max = max(len(b) for b in sets)
     piece = piece or n_max
     rounds = (n_max + piece - 1) // piece
-    plan = shards[0].exchange_plan(piece, n)
-    assert plan is not None, "the test sizes tables and inputs so that the exchange geometry exists"
-    nrec, ncnt, dcap = plan["records_per_owner"], plan["counts_per_owner"], plan["deferred_cap"]
+    plan0 = shards[0].exchange_plan(piece, n)
+    assert plan0 is not None, "the test sizes tables and inputs so that the exchange geometry exists"
+    dcap = plan0["deferred_cap"]
     deferred_total = 0
     for rnd in range(rounds):
-        send = [torch.empty((n, nrec), dtype=torch.int64, device="cuda") for _ in range(n)]
-        cnt = [torch.empty((n, ncnt), dtype=torch.int32, device="cuda") for _ in range(n)]
         dfr = [torch.empty(8 + 3 * dcap, dtype=torch.int64, device="cuda") for _ in range(n)]
         torch.cuda.synchronize()
-        for r in range(n):
+        found = []
+        for r in range(n):                  # first pass on every rank; the longest list of records sizes everybody's send lists
             pos = min(rnd * piece, len(sets[r]))
             end = min(pos + piece, len(sets[r]))
-            shards[r].exchange_partition(dev[r].data_ptr(), len(sets[r]), pos, end, piece, n, send[r].data_ptr(), cnt[r].data_ptr(), dfr[r].data_ptr(), dcap)
+            found.append(shards[r].exchange_scan(dev[r].data_ptr(), len(sets[r]), pos, end, piece, n, dfr[r].data_ptr(), dcap))
+        records_max = max(max(found), 1)
+        plan = shards[0].exchange_plan(piece, n, records_max)
+        assert plan["records_per_owner"] <= plan0["records_per_owner"]
+        nrec, ncnt = plan["records_per_owner"], plan["counts_per_owner"]
+        send = [torch.empty((n, nrec), dtype=torch.int64, device="cuda") for _ in range(n)]
+        cnt = [torch.empty((n, ncnt), dtype=torch.int32, device="cuda") for _ in range(n)]
+        torch.cuda.synchronize()
+        for r in range(n):
+            shards[r].exchange_partition(piece, records_max, n, send[r].data_ptr(), cnt[r].data_ptr(), dfr[r].data_ptr(), dcap)
             shards[r].sync()
         nd = [int(d[0].item()) for d in dfr]
         assert max(nd) <= dcap
+        assert sum(int(c.to(torch.int64).sum().item()) for c in cnt) + sum(nd) == sum(found)      # every record is in a list or deferred
         d_all = torch.cat([d[8:8 + 3 * m] for d, m in zip(dfr, nd)]).contiguous() if sum(nd) else None
         deferred_total += sum(nd)
         for o in range(n):
@@ -74,7 +83,8 @@ def exchange_in_process(KT, k, n, sets, slots, piece=None):
             rcnt = torch.stack([cnt[r][o] for r in range(n)]).contiguous()
             assert int(rcnt.max().item()) <= plan["slice_cap"]
             torch.cuda.synchronize()
-            shards[o].exchange_insert(recv.data_ptr(), rcnt.data_ptr(), piece, n, o, d_all.data_ptr() if d_all is not None else 0, sum(nd), whole_input=(rounds == 1))
+            shards[o].exchange_insert(recv.data_ptr(), rcnt.data_ptr(), piece, records_max, n, o, d_all.data_ptr() if d_all is not None else 0, sum(nd),
+                                      whole_input=(rounds == 1))
     return shards, plan, deferred_total
 
 
@@ -100,6 +110,8 @@ def test_exchange_of_region_lists_equals_one_table(KT, monkeypatch, k, n, ls, G,
     shards, plan, deferred = exchange_in_process(KT, k, n, sets, 1 << ls, piece)
     if heavy:
         assert deferred > 0, "the heavy k-mer was meant to overflow its list"
+    else:
+        assert deferred < 0.002 * full.info()["occurrences"], "lists sized at mean + 6 sigma should hardly ever overflow"
     assert all(t.info()["slots"] == 1 << ls for t in shards), "the test sizes the shards so that they do not grow"
     assert sum(t.info()["distinct"] for t in shards) == full.info()["distinct"]          # a disjoint cover
     assert sum(t.info()["occurrences"] for t in shards) == full.info()["occurrences"]
@@ -137,6 +149,8 @@ def test_no_exchange_geometry_is_reported_not_raised(KT):
     w = KT(51, min_slots=1 << 21)
     assert w.exchange_plan(1 << 26, 2) is None          # wide remainders: direct kernel only
     assert t.exchange_plan(1 << 26, 1) is None
+    big, small = t.exchange_plan(1 << 26, 2), t.exchange_plan(1 << 26, 2, records_max=(1 << 26) * 3 // 4)
+    assert small["records_per_owner"] < 0.8 * big["records_per_owner"]     # lists sized from the records, not the worst case
     t.close()
     w.close()
 
