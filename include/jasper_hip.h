@@ -136,6 +136,17 @@ int jasper_table_fit(jasper_table *t, double max_load);
  *   jasper_table_detach: back to a whole table.  Growing a table detaches it.
  * The owners' tables must not be written while any GPU reads them; that ordering is the caller's (a barrier). */
 int jasper_table_export_owner(jasper_table *t, void *d_dst, uint64_t cap_entries, uint32_t n_owners, uint64_t *counts);
+/* The read files as a FEED of base batches in HBM (role of `zcat -f $READS |` in front of a counter that is driven from outside,
+ * src/jasper.sh:177): the reader / inflater / parsers of jasper_count_reads_file_ranges run in a thread of their own, but every
+ * batch of bases they would have counted into t is handed to the caller instead.  `t` only lends its device and buffers (its
+ * table is not touched).  begins / ends: per-file byte ranges as for jasper_count_reads_file_ranges, or both NULL.
+ *   jasper_read_feed_next     waits for the next batch: *d_bases (text bases with a non-base byte between records, as
+ *                             jasper_count_bases_device takes them; no k-mer spans two batches), *n bytes.  *n == 0: the stream
+ *                             has ended and the feed is closed; a reader / parser error is returned here.
+ *   jasper_read_feed_release  the caller is done with the batch: its memory is reused for the next one. */
+int jasper_read_feed_start(jasper_table *t, const char *const *paths, const int64_t *begins, const int64_t *ends, int n_paths);
+int jasper_read_feed_next(jasper_table *t, const void **d_bases, uint64_t *n);
+int jasper_read_feed_release(jasper_table *t);
 /* Counting on several GPUs WITHOUT per-GPU tables that are merged afterwards (role of `jellyfish count` over all reads,
  * src/jasper.sh:177, and of JF::jellyfish/merge_files.cc:44-96): the reads of every GPU go through the two partition passes
  * of the atomic-free counting path; the second pass also groups by owner, so what owner o is to receive is one contiguous

@@ -58,6 +58,9 @@ SYMBOLS = {
     "jasper_table_import_packed_multi": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64), C.c_uint32]),
     "jasper_table_reserve": (C.c_int, [_P, C.c_uint64]),
     "jasper_table_fit": (C.c_int, [_P, C.c_double]),
+    "jasper_read_feed_start": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
+    "jasper_read_feed_next": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "jasper_read_feed_release": (C.c_int, [_P]),
     "jasper_count_exchange_plan": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
     "jasper_count_exchange_scan": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "jasper_count_exchange_partition": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, _P, _P, _P, C.c_uint64]),

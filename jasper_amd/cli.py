@@ -354,23 +354,56 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
         else:
             _timing("split")
             log("Creating jellyfish database mer_counts%d.jf" % kmer)
-            def count_my_ranges():
-                t = KmerTable(kmer, min_slots=max(1 << 20, int(1.25 * o.jf_size / world)), device=o.device)
-                t.count_file_ranges(jdist.plan_read_shards(reads, world)[rank])
-                return t
-            local = together(count_my_ranges, "Computing mer counts histogram from mer_counts%d.jf failed, please make sure that mer_counts%d.jf is a valid Jellyfish mer counts file" % (kmer, kmer))
-            _timing("count reads (file ranges -> local table)")
+            fail_msg = "Computing mer counts histogram from mer_counts%d.jf failed, please make sure that mer_counts%d.jf is a valid Jellyfish mer counts file" % (kmer, kmer)
+            my_ranges = jdist.plan_read_shards(reads, world)[rank]
+            # No table per GPU when the key owners' table has a geometry for it (dist.count_sharded): the file reader feeds batches
+            # of bases, every batch is partitioned into region lists by key owner, ONE all_to_all moves the lists, the owners insert.
+            sharded = None
+            if os.environ.get("JASPER_AMD_COUNT", "") != "local":
+                sharded = together(lambda: KmerTable(kmer, min_slots=max(1 << 21, int(1.25 * o.jf_size / world)), device=o.device), fail_msg)
+                if not jdist.all_reduce_ints([1 if sharded.exchange_plan(1 << 26, world) is not None else 0], device=dev, op="min")[0]:
+                    sharded.close()
+                    sharded = None
+            if sharded is not None:
+                feeder = KmerTable(kmer, min_slots=1 << 10, device=o.device)      # lends its device buffers to the reader
+                together(lambda: feeder.feed_start(my_ranges), fail_msg)
+                try:
+                    info = jdist.count_sharded(sharded, 0, 0, dev, feeder=feeder)
+                except jdist.ShardAttachError as e:         # (raised on every rank together, after all lists were inserted)
+                    sharded._attach_failed = str(e)
+                    info = dict(rounds=-1)
+                except RuntimeError as e:                   # (raised on every rank together)
+                    sys.stderr.write("jasper_amd: rank %d: %s\n" % (rank, e))
+                    error_exit(fail_msg)
+                finally:
+                    feeder.close()
+                assert info is not None
+                local = None
+                _timing("count reads (file ranges -> region lists -> owners' shards, %d rounds)" % info["rounds"])
+            else:
+                def count_my_ranges():
+                    t = KmerTable(kmer, min_slots=max(1 << 20, int(1.25 * o.jf_size / world)), device=o.device)
+                    t.count_file_ranges(my_ranges)
+                    return t
+                local = together(count_my_ranges, fail_msg)
+                _timing("count reads (file ranges -> local table)")
             counted = True
     else:
         local = together(lambda: KmerTable.from_jf_part(o.jf_db, rank, world, device=o.device),
                          "Computing mer counts histogram from %s failed, please make sure that %s is a valid Jellyfish mer counts file" % (o.jf_db, o.jf_db))
     # key-wise sum over the GPUs; the result stays sharded by key owner unless the peers' HBM cannot be mapped
-    table = KmerTable(local.k, min_slots=1 << 21, device=o.device)
     write_db = counted and os.environ.get("JASPER_AMD_NO_JF", "") not in ("1", "true", "yes")
     db_cmdline = ["count", "-C", "-t", str(o.num_threads), "-s", str(o.jf_size), "-m", str(kmer), "-o", "mer_counts%d.jf" % kmer] + (o.reads.split() if counted else [])
     try:
-        jdist.shard_tables(local, table, dev)
-        local.close()
+        if local is None:       # counted straight into the owners' shards
+            table = sharded
+            local = table       # (what the fallback below merges: the shards are disjoint, their key-wise sum is the whole table)
+            if getattr(table, "_attach_failed", None):
+                raise jdist.ShardAttachError(table._attach_failed)
+        else:
+            table = KmerTable(local.k, min_slots=1 << 21, device=o.device)
+            jdist.shard_tables(local, table, dev)
+            local.close()
         if write_db:       # :177 `... | tee $JF_DB | ...`: every GPU sorts and writes one consecutive piece of the file
             jdist.write_jf_sharded(table, "mer_counts%d.jf" % kmer, db_cmdline, dev)
             _timing("write mer_counts.jf")
@@ -380,7 +413,8 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
             sys.stderr.write("jasper_amd: %s -- replicating the merged table on every GPU instead\n" % e)
         table.detach()          # (whatever was mapped is unmapped on every rank before anybody frees its slot array)
         bar()
-        table.close()
+        if table is not local:
+            table.close()
         table = local
         jdist.merge_tables(table, dev)
         if write_db:

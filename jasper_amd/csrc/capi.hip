@@ -271,6 +271,18 @@ int jasper_table_export_owner(jasper_table *t, void *d_dst, uint64_t cap_entries
     if (!counts) { g_err = "counts is null"; return JASPER_ERR; }
     return t->t.export_owner(d_dst, cap_entries, n_owners, 0, counts, g_err);
 }
+int jasper_read_feed_start(jasper_table *t, const char *const *paths, const int64_t *begins, const int64_t *ends, int n_paths) {
+    if (!t || n_paths < 0 || (n_paths && !paths) || ((begins == nullptr) != (ends == nullptr))) { g_err = "bad argument"; return JASPER_ERR; }
+    return t->t.feed_start(paths, begins, ends, n_paths, g_err) ? JASPER_ERR : JASPER_OK;
+}
+int jasper_read_feed_next(jasper_table *t, const void **d_bases, uint64_t *n) {
+    if (!t || !d_bases || !n) { g_err = "bad argument"; return JASPER_ERR; }
+    return t->t.feed_next(d_bases, n, g_err) ? JASPER_ERR : JASPER_OK;
+}
+int jasper_read_feed_release(jasper_table *t) {
+    if (!t) { g_err = "bad argument"; return JASPER_ERR; }
+    return t->t.feed_release(g_err) ? JASPER_ERR : JASPER_OK;
+}
 int jasper_count_exchange_plan(jasper_table *t, uint64_t piece_max, uint64_t records_max, uint32_t n_owners, uint64_t *out8) {
     if (!t || !out8) { g_err = "bad argument"; return JASPER_ERR; }
     const int rc = t->t.xchg_plan(piece_max, records_max, n_owners, out8, g_err);

@@ -550,7 +550,7 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     PartGeom &G = *reinterpret_cast<PartGeom *>(geom_out);
     if (getenv("JASPER_COUNT_DIRECT")) return false;
     if (d.ext) return false;                              // wide remainders: the LDS images hold tags only
-    if (piece_bases < (getenv("JASPER_PART_TEST_SMALL") ? 1024u : (8u << 20))) return false;   // small pieces: the direct kernel is already latency-hidden (the env switch: tests)
+    if (piece_bases < (8u << 20)) return false;          // small pieces: the direct kernel is already latency-hidden
     const int B = d.B, s = d.s;
     const int need_p1 = B > 64 ? B - 64 : 0;              // records are 8 bytes
     int p1 = std::max(need_p1, (s - RG_MAXBITS + 1) / 2);
@@ -724,6 +724,8 @@ static uint32_t xchg_cap(double avg, double mult) { return (uint32_t)std::min<do
 static bool xchg_geometry(const Table &t, uint64_t piece_max, uint64_t records_max, uint32_t nown, PartGeom &G) {
     if (nown < 2 || nown > MAX_SHARDS) return false;
     alignas(16) char raw[64];
+    // (a feed's last batch may be small: the lists are then laid out as for the smallest piece the passes are tuned for)
+    piece_max = std::max<uint64_t>(piece_max, 8u << 20);
     if (!t.partition_geometry(piece_max, raw)) return false;
     G = *reinterpret_cast<const PartGeom *>(raw);
     if (((uint64_t)nown << G.p2) > (uint64_t)PT_MAXBUCKETS) return false;       // (a third pass would be needed: not built)

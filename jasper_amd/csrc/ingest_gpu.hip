@@ -465,12 +465,48 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
     uint64_t bases_len = 0;
     auto flush_bases = [&]() -> int {
         if (!bases_len) return 0;
-        const int rc = count_device(d_bases, bases_len, err);
+        const int rc = bases_sink ? bases_sink(d_bases, bases_len) : count_device(d_bases, bases_len, err);
         bases_len = 0;
         return rc;
     };
+    // what the host parser emits (whole records, a few MB at a time): counted from host memory, or (feed) collected in a
+    // device buffer and handed over when that is full / at the end of the stream
+    const size_t HOST_ACC = 256u << 20;
+    size_t host_acc = 0;
+    uint8_t *d_host = nullptr;
+    auto flush_host = [&]() -> int {
+        if (!host_acc) return 0;
+        HIPCHK(jk_stream_wait(stream));
+        const int rc = bases_sink(d_host, host_acc);
+        host_acc = 0;
+        return rc;
+    };
+    auto host_bases = [&](const char *b, size_t m) -> int {
+        if (!bases_sink) return this->count_host(b, m, err);
+        if (!d_host) {
+            d_host = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 5, HOST_ACC + 64, err));
+            if (!d_host) return -1;
+        }
+        for (size_t off = 0; off < m;) {
+            if (host_acc == HOST_ACC) { if (int rc = flush_host()) return rc; }
+            size_t n = std::min(HOST_ACC - host_acc, m - off);
+            if (off + n < m) {                             // cut after a separator, so that no k-mer spans two batches
+                size_t cut = n;
+                while (cut > 0 && b[off + cut - 1] != 'N') --cut;
+                if (cut > 0) n = cut;
+                else if (host_acc) { if (int rc = flush_host()) return rc; continue; }
+                else { err = "a run of bases without a separator longer than the feed buffer"; return -1; }
+            }
+            HIPCHK(hipMemcpyAsync(d_host + host_acc, b + off, n, hipMemcpyHostToDevice, stream));
+            HIPCHK(jk_stream_wait(stream));                // (b is the parser's buffer: reused as soon as this returns)
+            host_acc += n;
+            off += n;
+            if (off < m) { if (int rc = flush_host()) return rc; }
+        }
+        return 0;
+    };
     // the host state machine takes over from here (and keeps the rest of the stream)
-    FastxParser hp([this, &err](const char *b, size_t m) { return this->count_host(b, m, err); });
+    FastxParser hp(host_bases);
     auto host_rest = [&](int mode, const char *first, size_t first_n) -> int {
         if (int rc = flush_bases()) return rc;
         hp.resume(mode);
@@ -485,6 +521,7 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
         }
         if (!rc) rc = hp.finish();
         if (rc && !hp.error().empty()) err = hp.error();
+        if (!rc && bases_sink) rc = flush_host();
         return rc;
     };
 
@@ -549,6 +586,104 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
         if (carry) memmove(h_buf, h_buf + n_use, carry);
     }
     return flush_bases();
+}
+
+// ---- feed: the same reader and parsers, the bases handed to the caller instead of counted -----------------------------
+struct Table::Feed {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    enum { IDLE, READY, TAKEN, DONE } state = IDLE;
+    const uint8_t *ptr = nullptr;
+    uint64_t len = 0;
+    int rc = 0;
+    std::string err;
+    bool abort = false;
+    std::vector<std::string> paths;
+    std::vector<const char *> cpaths;
+    std::vector<int64_t> begins, ends;
+};
+
+int Table::feed_start(const char *const *paths, const int64_t *begins, const int64_t *ends, int n_paths, std::string &err) {
+    if (feed) { err = "a feed is already running on this table"; return -1; }
+    if (n_paths < 0 || (n_paths && !paths)) { err = "bad argument"; return -1; }
+    feed = new Feed();
+    Feed *F = feed;
+    for (int i = 0; i < n_paths; ++i) F->paths.emplace_back(paths[i]);
+    for (const std::string &p : F->paths) F->cpaths.push_back(p.c_str());
+    if (begins && ends) { F->begins.assign(begins, begins + n_paths); F->ends.assign(ends, ends + n_paths); }
+    bases_sink = [F](const uint8_t *d_bases, uint64_t n) -> int {
+        std::unique_lock<std::mutex> lk(F->m);
+        F->ptr = d_bases;
+        F->len = n;
+        F->state = Feed::READY;
+        F->cv.notify_all();
+        F->cv.wait(lk, [F] { return F->state == Feed::IDLE || F->abort; });
+        if (F->abort) { F->err = "feed stopped by the caller"; return -1; }
+        return 0;
+    };
+    F->th = std::thread([this, F] {
+        ingest_gpu_bytes = ingest_host_bytes = 0;
+        ingest_begin = F->begins.empty() ? nullptr : F->begins.data();
+        ingest_end = F->ends.empty() ? nullptr : F->ends.data();
+        std::string e;
+        const int rc = count_files_gpu(F->cpaths.data(), (int)F->cpaths.size(), &ingest_gpu_bytes, &ingest_host_bytes, e);
+        ingest_begin = ingest_end = nullptr;
+        std::unique_lock<std::mutex> lk(F->m);
+        F->rc = rc;
+        if (rc && F->err.empty()) F->err = e;
+        F->state = Feed::DONE;
+        F->cv.notify_all();
+    });
+    return 0;
+}
+
+int Table::feed_next(const void **d_bases, uint64_t *n, std::string &err) {
+    if (!feed) { err = "no feed on this table"; return -1; }
+    Feed *F = feed;
+    std::unique_lock<std::mutex> lk(F->m);
+    if (F->state == Feed::TAKEN) { err = "feed_next before feed_release of the last batch"; return -1; }
+    F->cv.wait(lk, [F] { return F->state == Feed::READY || F->state == Feed::DONE; });
+    if (F->state == Feed::DONE) {
+        lk.unlock();
+        if (F->th.joinable()) F->th.join();
+        const int rc = F->rc;
+        if (rc) err = F->err;
+        bases_sink = nullptr;
+        delete F;
+        feed = nullptr;
+        *d_bases = nullptr;
+        *n = 0;
+        return rc ? -1 : 0;
+    }
+    F->state = Feed::TAKEN;
+    *d_bases = F->ptr;
+    *n = F->len;
+    return 0;
+}
+
+int Table::feed_release(std::string &err) {
+    if (!feed) { err = "no feed on this table"; return -1; }
+    Feed *F = feed;
+    std::unique_lock<std::mutex> lk(F->m);
+    if (F->state != Feed::TAKEN) { err = "feed_release without a batch taken"; return -1; }
+    F->state = Feed::IDLE;
+    F->cv.notify_all();
+    return 0;
+}
+
+void Table::feed_stop() {
+    if (!feed) return;
+    Feed *F = feed;
+    {
+        std::unique_lock<std::mutex> lk(F->m);
+        F->abort = true;
+        F->cv.notify_all();
+    }
+    if (F->th.joinable()) F->th.join();
+    bases_sink = nullptr;
+    delete F;
+    feed = nullptr;
 }
 
 }  // namespace jk

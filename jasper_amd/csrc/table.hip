@@ -663,6 +663,7 @@ void *Table::workspace(int id, size_t bytes, std::string &err) {
 }
 
 void Table::destroy() {
+    feed_stop();
     (void)hipSetDevice(device);
     if (stream) (void)jk_stream_wait(stream);
     detach_shards();

@@ -7,6 +7,7 @@
 //   JF::sub_commands/histo_main.cc:34-44                              (histogram)
 #pragma once
 #include "kmer.hpp"
+#include <functional>
 #include <string>
 
 namespace jk {
@@ -362,6 +363,16 @@ struct Table {
     int count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_bytes, uint64_t *host_bytes, std::string &err);
     uint64_t ingest_gpu_bytes = 0, ingest_host_bytes = 0;
     const int64_t *ingest_begin = nullptr, *ingest_end = nullptr;   // per-file byte ranges of the next count_files_gpu call (or null)
+    // The read files as a FEED of base batches in HBM instead of counts in this table (ingest_gpu.hip, "feed"): a thread runs
+    // count_files_gpu with `bases_sink` set, every batch it would have counted is handed to the caller of feed_next and the
+    // thread waits until feed_release.  For counting paths that are driven from outside (dist.count_sharded).
+    std::function<int(const uint8_t *d_bases, uint64_t n)> bases_sink;
+    struct Feed;
+    Feed *feed = nullptr;
+    int feed_start(const char *const *paths, const int64_t *begins, const int64_t *ends, int n_paths, std::string &err);
+    int feed_next(const void **d_bases, uint64_t *n, std::string &err);      // *n == 0: the stream has ended (the thread is gone)
+    int feed_release(std::string &err);
+    void feed_stop();
     char *h_ingest = nullptr;      // pinned text staging of count_files_gpu
     size_t ingest_chunk = 0;
     int histogram(uint64_t *out10002, std::string &err);

@@ -423,17 +423,58 @@ def _attach_shards(shard, device, group=None):
         shard.release_retired()
 
 
-def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None, clear=False):
-    """Count this rank's reads (text bases in HBM, as for KmerTable.count_bases_device) into the OWNER-SHARDED table without a
-    table per GPU: every rank turns its reads into region lists grouped by the owner of the key (two partition passes of the
-    atomic-free counting path), ONE all_to_all moves every list to its owner (8 bytes per k-mer occurrence), and the owner
-    inserts what arrived straight into `shard` (include/jasper_hip.h: jasper_count_exchange_*).  Compared with counting into a
-    local table and shard_tables(): no local insert, no export pass, no add pass, and no memory for a local table.
+class _ResidentBases:
+    """one buffer of bases in HBM, cut into pieces of at most `piece` bases"""
+
+    def __init__(self, d_bases, n_bases, piece):
+        self.ptr, self.n, self.piece, self.pos = int(d_bases), int(n_bases), int(piece), 0
+
+    def next(self):
+        if self.pos >= self.n:
+            return None
+        pos, end = self.pos, min(self.pos + self.piece, self.n)
+        self.pos = end
+        return self.ptr, self.n, pos, end, end < self.n
+
+    def scanned(self):
+        pass
+
+
+class _FeedBases:
+    """the batches of a read feed (KmerTable.feed_start): every batch is a buffer of its own"""
+
+    def __init__(self, feeder):
+        self.feeder, self.open = feeder, True
+
+    def next(self):
+        if not self.open:
+            return None
+        ptr, n = self.feeder.feed_next()
+        if n == 0:
+            self.open = False
+            return None
+        return ptr, n, 0, n, True
+
+    def scanned(self):                                  # the reader may parse the next batch while this one travels
+        self.feeder.feed_release()
+
+
+def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None, clear=False, feeder=None):
+    """Count this rank's reads into the OWNER-SHARDED table without a table per GPU: every rank turns its reads into region
+    lists grouped by the owner of the key (the two partition passes of the atomic-free counting path), ONE all_to_all per
+    round moves every list to its owner (8 bytes per k-mer occurrence plus the slack of the lists), and the owner inserts what
+    arrived straight into `shard` (include/jasper_hip.h: jasper_count_exchange_*).  Compared with counting into a local table
+    and shard_tables(): no local insert, no export pass, no add pass, and no memory for a local table.
+
+    The reads: text bases in HBM (d_bases, n_bases -- as for KmerTable.count_bases_device; cut into rounds of piece_limit
+    bases), or `feeder` = a KmerTable on which feed_start(ranges) has been called: every batch the file reader delivers is a
+    round, and the reader parses the next batch while the last one is exchanged.
 
     Collective.  `shard` should be sized for the keys it will own (min_slots / reserve) -- it grows if it must.  Counts are
-    ADDED to what the shard holds; clear=True empties it first (at a point where no peer can still be reading it).  Returns None (collectively, nothing done) when the table / input size / k has no exchange
-    geometry -- count into a local table and call shard_tables() then -- else a dict with the rounds and bytes moved.
-    Afterwards lookups through `shard` read the owner's HBM (own or peer's), as after shard_tables()."""
+    ADDED to what the shard holds; clear=True empties it first (at a point where no peer can still be reading it).  Returns
+    None (collectively, nothing consumed) when the table / k has no exchange geometry -- count into a local table and call
+    shard_tables() then -- else a dict with the rounds and bytes moved.  Afterwards lookups through `shard` read the owner's HBM
+    (own or peer's), as after shard_tables()."""
     import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
@@ -441,65 +482,76 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     was_empty = clear or shard.info()["distinct"] == 0
-    agree = torch.tensor([int(n_bases), shard.info()["slots"], 0 if was_empty else 1], dtype=torch.int64, device=device)
+    agree = torch.tensor([shard.info()["slots"], 0 if was_empty else 1], dtype=torch.int64, device=device)
     dist.all_reduce(agree, op=dist.ReduceOp.MAX, group=group)
-    n_max, slots, any_filled = (int(v) for v in agree.tolist())
+    slots, any_filled = (int(v) for v in agree.tolist())
     # (every rank is here: none of them still reads the shards of the last step through its peer mappings)
-    if clear:
-        shard.clear()
-    if n_max == 0:
-        _attach_shards(shard, device, group)
-        return dict(rounds=0, wire_bytes=0, deferred=0)
     shard.reserve(slots)
-    piece = min(n_max, int(piece_limit or os.environ.get("JASPER_AMD_EXCHANGE_PIECE", 1 << 31)))
-    rounds = (n_max + piece - 1) // piece
-    plan = shard.exchange_plan(piece, world)
+    plan = shard.exchange_plan(1 << 26, world)          # (whether there is a geometry does not depend on the piece size)
     okt = torch.tensor([1 if plan is not None else 0], dtype=torch.int64, device=device)
     dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
     if not int(okt.item()):
         return None
-    wire = 0
-    n_deferred = 0
-    for rnd in range(rounds):
-        if rnd:                                         # a shard that grew in the last round changes the geometry for all
-            st = torch.tensor([shard.info()["slots"]], dtype=torch.int64, device=device)
-            dist.all_reduce(st, op=dist.ReduceOp.MAX, group=group)
-            shard.reserve(int(st.item()))
-            plan = shard.exchange_plan(piece, world)
-            okt = torch.tensor([1 if plan is not None else 0], dtype=torch.int64, device=device)
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
-            if not int(okt.item()):
-                raise RuntimeError("count_sharded: the shards outgrew the exchange geometry between rounds")
+    if clear:
+        shard.clear()
+    piece = int(piece_limit or os.environ.get("JASPER_AMD_EXCHANGE_PIECE", 1 << 31))
+    source = _FeedBases(feeder) if feeder is not None else _ResidentBases(d_bases, n_bases, piece)
+    wire = n_deferred = rounds = 0
+    records_max = 0
+    while True:
+        ok, why = 1, ""
+        mine = None
+        try:
+            mine = source.next()
+        except RuntimeError as e:                       # (a reader / parser error of the feed)
+            ok, why = 0, str(e)
+        length = (mine[3] - mine[2]) if mine else 0
+        more = 1 if (mine and mine[4]) else 0
+        st = torch.tensor([length, shard.info()["slots"], more, 1 - ok], dtype=torch.int64, device=device)
+        dist.all_reduce(st, op=dist.ReduceOp.MAX, group=group)
+        piece_max, slots, any_more, bad = (int(v) for v in st.tolist())
+        if bad:
+            raise RuntimeError("count_sharded: reading the reads failed on some rank" + (": " + why if why else ""))
+        if piece_max == 0:
+            break
+        shard.reserve(slots)                            # a shard that grew in the last round changes the geometry for all
+        plan = shard.exchange_plan(piece_max, world)
+        okt = torch.tensor([1 if plan is not None else 0], dtype=torch.int64, device=device)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
+        if not int(okt.item()):
+            raise RuntimeError("count_sharded: the shards outgrew the exchange geometry between rounds")
         dcap = plan["deferred_cap"]
         # (libjasper_hip works on its own stream: torch memory must be idle before it is handed over -- empty(), never zeros())
         deferred = torch.empty(8 + 3 * dcap, dtype=torch.int64, device=device)
         _sync(device)
-        pos = min(rnd * piece, int(n_bases))
-        end = min(pos + piece, int(n_bases))
-        ok, why, found = 1, "", 0
+        found = 0
         try:                                            # first pass: my reads -> level-1 lists inside the library; how many records?
-            found = shard.exchange_scan(d_bases, n_bases, pos, end, piece, world, deferred.data_ptr(), dcap)
+            if mine:
+                found = shard.exchange_scan(mine[0], mine[1], mine[2], mine[3], piece_max, world, deferred.data_ptr(), dcap)
+                source.scanned()
+            else:
+                found = shard.exchange_scan(0, 0, 0, 0, piece_max, world, deferred.data_ptr(), dcap)
         except RuntimeError as e:
             ok, why = 0, str(e)
-        agree = torch.tensor([found, 1 - ok], dtype=torch.int64, device=device)
-        dist.all_reduce(agree, op=dist.ReduceOp.MAX, group=group)
-        if int(agree[1].item()):
+        st = torch.tensor([found, 1 - ok], dtype=torch.int64, device=device)
+        dist.all_reduce(st, op=dist.ReduceOp.MAX, group=group)
+        if int(st[1].item()):
             raise RuntimeError("count_sharded: the first partition pass failed on some rank" + (": " + why if why else ""))
-        records_max = max(int(agree[0].item()), 1)      # the send lists are sized from the records that are really there
-        plan = shard.exchange_plan(piece, world, records_max)
+        records_max = max(int(st[0].item()), 1)         # the send lists are sized from the records that are really there
+        plan = shard.exchange_plan(piece_max, world, records_max)
         nrec, ncnt = plan["records_per_owner"], plan["counts_per_owner"]
         send = torch.empty((world, nrec), dtype=torch.int64, device=device)
         send_cnt = torch.empty((world, ncnt), dtype=torch.int32, device=device)
         _sync(device)
         try:                                            # second pass: level-1 lists -> region lists grouped by owner
-            shard.exchange_partition(piece, records_max, world, send.data_ptr(), send_cnt.data_ptr(), deferred.data_ptr(), dcap)
+            shard.exchange_partition(piece_max, records_max, world, send.data_ptr(), send_cnt.data_ptr(), deferred.data_ptr(), dcap)
             shard.sync()
         except RuntimeError as e:
             ok, why = 0, str(e)
-        mine = int(deferred[0].item()) if ok else 0
-        if mine > dcap:
-            ok, why = 0, "too many records found no room in their lists (%d): pass a larger size hint" % mine
-        nd = torch.tensor([mine, 1 - ok], dtype=torch.int64, device=device)
+        ndef = int(deferred[0].item()) if ok else 0
+        if ndef > dcap:
+            ok, why = 0, "too many records found no room in their lists (%d): pass a larger size hint" % ndef
+        nd = torch.tensor([ndef, 1 - ok], dtype=torch.int64, device=device)
         parts = [torch.zeros_like(nd) for _ in range(world)]
         dist.all_gather(parts, nd, group=group)
         parts = [p.tolist() for p in parts]
@@ -520,8 +572,8 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
         _sync(device)
         del send, send_cnt
         try:
-            shard.exchange_insert(recv.data_ptr(), recv_cnt.data_ptr(), piece, records_max, world, rank, d_all.data_ptr() if n_all else 0, n_all,
-                                  whole_input=(rounds == 1 and not any_filled))
+            shard.exchange_insert(recv.data_ptr(), recv_cnt.data_ptr(), piece_max, records_max, world, rank, d_all.data_ptr() if n_all else 0, n_all,
+                                  whole_input=(rounds == 0 and not any_more and not any_filled))
         except RuntimeError as e:
             ok, why = 0, str(e)
         okt = torch.tensor([ok], dtype=torch.int64, device=device)
@@ -529,6 +581,7 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
         if not int(okt.item()):
             raise RuntimeError("count_sharded: inserting the received lists failed on some rank" + (": " + why if why else ""))
         del recv, recv_cnt, deferred, d_all
+        rounds += 1
     _attach_shards(shard, device, group)
     return dict(rounds=rounds, wire_bytes=wire, deferred=n_deferred, plan=plan, records_max=records_max)
 
@@ -610,12 +663,12 @@ def histogram_merged(table, device, group=None):
     return [int(x) for x in h.tolist()]
 
 
-def all_reduce_ints(values, device=None):
-    """sum a short list of python ints over ranks (QV counters, k-mer totals)"""
+def all_reduce_ints(values, device=None, op="sum"):
+    """sum (or "min" / "max") a short list of python ints over ranks (QV counters, k-mer totals, agreed decisions)"""
     import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return list(values)
     t = torch.tensor(list(values), dtype=torch.int64, device=device)
-    dist.all_reduce(t)
+    dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op])
     return [int(x) for x in t.tolist()]

@@ -177,6 +177,24 @@ class KmerTable:
         e = (C.c_int64 * max(n, 1))(*[int(r[2]) for r in ranges])
         check(self._L.jasper_count_reads_file_ranges(self._h, arr, b, e, n))
 
+    # ---- the read files as a feed of base batches in HBM (include/jasper_hip.h, jasper_read_feed_*) ----
+    def feed_start(self, ranges):
+        """ranges as for count_file_ranges; this table only lends its device and buffers"""
+        n = len(ranges)
+        arr = (C.c_char_p * max(n, 1))(*[r[0].encode() for r in ranges])
+        b = (C.c_int64 * max(n, 1))(*[int(r[1]) for r in ranges])
+        e = (C.c_int64 * max(n, 1))(*[int(r[2]) for r in ranges])
+        check(self._L.jasper_read_feed_start(self._h, arr, b, e, n))
+
+    def feed_next(self):
+        """(device pointer, bytes) of the next batch of bases; bytes == 0: the stream has ended"""
+        p, n = C.c_void_p(0), C.c_uint64(0)
+        check(self._L.jasper_read_feed_next(self._h, C.byref(p), C.byref(n)))
+        return (p.value or 0), n.value
+
+    def feed_release(self):
+        check(self._L.jasper_read_feed_release(self._h))
+
     def last_ingest(self):
         """(text bytes parsed on the GPU, text bytes parsed by the host state machine) of the last count_files call"""
         a, b = C.c_uint64(0), C.c_uint64(0)

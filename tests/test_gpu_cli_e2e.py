@@ -96,10 +96,11 @@ def _free_port():
     return p
 
 
-def _torchrun_cli(cwd, args, nproc=2):
+def _torchrun_cli(cwd, args, nproc=2, extra_env=None):
     """the multi-GPU form of the driver: one process per GPU under torch.distributed.run; rehearsed here with both ranks on
     the one GPU of the test box and gloo as the transport (RCCL refuses two ranks on one device)"""
-    env = dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_DIST_BACKEND="gloo", JASPER_AMD_ONE_GPU="1")
+    env = dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_DIST_BACKEND="gloo", JASPER_AMD_ONE_GPU="1", JASPER_AMD_TIMING="1")
+    env.update(extra_env or {})
     if nproc > 2:
         # the test box allows 6 processes on its GPU: pytest + the launcher + nproc ranks leave no room for the throw-away
         # process that probes the IPC mapping (dist._ipc_probe_ok); two-rank runs keep it
@@ -120,6 +121,8 @@ def test_cli_two_ranks_matches_jasper_sh(hip, tmp_path):
     args = ["-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(meta["k"]), "-t", str(meta["threads"]), "-p", str(meta["passes"]), "-d"]
     p = _torchrun_cli(tmp_path, args)
     assert p.returncode == 0, p.stdout + p.stderr
+    # counted without a table per GPU: file reader -> batches of bases -> region lists by key owner -> one all_to_all -> owners' shards
+    assert "region lists -> owners' shards" in p.stderr and "local table" not in p.stderr, p.stderr
 
     def check_outputs():
         assert open(tmp_path / "threshold.txt").read() == open(os.path.join(E2E, "threshold.txt")).read()
@@ -175,16 +178,20 @@ def test_cli_two_ranks_matches_jasper_sh(hip, tmp_path):
     check_outputs()
 
 
-@pytest.mark.parametrize("nproc", [3] + ([4] if os.environ.get("JASPER_TEST_BIG") else []))    # (4 ranks sit at the test box's process limit)
-def test_cli_three_ranks(hip, tmp_path, nproc):
-    """rank counts beyond two, one of them not a power of two: that many byte ranges per read file, key owners, file pieces"""
+@pytest.mark.parametrize("nproc,count", [(3, "exchange"), (3, "local")] + ([(4, "exchange")] if os.environ.get("JASPER_TEST_BIG") else []))    # (4 ranks sit at the test box's process limit)
+def test_cli_three_ranks(hip, tmp_path, nproc, count):
+    """rank counts beyond two, one of them not a power of two: that many byte ranges per read file, key owners, file pieces;
+    counted by the exchange of region lists, and (JASPER_AMD_COUNT=local) into a table per GPU whose entries are then summed
+    by owner"""
     meta = json.load(open(os.path.join(E2E, "meta.json")))
     for fn in ("r1.fq", "r2.fq"):
         with open(tmp_path / fn, "wb") as f:
             f.write(gzip.open(os.path.join(E2E, fn + ".gz")).read())
     shutil.copy(os.path.join(E2E, "asm.fa"), tmp_path)
-    p = _torchrun_cli(tmp_path, ["-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(meta["k"]), "-t", str(meta["threads"]), "-p", str(meta["passes"])], nproc=nproc)
+    p = _torchrun_cli(tmp_path, ["-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(meta["k"]), "-t", str(meta["threads"]), "-p", str(meta["passes"])], nproc=nproc,
+                      extra_env={"JASPER_AMD_COUNT": "local"} if count == "local" else None)
     assert p.returncode == 0, p.stdout + p.stderr
+    assert ("local table" in p.stderr) == (count == "local"), p.stderr
     assert open(tmp_path / "threshold.txt").read() == open(os.path.join(E2E, "threshold.txt")).read()
     assert open(tmp_path / "jfhisto25.csv").read() == open(os.path.join(E2E, "jfhisto25.csv")).read()
     assert fasta_records(tmp_path / "asm.fa.polished.fasta") == fasta_records(os.path.join(E2E, "asm.fa.polished.fasta"))
