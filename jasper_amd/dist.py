@@ -441,22 +441,29 @@ class _ResidentBases:
 
 
 class _FeedBases:
-    """the batches of a read feed (KmerTable.feed_start): every batch is a buffer of its own"""
+    """the batches of a read feed (KmerTable.feed_start): every batch is a buffer of its own, cut into pieces of at most
+    `piece` bases; the reader goes on to parse the next batch as soon as the last piece of this one has been scanned"""
 
-    def __init__(self, feeder):
-        self.feeder, self.open = feeder, True
+    def __init__(self, feeder, piece):
+        self.feeder, self.piece, self.open = feeder, int(piece), True
+        self.ptr = self.n = self.pos = 0
 
     def next(self):
         if not self.open:
             return None
-        ptr, n = self.feeder.feed_next()
-        if n == 0:
-            self.open = False
-            return None
-        return ptr, n, 0, n, True
+        if self.pos >= self.n:
+            self.ptr, self.n = self.feeder.feed_next()
+            self.pos = 0
+            if self.n == 0:
+                self.open = False
+                return None
+        pos, end = self.pos, min(self.pos + self.piece, self.n)
+        self.pos = end
+        return self.ptr, self.n, pos, end, True
 
-    def scanned(self):                                  # the reader may parse the next batch while this one travels
-        self.feeder.feed_release()
+    def scanned(self):
+        if self.pos >= self.n:
+            self.feeder.feed_release()
 
 
 def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None, clear=False, feeder=None):
@@ -494,8 +501,18 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
         return None
     if clear:
         shard.clear()
+    # a round holds its send and receive lists (~10 bytes per base each) next to the shard: at most 2^31 bases, fewer when the
+    # memory is short (one value for all ranks: the buffers are sized by the longest piece of the round).  The gloo rehearsal
+    # gathers every rank's send buffer on every rank, and its ranks may share one GPU.
     piece = int(piece_limit or os.environ.get("JASPER_AMD_EXCHANGE_PIECE", 1 << 31))
-    source = _FeedBases(feeder) if feeder is not None else _ResidentBases(d_bases, n_bases, piece)
+    if device.type == "cuda" and not piece_limit:
+        torch.cuda.empty_cache()
+        per_base = 48 if dist.get_backend(group) == "nccl" else 48 + 48 * world
+        piece = max(8 << 20, min(piece, torch.cuda.mem_get_info(device)[0] // per_base))
+    pt = torch.tensor([piece], dtype=torch.int64, device=device)
+    dist.all_reduce(pt, op=dist.ReduceOp.MIN, group=group)
+    piece = int(pt.item())
+    source = _FeedBases(feeder, piece) if feeder is not None else _ResidentBases(d_bases, n_bases, piece)
     wire = n_deferred = rounds = 0
     records_max = 0
     while True:
@@ -582,6 +599,8 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
             raise RuntimeError("count_sharded: inserting the received lists failed on some rank" + (": " + why if why else ""))
         del recv, recv_cnt, deferred, d_all
         rounds += 1
+    if device.type == "cuda" and rounds > 1:
+        torch.cuda.empty_cache()                        # (rounds of different sizes leave cached blocks behind: back to the driver)
     _attach_shards(shard, device, group)
     return dict(rounds=rounds, wire_bytes=wire, deferred=n_deferred, plan=plan, records_max=records_max)
 
