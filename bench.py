@@ -220,8 +220,8 @@ def main():
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: all ranks share GPU 0")
     ap.add_argument("--count", choices=("auto", "exchange", "local"), default="auto",
                     help="N>1 with a sharded table: 'exchange' = reads become region lists grouped by key owner, one all_to_all, owners "
-                         "insert (no table per GPU); 'local' = count into a table per GPU, then sum by owner; auto = exchange when the "
-                         "table has a geometry for it")
+                         "insert (no table per GPU); 'local' = count into a table per GPU, then sum by owner; auto = whichever the "
+                         "bytes-per-link model of dist.prefer_exchange expects to be faster (exchange from about 6 GPUs on)")
     ap.add_argument("--table", choices=("auto", "sharded", "replicated"), default="auto",
                     help="N>1: keep the merged table key-sharded over the GPUs (lookups read the owner's HBM over xGMI) or replicate "
                          "it on every GPU; auto = sharded, replicated only if the peers' memory cannot be mapped")
@@ -275,6 +275,13 @@ def main():
     jf_size = int(nreads * (1 if sharded else world) * READ_LEN * 2.1 / 10)
     min_slots = max(1 << 21, int(1.25 * jf_size))
     exchange = sharded and a.count != "local"
+    if sharded and a.count == "auto":
+        # bytes per xGMI link decide (dist.prefer_exchange): a read shard of the N-fold genome at 30/N-fold coverage has
+        # about N x G x (1 - exp(-lambda/N)) genomic k-mers + one k-mer in ten with a read error
+        import math
+        occ = nreads * (READ_LEN - K + 1)
+        lam = COVERAGE * (READ_LEN - K + 1) / READ_LEN
+        exchange = jdist.prefer_exchange(world, occ, world * a.genome_mb * 1e6 * (1.0 - math.exp(-lam / world)) + 0.103 * occ)
     loc = {"table": None, "exchange": exchange, "make": lambda: KmerTable(K, min_slots=min_slots, device=local)}
     if not exchange:
         loc["table"] = loc["make"]()        # allocated once, like the reference's -s sized hash

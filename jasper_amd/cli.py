@@ -359,7 +359,11 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
             # No table per GPU when the key owners' table has a geometry for it (dist.count_sharded): the file reader feeds batches
             # of bases, every batch is partitioned into region lists by key owner, ONE all_to_all moves the lists, the owners insert.
             sharded = None
-            if os.environ.get("JASPER_AMD_COUNT", "") != "local":
+            how = os.environ.get("JASPER_AMD_COUNT", "auto")
+            if how == "auto":     # bytes per link decide (dist.prefer_exchange): FASTQ is ~2.1 bytes per base; -s is the expected number of distinct k-mers
+                occ = sum((e if e >= 0 else os.path.getsize(p)) - b for p, b, e in my_ranges) / 2.1
+                how = "exchange" if jdist.all_reduce_ints([1 if jdist.prefer_exchange(world, occ, o.jf_size) else 0], device=dev, op="min")[0] else "local"
+            if how != "local":
                 sharded = together(lambda: KmerTable(kmer, min_slots=max(1 << 21, int(1.25 * o.jf_size / world)), device=o.device), fail_msg)
                 if not jdist.all_reduce_ints([1 if sharded.exchange_plan(1 << 26, world) is not None else 0], device=dev, op="min")[0]:
                     sharded.close()

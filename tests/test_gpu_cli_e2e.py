@@ -119,7 +119,7 @@ def test_cli_two_ranks_matches_jasper_sh(hip, tmp_path):
             f.write(gzip.open(os.path.join(E2E, fn + ".gz")).read())
     shutil.copy(os.path.join(E2E, "asm.fa"), tmp_path)
     args = ["-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(meta["k"]), "-t", str(meta["threads"]), "-p", str(meta["passes"]), "-d"]
-    p = _torchrun_cli(tmp_path, args)
+    p = _torchrun_cli(tmp_path, args, extra_env={"JASPER_AMD_COUNT": "exchange"})
     assert p.returncode == 0, p.stdout + p.stderr
     # counted without a table per GPU: file reader -> batches of bases -> region lists by key owner -> one all_to_all -> owners' shards
     assert "region lists -> owners' shards" in p.stderr and "local table" not in p.stderr, p.stderr
@@ -189,7 +189,7 @@ def test_cli_three_ranks(hip, tmp_path, nproc, count):
             f.write(gzip.open(os.path.join(E2E, fn + ".gz")).read())
     shutil.copy(os.path.join(E2E, "asm.fa"), tmp_path)
     p = _torchrun_cli(tmp_path, ["-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(meta["k"]), "-t", str(meta["threads"]), "-p", str(meta["passes"])], nproc=nproc,
-                      extra_env={"JASPER_AMD_COUNT": "local"} if count == "local" else None)
+                      extra_env={"JASPER_AMD_COUNT": count})
     assert p.returncode == 0, p.stdout + p.stderr
     assert ("local table" in p.stderr) == (count == "local"), p.stderr
     assert open(tmp_path / "threshold.txt").read() == open(os.path.join(E2E, "threshold.txt")).read()

@@ -51,7 +51,7 @@ def _input_dir(ref, tmp_path_factory):
     return _inputs[key]
 
 
-def _run(ref, tmp_path_factory, ranks):
+def _run(ref, tmp_path_factory, ranks, count=None):
     from jasper_amd import synth
     src = _input_dir(ref, tmp_path_factory)
     d = str(tmp_path_factory.mktemp("run"))
@@ -69,7 +69,9 @@ def _run(ref, tmp_path_factory, ranks):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
-        env.update(JASPER_AMD_DIST_BACKEND="gloo", JASPER_AMD_ONE_GPU="1")
+        env.update(JASPER_AMD_DIST_BACKEND="gloo", JASPER_AMD_ONE_GPU="1", JASPER_AMD_TIMING="1")
+        if count:             # how the ranks' counts reach the key owners (default: cli picks by the bytes-per-link model, `local` at two ranks)
+            env["JASPER_AMD_COUNT"] = count
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                "--master-port", str(port), "-m", "jasper_amd.cli"] + args
     t0 = time.perf_counter()
@@ -85,12 +87,15 @@ def _run(ref, tmp_path_factory, ranks):
         assert not os.path.exists(os.path.join(d, "asm.fa.polished.fasta"))
         return
     assert p.returncode == 0, p.stdout + p.stderr
+    if ranks > 1:
+        assert ("region lists -> owners' shards" in p.stderr) == (count == "exchange"), p.stderr
     got = synth.output_digests(d, k=ref["k"])
     for key in ("threshold", "jfhisto_sha256", "polished_bases", "polished_fasta_sha256", "fixes_csv_lines", "fixes_csv_sha256"):
         assert got[key] == ref[key], (key, got[key], ref[key])
     # same log lines (dates and Q digits aside: bc is missing in the build container, so the reference printed "Inf")
     assert strip(mine) == strip(ref["stdout"])
-    print("%d-rank drop-in wall %.1f s vs reference %.1f s on %s" % (ranks, wall, ref["reference_wall_seconds"], ref["host"]))
+    print("%d-rank drop-in wall %.1f s%s vs reference %.1f s on %s" % (ranks, wall, " (counts by exchange of region lists)" if count == "exchange" else "",
+                                                                     ref["reference_wall_seconds"], ref["host"]))
     for fn in os.listdir(d):          # (GBs of intermediates per case)
         if not os.path.islink(os.path.join(d, fn)):
             os.remove(os.path.join(d, fn))
@@ -107,3 +112,10 @@ if BIG:
 @pytest.mark.parametrize("name,ranks", CASES)
 def test_cli_fullsize_matches_real_reference(hip, tmp_path_factory, name, ranks):
     _run(_ref(name), tmp_path_factory, ranks)
+
+
+@pytest.mark.parametrize("name,ranks", [("fullsize_cfg2", 2), ("fullsize_cfg3_quarter", 2), ("fullsize_cfg5_scaled", 2)] + ([("fullsize_cfg3", 2)] if BIG else []))
+def test_cli_fullsize_counts_by_exchange_of_region_lists(hip, tmp_path_factory, name, ranks):
+    """the same digests with no table per GPU: file reader -> batches of bases -> region lists grouped by key owner -> one
+    all_to_all per batch -> owners' shards (dist.count_sharded; what `auto` picks from about six GPUs on)"""
+    _run(_ref(name), tmp_path_factory, ranks, count="exchange")

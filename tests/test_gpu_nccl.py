@@ -169,10 +169,12 @@ def test_cli_two_gpus_matches_jasper_sh(hip, tmp_path):
 
 
 @needs2
-def test_bench_two_gpus_self_launch(hip):
-    """`python bench.py --gpus 2` starts its own ranks and prints ONE line that says which world it saw"""
+@pytest.mark.parametrize("count", ["auto", "exchange"])
+def test_bench_two_gpus_self_launch(hip, count):
+    """`python bench.py --gpus 2` starts its own ranks and prints ONE line that says which world it saw; with --count exchange
+    the region lists travel over RCCL instead of the entries of per-GPU tables"""
     env = dict(os.environ, PYTHONPATH=ROOT)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--genome-mb", "4"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--genome-mb", "4", "--count", count],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -180,3 +182,4 @@ def test_bench_two_gpus_self_launch(hip):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_world_size"] == 2 and out["backend"] == "nccl"
     assert "table" in out["config"] and out["value"] > 0
+    assert (out["count_exchange"] is not None) == (count == "exchange")
