@@ -201,3 +201,160 @@ def test_shard_tables_protocol_world2():
 def test_shard_tables_attach_failure_is_collective():
     res = _run_shard(fail_on=1)
     assert res[0] == ["attach-failed"] * 3 and res[1] == ["attach-failed"] * 3      # both ranks raise together, nobody hangs
+
+
+# ---- dist.count_sharded: the collective protocol of the list exchange, with host memory standing in for HBM ----------------
+class FakeExchangeTable(FakeTable):
+    """the methods dist.count_sharded calls.  The "reads" are bytes, every byte one record whose key is its value; owner =
+    key % n; a send list holds `cap` records, what does not fit is deferred -- like the real lists, only tiny."""
+
+    def __init__(self, geometry=True, fail_scan=False, **kw):
+        super().__init__(**kw)
+        self.geometry, self.fail_scan = geometry, fail_scan
+        self.scanned = None
+        self.whole = []
+        self.plans = []
+
+    @staticmethod
+    def _arr(ptr, n, ctype):
+        import ctypes
+        import numpy as np
+        return np.ctypeslib.as_array((ctype * n).from_address(ptr))
+
+    def _cap(self, piece_max, records_max, n):
+        return max(2, (records_max or piece_max) // n)            # the mean fill of the fullest sender: skewed keys overflow
+
+    def exchange_plan(self, piece_max, n, records_max=0):
+        if not self.geometry:
+            return None
+        cap = self._cap(piece_max, records_max, n)
+        self.plans.append((piece_max, records_max))
+        return dict(records_per_owner=cap, counts_per_owner=1, deferred_cap=1024, slice_cap=cap, p1=0, p2=0, region_bits=0, slices=1)
+
+    def exchange_scan(self, ptr, n, pos, end, piece_max, nown, d_deferred, dcap):
+        import ctypes
+        if self.fail_scan:
+            raise RuntimeError("scan failed on purpose")
+        assert end - pos <= piece_max
+        self.scanned = [int(b) for b in self._arr(ptr, n, ctypes.c_uint8)[pos:end]] if n else []
+        self._arr(d_deferred, 8, ctypes.c_int64)[:] = 0
+        return len(self.scanned)
+
+    def exchange_partition(self, piece_max, records_max, nown, d_send, d_send_cnt, d_deferred, dcap):
+        import ctypes
+        cap = self._cap(piece_max, records_max, nown)
+        send = self._arr(d_send, nown * cap, ctypes.c_int64).reshape(nown, cap)
+        cnt = self._arr(d_send_cnt, nown, ctypes.c_int32)
+        dfr = self._arr(d_deferred, 8 + 3 * dcap, ctypes.c_int64)
+        cnt[:] = 0
+        for key in self.scanned:
+            o = key % nown
+            if cnt[o] < cap:
+                send[o, cnt[o]] = key
+                cnt[o] += 1
+            else:
+                i = int(dfr[0])
+                if i < dcap:
+                    dfr[8 + 3 * i: 8 + 3 * i + 3] = (0, key, 1)
+                dfr[0] = i + 1
+        self.scanned = None
+
+    def exchange_insert(self, d_recv, d_recv_cnt, piece_max, records_max, nown, me, d_all=0, n_all=0, whole_input=False):
+        import ctypes
+        cap = self._cap(piece_max, records_max, nown)
+        recv = self._arr(d_recv, nown * cap, ctypes.c_int64).reshape(nown, cap)
+        cnt = self._arr(d_recv_cnt, nown, ctypes.c_int32)
+        for src in range(nown):
+            for key in recv[src, :cnt[src]]:
+                assert int(key) % nown == me
+                self.d[int(key)] = self.d.get(int(key), 0) + 1
+        if n_all:
+            ent = self._arr(d_all, 3 * n_all, ctypes.c_int64).reshape(n_all, 3)
+            for _, key, inc in ent:
+                if int(key) % nown == me:
+                    self.d[int(key)] = self.d.get(int(key), 0) + int(inc)
+        self.whole.append(bool(whole_input))
+
+
+def _reads_of(rank, step):
+    import numpy as np
+    rng = np.random.default_rng(100 * step + rank)
+    if step == 1 and rank == 1:
+        return np.zeros(0, dtype=np.uint8)                       # a rank with nothing to count
+    n = 400 if rank == 0 else 150
+    a = rng.integers(0, 40, n).astype(np.uint8)
+    if step == 2:
+        a[: n // 2] = 6                                          # one heavy key: its list overflows, records travel deferred
+    return a
+
+
+def _count_worker(rank, world, port, q, mode):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from jasper_amd import dist as jd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        shard = FakeExchangeTable(geometry=(mode != "nogeom" or rank == 0), fail_scan=(mode == "fail" and rank == 1), tag=rank + 1)
+        out = []
+        for step in range(4):
+            reads = torch.from_numpy(_reads_of(rank, step % 3).copy())
+            try:
+                info = jd.count_sharded(shard, reads.data_ptr() if reads.numel() else 0, reads.numel(), dev, clear=(step < 3),
+                                        piece_limit=(None if step != 0 else 128))
+            except RuntimeError as e:
+                out.append("raised: " + str(e)[:40])
+                continue
+            if info is None:
+                out.append(None)
+                continue
+            out.append((dict(shard.d), info["rounds"], info["deferred"], list(shard.whole), shard.slots, list(shard.attached)))
+            shard.whole.clear()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_count(mode):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_count_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_count_sharded_protocol_world2():
+    res = _run_count("ok")
+    carried = {}
+    for step in range(4):
+        exp = dict(carried) if step == 3 else {}                  # step 3 does not clear: it adds to what step 2 left
+        for r in range(2):
+            for key in _reads_of(r, step % 3):
+                exp[int(key)] = exp.get(int(key), 0) + 1
+        carried = exp
+        for r in range(2):
+            d, rounds, deferred, whole, slots, attached = res[r][step]
+            assert d == {k: c for k, c in exp.items() if k % 2 == r}          # owner r holds exactly its keys, summed over ranks and rounds
+        assert res[0][step][1] == res[1][step][1] and res[0][step][2] == res[1][step][2]
+        assert res[0][step][4] == res[1][step][4] and res[0][step][5] == res[1][step][5]      # one geometry, same handle list
+    assert res[0][0][1] == 4                     # step 0: 400 and 150 bytes in pieces of 128 -> 4 rounds, rank 1 idle in the last two
+    assert res[0][0][3] == [False] * 4           # ... and no round is "the whole input"
+    assert res[0][1][1] == 1 and res[0][1][3] == [True]          # step 1: one round although rank 1 has nothing
+    assert res[0][2][2] > 0                      # step 2: the heavy key overflowed its list and arrived as deferred entries
+    assert res[0][3][3] == [False]               # step 3: one round, but the shard was not empty
+
+
+def test_count_sharded_failures_are_collective():
+    res = _run_count("fail")
+    assert all(isinstance(x, str) and x.startswith("raised") for r in range(2) for x in res[r])      # both ranks raise together, nobody hangs
+    res = _run_count("nogeom")
+    assert res[0] == [None] * 4 and res[1] == [None] * 4          # one rank without a geometry: nobody consumes anything
