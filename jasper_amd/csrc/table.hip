@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <thread>
 #include <vector>
 
 namespace jk {
@@ -857,13 +858,13 @@ int Table::launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from
 // bases already in HBM. Processed in launches of at most nslots/4 bases so that the load factor is re-checked
 // (and the table grown) between launches. A piece starts k-1 bases early, rounded down to 16 bytes so the
 // kernel keeps its 16-byte vector loads; emit_from keeps every window counted exactly once.
-int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
+int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err, uint64_t first_new) {
     HIPCHK(hipSetDevice(device));
     if (read_stats(err)) return -1;
     histo_cached = false;
     const uint64_t halo = (uint64_t)(k - 1);
     const uint64_t misalign = reinterpret_cast<uintptr_t>(d_bases) & 15;
-    uint64_t pos = 0;
+    uint64_t pos = std::min(first_new, n);
     // Before anything has been measured, the caller's size hint plays the role of `jellyfish count -s`: the expected
     // number of distinct k-mers of this input.  hint / bases is then the expected share of new keys per k-mer; it is
     // only trusted for sizing the pieces (x1.5 below) -- an input that is less repetitive than promised still ends up
@@ -918,7 +919,7 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
         const uint64_t distinct_before = h_stats[ST_DISTINCT], occ_before = h_stats[ST_OCCURRENCES];
         const double t_l0 = dbg ? now_ms() : 0;
         if (dbg) fprintf(stderr, "[count] host: %.2f ms since call start (sizing, capacity)\n", t_l0 - t_call);
-        histo_request = started_empty && pos == 0 && end == n && h_stats[ST_DISTINCT] == 0;   // one piece, whole input, empty table
+        histo_request = started_empty && pos == 0 && first_new == 0 && end == n && h_stats[ST_DISTINCT] == 0;   // one piece, whole input, empty table
         histo_cached = false;
         const int lrc = launch_count(d_bases + start, end - start, pos - start, err);
         const bool fused_histo = histo_request;      // still set only if the partitioned path took the request
@@ -938,7 +939,7 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
             mz_off = true;
             if (clear(err)) return -1;
             if (read_stats(err)) return -1;
-            pos = 0;
+            pos = std::min(first_new, n);
             continue;
         }
         if (rc == -2 && have_ratio && started_empty) {
@@ -951,7 +952,7 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err) {
             if (grow(std::min(d.B, d.s + 2), err)) return -1;
             have_ratio = false;
             dup_ratio = 1.0;
-            pos = 0;
+            pos = std::min(first_new, n);
             continue;
         }
         if (rc) return rc;
@@ -987,6 +988,41 @@ int Table::count_host(const char *bases, uint64_t n, std::string &err) {
         }
     }
     const uint64_t halo = (uint64_t)(k - 1);
+    // A large input is first brought to the device in super-pieces of up to 1 GiB (several threads copy into the pinned staging
+    // buffers -- one thread's memcpy, ~9 GB/s, is otherwise what bounds this entry point -- while the DMA of the last chunk runs)
+    // and then counted like device-resident bases: the atomic-free paths instead of 64-MiB launches of the direct kernel.
+    if (n >= (96u << 20) && !getenv("JASPER_COUNT_HOST_STREAM")) {
+        const uint64_t SP = 1ull << 30;
+        uint8_t *d_all = reinterpret_cast<uint8_t *>(workspace(WS_HOSTBASES, std::min<uint64_t>(n, SP) + halo + 64 + 16, err));
+        if (!d_all) return -1;
+        unsigned nth = std::thread::hardware_concurrency();
+        if (const char *w = getenv("WORLD_SIZE")) { const long nw = atol(w); if (nw > 1) nth /= (unsigned)nw; }
+        nth = std::max(1u, std::min(8u, nth / 2));
+        for (uint64_t sp = 0; sp < n; sp += SP) {
+            const uint64_t start = sp >= halo ? sp - halo : 0, end = std::min(n, sp + SP), len = end - start;
+            int buf = 0;
+            for (uint64_t off = 0; off < len; off += stage_bytes) {
+                const uint64_t m = std::min<uint64_t>(stage_bytes, len - off);
+                HIPCHK(hipEventSynchronize(ev_stage[buf]));      // staging buffer free again?
+                {
+                    std::vector<std::thread> th;
+                    const uint64_t per = (m + nth - 1) / nth;
+                    for (unsigned i = 1; i < nth; ++i) {
+                        const uint64_t a = std::min(m, i * per), b = std::min(m, (i + 1) * per);
+                        if (b > a) th.emplace_back([=] { memcpy(h_stage[buf] + a, bases + start + off + a, b - a); });
+                    }
+                    memcpy(h_stage[buf], bases + start + off, std::min(m, per));
+                    for (std::thread &t : th) t.join();
+                }
+                HIPCHK(hipMemcpyAsync(d_all + off, h_stage[buf], m, hipMemcpyHostToDevice, stream));
+                HIPCHK(hipEventRecord(ev_stage[buf], stream));
+                buf ^= 1;
+            }
+            const int rc = count_device(d_all, len, err, sp - start);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     uint64_t pos = 0;
     int buf = 0;
     uint64_t pending = 0;   // bases launched since the table's load was last checked (worst case: all of them new keys)

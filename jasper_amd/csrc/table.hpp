@@ -334,7 +334,7 @@ struct Table {
     uint64_t size_hint = 0;   // caller's expected number of distinct k-mers (`jellyfish count -s`); 0 = none given
     // grow-only device workspace reused by the polisher across calls (hipMalloc of GBs costs far more than the kernels)
     struct WsBuf { void *p = nullptr; size_t bytes = 0; };
-    static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_INGEST = 44, WS_MZ = 50, WS_SLOTS = 54;
+    static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_INGEST = 44, WS_MZ = 50, WS_HOSTBASES = 54, WS_SLOTS = 55;
     WsBuf ws[WS_SLOTS];   // 0..WS_POLISH_MAX-1: polisher (polish_host.hip, in allocation order); WS_COUNT..+3: partitioned counting
     void *workspace(int id, size_t bytes, std::string &err);
 
@@ -356,7 +356,7 @@ struct Table {
     int ensure_narrow(std::string &err);             // whole remainders in the tags (what shards and region-wise imports need)
     int fit(double max_load, std::string &err);
     int after_batch(std::string &err);                // spill / fatal / growth handling
-    int count_device(const uint8_t *d_bases, uint64_t n, std::string &err);
+    int count_device(const uint8_t *d_bases, uint64_t n, std::string &err, uint64_t first_new = 0);   // first_new: bases before it are context only (k-mers ending there were counted before)
     int count_host(const char *bases, uint64_t n, std::string &err);
     // FASTA/FASTQ files (plain or gzip, one concatenated stream) parsed on the GPU, host state machine as the fallback
     // (ingest_gpu.hip); reports how many text bytes each parser handled

@@ -415,6 +415,33 @@ def test_device_resident_stream_equals_host_stream(KT):
     t2.close()
 
 
+def test_large_host_buffer_counts_like_resident_bases(KT):
+    """jasper_count_bases with more than 1 GiB of bases in host memory: brought over in super-pieces (the cut falls inside a
+    read, so k-mers span it) and counted by the atomic-free paths -- same table as the same bases resident in HBM"""
+    import torch
+    k = 37
+    G = 37_000_000
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    genome = synth.torch_genome(gen, G, dev)
+    nreads = G * 30 // 150
+    reads = synth.torch_reads_stream(gen, genome, nreads)
+    torch.cuda.synchronize()
+    assert reads.numel() > (1 << 30) and (1 << 30) % 151 != 0
+    a = KT(k, min_slots=1 << 28)
+    a.count_bases_device(reads.data_ptr(), reads.numel())
+    b = KT(k, min_slots=1 << 28)
+    b.count_bases(reads.cpu().numpy().tobytes())
+    assert b.info()["occurrences"] == a.info()["occurrences"] == nreads * (150 - k + 1)
+    assert b.info()["distinct"] == a.info()["distinct"]
+    assert b.histogram() == a.histogram()
+    assert b.count_stages()[1] >= 1                              # (the first GiB took an atomic-free path, not the direct kernel on 64-MiB pieces)
+    qs = [bytes(reads[i * 151:i * 151 + k].cpu().numpy()).decode() for i in range(0, nreads, nreads // 500)]
+    assert a.lookup(qs) == b.lookup(qs)
+    a.close()
+    b.close()
+
+
 def test_properties_at_scale(KT):
     """size-independent properties on a multi-Mb workload (the oracle would take minutes here)"""
     import torch
