@@ -72,6 +72,21 @@ def test_fuzz_reads_through_owner_shards(hip, tmp_path):
         _one(seed, S, polisher, O, G, F, tmp_path)
 
 
+def test_fuzz_counting_by_list_exchange(hip, tmp_path):
+    """the same cases counted the multi-GPU way on the one GPU (tools/fuzz_exchange.py): read feed -> every batch cut into
+    2..5 ranges wherever the cuts fall -> region lists by key owner -> owners' shards; all reads through the shards"""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    from jasper_amd import KmerTable, polisher
+    from oracle import oracle as O
+    import make_golden as G
+    import fuzz_vs_reference as F
+    from fuzz_exchange import exchanged_class
+    S = exchanged_class(KmerTable)
+    for seed in range(9500, 9560):
+        _one(seed, S, polisher, O, G, F, tmp_path)
+    assert S.taken[0] >= 30                         # (most cases have a table with an exchange geometry)
+
+
 def test_fuzz_wide_k(hip, tmp_path, monkeypatch):
     """the same generator with k in {38, 45, 51, 57, 63} mixed in (tables of few slots: remainders wider than the tag word);
     the oracle was checked against the real reference on these k too (tests/golden/fuzz_vs_reference.py with
