@@ -364,7 +364,9 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
                 occ = sum((e if e >= 0 else os.path.getsize(p)) - b for p, b, e in my_ranges) / 2.1
                 how = "exchange" if jdist.all_reduce_ints([1 if jdist.prefer_exchange(world, occ, o.jf_size) else 0], device=dev, op="min")[0] else "local"
             if how != "local":
-                sharded = together(lambda: KmerTable(kmer, min_slots=max(1 << 21, int(1.25 * o.jf_size / world)), device=o.device), fail_msg)
+                # (sized like the reference's `-s $JF_SIZE` hash, for the keys one owner will hold; JASPER_AMD_SHARD_SLOTS overrides)
+                shard_slots = int(os.environ.get("JASPER_AMD_SHARD_SLOTS", max(1 << 21, int(1.25 * o.jf_size / world))))
+                sharded = together(lambda: KmerTable(kmer, min_slots=shard_slots, device=o.device), fail_msg)
                 if not jdist.all_reduce_ints([1 if sharded.exchange_plan(1 << 26, world) is not None else 0], device=dev, op="min")[0]:
                     sharded.close()
                     sharded = None
@@ -376,15 +378,21 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
                 except jdist.ShardAttachError as e:         # (raised on every rank together, after all lists were inserted)
                     sharded._attach_failed = str(e)
                     info = dict(rounds=-1)
-                except RuntimeError as e:                   # (raised on every rank together)
-                    sys.stderr.write("jasper_amd: rank %d: %s\n" % (rank, e))
-                    error_exit(fail_msg)
+                except RuntimeError as e:                   # (raised on every rank together: e.g. shards sized from a hint that was far too small)
+                    if is0:
+                        sys.stderr.write("jasper_amd: %s -- counting into a table per GPU instead\n" % e)
+                    info = None
                 finally:
                     feeder.close()
-                assert info is not None
-                local = None
-                _timing("count reads (file ranges -> region lists -> owners' shards, %d rounds)" % info["rounds"])
-            else:
+                if info is None:                            # start over the round-1 way (the read files are read again)
+                    sharded.detach()
+                    bar()
+                    sharded.close()
+                    sharded = None
+                else:
+                    local = None
+                    _timing("count reads (file ranges -> region lists -> owners' shards, %d rounds)" % info["rounds"])
+            if sharded is None:
                 def count_my_ranges():
                     t = KmerTable(kmer, min_slots=max(1 << 20, int(1.25 * o.jf_size / world)), device=o.device)
                     t.count_file_ranges(my_ranges)

@@ -51,7 +51,7 @@ def _input_dir(ref, tmp_path_factory):
     return _inputs[key]
 
 
-def _run(ref, tmp_path_factory, ranks, count=None):
+def _run(ref, tmp_path_factory, ranks, count=None, extra_env=None, expect_stderr=None):
     from jasper_amd import synth
     src = _input_dir(ref, tmp_path_factory)
     d = str(tmp_path_factory.mktemp("run"))
@@ -70,6 +70,7 @@ def _run(ref, tmp_path_factory, ranks, count=None):
         port = s.getsockname()[1]
         s.close()
         env.update(JASPER_AMD_DIST_BACKEND="gloo", JASPER_AMD_ONE_GPU="1", JASPER_AMD_TIMING="1")
+        env.update(extra_env or {})
         if count:             # how the ranks' counts reach the key owners (default: cli picks by the bytes-per-link model, `local` at two ranks)
             env["JASPER_AMD_COUNT"] = count
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
@@ -87,7 +88,9 @@ def _run(ref, tmp_path_factory, ranks, count=None):
         assert not os.path.exists(os.path.join(d, "asm.fa.polished.fasta"))
         return
     assert p.returncode == 0, p.stdout + p.stderr
-    if ranks > 1:
+    if expect_stderr:
+        assert expect_stderr in p.stderr, p.stderr
+    elif ranks > 1:
         assert ("region lists -> owners' shards" in p.stderr) == (count == "exchange"), p.stderr
     got = synth.output_digests(d, k=ref["k"])
     for key in ("threshold", "jfhisto_sha256", "polished_bases", "polished_fasta_sha256", "fixes_csv_lines", "fixes_csv_sha256"):
@@ -119,3 +122,11 @@ def test_cli_fullsize_counts_by_exchange_of_region_lists(hip, tmp_path_factory, 
     """the same digests with no table per GPU: file reader -> batches of bases -> region lists grouped by key owner -> one
     all_to_all per batch -> owners' shards (dist.count_sharded; what `auto` picks from about six GPUs on)"""
     _run(_ref(name), tmp_path_factory, ranks, count="exchange")
+
+
+def test_cli_exchange_falls_back_when_the_shards_are_far_too_small(hip, tmp_path_factory):
+    """owners' shards of 2^16 slots for 6 M keys each (the reference's hash grows on demand, JF::jellyfish/mer_counter.cc; a size
+    hint that low would do this): the lists overflow many-fold, every rank hears of it, and the run starts over with a table
+    per GPU -- same digests"""
+    _run(_ref("fullsize_cfg1"), tmp_path_factory, 2, count="exchange", extra_env={"JASPER_AMD_SHARD_SLOTS": "65536"},
+         expect_stderr="counting into a table per GPU instead")
