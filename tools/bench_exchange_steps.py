@@ -33,6 +33,7 @@ cnt = torch.empty((W, ncnt), dtype=torch.int32, device=dev)
 dfr = torch.empty(8 + 3 * dcap, dtype=torch.int64, device=dev)
 recv = torch.empty((W, nrec), dtype=torch.int64, device=dev)
 rcnt = torch.empty((W, ncnt), dtype=torch.int32, device=dev)
+prev = [0.0] * 8
 for rep in range(reps):
     part = []
     for r in range(W):
@@ -56,7 +57,10 @@ for rep in range(reps):
     shard.exchange_insert(recv.data_ptr(), rcnt.data_ptr(), n, kmers, W, 0, 0, 0, whole_input=True)
     shard.sync()
     t1 = time.perf_counter()
-    st, _ = shard.count_stages()
+    acc, _ = shard.count_stages()                      # (accumulated over the calls on a table that never scans: per-call = difference)
+    acc = list(acc) + [0.0] * (8 - len(acc))
+    st = [a - b for a, b in zip(acc, prev)]
+    prev = acc
     info = shard.info()
     used = int(rcnt.to(torch.int64).sum().item())
     print("rep %d (last sender deferred %d): owner 0 received %d records (%.3f of one rank's k-mers) in %d x %d slices of cap %d (mean fill %.0f, fullest %d): "
@@ -64,18 +68,24 @@ for rep in range(reps):
           % (rep, ndef, used, used / kmers, W, ncnt, plan["slice_cap"], part[0][0], max(p[1] for p in part), st[2], st[3], st[4], (t1 - t0) * 1e3,
              info["distinct"], info["slots"].bit_length() - 1), flush=True)
 # a sender's stage times: the last partition call on `sender` followed by an (empty-handed) insert would mix tables; read the events through one more full cycle
-sender.clear()
 reads = bench.build_workload(torch, dev, 0, W, gmb, 2)[0]
 torch.cuda.synchronize()
-sender.exchange_scan(reads.data_ptr(), n, 0, n, n, W, dfr.data_ptr(), dcap)
-sender.exchange_partition(n, kmers, W, send.data_ptr(), cnt.data_ptr(), dfr.data_ptr(), dcap)
-sender.sync()
-for r in range(W):
-    recv[r].copy_(send[0]) if r == 0 else rcnt[r].zero_()
-rcnt[0].copy_(cnt[0])
-torch.cuda.synchronize()
-sender.exchange_insert(recv.data_ptr(), rcnt.data_ptr(), n, kmers, W, 0, 0, 0, whole_input=False)
-st, _ = sender.count_stages()
+best = None
+for rep in range(max(reps, 3)):
+    sender.clear()
+    sender.exchange_scan(reads.data_ptr(), n, 0, n, n, W, dfr.data_ptr(), dcap)
+    sender.exchange_partition(n, kmers, W, send.data_ptr(), cnt.data_ptr(), dfr.data_ptr(), dcap)
+    sender.sync()
+    for r in range(W):
+        recv[r].copy_(send[0]) if r == 0 else rcnt[r].zero_()
+    rcnt[0].copy_(cnt[0])
+    torch.cuda.synchronize()
+    sender.exchange_insert(recv.data_ptr(), rcnt.data_ptr(), n, kmers, W, 0, 0, 0, whole_input=False)
+    st, _ = sender.count_stages()                      # (the scan resets the stage times of its table)
+    print("sender rep %d: part1 %.2f ms, part2 by owner %.2f ms" % (rep, st[0], st[1]), flush=True)
+    if best is None or st[0] + st[1] < best[0] + best[1]:
+        best = st
+st = best
 wire = (W - 1) * (nrec * 8 + ncnt * 4)
 print("sender: part1 %.2f ms, part2 by owner %.2f ms; wire per rank %.2f GB padded (%.2f GB of records); sum sender + owner kernels %.2f ms -> %.1f Gk-mers/s per GPU"
       % (st[0], st[1], wire / 1e9, 8.0 * kmers * (W - 1) / W / 1e9, st[0] + st[1] + 0, kmers / ((st[0] + st[1]) * 1e-3) / 1e9), flush=True)
