@@ -481,6 +481,7 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__re
         for (int u = 0; u < PF; ++u)
             if ((uint32_t)u * PT_THREADS + t < nrec0) insert(pre[u]);
         if constexpr (MULTI) {
+            uint32_t x = 0;                                                       // slice of my current record: my indices only grow
             for (uint32_t i0 = 0; i0 < total; i0 += 4 * PT_THREADS) {
                 rec_t recs[4];
 #pragma unroll
@@ -488,7 +489,6 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__re
                     const uint32_t i = i0 + u * PT_THREADS + t;
                     recs[u] = rec_t{};
                     if (i < total) {
-                        uint32_t x = 0;
                         while (s_pref[x + 1] <= i) ++x;                           // (a handful of slices)
                         recs[u] = lists[slice_of(region, x) * cap + (i - s_pref[x])];
                     }
