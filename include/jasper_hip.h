@@ -156,7 +156,8 @@ int jasper_read_feed_release(jasper_table *t);
  * and records_max (the most records any rank's scan returned; 0 = not known, piece_max stands in: the lists, and with them
  * the bytes that travel, are then sized for the worst case).
  *   jasper_count_exchange_plan      out8 = { records (8 B) per owner block, slice counts (4 B) per owner block, deferred entries
- *                                   (24 B) to provide room for, p1, p2, region bits, slices per list, slice capacity };
+ *                                   (24 B) to provide room for, p1, p2 (+ 256 x the second-level bits left to an extra pass
+ *                                   on the owner: very large shards), region bits, slices per list, slice capacity };
  *                                   returns 1 (not an error) when this table / piece size / k has no such geometry: count into a
  *                                   table per GPU and use jasper_table_export_owner instead.
  *   jasper_count_exchange_scan      first pass over bases [pos, end) of d_bases (n bytes, text bases as for

@@ -250,7 +250,10 @@ constexpr int P2_MAXSL = 512;          // level-1 slices per bucket (= nblk1 <= 
 // OWN (the multi-GPU exchange, count_exchange below): a bucket is split 2^p2 * nown ways, by (owner_of(hash), next p2
 // hash bits), and the lists are laid out owner-major -- list ((o * 2^p1 + b1) << p2) + b2 -- so that everything owner o
 // is to receive is ONE contiguous block of out2 / cnt2: the region lists of o's own table, ready for lds_insert_kernel.
-template <bool OWN>
+// MIN (the owner's extra pass when the senders could not split finely enough, count_exchange below): the input slices of a
+// bucket come from nsrc senders, each of which laid out ITS lists of all buckets as one block -- slice j of bucket b =
+// sender j / (nblk1/nsrc), its slice j % (nblk1/nsrc): list index ((sender * buckets + b) * (nblk1/nsrc) + that).
+template <bool OWN, bool MIN = false>
 __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__restrict__ out1, const unsigned int *__restrict__ cnt1, TableDev T,
                                                             PartGeom G, uint64_t *__restrict__ out2, unsigned int *__restrict__ cnt2,
                                                             unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
@@ -266,13 +269,18 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
     const int nb2 = OWN ? (int)(nown << G.p2) : 1 << G.p2;
     const int shift2 = G.recbits - G.p2;               // the p2 bits right below the level-1 bucket bits
     const uint32_t nmine = (G.nblk1 - blockIdx.x + G.nblk2 - 1) / G.nblk2;                 // slices x, x+nblk2, ... < nblk1
+    const uint32_t in_per_src = MIN ? G.nblk1 / nown : G.nblk1;                            // (MIN: nown = the number of senders)
+    auto in_list = [&](uint32_t b1, uint32_t j) -> uint64_t {                              // list index of input slice j of bucket b1
+        if constexpr (MIN) return ((uint64_t)(j / in_per_src) * (1ull << G.p1) + b1) * in_per_src + j % in_per_src;
+        else return (uint64_t)b1 * G.nblk1 + j;
+    };
     for (uint32_t b1 = blockIdx.y; b1 < (1u << G.p1); b1 += gridDim.y) {
         for (int i = t; i < nb2; i += PT_THREADS) { s_cur[i] = 0; s_cnt[i] = 0; }
         if (t < 64) {                                  // exclusive prefix of my slices' lengths (wave 0)
             unsigned int carry = 0;
             for (uint32_t x0 = 0; x0 < nmine; x0 += 64) {
                 const uint32_t x = x0 + t;
-                const unsigned int v = x < nmine ? cnt1[(uint64_t)b1 * G.nblk1 + blockIdx.x + (uint64_t)x * G.nblk2] : 0u;
+                const unsigned int v = x < nmine ? cnt1[in_list(b1, blockIdx.x + x * G.nblk2)] : 0u;
                 unsigned int inc = v;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if (t >= o) inc += u; }
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
         }
         lds_barrier();
         const uint32_t total = s_pref[nmine];
-        const uint64_t *src0 = out1 + ((uint64_t)b1 * G.nblk1 + blockIdx.x) * G.cap1;      // slice x; slice x + j*nblk2 is j*nblk2*cap1 further
+        const uint64_t *src0 = out1 + ((uint64_t)b1 * G.nblk1 + blockIdx.x) * G.cap1;      // slice x; slice x + j*nblk2 is j*nblk2*cap1 further (not MIN)
         for (uint32_t tile0 = 0; tile0 < total; tile0 += PT_TILE) {
             // A. my 16 records (all loads in flight), their region, a rank in the tile's region histogram
             uint64_t rec[PT_GROUP];
@@ -302,7 +310,8 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
                 br[j] = 0xFFFFFFFFu;
                 if (i < total) {
                     while (s_pref[sl + 1] <= i) ++sl;                         // my records are 1024 apart: the slice moves on slowly
-                    rec[j] = src0[(uint64_t)sl * G.nblk2 * G.cap1 + (i - s_pref[sl])];
+                    if constexpr (MIN) rec[j] = out1[in_list(b1, blockIdx.x + sl * G.nblk2) * G.cap1 + (i - s_pref[sl])];
+                    else rec[j] = src0[(uint64_t)sl * G.nblk2 * G.cap1 + (i - s_pref[sl])];
                     br[j] = sl;                                               // (reused below)
                 }
             }
@@ -721,14 +730,21 @@ int Table::finish_deferred(unsigned long long *defer_e, unsigned long long *defe
 // table the caller sized for the keys (about a third full): records / (keys all shards were sized for).  A list that still
 // overflows (a k-mer far more frequent than the rest, or a table sized far too large) spends the deferred list, as everywhere.
 static uint32_t xchg_cap(double avg, double mult) { return (uint32_t)std::min<double>(4.0e9, avg + 6.0 * std::sqrt(avg * (1.0 + mult)) + 16.0); }
-static bool xchg_geometry(const Table &t, uint64_t piece_max, uint64_t records_max, uint32_t nown, PartGeom &G) {
+// G: what the senders and the wire use (G.p2 = the second-level bits the SENDER resolves); p2b: second-level bits left to the
+// owner -- a bucket can be split 2048 ways in one pass, and the senders also split by owner, so for very large shards (2^32
+// slots on 8 GPUs) the owner runs one more split pass over what it received (part2_kernel<false, MIN>) before lds_insert.
+static int xchg_max_lists() { const char *e = getenv("JASPER_XCHG_TEST_MAXLISTS"); return e ? std::max(2, atoi(e)) : PT_MAXBUCKETS; }   // (tests: force the extra pass on small tables)
+static bool xchg_geometry(const Table &t, uint64_t piece_max, uint64_t records_max, uint32_t nown, PartGeom &G, int &p2b) {
     if (nown < 2 || nown > MAX_SHARDS) return false;
     alignas(16) char raw[64];
     // (a feed's last batch may be small: the lists are then laid out as for the smallest piece the passes are tuned for)
     piece_max = std::max<uint64_t>(piece_max, 8u << 20);
     if (!t.partition_geometry(piece_max, raw)) return false;
     G = *reinterpret_cast<const PartGeom *>(raw);
-    if (((uint64_t)nown << G.p2) > (uint64_t)PT_MAXBUCKETS) return false;       // (a third pass would be needed: not built)
+    p2b = 0;
+    while (((uint64_t)nown << (G.p2 - p2b)) > (uint64_t)xchg_max_lists() && p2b < G.p2) ++p2b;
+    if (((uint64_t)nown << (G.p2 - p2b)) > (uint64_t)PT_MAXBUCKETS) return false;
+    G.p2 -= p2b;
     if (G.th1 != 1024) return false;
     const uint32_t nb1 = 1u << G.p1;
     G.nblk2 = nb1 >= 256 ? 1u : std::min<uint32_t>(G.nblk1, 8u);
@@ -745,12 +761,13 @@ static bool xchg_geometry(const Table &t, uint64_t piece_max, uint64_t records_m
 int Table::xchg_plan(uint64_t piece_max, uint64_t records_max, uint32_t nown, uint64_t out[8], std::string &err) {
     (void)err;
     PartGeom G;
-    if (!xchg_geometry(*this, piece_max, records_max, nown, G)) return 1;
+    int p2b = 0;
+    if (!xchg_geometry(*this, piece_max, records_max, nown, G, p2b)) return 1;
     const uint64_t lists_per_owner = (uint64_t)1 << (G.p1 + G.p2);
     out[0] = lists_per_owner * G.nblk2 * G.cap2;               // records (8 B) per owner block
     out[1] = lists_per_owner * G.nblk2;                        // slice counts (4 B) per owner block
     out[2] = std::max<uint64_t>(1u << 16, piece_max / 16);     // deferred entries (24 B) a rank may produce
-    out[3] = (uint64_t)G.p1; out[4] = (uint64_t)G.p2; out[5] = (uint64_t)G.rbits; out[6] = G.nblk2; out[7] = G.cap2;
+    out[3] = (uint64_t)G.p1; out[4] = (uint64_t)G.p2 | ((uint64_t)p2b << 8); out[5] = (uint64_t)G.rbits; out[6] = G.nblk2; out[7] = G.cap2;
     return 0;
 }
 
@@ -759,7 +776,8 @@ int Table::xchg_scan(const uint8_t *d_bases, uint64_t n, uint64_t pos, uint64_t 
                      uint64_t *records, std::string &err) {
     HIPCHK(hipSetDevice(device));
     PartGeom G;
-    if (!xchg_geometry(*this, piece_max, 0, nown, G)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
+    int p2b = 0;
+    if (!xchg_geometry(*this, piece_max, 0, nown, G, p2b)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
     if (end > n) end = n;
     const uint32_t nb1 = 1u << G.p1;
     unsigned long long *defer_n = (unsigned long long *)d_defer, *defer_e = defer_n + 8;
@@ -807,7 +825,8 @@ int Table::xchg_scan(const uint8_t *d_bases, uint64_t n, uint64_t pos, uint64_t 
 int Table::xchg_partition(uint64_t piece_max, uint64_t records_max, uint32_t nown, void *d_send, void *d_send_cnt, void *d_defer, uint64_t defer_cap, std::string &err) {
     HIPCHK(hipSetDevice(device));
     PartGeom G;
-    if (!xchg_geometry(*this, piece_max, records_max, nown, G)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
+    int p2b = 0;
+    if (!xchg_geometry(*this, piece_max, records_max, nown, G, p2b)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
     if (!xchg_partitioned) { err = "count exchange: partition without a scan before it"; return -1; }
     const uint32_t nb1 = 1u << G.p1;
     unsigned long long *defer_n = (unsigned long long *)d_defer, *defer_e = defer_n + 8;
@@ -849,9 +868,10 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
                        uint64_t n_defer_all, int whole_input, std::string &err) {
     HIPCHK(hipSetDevice(device));
     PartGeom G;
-    if (!xchg_geometry(*this, piece_max, records_max, nown, G)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
+    int p2b = 0;
+    if (!xchg_geometry(*this, piece_max, records_max, nown, G, p2b)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
     if (read_stats(err)) return -1;
-    const uint32_t nregions = 1u << (G.p1 + G.p2);
+    const uint32_t nregions = 1u << (G.p1 + G.p2 + p2b);
     const bool empty = h_stats[ST_DISTINCT] == 0;
     histo_cached = false;
     unsigned long long *histo = whole_input && empty ? d_histo : nullptr;
@@ -874,11 +894,39 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
     count_path = 3;
     part_stage_n = 5;
     HIPCHK(hipEventRecord(ev_stage_t[3], stream));
+    const void *lists = d_recv;
+    const unsigned int *lcnt = (const unsigned int *)d_recv_cnt;
+    uint32_t lcap = G.cap2, nsl = nown * G.nblk2;
+    PartGeom GI = G;                                           // what lds_insert sees: all second-level bits resolved
+    GI.p2 = G.p2 + p2b;
+    if (p2b) {
+        // the senders resolved only G.p2 of the second-level bits: one more split pass here, over what arrived.  Its buckets are
+        // the received lists (2^(p1 + G.p2) of them, nown * nblk2 slices each), its record bits the ones below those lists' bits
+        PartGeom G2 = G;
+        G2.p1 = G.p1 + G.p2; G2.p2 = p2b; G2.recbits = G.recbits - G.p2;
+        G2.nblk1 = nown * G.nblk2; G2.cap1 = G.cap2; G2.nblk2 = 1;
+        G2.cap2 = list_cap((double)std::max<uint64_t>(records_max, 1) / (double)nregions);
+        uint64_t *out2 = (uint64_t *)workspace(WS_MZ + 1, (size_t)nregions * G2.cap2 * 8, err);
+        unsigned int *cnt2 = (unsigned int *)workspace(WS_MZ + 2, ((size_t)nregions + 4) * 4, err);
+        if (!out2 || !cnt2) return -2;
+        static bool attr2_set = false;
+        if (!attr2_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_insert_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr2_set = true;
+        }
+        hipLaunchKernelGGL((part2_kernel<false, true>), dim3(1, std::min<uint32_t>(1u << G2.p1, 2048)), dim3(PT_THREADS), P2_LDS, stream, (const uint64_t *)d_recv,
+                           (const unsigned int *)d_recv_cnt, d, G2, out2, cnt2, defer_e, defer_n, own_cap, nown);
+        HIPCHK(hipGetLastError());
+        lists = out2; lcnt = cnt2; lcap = G2.cap2; nsl = 1;
+    }
     for (uint32_t parity = 0; parity < 2; ++parity) {
         if (!(nregions == 1 && parity == 1)) {
             const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
-            hipLaunchKernelGGL((lds_insert_kernel<false, true>), dim3(nblk), dim3(PT_THREADS), lds, stream, d_recv, (const unsigned int *)d_recv_cnt, G.cap2, nown * G.nblk2, d, G,
-                               nregions, parity, fresh, defer_e, defer_n, own_cap, histo, nown);
+            if (p2b) hipLaunchKernelGGL((lds_insert_kernel<false, false>), dim3(nblk), dim3(PT_THREADS), lds, stream, lists, lcnt, lcap, nsl, d, GI, nregions, parity, fresh,
+                                        defer_e, defer_n, own_cap, histo, 1u);
+            else hipLaunchKernelGGL((lds_insert_kernel<false, true>), dim3(nblk), dim3(PT_THREADS), lds, stream, lists, lcnt, lcap, nsl, d, GI, nregions, parity, fresh,
+                                    defer_e, defer_n, own_cap, histo, nown);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(ev_stage_t[4 + parity], stream));

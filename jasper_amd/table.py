@@ -356,7 +356,9 @@ class KmerTable:
             return None
         check(rc)
         names = ("records_per_owner", "counts_per_owner", "deferred_cap", "p1", "p2", "region_bits", "slices", "slice_cap")
-        return dict(zip(names, (int(v) for v in out)))
+        d = dict(zip(names, (int(v) for v in out)))
+        d["p2"], d["p2_owner"] = d["p2"] & 0xFF, d["p2"] >> 8      # second-level bits split by the senders / left to the owner's extra pass
+        return d
 
     def exchange_scan(self, d_bases, n, pos, end, piece_max, n_owners, d_deferred, deferred_cap):
         """first pass (returns when it is done): the number of k-mer occurrences found in [pos, end)"""

@@ -88,25 +88,30 @@ def exchange_in_process(KT, k, n, sets, slots, piece=None):
     return shards, plan, deferred_total
 
 
-CASES = [  # k, ranks, log2 slots per shard, genome, rounds, heavy reads
-    (37, 2, 21, 300_000, 1, 0),       # p1 = 10 (records are 64 bits), no second-level bits: lists split by owner only
-    (37, 8, 21, 300_000, 1, 0),
-    (37, 4, 25, 300_000, 1, 0),       # second-level bits AND owners in one pass
-    (25, 3, 21, 300_000, 1, 0),       # one-word k-mers, an odd number of owners
-    (25, 2, 21, 300_000, 3, 0),       # several rounds: later rounds add to a filled shard
-    (31, 4, 22, 200_000, 1, 400),    # a list overflows: deferred records travel to their owner
-    (21, 8, 20, 100_000, 2, 0),
+CASES = [  # k, ranks, log2 slots per shard, genome, rounds, heavy reads, lists a sender may split a bucket into (None: 2048)
+    (37, 2, 21, 300_000, 1, 0, None),       # p1 = 10 (records are 64 bits), no second-level bits: lists split by owner only
+    (37, 8, 21, 300_000, 1, 0, None),
+    (37, 4, 25, 300_000, 1, 0, None),       # second-level bits AND owners in one pass
+    (25, 3, 21, 300_000, 1, 0, None),       # one-word k-mers, an odd number of owners
+    (25, 2, 21, 300_000, 3, 0, None),       # several rounds: later rounds add to a filled shard
+    (31, 4, 22, 200_000, 1, 400, None),     # a list overflows: deferred records travel to their owner
+    (21, 8, 20, 100_000, 2, 0, None),
+    (25, 4, 25, 300_000, 1, 0, 32),         # as for 2^32-slot shards on 8 GPUs: the senders resolve 3 of 6 second-level bits, the owner the rest
+    (37, 3, 25, 300_000, 2, 400, 4),        # ... none of 2 bits, two rounds, an overflowing list
 ]
 
 
-@pytest.mark.parametrize("k,n,ls,G,rounds,heavy", CASES)
-def test_exchange_of_region_lists_equals_one_table(KT, monkeypatch, k, n, ls, G, rounds, heavy):
+@pytest.mark.parametrize("k,n,ls,G,rounds,heavy,maxlists", CASES)
+def test_exchange_of_region_lists_equals_one_table(KT, monkeypatch, k, n, ls, G, rounds, heavy, maxlists):
+    if maxlists:
+        monkeypatch.setenv("JASPER_XCHG_TEST_MAXLISTS", str(maxlists))
     sets, asm = read_sets(1000 + k + n, G, n, heavy)
     full = KT(k, min_slots=1 << 22)
     full.count_bases(b"".join(sets))
     n_max = max(len(b) for b in sets)
     piece = None if rounds == 1 else (n_max + rounds - 1) // rounds
     shards, plan, deferred = exchange_in_process(KT, k, n, sets, 1 << ls, piece)
+    assert (plan["p2_owner"] > 0) == bool(maxlists)
     if heavy:
         assert deferred > 0, "the heavy k-mer was meant to overflow its list"
     else:
