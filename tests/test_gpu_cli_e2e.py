@@ -203,9 +203,10 @@ def test_cli_three_ranks(hip, tmp_path, nproc, count):
     assert order == sorted(order) and len(set(order)) == len(order)
 
 
-def test_cli_two_ranks_degenerate_inputs(hip, tmp_path):
+@pytest.mark.parametrize("count", ["local", "exchange"])
+def test_cli_two_ranks_degenerate_inputs(hip, tmp_path, count):
     """a rank with nothing to count, a rank with no batch file, and the run the reference aborts (no usable threshold):
-    two ranks behave like one process"""
+    two ranks behave like one process, whichever way the counts reach the key owners"""
     rng = __import__("numpy").random.default_rng(4)
     genome = "".join(rng.choice(list("ACGT"), 3000))
     (tmp_path / "asm.fa").write_text(">c1\n" + genome + "\n")
@@ -220,7 +221,7 @@ def test_cli_two_ranks_degenerate_inputs(hip, tmp_path):
         for fn in ("asm.fa", "one.fq"):
             shutil.copy(tmp_path / fn, d)
     p1 = subprocess.run([sys.executable, "-m", "jasper_amd.cli"] + args, cwd=one, env=env, capture_output=True, text=True, timeout=300)
-    p2 = _torchrun_cli(two, args)
+    p2 = _torchrun_cli(two, args, extra_env={"JASPER_AMD_COUNT": count})
     assert p1.returncode == 1 and "Local min of kmer counts is smaller than 4" in p1.stderr
     assert p2.returncode != 0 and "Local min of kmer counts is smaller than 4" in p2.stderr
     assert open(one / "jfhisto25.csv").read() == open(two / "jfhisto25.csv").read() == "1 126\n"
@@ -230,12 +231,14 @@ def test_cli_two_ranks_degenerate_inputs(hip, tmp_path):
     for d in (one, two):
         for fn in os.listdir(d):
             os.remove(d / fn)
+        # (one plain file that is cut in two byte ranges, and one gzip file, which goes whole to one rank)
         with open(d / "many.fq", "wb") as f:
-            f.write(gzip.open(os.path.join(E2E, "r1.fq.gz")).read() + gzip.open(os.path.join(E2E, "r2.fq.gz")).read())
+            f.write(gzip.open(os.path.join(E2E, "r1.fq.gz")).read())
+        shutil.copy(os.path.join(E2E, "r2.fq.gz"), d / "r2.fq.gz")
         (d / "asm.fa").write_text("%s\n%s\n" % (name, seq[:3000]))
-    args = ["-r", "many.fq", "-a", "asm.fa", "-k", "25", "-t", "1", "-p", "2"]
+    args = ["-r", "many.fq r2.fq.gz", "-a", "asm.fa", "-k", "25", "-t", "1", "-p", "2"]
     p1 = subprocess.run([sys.executable, "-m", "jasper_amd.cli"] + args, cwd=one, env=env, capture_output=True, text=True, timeout=300)
-    p2 = _torchrun_cli(two, args)
+    p2 = _torchrun_cli(two, args, extra_env={"JASPER_AMD_COUNT": count})
     assert p1.returncode == 0 and p2.returncode == 0, p1.stderr + p2.stdout + p2.stderr
     for fn in ("asm.fa.polished.fasta", "asm.fa.fixes.csv", "threshold.txt", "jfhisto25.csv"):
         assert open(one / fn, newline="").read() == open(two / fn, newline="").read(), fn
