@@ -758,6 +758,7 @@ bool Table::minimizer_geometry(uint64_t piece_bases, void *geom_out) const {
     // fewer keys are cut in two by a flush
     int nbits = 0;
     while (nbits < MZ_IDBITS && (piece_bases >> nbits) > 6144) ++nbits;
+    if (const char *e = getenv("JASPER_MZ_TEST_NBITS")) nbits = std::min(nbits, std::max(8, atoi(e)));   // experiments: coarser buckets
     G.pc = std::min(8, nbits);
     G.pf = std::min(10, nbits - G.pc);
     G.rbits = std::min(13, s);
