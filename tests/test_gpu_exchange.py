@@ -147,6 +147,61 @@ def test_exchange_of_region_lists_equals_one_table(KT, monkeypatch, k, n, ls, G,
         t.close()
 
 
+def test_exchange_at_bench_size(KT):
+    """two ranks' worth of bench.py's workload (2 x 9.4 M reads over a 94 Mb genome, k = 37) through the exchange, all on the
+    one GPU: every window of every read arrives exactly once (occurrences), the owners' histograms add up to the histogram of
+    ONE table that counted both read sets, and the key sets are a disjoint, even cover"""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    n, k = 2, bench.K
+    dev = torch.device("cuda", 0)
+    sets = [bench.build_workload(torch, dev, r, n, 47.0, 2)[0] for r in range(n)]
+    nb = sets[0].numel()
+    assert all(t.numel() == nb for t in sets)
+    kmers = (nb // (bench.READ_LEN + 1)) * (bench.READ_LEN - k + 1)
+    full = KT(k, min_slots=1 << 30)
+    for t in sets:
+        full.count_bases_device(t.data_ptr(), nb)
+    assert full.info()["occurrences"] == n * kmers
+    want = full.histogram()
+    distinct = full.info()["distinct"]
+    full.close()
+    shards = [KT(k, min_slots=1 << 29) for _ in range(n)]
+    plan0 = shards[0].exchange_plan(nb, n)
+    dcap = plan0["deferred_cap"]
+    dfr = [torch.empty(8 + 3 * dcap, dtype=torch.int64, device=dev) for _ in range(n)]
+    torch.cuda.synchronize()
+    found = [shards[r].exchange_scan(sets[r].data_ptr(), nb, 0, nb, nb, n, dfr[r].data_ptr(), dcap) for r in range(n)]
+    assert found == [kmers] * n
+    plan = shards[0].exchange_plan(nb, n, max(found))
+    assert plan["records_per_owner"] * 8 * n < 1.25 * 8 * kmers                 # what travels: less than a quarter of slack
+    send = [torch.empty((n, plan["records_per_owner"]), dtype=torch.int64, device=dev) for _ in range(n)]
+    cnt = [torch.empty((n, plan["counts_per_owner"]), dtype=torch.int32, device=dev) for _ in range(n)]
+    torch.cuda.synchronize()
+    for r in range(n):
+        shards[r].exchange_partition(nb, max(found), n, send[r].data_ptr(), cnt[r].data_ptr(), dfr[r].data_ptr(), dcap)
+        shards[r].sync()
+    nd = [int(d[0].item()) for d in dfr]
+    assert sum(nd) < 1e-4 * n * kmers
+    assert sum(int(c.to(torch.int64).sum().item()) for c in cnt) + sum(nd) == n * kmers
+    d_all = torch.cat([d[8:8 + 3 * m] for d, m in zip(dfr, nd)]).contiguous() if sum(nd) else None
+    for o in range(n):
+        recv = torch.stack([send[r][o] for r in range(n)]).contiguous()
+        rcnt = torch.stack([cnt[r][o] for r in range(n)]).contiguous()
+        torch.cuda.synchronize()
+        shards[o].exchange_insert(recv.data_ptr(), rcnt.data_ptr(), nb, max(found), n, o, d_all.data_ptr() if d_all is not None else 0, sum(nd), whole_input=True)
+        del recv, rcnt
+    assert sum(t.info()["distinct"] for t in shards) == distinct
+    assert max(t.info()["distinct"] for t in shards) - min(t.info()["distinct"] for t in shards) < 0.01 * distinct
+    acc = [0] * 10002
+    for t in shards:
+        acc = [a + b for a, b in zip(acc, t.histogram())]
+    assert acc == want
+    for t in shards:
+        t.close()
+
+
 def test_no_exchange_geometry_is_reported_not_raised(KT):
     t = KT(37, min_slots=1 << 21)
     assert t.exchange_plan(1 << 16, 2) is not None      # (small pieces use the layout of the smallest tuned piece)
