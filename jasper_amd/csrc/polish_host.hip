@@ -280,13 +280,23 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         };
         auto run_segments = [&](std::vector<SegDev> &sv, std::string &e2) -> int {
             if (sv.empty()) return 0;
+            const bool fine = dbg && getenv("JASPER_POLISH_DEBUG") && atoi(getenv("JASPER_POLISH_DEBUG")) >= 2;   // (waits between the steps: their times, not the pass's)
+            double tf[5] = {fine ? now() : 0, 0, 0, 0, 0};
             if (hipMemcpyAsync(b_segs.p, sv.data(), sv.size() * sizeof(SegDev), hipMemcpyHostToDevice, st) != hipSuccess) { e2 = "polish: H2D segs"; return -1; }
+            if (fine) { (void)jk_stream_wait(st); tf[1] = now(); }
             launch_seg_init(b_segs.as<SegDev>(), (int)sv.size(), (const uint8_t *const *)dIn, st);
             if (hipMemsetAsync(b_arrive.p, 0x80, (sv.size() + 2) * 8, st) != hipSuccess) { e2 = "polish: memset"; return -1; }   // ARRIVE_PENDING
+            if (fine) { (void)jk_stream_wait(st); tf[2] = now(); }
             launch_seg_walk(T.d, b_segs.as<SegDev>(), (int)sv.size(), pp, pass, pool, b_ticket.as<unsigned int>(), st);
             if (hipGetLastError() != hipSuccess) { e2 = "polish: kernel launch failed"; return -1; }
+            if (fine) { (void)jk_stream_wait(st); tf[3] = now(); }
             if (hipMemcpyAsync(sv.data(), b_segs.p, sv.size() * sizeof(SegDev), hipMemcpyDeviceToHost, st) != hipSuccess) { e2 = "polish: D2H segs"; return -1; }
             if (jk_stream_wait(st) != hipSuccess) { e2 = "polish: kernel execution failed"; return -1; }
+            if (fine) {
+                tf[4] = now();
+                fprintf(stderr, "[polish]     %zu segments x %zu B: H2D %.3f ms, init + memset %.3f ms, walk %.3f ms, D2H %.3f ms\n", sv.size(), sizeof(SegDev), tf[1] - tf[0], tf[2] - tf[1],
+                        tf[3] - tf[2], tf[4] - tf[3]);
+            }
             return 0;
         };
         std::vector<int> all(n_chunks);
