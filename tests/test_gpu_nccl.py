@@ -144,21 +144,23 @@ def test_replicated_merge_over_rccl_equals_single_gpu(hip):
 
 
 @needs2
-def test_cli_two_gpus_matches_jasper_sh(hip, tmp_path):
+@pytest.mark.parametrize("count", ["local", "exchange"])
+def test_cli_two_gpus_matches_jasper_sh(hip, tmp_path, count):
     """`python -m jasper_amd.cli --gpus 2 ...`: the driver starts its own two ranks (one per GPU, RCCL) -- same artefacts
-    as the real jasper.sh run kept under tests/golden/e2e"""
+    as the real jasper.sh run kept under tests/golden/e2e, with the counts travelling as table entries or as region lists"""
     from test_gpu_cli_e2e import fasta_records
     meta = json.load(open(os.path.join(E2E, "meta.json")))
     for fn in ("r1.fq", "r2.fq"):
         with open(tmp_path / fn, "wb") as f:
             f.write(gzip.open(os.path.join(E2E, fn + ".gz")).read())
     shutil.copy(os.path.join(E2E, "asm.fa"), tmp_path)
-    env = dict(os.environ, PYTHONPATH=ROOT)
+    env = dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_COUNT=count, JASPER_AMD_TIMING="1")
     for v in ("JASPER_AMD_DIST_BACKEND", "JASPER_AMD_ONE_GPU"):
         env.pop(v, None)
     p = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "--gpus", "2", "-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(meta["k"]),
                         "-t", str(meta["threads"]), "-p", str(meta["passes"])], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
+    assert ("region lists -> owners' shards" in p.stderr) == (count == "exchange"), p.stderr
     assert open(tmp_path / "threshold.txt").read() == open(os.path.join(E2E, "threshold.txt")).read()
     assert open(tmp_path / "jfhisto25.csv").read() == open(os.path.join(E2E, "jfhisto25.csv")).read()
     assert fasta_records(tmp_path / "asm.fa.polished.fasta") == fasta_records(os.path.join(E2E, "asm.fa.polished.fasta"))
