@@ -167,17 +167,26 @@ int jasper_read_feed_release(jasper_table *t);
  *                                   no room in their list, here or in the next call.  Returns when the pass is done.
  *   jasper_count_exchange_partition second pass: the lists of the scan -> d_send (n_owners blocks of records), d_send_counts
  *                                   (n_owners blocks of counts); asynchronous like the counting calls (jasper_table_sync).
+ *   jasper_count_exchange_dedupe    optional, between partition and the all_to_all: every list of d_send is deduplicated in
+ *                                   place -- one record per distinct key, (occurrences - 1) in *count_bits of the record's bits
+ *                                   that its list implies -- the counts are updated and *max_fill = records in the fullest
+ *                                   list: only that many per list need to travel (the caller packs [list][slice capacity] to
+ *                                   [list][max over ranks of max_fill]).  Returns 1 (not an error, nothing done) when the
+ *                                   geometry has no such bits.  Returns when the pass is done.
  *   jasper_count_exchange_insert    d_recv / d_recv_counts: block s = what rank s put into its block `self`; d_deferred_all: the
  *                                   deferred entries of ALL ranks back to back (the ones owned by `self` are added);
  *                                   whole_input != 0: these lists are all that goes into the (empty) shard, so the multiplicity
- *                                   histogram is taken on the way (jasper_histogram_is_fused). */
+ *                                   histogram is taken on the way (jasper_histogram_is_fused).  slice_cap / count_bits: 0, or the
+ *                                   packed slice capacity and the count bits after jasper_count_exchange_dedupe. */
 int jasper_count_exchange_plan(jasper_table *t, uint64_t piece_max, uint64_t records_max, uint32_t n_owners, uint64_t *out8);
 int jasper_count_exchange_scan(jasper_table *t, const void *d_bases, uint64_t n, uint64_t pos, uint64_t end, uint64_t piece_max, uint32_t n_owners, void *d_deferred,
                                uint64_t deferred_cap, uint64_t *records);
 int jasper_count_exchange_partition(jasper_table *t, uint64_t piece_max, uint64_t records_max, uint32_t n_owners, void *d_send, void *d_send_counts, void *d_deferred,
                                     uint64_t deferred_cap);
+int jasper_count_exchange_dedupe(jasper_table *t, uint64_t piece_max, uint64_t records_max, uint32_t n_owners, void *d_send, void *d_send_counts, uint32_t *max_fill,
+                                 int *count_bits);
 int jasper_count_exchange_insert(jasper_table *t, const void *d_recv, const void *d_recv_counts, uint64_t piece_max, uint64_t records_max, uint32_t n_owners,
-                                 uint32_t self, const void *d_deferred_all, uint64_t n_deferred_all, int whole_input);
+                                 uint32_t self, const void *d_deferred_all, uint64_t n_deferred_all, int whole_input, uint32_t slice_cap, int count_bits);
 /* A binary/sorted database written by several GPUs: the file order (pos, key) with `size` = 2^size_log2 is the numeric order
  * of the key rotated right by size_log2 bits, so cutting the value range of the key's low size_log2 bits into n_ranges equal
  * parts cuts the file into n_ranges consecutive pieces.  jasper_table_export_file_ranges groups the entries of t by that

@@ -64,7 +64,8 @@ SYMBOLS = {
     "jasper_count_exchange_plan": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
     "jasper_count_exchange_scan": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "jasper_count_exchange_partition": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, _P, _P, _P, C.c_uint64]),
-    "jasper_count_exchange_insert": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_int]),
+    "jasper_count_exchange_dedupe": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "jasper_count_exchange_insert": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_int, C.c_uint32, C.c_int]),
     "jasper_table_export_owner": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
     "jasper_table_export_file_ranges": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)]),
     "jasper_table_write_jf_piece": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int]),

@@ -299,10 +299,17 @@ int jasper_count_exchange_partition(jasper_table *t, uint64_t piece_max, uint64_
     if (!t || !d_send || !d_send_counts || !d_deferred) { g_err = "bad argument"; return JASPER_ERR; }
     return t->t.xchg_partition(piece_max, records_max, n_owners, d_send, d_send_counts, d_deferred, deferred_cap, g_err) ? JASPER_ERR : JASPER_OK;
 }
+int jasper_count_exchange_dedupe(jasper_table *t, uint64_t piece_max, uint64_t records_max, uint32_t n_owners, void *d_send, void *d_send_counts, uint32_t *max_fill,
+                                 int *count_bits) {
+    if (!t || !d_send || !d_send_counts || !max_fill || !count_bits) { g_err = "bad argument"; return JASPER_ERR; }
+    const int rc = t->t.xchg_dedupe(piece_max, records_max, n_owners, d_send, d_send_counts, max_fill, count_bits, g_err);
+    return rc == 0 ? JASPER_OK : rc == 1 ? 1 : JASPER_ERR;
+}
 int jasper_count_exchange_insert(jasper_table *t, const void *d_recv, const void *d_recv_counts, uint64_t piece_max, uint64_t records_max, uint32_t n_owners,
-                                 uint32_t self, const void *d_deferred_all, uint64_t n_deferred_all, int whole_input) {
-    if (!t || !d_recv || !d_recv_counts || self >= n_owners || (n_deferred_all && !d_deferred_all)) { g_err = "bad argument"; return JASPER_ERR; }
-    return t->t.xchg_insert(d_recv, d_recv_counts, piece_max, records_max, n_owners, self, d_deferred_all, n_deferred_all, whole_input, g_err) ? JASPER_ERR : JASPER_OK;
+                                 uint32_t self, const void *d_deferred_all, uint64_t n_deferred_all, int whole_input, uint32_t slice_cap, int count_bits) {
+    if (!t || !d_recv || !d_recv_counts || self >= n_owners || (n_deferred_all && !d_deferred_all) || count_bits < 0) { g_err = "bad argument"; return JASPER_ERR; }
+    return t->t.xchg_insert(d_recv, d_recv_counts, piece_max, records_max, n_owners, self, d_deferred_all, n_deferred_all, whole_input, slice_cap, count_bits, g_err)
+               ? JASPER_ERR : JASPER_OK;
 }
 int jasper_table_export_file_ranges(jasper_table *t, void *d_dst, uint64_t cap_entries, uint32_t n_ranges, int size_log2, uint64_t *counts) {
     if (!counts || size_log2 < 1) { g_err = "bad argument"; return JASPER_ERR; }

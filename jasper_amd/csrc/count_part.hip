@@ -392,7 +392,9 @@ template <bool ENT, bool MULTI = false>
 __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__restrict__ lists_v, const unsigned int *__restrict__ cnt, uint32_t cap,
                                                                  uint32_t nsl, TableDev T, PartGeom G, uint32_t nregions, uint32_t parity, int fresh_table,
                                                                  unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
-                                                                 uint64_t deferred_cap, unsigned long long *__restrict__ histo, uint32_t nsrc) {
+                                                                 uint64_t deferred_cap, unsigned long long *__restrict__ histo, uint32_t nsrc, int cbits = 0) {
+    // cbits > 0 (lists deduplicated by the sender, list_dedupe_kernel): the p2 bits of a record that its list implies hold
+    // (occurrences - 1) in their low cbits
     extern __shared__ __align__(16) unsigned long long s_img[];    // 2 words per slot: (R + halo) slots
     using rec_t = typename std::conditional<ENT, ulonglong2, uint64_t>::type;
     const rec_t *lists = reinterpret_cast<const rec_t *>(lists_v);
@@ -437,7 +439,15 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__re
             uint64_t rec, inc;
             u128 hfull = mk(0, 0);
             if constexpr (ENT) { rec = recv.x; inc = recv.y >> 32; hfull = mk(recv.y & 0xFFFFFFFFull, recv.x); }
-            else { rec = recv; inc = 1ull; }
+            else {
+                rec = recv; inc = 1ull;
+                if (cbits) {                                   // (uniform) the count, and the record as it was before the sender put it there
+                    const int csh = G.recbits - G.p2;
+                    const uint64_t fmask = ((1ull << G.p2) - 1ull) << csh;
+                    inc = ((rec >> csh) & ((1ull << cbits) - 1ull)) + 1ull;
+                    rec = (rec & ~fmask) | ((uint64_t)(region & ((1u << G.p2) - 1u)) << csh);
+                }
+            }
             uint64_t rem = rec & rmask;
             uint32_t local = (uint32_t)(rec >> rs) & (R - 1);
             if constexpr (ENT) { local = (uint32_t)shr(hfull, rs).lo & (R - 1); }      // (rs may exceed the low word's reach)
@@ -461,6 +471,11 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__re
                 if constexpr (ENT) {
                     const unsigned long long di = atomicAdd(deferred_n, 1ull);
                     if (di < deferred_cap) { deferred[3 * di] = hfull.hi; deferred[3 * di + 1] = hfull.lo; deferred[3 * di + 2] = inc; }
+                    else atomicExch(&T.stats[ST_FATAL], 1ull);
+                } else if (cbits) {
+                    const u128 hh = hash_of(b1, rec, G.recbits);
+                    const unsigned long long di = atomicAdd(deferred_n, 1ull);
+                    if (di < deferred_cap) { deferred[3 * di] = hh.hi; deferred[3 * di + 1] = hh.lo; deferred[3 * di + 2] = inc; }
                     else atomicExch(&T.stats[ST_FATAL], 1ull);
                 } else {
                     defer_record(T, hash_of(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
@@ -846,6 +861,98 @@ int Table::xchg_partition(uint64_t piece_max, uint64_t records_max, uint32_t now
     return 0;
 }
 
+// ---- what travels, made smaller: the sender's lists deduplicated in place --------------------------------------------------
+// A read shard repeats its k-mers (coverage / number of GPUs times), and every copy of a k-mer is in the same list.  One
+// workgroup per list: chunks of 4096 records go through an LDS hash set with counters and come back as one record per distinct
+// key, written over the front of the list, with (occurrences - 1) in the bits of the record that the LIST implies anyway (the
+// p2 second-level bits; a key with more than 2^cbits occurrences leaves as several records).  The list counts are updated and
+// the fullest list reported: the caller then ships only that many records per list.
+constexpr int DD_TH = 256, DD_SLOTS = 8192, DD_CHUNK = 4096;
+__global__ __launch_bounds__(DD_TH) void list_dedupe_kernel(uint64_t *__restrict__ lists, unsigned int *__restrict__ cnt, uint32_t cap, uint64_t nlists, int cshift,
+                                                            int cbits, unsigned int *__restrict__ max_fill) {
+    __shared__ unsigned long long s_key[DD_SLOTS];
+    __shared__ unsigned int s_cnt[DD_SLOTS];
+    __shared__ unsigned int s_out, s_all1;
+    const int t = threadIdx.x;
+    constexpr unsigned long long EMPTY = ~0ull;
+    const uint64_t fmask = ((1ull << cbits) - 1ull) << cshift;
+    const unsigned int per = 1u << cbits;
+    unsigned int fullest = 0;
+    for (int i = t; i < DD_SLOTS; i += DD_TH) { s_key[i] = EMPTY; s_cnt[i] = 0; }
+    for (uint64_t L = blockIdx.x; L < nlists; L += gridDim.x) {
+        const unsigned int n = cnt[L] < cap ? cnt[L] : cap;
+        uint64_t *lst = lists + L * (uint64_t)cap;
+        if (t == 0) { s_out = 0; s_all1 = 0; }
+        __syncthreads();
+        for (unsigned int c0 = 0; c0 < n; c0 += DD_CHUNK) {
+            const unsigned int m = n - c0 < (unsigned int)DD_CHUNK ? n - c0 : (unsigned int)DD_CHUNK;
+            for (unsigned int i = t; i < m; i += DD_TH) {
+                const unsigned long long r = lst[c0 + i];
+                if (r == EMPTY) { atomicAdd(&s_all1, 1u); continue; }          // (the one value the set cannot hold)
+                uint32_t h = (uint32_t)((r * 0x9E3779B97F4A7C15ull) >> 40) & (DD_SLOTS - 1);
+                for (;;) {
+                    unsigned long long cur = s_key[h];
+                    if (cur == EMPTY) { cur = atomicCAS(&s_key[h], EMPTY, r); if (cur == EMPTY) cur = r; }
+                    if (cur == r) { atomicAdd(&s_cnt[h], 1u); break; }
+                    h = (h + 1) & (DD_SLOTS - 1);
+                }
+            }
+            __syncthreads();                                   // the chunk has been read: its place (and what lies before it) may be written
+            for (int i = t; i < DD_SLOTS; i += DD_TH) {
+                unsigned int left = s_cnt[i];
+                if (!left) continue;
+                const unsigned long long r = s_key[i];
+                while (left) {
+                    const unsigned int take = left < per ? left : per;
+                    lst[atomicAdd(&s_out, 1u)] = (r & ~fmask) | ((uint64_t)(take - 1u) << cshift);
+                    left -= take;
+                }
+                s_key[i] = EMPTY;
+                s_cnt[i] = 0;
+            }
+            if (t == 0 && s_all1) {
+                unsigned int left = s_all1;
+                while (left) {
+                    const unsigned int take = left < per ? left : per;
+                    lst[atomicAdd(&s_out, 1u)] = (EMPTY & ~fmask) | ((uint64_t)(take - 1u) << cshift);
+                    left -= take;
+                }
+                s_all1 = 0;
+            }
+            __syncthreads();
+        }
+        if (t == 0) cnt[L] = n ? s_out : 0u;
+        fullest = s_out > fullest ? s_out : fullest;
+        __syncthreads();
+    }
+    if (t == 0 && fullest) atomicMax(max_fill, fullest);
+}
+
+// 0 done (*max_fill = records in the fullest list now), 1 this geometry has no bits to hold the counts (nothing done)
+int Table::xchg_dedupe(uint64_t piece_max, uint64_t records_max, uint32_t nown, void *d_send, void *d_send_cnt, uint32_t *max_fill, int *cbits_out, std::string &err) {
+    HIPCHK(hipSetDevice(device));
+    PartGeom G;
+    int p2b = 0;
+    if (!xchg_geometry(*this, piece_max, records_max, nown, G, p2b)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
+    if (G.p2 < 1 || p2b) return 1;
+    const int cbits = std::min(G.p2, 16);
+    const uint64_t nlists = ((uint64_t)nown << (G.p1 + G.p2)) * G.nblk2;
+    unsigned int *d_max = (unsigned int *)workspace(WS_MZ + 3, 64, err);
+    if (!d_max) return -2;
+    HIPCHK(hipMemsetAsync(d_max, 0, 4, stream));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nlists, 256u * 8u);
+    hipLaunchKernelGGL(list_dedupe_kernel, dim3(grid), dim3(DD_TH), 0, stream, (uint64_t *)d_send, (unsigned int *)d_send_cnt, G.cap2, nlists, G.recbits - G.p2, cbits, d_max);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ev_stage_t[7], stream));             // (stage "dedupe": between the partition and this)
+    unsigned int h = 0;
+    HIPCHK(hipMemcpyAsync(&h, d_max, 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(jk_stream_wait(stream));
+    if (max_fill) *max_fill = h;
+    if (cbits_out) *cbits_out = cbits;
+    xchg_deduped = true;
+    return 0;
+}
+
 // deferred records of ALL ranks (they are rare): the ones this rank owns go in through the direct path
 __global__ __launch_bounds__(256) void import3_owned_kernel(const unsigned long long *__restrict__ entries, uint64_t n, TableDev T, uint32_t nown, uint32_t self,
                                                             unsigned long long *__restrict__ histo_incomplete) {
@@ -865,7 +972,7 @@ __global__ __launch_bounds__(256) void import3_owned_kernel(const unsigned long 
 // d_recv / d_recv_cnt: block src = what rank src's xchg_partition put into ITS block `self`.  whole_input: these lists are
 // everything that goes into this (empty) shard -> the multiplicity histogram is taken on the way out.
 int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piece_max, uint64_t records_max, uint32_t nown, uint32_t self, const void *d_defer_all,
-                       uint64_t n_defer_all, int whole_input, std::string &err) {
+                       uint64_t n_defer_all, int whole_input, uint32_t slice_cap, int cbits, std::string &err) {
     HIPCHK(hipSetDevice(device));
     PartGeom G;
     int p2b = 0;
@@ -894,6 +1001,8 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
     count_path = 3;
     part_stage_n = 5;
     HIPCHK(hipEventRecord(ev_stage_t[3], stream));
+    if (cbits && (p2b || cbits > G.p2)) { err = "count exchange: counted records do not fit this geometry"; return -1; }
+    if (slice_cap) G.cap2 = slice_cap;                         // (lists packed by the caller after xchg_dedupe)
     const void *lists = d_recv;
     const unsigned int *lcnt = (const unsigned int *)d_recv_cnt;
     uint32_t lcap = G.cap2, nsl = nown * G.nblk2;
@@ -926,7 +1035,7 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
             if (p2b) hipLaunchKernelGGL((lds_insert_kernel<false, false>), dim3(nblk), dim3(PT_THREADS), lds, stream, lists, lcnt, lcap, nsl, d, GI, nregions, parity, fresh,
                                         defer_e, defer_n, own_cap, histo, 1u);
             else hipLaunchKernelGGL((lds_insert_kernel<false, true>), dim3(nblk), dim3(PT_THREADS), lds, stream, lists, lcnt, lcap, nsl, d, GI, nregions, parity, fresh,
-                                    defer_e, defer_n, own_cap, histo, nown);
+                                    defer_e, defer_n, own_cap, histo, nown, cbits);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(ev_stage_t[4 + parity], stream));
@@ -942,6 +1051,12 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
     const int rc = after_batch(err);                           // (waits; spilled insertions / growth as on the other paths)
     if (rc) return rc;
     histo_cached = histo != nullptr;
+    if (xchg_partitioned && xchg_deduped) {                    // the sender's dedupe pass counts as part of its second stage
+        float m = 0;
+        if (hipEventElapsedTime(&m, ev_stage_t[2], ev_stage_t[7]) == hipSuccess) { part_stage_ms[1] += m; count_kernel_ms += m; }
+        else (void)hipGetLastError();
+    }
+    xchg_deduped = false;
     const int pairs[5][2] = {{0, 1}, {1, 2}, {3, 4}, {4, 5}, {5, 6}};
     for (int i = xchg_partitioned ? 0 : 2; i < 5; ++i) {       // (a shard that only received: no sender stages of its own)
         float m = 0;

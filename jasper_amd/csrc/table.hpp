@@ -323,6 +323,7 @@ struct Table {
     bool mz_off = false;           // count_mz.hip overflowed its lists on this table's input once: not tried again
     bool part_stage_pending = false;
     bool xchg_partitioned = false;  // xchg_partition has recorded its stage events since the last xchg_insert
+    bool xchg_deduped = false;      // ... and xchg_dedupe its own
     // Multiplicity histogram taken for free while lds_insert_kernel writes the final region images back: valid when one
     // partitioned piece counted the whole input into an empty table and nothing had to take the deferred (direct) path.
     // d_histo: [0, HISTO_WORDS) fused histogram + "deferred records existed" flag, [HISTO_WORDS, 2*HISTO_WORDS) scratch of
@@ -396,8 +397,9 @@ struct Table {
     int xchg_scan(const uint8_t *d_bases, uint64_t n, uint64_t pos, uint64_t end, uint64_t piece_max, uint32_t nown, void *d_defer, uint64_t defer_cap, uint64_t *records,
                   std::string &err);
     int xchg_partition(uint64_t piece_max, uint64_t records_max, uint32_t nown, void *d_send, void *d_send_cnt, void *d_defer, uint64_t defer_cap, std::string &err);
+    int xchg_dedupe(uint64_t piece_max, uint64_t records_max, uint32_t nown, void *d_send, void *d_send_cnt, uint32_t *max_fill, int *cbits_out, std::string &err);
     int xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piece_max, uint64_t records_max, uint32_t nown, uint32_t self, const void *d_defer_all,
-                    uint64_t n_defer_all, int whole_input, std::string &err);
+                    uint64_t n_defer_all, int whole_input, uint32_t slice_cap, int cbits, std::string &err);
     int ipc_handle(void *out64, std::string &err);
     int attach_ipc(const void *handles64, uint32_t n, uint32_t self, std::string &err);
     int attach_tables(Table *const *peers, uint32_t n, uint32_t self, std::string &err);

@@ -481,7 +481,7 @@ class _FeedBases:
             self.feeder.feed_release()
 
 
-def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None, clear=False, feeder=None):
+def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None, clear=False, feeder=None, dedupe=None):
     """Count this rank's reads into the OWNER-SHARDED table without a table per GPU: every rank turns its reads into region
     lists grouped by the owner of the key (the two partition passes of the atomic-free counting path), ONE all_to_all per
     round moves every list to its owner (8 bytes per k-mer occurrence plus the slack of the lists), and the owner inserts what
@@ -519,6 +519,8 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
     # a round holds its send and receive lists (~10 bytes per base each) next to the shard: at most 2^31 bases, fewer when the
     # memory is short (one value for all ranks: the buffers are sized by the longest piece of the round).  The gloo rehearsal
     # gathers every rank's send buffer on every rank, and its ranks may share one GPU.
+    if dedupe is None:
+        dedupe = os.environ.get("JASPER_AMD_EXCHANGE_DEDUPE", "1") not in ("0", "no", "false")
     piece = int(piece_limit or os.environ.get("JASPER_AMD_EXCHANGE_PIECE", 1 << 31))
     if device.type == "cuda" and not piece_limit:
         torch.cuda.empty_cache()
@@ -583,12 +585,28 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
         ndef = int(deferred[0].item()) if ok else 0
         if ndef > dcap:
             ok, why = 0, "too many records found no room in their lists (%d): pass a larger size hint" % ndef
-        nd = torch.tensor([ndef, 1 - ok], dtype=torch.int64, device=device)
+        # third pass (optional): a read shard repeats its k-mers, and all copies of one are in the same list -- the lists are
+        # deduplicated in place (one record per distinct key, its occurrences in bits the list implies) and only the filled part
+        # of every list, as long as the fullest list of any rank, travels
+        fill, cbits = 0, 0
+        if ok and dedupe and plan["p2"] >= 1 and not plan["p2_owner"]:
+            try:
+                dd = shard.exchange_dedupe(piece_max, records_max, world, send.data_ptr(), send_cnt.data_ptr())
+                if dd is not None:
+                    fill, cbits = dd
+            except RuntimeError as e:
+                ok, why = 0, str(e)
+        nd = torch.tensor([ndef, 1 - ok, fill], dtype=torch.int64, device=device)
         parts = [torch.zeros_like(nd) for _ in range(world)]
         dist.all_gather(parts, nd, group=group)
         parts = [p.tolist() for p in parts]
         if any(p[1] for p in parts):
             raise RuntimeError("count_sharded: partitioning failed on some rank" + (": " + why if why else ""))
+        slice_cap = 0
+        if cbits:
+            slice_cap = max(max(p[2] for p in parts), 1)
+            send = send.view(world * ncnt, plan["slice_cap"])[:, :slice_cap].contiguous().view(world, ncnt * slice_cap)
+            nrec = ncnt * slice_cap
         recv = _all_to_all_rows(send, group)
         recv_cnt = _all_to_all_rows(send_cnt, group)
         wire += (world - 1) * (nrec * 8 + ncnt * 4)
@@ -605,7 +623,7 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
         del send, send_cnt
         try:
             shard.exchange_insert(recv.data_ptr(), recv_cnt.data_ptr(), piece_max, records_max, world, rank, d_all.data_ptr() if n_all else 0, n_all,
-                                  whole_input=(rounds == 0 and not any_more and not any_filled))
+                                  whole_input=(rounds == 0 and not any_more and not any_filled), slice_cap=slice_cap, count_bits=cbits)
         except RuntimeError as e:
             ok, why = 0, str(e)
         okt = torch.tensor([ok], dtype=torch.int64, device=device)
@@ -617,7 +635,7 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
     if device.type == "cuda" and rounds > 1:
         torch.cuda.empty_cache()                        # (rounds of different sizes leave cached blocks behind: back to the driver)
     _attach_shards(shard, device, group)
-    return dict(rounds=rounds, wire_bytes=wire, deferred=n_deferred, plan=plan, records_max=records_max)
+    return dict(rounds=rounds, wire_bytes=wire, deferred=n_deferred, plan=plan, records_max=records_max, deduplicated=bool(cbits), slice_cap_sent=slice_cap or plan["slice_cap"])
 
 
 def write_jf_sharded(shard, path, cmdline, device, group=None):

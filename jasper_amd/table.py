@@ -371,9 +371,22 @@ class KmerTable:
         check(self._L.jasper_count_exchange_partition(self._h, int(piece_max), int(records_max), int(n_owners), C.c_void_p(d_send), C.c_void_p(d_send_counts),
                                                       C.c_void_p(d_deferred), int(deferred_cap)))
 
-    def exchange_insert(self, d_recv, d_recv_counts, piece_max, records_max, n_owners, self_index, d_deferred_all=0, n_deferred_all=0, whole_input=False):
+    def exchange_dedupe(self, piece_max, records_max, n_owners, d_send, d_send_counts):
+        """the lists of the send buffers deduplicated in place: (records in the fullest list, count bits), or None when the
+        geometry has no bits for the counts (nothing done)"""
+        mx, cb = C.c_uint32(0), C.c_int(0)
+        rc = self._L.jasper_count_exchange_dedupe(self._h, int(piece_max), int(records_max), int(n_owners), C.c_void_p(d_send), C.c_void_p(d_send_counts),
+                                                  C.byref(mx), C.byref(cb))
+        if rc == 1:
+            return None
+        check(rc)
+        return mx.value, cb.value
+
+    def exchange_insert(self, d_recv, d_recv_counts, piece_max, records_max, n_owners, self_index, d_deferred_all=0, n_deferred_all=0, whole_input=False,
+                        slice_cap=0, count_bits=0):
         check(self._L.jasper_count_exchange_insert(self._h, C.c_void_p(d_recv), C.c_void_p(d_recv_counts), int(piece_max), int(records_max), int(n_owners),
-                                                   int(self_index), C.c_void_p(d_deferred_all or None), int(n_deferred_all), 1 if whole_input else 0))
+                                                   int(self_index), C.c_void_p(d_deferred_all or None), int(n_deferred_all), 1 if whole_input else 0,
+                                                   int(slice_cap), int(count_bits)))
 
     # ---- owner-sharded table (include/jasper_hip.h, "Owner-sharded table") ----------------------------
     def export_owner(self, dev_ptr, cap_entries, n_owners):

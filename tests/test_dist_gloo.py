@@ -229,7 +229,7 @@ class FakeExchangeTable(FakeTable):
             return None
         cap = self._cap(piece_max, records_max, n)
         self.plans.append((piece_max, records_max))
-        return dict(records_per_owner=cap, counts_per_owner=1, deferred_cap=1024, slice_cap=cap, p1=0, p2=0, region_bits=0, slices=1)
+        return dict(records_per_owner=cap, counts_per_owner=1, deferred_cap=1024, slice_cap=cap, p1=0, p2=0, p2_owner=0, region_bits=0, slices=1)
 
     def exchange_scan(self, ptr, n, pos, end, piece_max, nown, d_deferred, dcap):
         import ctypes
@@ -259,7 +259,8 @@ class FakeExchangeTable(FakeTable):
                 dfr[0] = i + 1
         self.scanned = None
 
-    def exchange_insert(self, d_recv, d_recv_cnt, piece_max, records_max, nown, me, d_all=0, n_all=0, whole_input=False):
+    def exchange_insert(self, d_recv, d_recv_cnt, piece_max, records_max, nown, me, d_all=0, n_all=0, whole_input=False, slice_cap=0, count_bits=0):
+        assert not slice_cap and not count_bits            # (this table's plan says p2 = 0: no bits for counts, nothing is deduplicated)
         import ctypes
         cap = self._cap(piece_max, records_max, nown)
         recv = self._arr(d_recv, nown * cap, ctypes.c_int64).reshape(nown, cap)

@@ -43,7 +43,7 @@ def read_sets(seed, G, n, heavy=0):
     return sets, asm
 
 
-def exchange_in_process(KT, k, n, sets, slots, piece=None):
+def exchange_in_process(KT, k, n, sets, slots, piece=None, dedupe=True):
     """what dist.count_sharded does, with the ranks played one after the other; returns the n shards and statistics"""
     import torch
     shards = [KT(k, min_slots=slots) for _ in range(n)]
@@ -55,6 +55,7 @@ def exchange_in_process(KT, k, n, sets, slots, piece=None):
     assert plan0 is not None, "the test sizes tables and inputs so that the exchange geometry exists"
     dcap = plan0["deferred_cap"]
     deferred_total = 0
+    stats = {"dedupe": []}
     for rnd in range(rounds):
         dfr = [torch.empty(8 + 3 * dcap, dtype=torch.int64, device="cuda") for _ in range(n)]
         torch.cuda.synchronize()
@@ -78,13 +79,26 @@ def exchange_in_process(KT, k, n, sets, slots, piece=None):
         assert sum(int(c.to(torch.int64).sum().item()) for c in cnt) + sum(nd) == sum(found)      # every record is in a list or deferred
         d_all = torch.cat([d[8:8 + 3 * m] for d, m in zip(dfr, nd)]).contiguous() if sum(nd) else None
         deferred_total += sum(nd)
+        slice_cap, cbits = 0, 0
+        if dedupe and plan["p2"] >= 1 and not plan["p2_owner"]:      # third pass: one record per distinct key of a list, counts inside
+            before = sum(int(c.to(torch.int64).sum().item()) for c in cnt)
+            dd = [shards[r].exchange_dedupe(piece, records_max, n, send[r].data_ptr(), cnt[r].data_ptr()) for r in range(n)]
+            assert all(d is not None for d in dd)
+            cbits = dd[0][1]
+            slice_cap = max(max(d[0] for d in dd), 1)
+            assert slice_cap == max(int(c.max().item()) for c in cnt) or slice_cap == 1
+            after = sum(int(c.to(torch.int64).sum().item()) for c in cnt)
+            assert after <= before
+            stats["dedupe"].append((before, after))
+            send = [t.view(n * ncnt, plan["slice_cap"])[:, :slice_cap].contiguous().view(n, ncnt * slice_cap) for t in send]
         for o in range(n):
             recv = torch.stack([send[r][o] for r in range(n)]).contiguous()
             rcnt = torch.stack([cnt[r][o] for r in range(n)]).contiguous()
-            assert int(rcnt.max().item()) <= plan["slice_cap"]
+            assert int(rcnt.max().item()) <= (slice_cap or plan["slice_cap"])
             torch.cuda.synchronize()
             shards[o].exchange_insert(recv.data_ptr(), rcnt.data_ptr(), piece, records_max, n, o, d_all.data_ptr() if d_all is not None else 0, sum(nd),
-                                      whole_input=(rounds == 1))
+                                      whole_input=(rounds == 1), slice_cap=slice_cap, count_bits=cbits)
+    plan = dict(plan, dedupe=stats["dedupe"])
     return shards, plan, deferred_total
 
 
@@ -112,6 +126,9 @@ def test_exchange_of_region_lists_equals_one_table(KT, monkeypatch, k, n, ls, G,
     piece = None if rounds == 1 else (n_max + rounds - 1) // rounds
     shards, plan, deferred = exchange_in_process(KT, k, n, sets, 1 << ls, piece)
     assert (plan["p2_owner"] > 0) == bool(maxlists)
+    if plan["p2"] >= 1 and not plan["p2_owner"]:
+        # 30x reads over n <= 8 shares: most records are repeats (a list kept in several slices -- small tables -- is deduplicated per slice)
+        assert plan["dedupe"] and all(a < (0.6 if plan["slices"] == 1 else 1.0) * b for b, a in plan["dedupe"]), plan["dedupe"]
     if heavy:
         assert deferred > 0, "the heavy k-mer was meant to overflow its list"
     else:

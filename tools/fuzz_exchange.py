@@ -21,7 +21,7 @@ def exchanged_class(KmerTable):
 
     class Exchanged(Base):
         """count_files fills n owner shards through the list exchange; everything else reads through them (Base)"""
-        taken = [0, 0]            # cases counted by the exchange / counted whole and split
+        taken = [0, 0, 0]         # cases counted by the exchange / counted whole and split / batches whose lists were deduplicated
 
         def count_files(self, paths):
             info = KmerTable.info(self)
@@ -57,11 +57,19 @@ def exchanged_class(KmerTable):
                     nd = [int(d[0].item()) for d in dfr]
                     assert max(nd) <= dcap
                     d_all = torch.cat([d[8:8 + 3 * m] for d, m in zip(dfr, nd)]).contiguous() if sum(nd) else None
+                    slice_cap, cbits = 0, 0
+                    if size % 3 and plan["p2"] >= 1 and not plan["p2_owner"]:      # (two cases in three) the lists deduplicated by their senders, packed
+                        dd = [shards[r].exchange_dedupe(piece, rmax, n, send[r].data_ptr(), cnt[r].data_ptr()) for r in range(n)]
+                        cbits, slice_cap = dd[0][1], max(max(d[0] for d in dd), 1)
+                        lists = n * plan["counts_per_owner"]
+                        send = [t.view(lists, plan["slice_cap"])[:, :slice_cap].contiguous().view(n, -1) for t in send]
+                        Exchanged.taken[2] += 1
                     for o in range(n):
                         recv = torch.stack([send[r][o] for r in range(n)]).contiguous()
                         rcnt = torch.stack([cnt[r][o] for r in range(n)]).contiguous()
                         torch.cuda.synchronize()
-                        shards[o].exchange_insert(recv.data_ptr(), rcnt.data_ptr(), piece, rmax, n, o, d_all.data_ptr() if d_all is not None else 0, sum(nd))
+                        shards[o].exchange_insert(recv.data_ptr(), rcnt.data_ptr(), piece, rmax, n, o, d_all.data_ptr() if d_all is not None else 0, sum(nd),
+                                                  slice_cap=slice_cap, count_bits=cbits)
             finally:
                 feeder.close()
             # one geometry for all owners (a shard that had to grow), then every read goes through the sharded view
@@ -96,6 +104,6 @@ if __name__ == "__main__":
         for f in tmp.iterdir():
             f.unlink()
         if (i + 1) % 100 == 0:
-            log.write("%d cases, %d failing, %.0f s (%d by exchange, %d split)\n" % (i + 1, bad, time.time() - t0, S.taken[0], S.taken[1]))
+            log.write("%d cases, %d failing, %.0f s (%d by exchange, %d split, %d batches deduplicated)\n" % (i + 1, bad, time.time() - t0, S.taken[0], S.taken[1], S.taken[2]))
             log.flush()
-    log.write("done (counting by list exchange): seeds %d..%d, %d failing; %d cases by exchange, %d counted whole and split\n" % (seed0, seed0 + n - 1, bad, S.taken[0], S.taken[1]))
+    log.write("done (counting by list exchange): seeds %d..%d, %d failing; %d cases by exchange (%d batches with deduplicated lists), %d counted whole and split\n" % (seed0, seed0 + n - 1, bad, S.taken[0], S.taken[2], S.taken[1]))
