@@ -221,7 +221,7 @@ def main():
     ap.add_argument("--count", choices=("auto", "exchange", "local"), default="auto",
                     help="N>1 with a sharded table: 'exchange' = reads become region lists grouped by key owner, one all_to_all, owners "
                          "insert (no table per GPU); 'local' = count into a table per GPU, then sum by owner; auto = whichever the "
-                         "bytes-per-link model of dist.prefer_exchange expects to be faster (exchange from about 6 GPUs on)")
+                         "bytes-per-link model of dist.prefer_exchange expects to be faster (with deduplicated lists: the exchange)")
     ap.add_argument("--table", choices=("auto", "sharded", "replicated"), default="auto",
                     help="N>1: keep the merged table key-sharded over the GPUs (lookups read the owner's HBM over xGMI) or replicate "
                          "it on every GPU; auto = sharded, replicated only if the peers' memory cannot be mapped")
@@ -275,19 +275,24 @@ def main():
     jf_size = int(nreads * (1 if sharded else world) * READ_LEN * 2.1 / 10)
     min_slots = max(1 << 21, int(1.25 * jf_size))
     exchange = sharded and a.count != "local"
+    # the owner's shard: with the exchange it is the only table and is sized like the reference's -s hash for the keys it will own
+    # (1/N of an N times larger genome); behind local tables it grows to its size in the first warm-up step
+    shard = KmerTable(K, min_slots=(min_slots if exchange else 1 << 21), device=local) if sharded else None
     if sharded and a.count == "auto":
         # bytes per xGMI link decide (dist.prefer_exchange): a read shard of the N-fold genome at 30/N-fold coverage has
         # about N x G x (1 - exp(-lambda/N)) genomic k-mers + one k-mer in ten with a read error
         import math
         occ = nreads * (READ_LEN - K + 1)
         lam = COVERAGE * (READ_LEN - K + 1) / READ_LEN
-        exchange = jdist.prefer_exchange(world, occ, world * a.genome_mb * 1e6 * (1.0 - math.exp(-lam / world)) + 0.103 * occ)
+        plan = shard.exchange_plan(reads.numel(), world)
+        dedup = plan is not None and plan["p2"] >= 1 and not plan["p2_owner"] and os.environ.get("JASPER_AMD_EXCHANGE_DEDUPE", "1") not in ("0", "no", "false")
+        exchange = plan is not None and jdist.prefer_exchange(world, occ, world * a.genome_mb * 1e6 * (1.0 - math.exp(-lam / world)) + 0.103 * occ, deduplicated=dedup)
+        if not exchange:
+            shard.close()
+            shard = KmerTable(K, min_slots=1 << 21, device=local)
     loc = {"table": None, "exchange": exchange, "make": lambda: KmerTable(K, min_slots=min_slots, device=local)}
     if not exchange:
         loc["table"] = loc["make"]()        # allocated once, like the reference's -s sized hash
-    # the owner's shard: with the exchange it is the only table and is sized like the reference's -s hash for the keys it will own
-    # (1/N of an N times larger genome); behind local tables it grows to its size in the first warm-up step
-    shard = KmerTable(K, min_slots=(min_slots if exchange else 1 << 21), device=local) if sharded else None
 
     def barrier():
         torch.cuda.synchronize(dev)

@@ -360,14 +360,17 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
             # of bases, every batch is partitioned into region lists by key owner, ONE all_to_all moves the lists, the owners insert.
             sharded = None
             how = os.environ.get("JASPER_AMD_COUNT", "auto")
-            if how == "auto":     # bytes per link decide (dist.prefer_exchange): FASTQ is ~2.1 bytes per base; -s is the expected number of distinct k-mers
-                occ = sum((e if e >= 0 else os.path.getsize(p)) - b for p, b, e in my_ranges) / 2.1
-                how = "exchange" if jdist.all_reduce_ints([1 if jdist.prefer_exchange(world, occ, o.jf_size) else 0], device=dev, op="min")[0] else "local"
             if how != "local":
                 # (sized like the reference's `-s $JF_SIZE` hash, for the keys one owner will hold; JASPER_AMD_SHARD_SLOTS overrides)
                 shard_slots = int(os.environ.get("JASPER_AMD_SHARD_SLOTS", max(1 << 21, int(1.25 * o.jf_size / world))))
                 sharded = together(lambda: KmerTable(kmer, min_slots=shard_slots, device=o.device), fail_msg)
-                if not jdist.all_reduce_ints([1 if sharded.exchange_plan(1 << 26, world) is not None else 0], device=dev, op="min")[0]:
+                plan = sharded.exchange_plan(1 << 26, world)
+                take = plan is not None
+                if take and how == "auto":   # bytes per link decide (dist.prefer_exchange): FASTQ is ~2.1 bytes per base; -s is the expected number of distinct k-mers
+                    occ = sum((e if e >= 0 else os.path.getsize(p)) - b for p, b, e in my_ranges) / 2.1
+                    dedup = plan["p2"] >= 1 and not plan["p2_owner"] and os.environ.get("JASPER_AMD_EXCHANGE_DEDUPE", "1") not in ("0", "no", "false")
+                    take = jdist.prefer_exchange(world, occ, o.jf_size, deduplicated=dedup)
+                if not jdist.all_reduce_ints([1 if take else 0], device=dev, op="min")[0]:
                     sharded.close()
                     sharded = None
             if sharded is not None:

@@ -867,9 +867,11 @@ int Table::xchg_partition(uint64_t piece_max, uint64_t records_max, uint32_t now
 // key, written over the front of the list, with (occurrences - 1) in the bits of the record that the LIST implies anyway (the
 // p2 second-level bits; a key with more than 2^cbits occurrences leaves as several records).  The list counts are updated and
 // the fullest list reported: the caller then ships only that many records per list.
-constexpr int DD_TH = 256, DD_SLOTS = 8192, DD_CHUNK = 4096;
+constexpr int DD_TH = 256, DD_SLOTS = 4096, DD_CHUNK = 3072, DD_PER = DD_CHUNK / DD_TH;      // (a chunk of all-distinct records fills the set to 3/4)
 __global__ __launch_bounds__(DD_TH) void list_dedupe_kernel(uint64_t *__restrict__ lists, unsigned int *__restrict__ cnt, uint32_t cap, uint64_t nlists, int cshift,
                                                             int cbits, unsigned int *__restrict__ max_fill) {
+    // 48 KB of LDS: three workgroups per CU.  The thread whose compare-and-swap put a key into the set is its claimant: after
+    // the barrier it writes the key's record(s) out and empties the slot again, so the set is never scanned or cleared as a whole.
     __shared__ unsigned long long s_key[DD_SLOTS];
     __shared__ unsigned int s_cnt[DD_SLOTS];
     __shared__ unsigned int s_out, s_all1;
@@ -886,29 +888,39 @@ __global__ __launch_bounds__(DD_TH) void list_dedupe_kernel(uint64_t *__restrict
         __syncthreads();
         for (unsigned int c0 = 0; c0 < n; c0 += DD_CHUNK) {
             const unsigned int m = n - c0 < (unsigned int)DD_CHUNK ? n - c0 : (unsigned int)DD_CHUNK;
-            for (unsigned int i = t; i < m; i += DD_TH) {
-                const unsigned long long r = lst[c0 + i];
-                if (r == EMPTY) { atomicAdd(&s_all1, 1u); continue; }          // (the one value the set cannot hold)
-                uint32_t h = (uint32_t)((r * 0x9E3779B97F4A7C15ull) >> 40) & (DD_SLOTS - 1);
+            unsigned long long r[DD_PER];
+            unsigned short slot[DD_PER];                       // where my record's key sits if I am its claimant, else 0xFFFF
+#pragma unroll
+            for (int u = 0; u < DD_PER; ++u) { const unsigned int i = (unsigned int)u * DD_TH + t; r[u] = i < m ? lst[c0 + i] : EMPTY; }
+#pragma unroll
+            for (int u = 0; u < DD_PER; ++u) {
+                slot[u] = 0xFFFFu;
+                const unsigned int i = (unsigned int)u * DD_TH + t;
+                if (i >= m) continue;
+                if (r[u] == EMPTY) { atomicAdd(&s_all1, 1u); continue; }       // (the one value the set cannot hold)
+                uint32_t h = (uint32_t)((r[u] * 0x9E3779B97F4A7C15ull) >> 40) & (DD_SLOTS - 1);
                 for (;;) {
                     unsigned long long cur = s_key[h];
-                    if (cur == EMPTY) { cur = atomicCAS(&s_key[h], EMPTY, r); if (cur == EMPTY) cur = r; }
-                    if (cur == r) { atomicAdd(&s_cnt[h], 1u); break; }
+                    if (cur == EMPTY) {
+                        cur = atomicCAS(&s_key[h], EMPTY, r[u]);
+                        if (cur == EMPTY) { cur = r[u]; slot[u] = (unsigned short)h; }
+                    }
+                    if (cur == r[u]) { atomicAdd(&s_cnt[h], 1u); break; }
                     h = (h + 1) & (DD_SLOTS - 1);
                 }
             }
             __syncthreads();                                   // the chunk has been read: its place (and what lies before it) may be written
-            for (int i = t; i < DD_SLOTS; i += DD_TH) {
-                unsigned int left = s_cnt[i];
-                if (!left) continue;
-                const unsigned long long r = s_key[i];
+#pragma unroll
+            for (int u = 0; u < DD_PER; ++u) {
+                if (slot[u] == 0xFFFFu) continue;
+                unsigned int left = s_cnt[slot[u]];
                 while (left) {
                     const unsigned int take = left < per ? left : per;
-                    lst[atomicAdd(&s_out, 1u)] = (r & ~fmask) | ((uint64_t)(take - 1u) << cshift);
+                    lst[atomicAdd(&s_out, 1u)] = (r[u] & ~fmask) | ((uint64_t)(take - 1u) << cshift);
                     left -= take;
                 }
-                s_key[i] = EMPTY;
-                s_cnt[i] = 0;
+                s_key[slot[u]] = EMPTY;
+                s_cnt[slot[u]] = 0;
             }
             if (t == 0 && s_all1) {
                 unsigned int left = s_all1;
@@ -940,7 +952,7 @@ int Table::xchg_dedupe(uint64_t piece_max, uint64_t records_max, uint32_t nown, 
     unsigned int *d_max = (unsigned int *)workspace(WS_MZ + 3, 64, err);
     if (!d_max) return -2;
     HIPCHK(hipMemsetAsync(d_max, 0, 4, stream));
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(nlists, 256u * 8u);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nlists, 256u * 3u * 8u);
     hipLaunchKernelGGL(list_dedupe_kernel, dim3(grid), dim3(DD_TH), 0, stream, (uint64_t *)d_send, (unsigned int *)d_send_cnt, G.cap2, nlists, G.recbits - G.p2, cbits, d_max);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_stage_t[7], stream));             // (stage "dedupe": between the partition and this)

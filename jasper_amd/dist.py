@@ -423,18 +423,22 @@ def _attach_shards(shard, device, group=None):
         shard.release_retired()
 
 
-def prefer_exchange(world, occurrences_per_rank, distinct_per_rank, link_gb_s=70.0):
+def prefer_exchange(world, occurrences_per_rank, distinct_per_rank, link_gb_s=70.0, deduplicated=True):
     """Which way of getting a rank's counts to the key owners is expected to be faster ("which exchange"):
       local    count into a table of this rank's reads, ship its (hash, count) entries: 16 B per LOCAL distinct k-mer over
                the wire, ~33 ms of kernels per 10^9 occurrences (count + export by owner + the owner's add);
-      exchange ship the region lists: 8 B x ~1.2 per k-mer OCCURRENCE, ~20 ms of kernels per 10^9 occurrences, no local table.
+      exchange ship the region lists, deduplicated by the sender: 8 B x ~1.3 per LOCAL distinct k-mer, ~23 ms of kernels per
+               10^9 occurrences, no local table.  Without the dedupe pass (tables too small to have second-level bits) the
+               lists carry 8 B x ~1.2 per OCCURRENCE at ~20 ms of kernels.
     Every GPU talks to each of its world-1 peers over a link of its own (xGMI is point to point; ~70 GB/s per direction is
-    assumed, nothing here has run on more than one GPU), so the bytes per link decide: reads that repeat their k-mers inside one
-    rank's share (a fixed genome spread over few GPUs) favour `local`, many GPUs or shares with little repetition `exchange`."""
+    assumed, nothing here has run on more than one GPU), so the bytes per link decide."""
     occ, dis = float(occurrences_per_rank), float(min(distinct_per_rank, occurrences_per_rank))
     per_link = 1.0 / max(world, 2)                       # each peer gets 1/world of what a rank produces
     t_local = 33e-3 * occ / 1e9 + 16.0 * dis * per_link / (link_gb_s * 1e9)
-    t_exchange = 20e-3 * occ / 1e9 + 9.6 * occ * per_link / (link_gb_s * 1e9)
+    if deduplicated:
+        t_exchange = 23e-3 * occ / 1e9 + 8.0 * 1.3 * dis * per_link / (link_gb_s * 1e9)
+    else:
+        t_exchange = 20e-3 * occ / 1e9 + 9.6 * occ * per_link / (link_gb_s * 1e9)
     return t_exchange < t_local
 
 

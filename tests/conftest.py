@@ -22,3 +22,14 @@ def hip():
     _lib.check(L.jasper_device_count(C.byref(n)))
     assert n.value >= 1, "no HIP device visible"
     return L
+
+
+@pytest.fixture(autouse=True)
+def _give_cached_gpu_memory_back(request):
+    """a GPU test that used torch tensors leaves them in torch's caching allocator; the CLI tests run OTHER processes (up to
+    two ranks sharing the one GPU, tables of tens of GB each) that need that memory"""
+    yield
+    if request.node.get_closest_marker("gpu") is not None and "torch" in sys.modules:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()

@@ -184,4 +184,5 @@ def test_bench_two_gpus_self_launch(hip, count):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_world_size"] == 2 and out["backend"] == "nccl"
     assert "table" in out["config"] and out["value"] > 0
-    assert (out["count_exchange"] is not None) == (count == "exchange")
+    if count == "exchange":
+        assert out["count_exchange"] is not None

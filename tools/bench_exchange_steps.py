@@ -33,6 +33,8 @@ cnt = torch.empty((W, ncnt), dtype=torch.int32, device=dev)
 dfr = torch.empty(8 + 3 * dcap, dtype=torch.int64, device=dev)
 recv = torch.empty((W, nrec), dtype=torch.int64, device=dev)
 rcnt = torch.empty((W, ncnt), dtype=torch.int32, device=dev)
+DEDUPE = os.environ.get("DEDUPE", "1") != "0"
+slice_cap, cbits = 0, 0
 prev = [0.0] * 8
 for rep in range(reps):
     part = []
@@ -45,6 +47,17 @@ for rep in range(reps):
             sender.exchange_partition(n, kmers, W, send.data_ptr(), cnt.data_ptr(), dfr.data_ptr(), dcap)
             sender.sync()
         ndef = int(dfr[0].item())
+        if DEDUPE:
+            before = int(cnt.to(torch.int64).sum().item())
+            t0 = time.perf_counter()
+            dd = sender.exchange_dedupe(n, kmers, W, send.data_ptr(), cnt.data_ptr())
+            t_dd = (time.perf_counter() - t0) * 1e3
+            assert dd is not None
+            after = int(cnt.to(torch.int64).sum().item())
+            if rep == 0:
+                slice_cap, cbits = max(slice_cap, dd[0]), dd[1]          # (the fullest list of any sender sizes what everybody ships)
+            if r == W - 1:
+                print("   sender %d: dedupe %.2f ms (wall, incl. the wait): %d -> %d records (%.2fx), fullest list %d of cap %d" % (r, t_dd, before, after, before / max(after, 1), dd[0], plan["slice_cap"]), flush=True)
         recv[r].copy_(send[0])
         rcnt[r].copy_(cnt[0])
         torch.cuda.synchronize()
@@ -54,7 +67,13 @@ for rep in range(reps):
     shard.clear()
     shard.sync()
     t0 = time.perf_counter()
-    shard.exchange_insert(recv.data_ptr(), rcnt.data_ptr(), n, kmers, W, 0, 0, 0, whole_input=True)
+    if DEDUPE and rep > 0:       # (from the second repetition on the fullest list is known: pack what owner 0 received as the all_to_all would deliver it)
+        packed = recv.view(W * ncnt, plan["slice_cap"])[:, :slice_cap].contiguous()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        shard.exchange_insert(packed.data_ptr(), rcnt.data_ptr(), n, kmers, W, 0, 0, 0, whole_input=True, slice_cap=slice_cap, count_bits=cbits)
+    else:
+        shard.exchange_insert(recv.data_ptr(), rcnt.data_ptr(), n, kmers, W, 0, 0, 0, whole_input=True, slice_cap=0, count_bits=cbits if DEDUPE else 0)
     shard.sync()
     t1 = time.perf_counter()
     acc, _ = shard.count_stages()                      # (accumulated over the calls on a table that never scans: per-call = difference)
@@ -76,16 +95,18 @@ for rep in range(max(reps, 3)):
     sender.exchange_scan(reads.data_ptr(), n, 0, n, n, W, dfr.data_ptr(), dcap)
     sender.exchange_partition(n, kmers, W, send.data_ptr(), cnt.data_ptr(), dfr.data_ptr(), dcap)
     sender.sync()
+    if DEDUPE:
+        sender.exchange_dedupe(n, kmers, W, send.data_ptr(), cnt.data_ptr())
     for r in range(W):
         recv[r].copy_(send[0]) if r == 0 else rcnt[r].zero_()
     rcnt[0].copy_(cnt[0])
     torch.cuda.synchronize()
-    sender.exchange_insert(recv.data_ptr(), rcnt.data_ptr(), n, kmers, W, 0, 0, 0, whole_input=False)
+    sender.exchange_insert(recv.data_ptr(), rcnt.data_ptr(), n, kmers, W, 0, 0, 0, whole_input=False, slice_cap=0, count_bits=cbits if DEDUPE else 0)
     st, _ = sender.count_stages()                      # (the scan resets the stage times of its table)
-    print("sender rep %d: part1 %.2f ms, part2 by owner %.2f ms" % (rep, st[0], st[1]), flush=True)
+    print("sender rep %d: part1 %.2f ms, part2 by owner%s %.2f ms" % (rep, st[0], " + dedupe" if DEDUPE else "", st[1]), flush=True)
     if best is None or st[0] + st[1] < best[0] + best[1]:
         best = st
 st = best
-wire = (W - 1) * (nrec * 8 + ncnt * 4)
-print("sender: part1 %.2f ms, part2 by owner %.2f ms; wire per rank %.2f GB padded (%.2f GB of records); sum sender + owner kernels %.2f ms -> %.1f Gk-mers/s per GPU"
+wire = (W - 1) * ((ncnt * slice_cap if slice_cap else nrec) * 8 + ncnt * 4)
+print("sender: part1 %.2f ms, part2 by owner (+ dedupe) %.2f ms; wire per rank %.2f GB as shipped (%.2f GB of raw records); sum sender + owner kernels %.2f ms -> %.1f Gk-mers/s per GPU"
       % (st[0], st[1], wire / 1e9, 8.0 * kmers * (W - 1) / W / 1e9, st[0] + st[1] + 0, kmers / ((st[0] + st[1]) * 1e-3) / 1e9), flush=True)
