@@ -2,23 +2,26 @@
 """bench.py -- the reference's headline metric on MI355X: assembly Mbp/s polished + Gk-mers/s counted, k=37.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: starts its own ranks, or runs under python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One STEP = one pass of the whole hot path over one batch of synthetic input that is already resident in HBM:
-    new table -> count canonical 37-mers of the read shard (K1+K2) -> [N>1: key-wise sum of the per-GPU tables
-    over RCCL, the result kept key-sharded over the GPUs] -> histogram (K3) -> threshold (src/jellyfish.py) -> P fixing passes + 1 QV pass over this rank's
+    new table -> count canonical 37-mers of the read shard (K1+K2) -> [N>1: the counts brought together by key owner
+    over RCCL, the table kept key-sharded over the GPUs: --count] -> histogram (K3) -> threshold (src/jellyfish.py) -> P fixing passes + 1 QV pass over this rank's
     chunk records (K4-K6) -> polished text (left in HBM, like the inputs) + fix records and QV counters on the host.
 After the timed region the same polish call is repeated with host buffers in and out (`polish_host_io_ms`, the
 PCIe-inclusive figure) and its text is compared with the HBM-resident result.
 Workload at N=1 = BASELINE.json configs[1]: "human chr21"-sized synthetic genome (47 Mb) + 30x 150-bp reads, k=37,
 2 passes, chunked as `jasper.sh -t 16` would (BATCH_SIZE = int(47e6/16*.9)).  For N>1 the genome, the reads and
 the assembly grow with N (weak scaling): every rank counts 1/N of the reads of the N x 47 Mb genome and polishes
-its share of the chunks, with the exchange in between: one all_to_all sends every (key, count) to the key's owner GPU,
-and the polishing kernels then read each key from its owner's HBM (their own, or a peer's over xGMI).
+its share of the chunks, with the exchange in between: the reads leave the partition passes of the counting pipeline as
+region lists grouped by key owner and deduplicated, one all_to_all delivers them, the owners insert them into their shards
+(--count exchange; --count local: a table per GPU whose (key, count) entries are sent to the owners instead), and the
+polishing kernels then read each key from its owner's HBM (their own, or a peer's over xGMI).
 
 Prints ONE JSON line (rank 0). `value` = assembly bases polished per second of whole-job wall time (Mbp/s);
-the counting rate, the polishing-only rate, the roofline of the dominant kernel (count_kernel, HIP-event timed
-on the table's own stream) and a CPU baseline (the C oracle on a bounded sample, rank 0 at N=1 only) ride along.
+the counting rate, the polishing-only rate, the roofline of the dominant kernels (the counting pipeline, HIP-event timed
+on the table's own stream; `roofline_polish`) and a CPU baseline (the C restatement, multi-threaded, on the WHOLE workload of
+a step with its results compared with the GPU's; rank 0 at N=1 only) ride along.
 """
 import argparse
 import json
