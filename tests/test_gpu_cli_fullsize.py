@@ -118,7 +118,7 @@ def test_cli_fullsize_matches_real_reference(hip, tmp_path_factory, name, ranks)
     _run(_ref(name), tmp_path_factory, ranks, count=("local" if ranks > 1 else None))
 
 
-@pytest.mark.parametrize("name,ranks", [("fullsize_cfg2", 2), ("fullsize_cfg3_quarter", 2), ("fullsize_cfg5_scaled", 2)] + ([("fullsize_cfg3", 2)] if BIG else []))
+@pytest.mark.parametrize("name,ranks", [("fullsize_cfg2", 2), ("fullsize_cfg3_quarter", 2), ("fullsize_cfg5_scaled", 2), ("fullsize_cfg3", 2)])
 def test_cli_fullsize_counts_by_exchange_of_region_lists(hip, tmp_path_factory, name, ranks):
     """the same digests with no table per GPU: file reader -> batches of bases -> region lists grouped by key owner -> one
     all_to_all per batch -> owners' shards (dist.count_sharded; what `auto` picks whenever the table has a geometry for it)"""
