@@ -143,28 +143,102 @@ def parse_args(argv):
     return o
 
 
-def read_assembly(path):
-    """perl #1 of src/jasper.sh:155: header = first whitespace token of a '>' line, sequence = first tokens of other lines"""
-    contigs = []
-    name, parts = None, []
+_SAFE_BODY = bytes(range(0x21, 0x7f)) + b"\n"     # printable ASCII and '\n': anything else in a sequence line and the line-by-line rules decide
+
+
+def _header_spans(data):
+    """(start, end) of every line of `data` that starts with '>' (end = past its '\n', or the end of the data)"""
+    spans = []
+    pos = 0 if data.startswith(b">") else data.find(b"\n>") + 1
+    while pos > 0 or (pos == 0 and data.startswith(b">") and not spans):
+        end = data.find(b"\n", pos)
+        end = len(data) if end < 0 else end + 1
+        spans.append((pos, end))
+        nxt = data.find(b"\n>", end - 1)
+        if nxt < 0:
+            break
+        pos = nxt + 1
+    return spans
+
+
+def _fasta_events(path, fast=True):
+    """The lines of a FASTA-like file as the perl one-liners of src/jasper.sh:155,220 see them: an event per non-empty line,
+    ("h", first whitespace token) when that token starts with '>', else ("s", first whitespace token); consecutive "s" events
+    come merged into one.  Fast path for the ordinary file (sequence lines of printable ASCII without blanks): whole bodies
+    between header lines at once; anything else -- blanks or tabs in sequence lines, '\r', a '>' after leading blanks,
+    non-ASCII bytes -- goes line by line through str.split(), like the text-mode reader this replaces."""
+    if fast:
+        with open(path, "rb") as f:
+            data = f.read()
+        import locale
+        enc = locale.getpreferredencoding(False)     # (what open(path, "r") decodes with)
+        events, pos, ok = [], 0, b"\r" not in data    # (text mode also ends lines at a lone '\r': line by line then)
+
+        def body_event(body):
+            if not body:
+                return True
+            if body.translate(None, _SAFE_BODY):
+                return False
+            body = body.translate(None, b"\n")
+            if body:
+                events.append(("s", body.decode("ascii")))
+            return True
+
+        for hs, he in _header_spans(data) if ok else ():
+            if not body_event(data[pos:hs]):
+                ok = False
+                break
+            F = data[hs:he].decode(enc, "replace").split()
+            if not F or not F[0].startswith(">"):     # (cannot happen: the line starts with '>')
+                ok = False
+                break
+            events.append(("h", F[0]))
+            pos = he
+        if ok and body_event(data[pos:]):
+            return events
+    events, parts = [], []
     with open(path, "r", errors="replace") as f:
         for line in f:
             F = line.split()
             if not F:
                 continue
             if F[0].startswith(">"):
-                if name is not None and parts:
-                    contigs.append((name, "".join(parts)))
-                name, parts = F[0], []
+                if parts:
+                    events.append(("s", "".join(parts)))
+                    parts = []
+                events.append(("h", F[0]))
             else:
                 parts.append(F[0])
-    if name is not None and parts:
-        contigs.append((name, "".join(parts)))
+    if parts:
+        events.append(("s", "".join(parts)))
+    return events
+
+
+def read_assembly(path, fast=True):
+    """perl #1 of src/jasper.sh:155: header = first whitespace token of a '>' line, sequence = first tokens of other lines"""
+    contigs = []
+    name, seq = None, ""
+    for kind, tok in _fasta_events(path, fast):
+        if kind == "h":
+            if name is not None and seq:
+                contigs.append((name, seq))
+            name, seq = tok, ""
+        else:
+            seq += tok                        # (events come merged: at most one "s" between two headers)
+    if name is not None and seq:
+        contigs.append((name, seq))
     return contigs
 
 
-def sequence_bytes(path):
+def sequence_bytes(path, fast=True):
     """`grep -v '^>' $QUERY | tr -d '\\n' | wc` third column (src/jasper.sh:132)"""
+    if fast:
+        with open(path, "rb") as f:
+            data = f.read()
+        n = len(data) - data.count(b"\n")
+        for hs, he in _header_spans(data):                        # header lines do not count (their '\n' was taken off above)
+            n -= (he - hs) - (1 if data[he - 1:he] == b"\n" else 0)
+        return n
     n = 0
     with open(path, "rb") as f:
         for line in f:
@@ -203,28 +277,23 @@ def split_batches(contigs, batch_size, query_fn):
     return files
 
 
-def join_polished(fixed_files, batch_size, contig_order):
+def join_polished(fixed_files, batch_size, contig_order, fast=True):
     """perl of src/jasper.sh:220: chunks keyed '>name:offset', emitted per contig by walking offsets 0, bs, 2bs ..."""
     bs = int(batch_size)
     if bs <= 0:
         bs = 1
     h = {}
-    ctg, seq = None, []
-    for path in fixed_files:
-        with open(path) as f:
-            for line in f:
-                F = line.split()
-                if not F:
-                    continue
-                if F[0].startswith(">"):
-                    if seq:
-                        h[ctg] = "".join(seq)
-                        seq = []
-                    ctg = F[0]
-                else:
-                    seq.append(F[0])
-    if ctg is not None:
-        h[ctg] = "".join(seq)
+    ctg, seq = "", ""                         # (perl's undef $ctg is the hash key "")
+    for path in fixed_files:                  # (one stream: a sequence may go on in the next file, as for `cat`)
+        for kind, tok in _fasta_events(path, fast):
+            if kind == "h":
+                if seq:
+                    h[ctg] = seq
+                    seq = ""
+                ctg = tok
+            else:
+                seq += tok
+    h[ctg] = seq
     out = []
     keys = [c for c in h if c.endswith(":0")]
     rank = {n: i for i, n in enumerate(contig_order)}

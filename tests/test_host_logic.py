@@ -139,3 +139,37 @@ def test_synth_recipe_small():
     assert r.size == (50000 * 5 // 100) * 101 and set(np.unique(r)) <= set(b"ACGTN")
     a = synth.make_assembly(rng, g, err=1e-3, n_every=20000, n_len=50)
     assert abs(len(a) - len(g)) < 50 and b"N" * 50 in a.tobytes()
+
+
+def test_fast_text_paths_equal_the_line_by_line_rules(tmp_path):
+    """read_assembly / sequence_bytes / join_polished take whole bodies at once when a file is ordinary (printable ASCII
+    sequence lines) and fall back to the perl one-liners' line-by-line rules otherwise: same results on files that are
+    anything but ordinary"""
+    import random
+    from jasper_amd import cli
+    rnd = random.Random(7)
+    pieces = ["ACGT" * 3, "acgtn", "NNNN", "", "A C", "\tACG", "ACG\t", " >x y", ">c1 desc more", ">c2", ">", "> lead", ">c3:0", ">c3:40", "AC\rGT",
+              "ACGT\r", "\x0bAC", "AC\x1cGT", "caf\xc3\xa9", "\xff\xfe", ">n\xc3\xa4me z", "!#%~", ">c4\r", ">a\rb c"]
+    files = []
+    for i in range(400):
+        n = rnd.randrange(0, 12)
+        ordinary = rnd.random() < 0.5
+        pool = [p for p in pieces if not ordinary or (p.isascii() and not any(ch in p for ch in " \t\r\x0b\x1c") or p.startswith(">") and "\r" not in p)]
+        lines = [rnd.choice(pool) for _ in range(n)]
+        data = "\n".join(lines).encode("latin-1") + (b"\n" if rnd.random() < 0.7 else b"")
+        p = tmp_path / ("f%d.fa" % i)
+        p.write_bytes(data)
+        files.append(str(p))
+        assert cli._fasta_events(str(p), True) == cli._fasta_events(str(p), False), data
+        assert cli.read_assembly(str(p), True) == cli.read_assembly(str(p), False), data
+        assert cli.sequence_bytes(str(p), True) == cli.sequence_bytes(str(p), False), data
+    for j in range(0, 400, 7):
+        group = files[j:j + 7]
+        order = [">c1", ">c3", ">c2"]
+        assert cli.join_polished(group, 40, order, True) == cli.join_polished(group, 40, order, False)
+    # an ordinary file does take the fast path (the same events, and no '\r' / blanks in it)
+    p = tmp_path / "plain.fa"
+    p.write_bytes(b">chr1 some text\n" + b"\n".join([b"ACGT" * 15] * 1000) + b"\n>chr2\nAC\n\nGT")
+    ev = cli._fasta_events(str(p))
+    assert ev == [("h", ">chr1"), ("s", "ACGT" * 15000), ("h", ">chr2"), ("s", "ACGT")] == cli._fasta_events(str(p), False)
+    assert cli.sequence_bytes(str(p)) == 60000 + 4
