@@ -587,6 +587,30 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
     return 0
 
 
+class _EarlyTable:
+    """KmerTable(k, min_slots) created by a thread (the library call releases the GIL); get() hands it over, or raises what
+    the creation raised"""
+
+    def __init__(self, k, min_slots, device):
+        import threading
+        self.out, self.err = None, None
+
+        def work():
+            try:
+                self.out = KmerTable(k, min_slots=min_slots, device=device)
+            except BaseException as e:          # noqa: BLE001 -- handed to the caller of get()
+                self.err = e
+
+        self.th = threading.Thread(target=work, daemon=True)
+        self.th.start()
+
+    def get(self):
+        self.th.join()
+        if self.err is not None:
+            raise self.err
+        return self.out
+
+
 def _join_and_merge(o, qfn, batch_size, last_it, contigs):
     """src/jasper.sh:218-232"""
     fixed_files = sorted(glob.glob("_iter%d_%s.batch.*.fa.fixed.fa" % (last_it, glob.escape(qfn))))
@@ -683,6 +707,12 @@ def run(argv):
     if multi:
         return _run_multi(o, rank, world, dev, batch_size, passes, kmer)
 
+    # the counting table (its allocation, and the start of the GPU runtime: 0.2-0.8 s) is set up by a thread while this one splits
+    early = None
+    if (o.jf_db is None and not (os.path.isfile("mer_counts%d.jf" % kmer) and os.path.getsize("mer_counts%d.jf" % kmer) > 0)
+            and not os.environ.get("JASPER_AMD_NO_EARLY_TABLE") and o.reads.split() and all(os.path.isfile(fn) and os.path.getsize(fn) > 0 for fn in o.reads.split())):   # (only when counting WILL happen: no exit while the thread is in the driver)
+        early = _EarlyTable(kmer, max(1 << 20, int(1.25 * o.jf_size)), o.device)
+
     if not os.path.exists("jasper.split.success"):                      # :152-159
         log("Splitting query into batches for parallel execution")
         for p in glob.glob("%s.batch.*.fa" % glob.escape(qfn)):
@@ -712,7 +742,8 @@ def run(argv):
         else:
             _timing("split")
             log("Creating jellyfish database mer_counts%d.jf" % kmer)
-            table = KmerTable(kmer, min_slots=max(1 << 20, int(1.25 * o.jf_size)), device=o.device)
+            table = early.get() if early is not None else KmerTable(kmer, min_slots=max(1 << 20, int(1.25 * o.jf_size)), device=o.device)
+            early = None
             table.count_files(reads)
             _timing("count reads (files -> table)")
             if os.environ.get("JASPER_AMD_NO_JF", "") not in ("1", "true", "yes"):
