@@ -378,9 +378,19 @@ def main():
     # HBM bytes of the counting pipeline per launch, from the PMC passes committed with the same build (rocprofv3 cannot
     # collect FETCH_SIZE / WRITE_SIZE inside this process); null when that file is absent
     traffic, traffic_src = None, None
+    pol_traffic, pol_traffic_src = None, None
     for rnd in (("round2", "round1") if (world == 1 and a.genome_mb == 47.0) else ()):      # (the committed counters are those of the N=1 configs[1] run)
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", rnd, "bench_hbm_counters.json")))
+            try:    # the polishing kernels of one polish call (scan_batch runs once per call): FETCH_SIZE + WRITE_SIZE as reported
+                pk = ("scan_batch", "classify_batch", "find_sync_batch", "find_clean_batch", "seg_init", "seg_walk", "seg_gather", "seg_stitch", "rescan_batch")
+                calls = pj["FETCH_SIZE"]["jk::scan_batch_kernel"]["dispatches"]
+                kb = sum(pj[c]["jk::%s_kernel" % n]["sum_KB"] for c in ("FETCH_SIZE", "WRITE_SIZE") for n in pk if "jk::%s_kernel" % n in pj[c])
+                pol_traffic = int(kb * 1024 / calls)
+                pol_traffic_src = ("profiles/%s/bench_hbm_counters.json: FETCH_SIZE + WRITE_SIZE of the polishing kernels per polish call, as reported (their reads are "
+                                   "mostly 16-byte slot probes that each bring a 64-byte sector: not the wide streaming reads whose FETCH_SIZE gfx950 halves)" % rnd)
+            except Exception:
+                pass
             cp = pj["counting_pipeline"]
             if "hbm_bytes_per_step_corrected" in cp:
                 traffic = int(cp["hbm_bytes_per_step_corrected"] / launches)
@@ -444,7 +454,8 @@ def main():
                               "achieved": round(polish_bytes / pol_s / 1e9, 1) if pol_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(polish_bytes / pol_s / 1e9 / HBM_PEAK_GBS, 4) if pol_s > 0 else 0.0,
                               "algorithmic_bytes_per_step": int(polish_bytes), "device_ms": round(pol_s * 1e3, 3),
-                              "lookups_per_base_and_scan": round(T["lookups"] / max(asm_len * (PASSES + 1), 1), 4), "traffic": None}
+                              "lookups_per_base_and_scan": round(T["lookups"] / max(asm_len * (PASSES + 1), 1), 4), "traffic": pol_traffic,
+                              "traffic_source": pol_traffic_src}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             # the last step's fix records as the rows jasper.py would write (per pass, chunk order), like polisher.polish_batch
