@@ -288,7 +288,7 @@ def main():
         occ = nreads * (READ_LEN - K + 1)
         lam = COVERAGE * (READ_LEN - K + 1) / READ_LEN
         plan = shard.exchange_plan(reads.numel(), world)
-        dedup = plan is not None and plan["p2"] >= 1 and not plan["p2_owner"] and os.environ.get("JASPER_AMD_EXCHANGE_DEDUPE", "1") not in ("0", "no", "false")
+        dedup = plan is not None and plan["p2"] >= 1 and os.environ.get("JASPER_AMD_EXCHANGE_DEDUPE", "1") not in ("0", "no", "false")
         exchange = plan is not None and jdist.prefer_exchange(world, occ, world * a.genome_mb * 1e6 * (1.0 - math.exp(-lam / world)) + 0.103 * occ, deduplicated=dedup)
         if not exchange:
             shard.close()

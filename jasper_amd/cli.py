@@ -437,7 +437,7 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
                 take = plan is not None
                 if take and how == "auto":   # bytes per link decide (dist.prefer_exchange): FASTQ is ~2.1 bytes per base; -s is the expected number of distinct k-mers
                     occ = sum((e if e >= 0 else os.path.getsize(p)) - b for p, b, e in my_ranges) / 2.1
-                    dedup = plan["p2"] >= 1 and not plan["p2_owner"] and os.environ.get("JASPER_AMD_EXCHANGE_DEDUPE", "1") not in ("0", "no", "false")
+                    dedup = plan["p2"] >= 1 and os.environ.get("JASPER_AMD_EXCHANGE_DEDUPE", "1") not in ("0", "no", "false")
                     take = jdist.prefer_exchange(world, occ, o.jf_size, deduplicated=dedup)
                 if not jdist.all_reduce_ints([1 if take else 0], device=dev, op="min")[0]:
                     sharded.close()

@@ -257,7 +257,9 @@ template <bool OWN, bool MIN = false>
 __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__restrict__ out1, const unsigned int *__restrict__ cnt1, TableDev T,
                                                             PartGeom G, uint64_t *__restrict__ out2, unsigned int *__restrict__ cnt2,
                                                             unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
-                                                            uint64_t deferred_cap, uint32_t nown) {
+                                                            uint64_t deferred_cap, uint32_t nown, int cbits = 0) {
+    // cbits > 0 (MIN only: lists deduplicated by their senders): the bits of a record right above G.recbits -- implied by the
+    // input list it is in -- hold (occurrences - 1); they travel on untouched, only a record that finds no room is taken apart
     extern __shared__ __align__(16) unsigned char s_raw[];
     uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_raw);                               // PT_TILE records
     unsigned int *s_cur = reinterpret_cast<unsigned int *>(s_raw + (size_t)PT_TILE * 8);   // PT_MAXBUCKETS slice cursors (per b1)
@@ -361,7 +363,12 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
                         const unsigned int pos = cur + q;
                         const uint64_t rr = s_stage[off + q];
                         if (pos < G.cap2) dst[pos] = rr;
-                        else defer_record(T, hash_of(b1, rr, G.recbits), deferred, deferred_n, deferred_cap);
+                        else if (MIN && cbits) {
+                            const u128 hh = hash_of(b1, rr & ((1ull << G.recbits) - 1ull), G.recbits);
+                            const unsigned long long di = atomicAdd(deferred_n, 1ull);
+                            if (di < deferred_cap) { deferred[3 * di] = hh.hi; deferred[3 * di + 1] = hh.lo; deferred[3 * di + 2] = ((rr >> G.recbits) & ((1ull << cbits) - 1ull)) + 1ull; }
+                            else atomicExch(&T.stats[ST_FATAL], 1ull);
+                        } else defer_record(T, hash_of(b1, rr, G.recbits), deferred, deferred_n, deferred_cap);
                     }
                 }
             }
@@ -392,9 +399,10 @@ template <bool ENT, bool MULTI = false>
 __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__restrict__ lists_v, const unsigned int *__restrict__ cnt, uint32_t cap,
                                                                  uint32_t nsl, TableDev T, PartGeom G, uint32_t nregions, uint32_t parity, int fresh_table,
                                                                  unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
-                                                                 uint64_t deferred_cap, unsigned long long *__restrict__ histo, uint32_t nsrc, int cbits = 0) {
-    // cbits > 0 (lists deduplicated by the sender, list_dedupe_kernel): the p2 bits of a record that its list implies hold
-    // (occurrences - 1) in their low cbits
+                                                                 uint64_t deferred_cap, unsigned long long *__restrict__ histo, uint32_t nsrc, int cbits = 0,
+                                                                 int fbits = 0) {
+    // cbits > 0 (lists deduplicated by the sender, list_dedupe_kernel): the top fbits of a record's p2 field -- the second-level
+    // bits the SENDER resolved, implied by the list it made -- hold (occurrences - 1) in their low cbits
     extern __shared__ __align__(16) unsigned long long s_img[];    // 2 words per slot: (R + halo) slots
     using rec_t = typename std::conditional<ENT, ulonglong2, uint64_t>::type;
     const rec_t *lists = reinterpret_cast<const rec_t *>(lists_v);
@@ -442,10 +450,10 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__re
             else {
                 rec = recv; inc = 1ull;
                 if (cbits) {                                   // (uniform) the count, and the record as it was before the sender put it there
-                    const int csh = G.recbits - G.p2;
-                    const uint64_t fmask = ((1ull << G.p2) - 1ull) << csh;
+                    const int csh = G.recbits - fbits;
+                    const uint64_t fmask = ((1ull << fbits) - 1ull) << csh;
                     inc = ((rec >> csh) & ((1ull << cbits) - 1ull)) + 1ull;
-                    rec = (rec & ~fmask) | ((uint64_t)(region & ((1u << G.p2) - 1u)) << csh);
+                    rec = (rec & ~fmask) | ((uint64_t)((region >> (G.p2 - fbits)) & ((1u << fbits) - 1u)) << csh);
                 }
             }
             uint64_t rem = rec & rmask;
@@ -946,7 +954,7 @@ int Table::xchg_dedupe(uint64_t piece_max, uint64_t records_max, uint32_t nown, 
     PartGeom G;
     int p2b = 0;
     if (!xchg_geometry(*this, piece_max, records_max, nown, G, p2b)) { err = "count exchange: no geometry for this table / piece size"; return -1; }
-    if (G.p2 < 1 || p2b) return 1;
+    if (G.p2 < 1) return 1;                                    // (G.p2: the second-level bits the senders resolve)
     const int cbits = std::min(G.p2, 16);
     const uint64_t nlists = ((uint64_t)nown << (G.p1 + G.p2)) * G.nblk2;
     unsigned int *d_max = (unsigned int *)workspace(WS_MZ + 3, 64, err);
@@ -1013,7 +1021,7 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
     count_path = 3;
     part_stage_n = 5;
     HIPCHK(hipEventRecord(ev_stage_t[3], stream));
-    if (cbits && (p2b || cbits > G.p2)) { err = "count exchange: counted records do not fit this geometry"; return -1; }
+    if (cbits && cbits > G.p2) { err = "count exchange: counted records do not fit this geometry"; return -1; }
     if (slice_cap) G.cap2 = slice_cap;                         // (lists packed by the caller after xchg_dedupe)
     const void *lists = d_recv;
     const unsigned int *lcnt = (const unsigned int *)d_recv_cnt;
@@ -1037,7 +1045,7 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
             attr2_set = true;
         }
         hipLaunchKernelGGL((part2_kernel<false, true>), dim3(1, std::min<uint32_t>(1u << G2.p1, 2048)), dim3(PT_THREADS), P2_LDS, stream, (const uint64_t *)d_recv,
-                           (const unsigned int *)d_recv_cnt, d, G2, out2, cnt2, defer_e, defer_n, own_cap, nown);
+                           (const unsigned int *)d_recv_cnt, d, G2, out2, cnt2, defer_e, defer_n, own_cap, nown, cbits);
         HIPCHK(hipGetLastError());
         lists = out2; lcnt = cnt2; lcap = G2.cap2; nsl = 1;
     }
@@ -1045,9 +1053,9 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
         if (!(nregions == 1 && parity == 1)) {
             const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
             if (p2b) hipLaunchKernelGGL((lds_insert_kernel<false, false>), dim3(nblk), dim3(PT_THREADS), lds, stream, lists, lcnt, lcap, nsl, d, GI, nregions, parity, fresh,
-                                        defer_e, defer_n, own_cap, histo, 1u);
+                                        defer_e, defer_n, own_cap, histo, 1u, cbits, G.p2);
             else hipLaunchKernelGGL((lds_insert_kernel<false, true>), dim3(nblk), dim3(PT_THREADS), lds, stream, lists, lcnt, lcap, nsl, d, GI, nregions, parity, fresh,
-                                    defer_e, defer_n, own_cap, histo, nown, cbits);
+                                    defer_e, defer_n, own_cap, histo, nown, cbits, G.p2);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(ev_stage_t[4 + parity], stream));

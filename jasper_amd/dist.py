@@ -593,7 +593,7 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
         # deduplicated in place (one record per distinct key, its occurrences in bits the list implies) and only the filled part
         # of every list, as long as the fullest list of any rank, travels
         fill, cbits = 0, 0
-        if ok and dedupe and plan["p2"] >= 1 and not plan["p2_owner"]:
+        if ok and dedupe and plan["p2"] >= 1:
             try:
                 dd = shard.exchange_dedupe(piece_max, records_max, world, send.data_ptr(), send_cnt.data_ptr())
                 if dd is not None:

@@ -58,7 +58,7 @@ def exchanged_class(KmerTable):
                     assert max(nd) <= dcap
                     d_all = torch.cat([d[8:8 + 3 * m] for d, m in zip(dfr, nd)]).contiguous() if sum(nd) else None
                     slice_cap, cbits = 0, 0
-                    if size % 3 and plan["p2"] >= 1 and not plan["p2_owner"]:      # (two cases in three) the lists deduplicated by their senders, packed
+                    if size % 3 and plan["p2"] >= 1:      # (two cases in three) the lists deduplicated by their senders, packed
                         dd = [shards[r].exchange_dedupe(piece, rmax, n, send[r].data_ptr(), cnt[r].data_ptr()) for r in range(n)]
                         cbits, slice_cap = dd[0][1], max(max(d[0] for d in dd), 1)
                         lists = n * plan["counts_per_owner"]
