@@ -409,7 +409,6 @@ __global__ __launch_bounds__(MC_TH) void mz_count_kernel(const ulonglong2 *__res
     const u128 kmask = maskbits(2 * k);
     const int hb = WIDE ? B - 64 : 0;
     const uint64_t himask = WIDE ? (hb == 64 ? ~0ull : ((1ull << hb) - 1ull)) : 0ull;
-    const int hshift = WIDE ? 64 - hb : 0;
     const int rcins_w = 2 * (k - 1) - 64, rcins_n = 2 * (k - 1);
     const uint64_t lomask = (!WIDE && 2 * k < 64) ? ((1ull << (2 * k)) - 1ull) : ~0ull;
     const int e1sh = B - G.pe1, idxsh = B - MC_KTBITS;
@@ -455,9 +454,8 @@ __global__ __launch_bounds__(MC_TH) void mz_count_kernel(const ulonglong2 *__res
             if (WIDE) {
                 const bool take_rc = rh < fh || (rh == fh && rl < fl);
                 const uint64_t mh = take_rc ? rh : fh, ml = take_rc ? rl : fl;
-                uint64_t mid;
-                hlo = mix64_mid(ml, mid);
-                hhi = (mh ^ (mid >> hshift)) & himask;
+                hlo = mix64(ml);                                 // = mix() for 2k > 64 (kmer.hpp)
+                hhi = (mh ^ rotr64(hlo, 30)) & himask;
             } else {
                 const u128 h = mix(mk(0, rl < fl ? rl : fl), B);
                 hhi = 0; hlo = h.lo;

@@ -51,16 +51,16 @@ constexpr int PT_GROUP = 16;
 constexpr int PT_TILE = PT_THREADS * PT_GROUP;   // 16384 records per block iteration
 constexpr int PT_HALO = 4;
 constexpr int PT_MAXBUCKETS = 2048;              // p1, p2 <= 11
-constexpr int RG_MAXBITS = 13;                   // region <= 8192 slots = 128 KB of LDS
+constexpr int RG_MAXBITS = 12;                   // region = 4096 slots: 48 KB of LDS in region_insert_kernel, three workgroups per CU (8192 for the largest tables)
 constexpr int RG_HALO = 128;                     // slots of the next region a probe may run into
 
 struct PartGeom {
-    int th1;             // threads per part1 block (1024: one block per CU; 512: two half-size blocks)
     int p1, p2, rbits;       // p1 + p2 + rbits == s
     int recbits;             // 2k - p1  (<= 64): bits kept in a record
     uint32_t nblk1;          // part1 grid: every block owns one SLICE of every level-1 list
     uint32_t nblk2;          // part2 blocks per level-1 bucket: every one owns a slice of each of the bucket's region lists
     uint32_t cap1, cap2;     // slice capacities (records)
+    int exp;                 // tuning experiments only (JASPER_EXPERIMENT_P1): 0 = the product
 };
 // level-1 list of bucket b = slices  out1[(b * nblk1 + blk) * cap1 ...], filled counts cnt1[b * nblk1 + blk]
 // region list of region r  = slices  out2[(r * nblk2 + x) * cap2 ...],   filled counts cnt2[r * nblk2 + x]
@@ -75,169 +75,253 @@ __device__ __forceinline__ void defer_record(const TableDev &T, u128 h, unsigned
     else atomicExch(&T.stats[ST_FATAL], 1ull);
 }
 
-__device__ __forceinline__ void pt_stage(const uint8_t *__restrict__ bases, int64_t pos, uint64_t n, bool /*aligned*/, uint32_t &codes, uint32_t &inv) {
-    stage16(bases, pos, (int64_t)n, codes, inv);
-}
-
 // ---- level 1: bases -> records in 2^p1 bucket lists --------------------------------------------------------
-// Every block owns one slice of every bucket list and keeps the slice cursors in LDS, so there is no global atomic.
-// A tile's 16 K records are first sorted by bucket inside LDS (rank from a returning LDS atomic, offsets from a block
-// scan) and then copied out in bucket order: consecutive lanes write consecutive records of one slice, i.e. whole
+// Every block owns one slice of every bucket list; thread t keeps the cursor of bucket t's slice in a register, so there is
+// no global atomic.  A tile's records are first sorted by bucket inside LDS (rank from a returning LDS atomic, offsets from
+// a block scan) and then copied out in bucket order: consecutive lanes write consecutive records of one slice, i.e. whole
 // 128-B runs.  (Writing each 8-B record straight from the thread that produced it cost 3.9x the bytes in WRITE_SIZE:
 // 1024 open lines per block x 2 blocks per CU do not stay in the 4 MiB L2 until they are full.)
+//
+// The kernel is bound by instruction ISSUE, not by bytes (round 2: 196 wave instructions per record at 4 waves per SIMD), so it
+// is written for few instructions per base:
+//   * NW = number of 32-bit words of a k-mer is a template parameter: both strands roll by v_alignbit_b32 on words (2 x NW
+//     instructions per base; 64-bit shifts by run-time amounts cost several each), the canonical choice is one compare chain;
+//   * the hash is ONE 64-bit multiply (kmer.hpp: mix);
+//   * no branch in the per-base loop except around the rank atomic;
+//   * the copy-out is per RECORD, not per bucket: a second LDS array holds the bucket of every staged record, so a lane needs
+//     three LDS reads and one multiply-add for its destination (the per-bucket loop of round 2 spent ~35 instructions per
+//     record on 16-lane groups that were 3/4 full);
+//   * five barriers per tile: thread t zeroes bucket t's counter in the scan, cursors live in registers.
+// The stage holds P1_STAGE records; a tile with more (only input without read boundaries: a genome) is staged in two rounds.
 constexpr int P1_MAXB = 1024;          // part1 handles p1 <= 10; larger p1 falls back to the direct kernel
-// WIDE = (k > 32): the k-mer needs two 64-bit words; its inner loop is written out on word pairs with the shift amounts
-// fixed by WIDE (the generic u128 helpers shift by run-time amounts: a scalar branch per helper call, ~8 per k-mer, and
-// twice the ALU work where one word would do).  Hashing is ALU-bound here, so instruction count is what matters.
-template <bool WIDE, int TH>
-__global__ __launch_bounds__(TH) void part1_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t ntiles, uint64_t emit_from,
-                                                            TableDev T, PartGeom G, uint64_t *__restrict__ out1, unsigned int *__restrict__ cnt1,
-                                                            unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
-                                                            uint64_t deferred_cap) {
+constexpr int P1_TH = 1024;
+constexpr int P1_STAGE = 13824;        // records per staging round (a tile of 150-base reads holds ~12.4 K)
+constexpr size_t P1_LDS = (size_t)P1_STAGE * 10 + (size_t)(2 * P1_MAXB + 4 + 32) * 4 + (size_t)2 * (P1_TH + PT_HALO) * 4 + (size_t)P1_MAXB * 8;
+typedef __attribute__((address_space(1))) uint64_t global_u64;      // a pointer known to be global memory (kept as an integer in LDS)
+
+// inclusive prefix sum over the 64 lanes of a wave in six DPP adds (row shifts inside the rows of 16, then the two row broadcasts)
+__device__ __forceinline__ unsigned int wave_scan_incl(unsigned int v) {
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);    // row_bcast:15 -> rows 1 and 3
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);    // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+template <int NW>
+__global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t ntiles, uint64_t emit_from, TableDev T, PartGeom G,
+                                                      uint64_t *__restrict__ out1, unsigned int *__restrict__ cnt1, unsigned long long *__restrict__ deferred,
+                                                      unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
     extern __shared__ __align__(16) unsigned char s_raw[];
-    uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_raw);                               // (TH * PT_GROUP) records
-    // the staged base codes are consumed (into registers) before the first record is staged: they share the stage's memory
-    uint32_t *s_code = reinterpret_cast<uint32_t *>(s_raw);                                // TH + PT_HALO
-    uint32_t *s_inv = s_code + (TH + PT_HALO);
-    unsigned int *s_cur = reinterpret_cast<unsigned int *>(s_raw + (size_t)(TH * PT_GROUP) * 8);   // P1_MAXB   slice cursors (persistent)
-    unsigned int *s_cnt = s_cur + P1_MAXB;                                                 // P1_MAXB   records of this tile per bucket
-    unsigned int *s_off = s_cnt + P1_MAXB;                                                 // P1_MAXB+1 exclusive prefix of s_cnt
-    unsigned int *s_wsum = s_off + P1_MAXB + 1;                                            // 16 wave totals
+    // (the small arrays come first: their addresses fit the 16-bit offset field of the LDS instructions)
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_raw);                           // P1_MAXB   records of this tile per bucket
+    unsigned int *s_off = s_cnt + P1_MAXB;                                                   // P1_MAXB+4 exclusive prefix of s_cnt
+    unsigned int *s_wsum = s_off + P1_MAXB + 4;                                              // 16 wave totals, [16] = "a slice overflows in this tile"
+    uint32_t *s_code = reinterpret_cast<uint32_t *>(s_wsum + 32);                            // P1_TH + PT_HALO
+    uint32_t *s_inv = s_code + (P1_TH + PT_HALO);
+    // where stage index 0 of this tile would go in my slice of each bucket's list (slice base + (cursor - s_off) records), as an integer
+    uint64_t *s_base = reinterpret_cast<uint64_t *>(s_inv + (P1_TH + PT_HALO));              // P1_MAXB
+    unsigned short *s_bkt = reinterpret_cast<unsigned short *>(s_base + P1_MAXB);            // bucket of each staged record
+    uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_bkt + P1_STAGE);                      // P1_STAGE records, bucket order
     const int t = threadIdx.x;
     const int k = T.k;
     const int nb = 1 << G.p1;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(bases) & 15) == 0);
-    const u128 kmask = maskbits(2 * k);
-    // word-level constants of the inner loop (see WIDE above)
-    const int hb = WIDE ? 2 * k - 64 : 0;                                       // k-mer / hash bits in the high word
-    const uint64_t himask = WIDE ? (hb == 64 ? ~0ull : ((1ull << hb) - 1ull)) : 0ull;
-    const uint64_t lomask = WIDE ? ~0ull : (2 * k == 64 ? ~0ull : ((1ull << (2 * k)) - 1ull));
-    const int rcins = WIDE ? 2 * (k - 1) - 64 : 2 * (k - 1);
-    const int hshift = WIDE ? 64 - hb : 0;
-    const bool rec64 = G.recbits >= 64;                                         // WIDE with p1 == hb: record = the whole low word
+    // word-level constants: the k-mer's 2k bits fill words 0 .. NW-1, `topbits` of them in word NW-1
+    const int topbits = 2 * k - 32 * (NW - 1);                                  // 2..32
+    const uint32_t topmask = topbits >= 32 ? ~0u : ((1u << topbits) - 1u);
+    const int rsh = topbits - 2;                                                // where the complement of a new base enters rc's top word
+    const int hb = NW > 2 ? 2 * k - 64 : 0;                                     // hash bits above the low 64 (2k > 64)
+    const uint64_t himask = NW > 2 ? (hb >= 64 ? ~0ull : ((1ull << hb) - 1ull)) : 0ull;
+    const uint64_t lomask = NW > 2 || 2 * k >= 64 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const int hh = k;                                                           // (2k <= 64) xor-shift by half the width
+    const int e = NW > 2 ? G.p1 - hb : 0;                                       // bucket bits taken from the low 64 hash bits (2k > 64: p1 >= hb)
     const uint64_t recmask = G.recbits >= 64 ? ~0ull : ((1ull << G.recbits) - 1ull);
-    const int bsh = WIDE && !rec64 ? 64 - G.recbits : 0;                        // hi word's place in the bucket number
-    unsigned long long added = 0, fresh = 0;
-    for (int i = t; i < nb; i += TH) { s_cur[i] = 0; s_cnt[i] = 0; }
-    lds_barrier();
+    unsigned int cur = 0;                                                       // cursor of bucket t's slice
+    unsigned long long added = 0;
+    s_cnt[t] = 0;
+    if (t == 0) s_wsum[16] = 0;
+    const uint64_t slice0 = reinterpret_cast<uint64_t>(out1 + ((uint64_t)t * G.nblk1 + blockIdx.x) * G.cap1);     // my slice of bucket t's list
     // my 16 bases of the NEXT tile are requested while the current one is processed (one block per CU: nothing else
     // would hide that latency)
-    Raw16 raw = load16(bases, (int64_t)(blockIdx.x * (uint64_t)(TH * PT_GROUP)) + (int64_t)t * PT_GROUP, (int64_t)n);
+    Raw16 raw = load16(bases, (int64_t)(blockIdx.x * (uint64_t)PT_TILE) + (int64_t)t * PT_GROUP, (int64_t)n);
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t base0 = (int64_t)(tile * (TH * PT_GROUP));
+        const int64_t base0 = (int64_t)(tile * PT_TILE);
         uint32_t c, iv;
         encode16(raw.w, c, iv);
-        if (tile + gridDim.x < ntiles) raw = load16(bases, (int64_t)((tile + gridDim.x) * (TH * PT_GROUP)) + (int64_t)t * PT_GROUP, (int64_t)n);
+        if (tile + gridDim.x < ntiles) raw = load16(bases, (int64_t)((tile + gridDim.x) * PT_TILE) + (int64_t)t * PT_GROUP, (int64_t)n);
         s_code[t + PT_HALO] = c;
         s_inv[t + PT_HALO] = iv;
         if (t < PT_HALO) {
             uint32_t hc, hiv;
-            pt_stage(bases, base0 - (int64_t)(PT_HALO - t) * PT_GROUP, n, aligned, hc, hiv);
+            stage16(bases, base0 - (int64_t)(PT_HALO - t) * PT_GROUP, (int64_t)n, hc, hiv);
             s_code[t] = hc;
             s_inv[t] = hiv;
         }
         lds_barrier();
         // A. hash my 16 windows, take a rank in the tile's bucket histogram
-        const uint32_t w4 = s_code[t], w3 = s_code[t + 1], w2 = s_code[t + 2], w1 = s_code[t + 3];
-        const uint64_t ivprev = ((uint64_t)s_inv[t] << 48) | ((uint64_t)s_inv[t + 1] << 32) | ((uint64_t)s_inv[t + 2] << 16) | (uint64_t)s_inv[t + 3];
-        const u128 fwd0 = band(mk(((uint64_t)w4 << 32) | w3, ((uint64_t)w2 << 32) | w1), kmask);
-        const u128 rc0 = revcomp(fwd0, k);
-        uint64_t fl = fwd0.lo, fh = fwd0.hi, rl = rc0.lo, rh = rc0.hi;     // forward / reverse-complement k-mer, (hi, lo) words
-        int run = ivprev ? (int)__builtin_ctzll(ivprev) : 64;
+        uint32_t f[NW], r[NW];
+        int run;
+        {
+            const uint32_t w4 = s_code[t], w3 = s_code[t + 1], w2 = s_code[t + 2], w1 = s_code[t + 3];
+            const uint64_t ivprev = ((uint64_t)s_inv[t] << 48) | ((uint64_t)s_inv[t + 1] << 32) | ((uint64_t)s_inv[t + 2] << 16) | (uint64_t)s_inv[t + 3];
+            const u128 fwd0 = band(mk(((uint64_t)w4 << 32) | w3, ((uint64_t)w2 << 32) | w1), maskbits(2 * k));
+            const u128 rc0 = revcomp(fwd0, k);
+            const uint32_t fw[4] = {(uint32_t)fwd0.lo, (uint32_t)(fwd0.lo >> 32), (uint32_t)fwd0.hi, (uint32_t)(fwd0.hi >> 32)};
+            const uint32_t rw[4] = {(uint32_t)rc0.lo, (uint32_t)(rc0.lo >> 32), (uint32_t)rc0.hi, (uint32_t)(rc0.hi >> 32)};
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { f[w] = fw[w]; r[w] = rw[w]; }
+            run = ivprev ? (int)__builtin_ctzll(ivprev) : 64;
+        }
+        // k-mers that END before emit_from belong to the piece before this one
+        const int64_t mine = base0 + (int64_t)t * PT_GROUP;
+        int jfirst = (int64_t)emit_from > mine ? (int)((int64_t)emit_from - mine < PT_GROUP ? (int64_t)emit_from - mine : PT_GROUP) : 0;
+        asm volatile("" : "+v"(jfirst));                                            // (keeps the 16 tests below 32-bit compares with a register)
         uint64_t rec[PT_GROUP];
-        uint32_t br[PT_GROUP];     // bucket << 16 | rank in tile ; 0xFFFFFFFF = no record
+        uint32_t bkt[PT_GROUP];    // bucket, or 0xFFFF = no record
+        uint32_t rnk[PT_GROUP];    // rank among the tile's records of that bucket
 #pragma unroll
         for (int j = 0; j < PT_GROUP; ++j) {
-            const uint64_t cj = (c >> (30 - 2 * j)) & 3u;
-            const bool bad = (iv >> (15 - j)) & 1u;
-            if (WIDE) {               // 2k in 66..128: the new base enters rc in the high word at bit 2(k-1)-64
-                fh = ((fh << 2) | (fl >> 62)) & himask;
-                fl = (fl << 2) | cj;
-                rl = (rl >> 2) | (rh << 62);
-                rh = (rh >> 2) | ((3ull - cj) << rcins);
-            } else {                  // 2k <= 64: one word
-                fl = ((fl << 2) | cj) & lomask;
-                rl = (rl >> 2) | ((3ull - cj) << rcins);
+            const uint32_t cj = (c >> (30 - 2 * j)) & 3u;
+            // forward strand: shift left by one base; reverse complement: shift right, the complement enters on top
+#pragma unroll
+            for (int w = NW - 1; w > 0; --w) f[w] = __builtin_amdgcn_alignbit(f[w], f[w - 1], 30);
+            f[0] = (f[0] << 2) | cj;
+            f[NW - 1] &= topmask;
+#pragma unroll
+            for (int w = 0; w < NW - 1; ++w) r[w] = __builtin_amdgcn_alignbit(r[w + 1], r[w], 2);
+            r[NW - 1] = (r[NW - 1] >> 2) | ((cj ^ 3u) << rsh);
+            run = ((iv >> (15 - j)) & 1u) ? 0 : run + 1;
+            const bool valid = run >= k && j >= jfirst;
+            // canonical = numeric min of the two strands: borrow chain of r - f from the low word up, then one select per word
+            // (written out: the compiler turns the same chain into 2 compares per word plus scalar mask logic)
+            uint32_t m[NW];
+            if constexpr (NW == 3) {
+                uint32_t d;
+                asm("v_sub_co_u32_e32 %3, vcc, %4, %7\n\tv_subb_co_u32_e32 %3, vcc, %5, %8, vcc\n\tv_subb_co_u32_e32 %3, vcc, %6, %9, vcc\n\t"
+                    "v_cndmask_b32_e32 %0, %7, %4, vcc\n\tv_cndmask_b32_e32 %1, %8, %5, vcc\n\tv_cndmask_b32_e32 %2, %9, %6, vcc"
+                    : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(d) : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(f[0]), "v"(f[1]), "v"(f[2]) : "vcc");
+            } else if constexpr (NW == 2) {
+                uint32_t d;
+                asm("v_sub_co_u32_e32 %2, vcc, %3, %5\n\tv_subb_co_u32_e32 %2, vcc, %4, %6, vcc\n\t"
+                    "v_cndmask_b32_e32 %0, %5, %3, vcc\n\tv_cndmask_b32_e32 %1, %6, %4, vcc"
+                    : "=&v"(m[0]), "=&v"(m[1]), "=&v"(d) : "v"(r[0]), "v"(r[1]), "v"(f[0]), "v"(f[1]) : "vcc");
+            } else {
+                m[0] = r[0] < f[0] ? r[0] : f[0];
             }
-            run = bad ? 0 : run + 1;
-            br[j] = 0xFFFFFFFFu;
-            rec[j] = 0;
-            if (run >= k && (uint64_t)(base0 + t * PT_GROUP + j) >= emit_from) {
-                uint32_t b;
-                if (WIDE) {
-                    const bool take_rc = rh < fh || (rh == fh && rl < fl);            // canonical = numeric min
-                    const uint64_t mh = take_rc ? rh : fh, ml = take_rc ? rl : fl;
-                    uint64_t mid;
-                    const uint64_t lo = mix64_mid(ml, mid);                            // = mix() for 2k > 64 (kmer.hpp)
-                    const uint64_t hi = (mh ^ (mid >> hshift)) & himask;
-                    // bucket = top p1 bits of the 2k-bit hash (hi:hb bits, lo:64 bits), p1 >= hb here; record = the rest
-                    b = rec64 ? (uint32_t)hi : (uint32_t)((hi << bsh) | (lo >> G.recbits));
-                    rec[j] = rec64 ? lo : (lo & recmask);
-                } else {
-                    const uint64_t m = rl < fl ? rl : fl;
-                    const uint64_t h = mix(mk(0, m), T.B).lo;
-                    b = (uint32_t)(h >> G.recbits);
-                    rec[j] = h & recmask;
-                }
-                br[j] = (b << 16) | (atomicAdd(&s_cnt[b], 1u) & 0xFFFFu);    // LDS returning atomic; a tile holds < 2^15 records
-                ++added;
+            uint32_t b;
+            if constexpr (NW > 2) {                                                 // 64 < 2k <= 74 (p1 <= 10 bucket bits cover the bits above 64): kmer.hpp mix()
+                const uint64_t lo = mix64(((uint64_t)m[1] << 32) | m[0]);
+                const uint32_t lo_hi = (uint32_t)(lo >> 32);
+                const uint32_t hi = (m[2] ^ __builtin_amdgcn_alignbit(lo_hi, (uint32_t)lo, 30)) & (uint32_t)himask;
+                // bucket = top p1 bits of the 2k-bit hash (hi: hb bits, lo: 64 bits), p1 >= hb; record = the rest
+                b = (hi << e) | ((lo_hi >> 1) >> (31 - e));
+                rec[j] = lo & recmask;
+            } else {
+                uint64_t v = m[0];
+                if constexpr (NW > 1) v |= (uint64_t)m[1] << 32;
+                v ^= v >> hh;
+                v = (v * JK_C1) & lomask;
+                v ^= v >> hh;
+                b = (uint32_t)(v >> G.recbits);
+                rec[j] = v & recmask;
             }
+            bkt[j] = valid ? b : 0xFFFFu;
+            rnk[j] = 0;
+            if (valid) rnk[j] = atomicAdd(&s_cnt[b], 1u);                           // LDS returning atomic
         }
         lds_barrier();
-        // B. exclusive prefix of the bucket counts (P1_MAXB / TH buckets per thread, wave scan + wave totals)
+        // B. exclusive prefix of the bucket counts: thread t owns bucket t (wave scan + wave totals); the counter is zeroed
+        //    for the next tile and the slice cursor advanced here
+        unsigned int total;
         {
-            constexpr int BPT = P1_MAXB / TH;
-            unsigned int vb[BPT];
-            unsigned int v = 0;
-#pragma unroll
-            for (int u = 0; u < BPT; ++u) { vb[u] = t * BPT + u < nb ? s_cnt[t * BPT + u] : 0u; v += vb[u]; }
-            unsigned int inc = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
+            const unsigned int v = t < nb ? s_cnt[t] : 0u;
+            s_cnt[t] = 0;
+            const unsigned int inc = wave_scan_incl(v);
             if ((t & 63) == 63) s_wsum[t >> 6] = inc;
             lds_barrier();
-            unsigned int wbase = 0;
-            for (int w = 0; w < (t >> 6); ++w) wbase += s_wsum[w];
-            unsigned int ex = wbase + inc - v;
-#pragma unroll
-            for (int u = 0; u < BPT; ++u) { if (t * BPT + u < nb) s_off[t * BPT + u] = ex; ex += vb[u]; }
-            if (t == TH - 1) s_off[nb] = wbase + inc;                         // tile total
+            // the 16 wave totals: scanned again by every wave (lanes 0..15), base of my wave and tile total by lane reads
+            const unsigned int ws = wave_scan_incl((t & 63) < P1_TH / 64 ? s_wsum[t & 63] : 0u);
+            const unsigned int wbase = (t >> 6) ? (unsigned int)__builtin_amdgcn_readlane((int)ws, (t >> 6) - 1) : 0u;
+            total = (unsigned int)__builtin_amdgcn_readlane((int)ws, P1_TH / 64 - 1);
+            const unsigned int ex = wbase + inc - v;
+            s_off[t] = ex;
+            s_base[t] = slice0 + ((uint64_t)cur - (uint64_t)ex) * 8ull;
+            cur += v;
+            if (cur > G.cap1 && v) s_wsum[16] = 1;                                   // (stays set: the slice stays full)
         }
+        if (t == 0) added += total;
         lds_barrier();
-        // C. records into LDS in bucket order
+        if (G.exp & 2) continue;                                                    // (timing experiment: hashing and ranking only)
+        for (unsigned int r0 = 0; r0 < total; r0 += P1_STAGE) {
+            if (r0) lds_barrier();                                                  // the previous round has been copied out
+            // C. records into LDS in bucket order
+            if (total <= (unsigned int)P1_STAGE) {                                  // (block-uniform) the usual case: one round holds the tile
 #pragma unroll
-        for (int j = 0; j < PT_GROUP; ++j)
-            if (br[j] != 0xFFFFFFFFu) s_stage[s_off[br[j] >> 16] + (br[j] & 0xFFFFu)] = rec[j];
-        lds_barrier();
-        // D. copy out, one bucket per 16 lanes: a tile holds ~16 records per bucket, so a 16-lane group writes one
-        //    128-B run of its bucket's slice per round (three LDS reads per bucket instead of a binary search per record)
-        {
-            const int g16 = t >> 4, r16 = t & 15;
-#pragma unroll 4
-            for (int b = g16; b < nb; b += TH / 16) {
-                const unsigned int off = s_off[b], cnt = s_cnt[b], cur = s_cur[b];
-                uint64_t *dst = out1 + ((uint64_t)b * G.nblk1 + blockIdx.x) * G.cap1;
-                for (unsigned int q = r16; q < cnt; q += 16) {
-                    const unsigned int pos = cur + q;
-                    const uint64_t r = s_stage[off + q];
-                    if (pos < G.cap1) dst[pos] = r;
-                    else defer_record(T, hash_of((uint64_t)b, r, G.recbits), deferred, deferred_n, deferred_cap);   // slice full
+                for (int j = 0; j < PT_GROUP; ++j) {
+                    if (bkt[j] != 0xFFFFu) {
+                        const unsigned int pos = s_off[bkt[j]] + rnk[j];
+                        unsigned int pos2 = pos;
+                        asm("" : "+v"(pos2));                                       // (its own shift: derived from pos * 8 it becomes a 64-bit multiply-add)
+                        s_stage[pos] = rec[j];
+                        s_bkt[pos2] = (unsigned short)bkt[j];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < PT_GROUP; ++j) {
+                    if (bkt[j] != 0xFFFFu) {
+                        const unsigned int pos = s_off[bkt[j]] + rnk[j] - r0;
+                        if (pos < (unsigned int)P1_STAGE) { s_stage[pos] = rec[j]; s_bkt[pos] = (unsigned short)bkt[j]; }
+                    }
+                }
+            }
+            lds_barrier();
+            // D. copy out: lane i takes staged record i -- consecutive lanes, consecutive records of one slice
+            const unsigned int nr = total - r0 < (unsigned int)P1_STAGE ? total - r0 : (unsigned int)P1_STAGE;
+            if (!s_wsum[16]) {                                                      // (block-uniform) no slice of mine is full
+#pragma unroll 2
+                for (unsigned int i = t; i < nr; i += P1_TH) {
+                    const uint64_t rr = s_stage[i];
+                    const uint32_t b = s_bkt[i];
+                    if (G.exp & 1) reinterpret_cast<global_u64 *>(s_base[b & 7])[(r0 + i) & 1023] = rr;     // (timing experiment: stores that stay in cache)
+                    else reinterpret_cast<global_u64 *>(s_base[b])[r0 + i] = rr;
+                }
+            } else {
+                for (unsigned int i = t; i < nr; i += P1_TH) {
+                    const uint64_t rr = s_stage[i];
+                    const uint32_t b = s_bkt[i];
+                    const uint64_t first = reinterpret_cast<uint64_t>(out1 + ((uint64_t)b * G.nblk1 + blockIdx.x) * G.cap1);
+                    const uint64_t pos = (uint64_t)(((int64_t)(s_base[b] - first) >> 3) + (int64_t)(r0 + i));   // position in the bucket's slice (s_base may lie below it)
+                    if (pos < G.cap1) reinterpret_cast<global_u64 *>(first)[pos] = rr;
+                    else defer_record(T, hash_of((uint64_t)b, rr, G.recbits), deferred, deferred_n, deferred_cap);   // slice full
                 }
             }
         }
-        lds_barrier();
-        for (int i = t; i < nb; i += TH) { s_cur[i] += s_cnt[i]; s_cnt[i] = 0; }
-        // (the next tile's first barrier orders this against its histogram updates)
+        // (the next tile's barriers order its writes to the stage, s_off and s_base against this copy-out)
     }
-    lds_barrier();
-    for (int i = t; i < nb; i += TH) cnt1[(uint64_t)i * G.nblk1 + blockIdx.x] = s_cur[i] < G.cap1 ? s_cur[i] : G.cap1;
-    for (int o = 32; o > 0; o >>= 1) { added += __shfl_xor(added, o); fresh += __shfl_xor(fresh, o); }
-    if ((threadIdx.x & 63) == 0) {
-        if (added) atomicAdd(&T.stats[ST_OCCURRENCES], added);
-        if (fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
-    }
+    if (t < nb) cnt1[(uint64_t)t * G.nblk1 + blockIdx.x] = G.exp ? 0u : (cur < G.cap1 ? cur : G.cap1);
+    if (t == 0 && added) atomicAdd(&T.stats[ST_OCCURRENCES], added);
 }
-constexpr size_t p1_lds(int th) { return (size_t)th * PT_GROUP * 8 + (size_t)(3 * P1_MAXB + 1 + 16) * 4; }
+// one launch site for the three word counts: k <= 16, 17..32, 33..37
+static hipError_t launch_part1(hipStream_t stream, int k, const uint8_t *d_piece, uint64_t len, uint64_t ntiles, uint64_t emit_from, const TableDev &d, const PartGeom &G,
+                               uint64_t *out1, unsigned int *cnt1, unsigned long long *defer_e, unsigned long long *defer_n, uint64_t deferred_cap) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e;
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+        attr_set = true;
+    }
+#define JK_P1_LAUNCH(NW_) hipLaunchKernelGGL((part1_kernel<NW_>), dim3(G.nblk1), dim3(P1_TH), P1_LDS, stream, d_piece, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, deferred_cap)
+    if (k <= 16) JK_P1_LAUNCH(1);
+    else if (k <= 32) JK_P1_LAUNCH(2);
+    else JK_P1_LAUNCH(3);                     // (k <= 37: partition_geometry gives 8-byte records only while 2k - 64 <= p1 <= 10)
+#undef JK_P1_LAUNCH
+    return hipGetLastError();
+}
 
 // ---- level 2: every bucket list -> 2^p2 region lists ---------------------------------------------------------
 // grid (nblk2, buckets): block (x, b1) reads the level-1 slices x, x+nblk2, ... of bucket b1 (as one concatenated
@@ -563,6 +647,176 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__re
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
 }
 
+// ---- final, single-GPU form: one launch, no halo, 12 bytes of LDS per slot ------------------------------------------------------
+// One workgroup per region of R = 2^rbits slots (R <= 4096 here: 48 KB of LDS, three workgroups of 512 threads per CU, so that
+// one's record loads and image write-out overlap another's insert loop).  The LDS image keeps the tag (8 bytes, the table's own
+// format) and -- on a table that starts empty (FRESH) -- a 32-bit count of what this pass adds; the slot's 16 bytes are put
+// together on the way out.  A region is exactly the block's own slots: a record whose probe sequence leaves the region (0.03 % of
+// them at load 0.3) goes to the deferred list and takes the direct path afterwards, so all regions run in ONE launch and every
+// slot is written, and binned into the multiplicity histogram, exactly once (import3h_kernel moves the bins of the few keys it
+// touches).  Round 2's form (lds_insert_kernel above: 16-byte LDS slots, a 128-slot halo, even and odd regions in two launches,
+// one 1024-thread workgroup per CU) spent 178 wave instructions per record, most of them scalar branch bookkeeping of the probe
+// loop; here the first probe of four records is straight-line code and only the lanes that miss it loop.
+constexpr int RI_TH = 512;
+constexpr int RI_PF = 8;              // records per lane in flight
+template <bool FRESH>
+__global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__restrict__ lists, const unsigned int *__restrict__ cnt, uint32_t cap, uint32_t nsl,
+                                                              TableDev T, PartGeom G, uint32_t nregions, unsigned long long *__restrict__ deferred,
+                                                              unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap,
+                                                              unsigned long long *__restrict__ histo) {
+    using cnt_t = typename std::conditional<FRESH, unsigned int, unsigned long long>::type;
+    extern __shared__ __align__(16) unsigned long long s_tag[];                      // R tags, R counts, LDS_HBINS bins
+    const uint32_t R = 1u << G.rbits;
+    cnt_t *s_cnt = reinterpret_cast<cnt_t *>(s_tag + R);
+    unsigned int *s_bins = reinterpret_cast<unsigned int *>(s_cnt + R);
+    const int t = threadIdx.x;
+    const int rs = T.B - T.s;                                                        // remainder bits (<= 53 by the tag format)
+    const uint64_t rmask = (1ull << rs) - 1ull;
+    const bool whole = nregions == 1;                                                // the whole table is one region: probes wrap inside it
+    unsigned long long fresh = 0;
+    if (histo) {
+        for (int i = t; i < LDS_HBINS; i += RI_TH) s_bins[i] = 0;
+    }
+    for (uint32_t region = blockIdx.x; region < nregions; region += gridDim.x) {
+        const uint64_t first = (uint64_t)region << G.rbits;                          // first slot of the region
+        const uint64_t b1 = region >> G.p2;
+        const uint64_t *src = lists + (uint64_t)region * nsl * cap;
+        uint32_t nrec = cnt[(uint64_t)region * nsl];
+        if (!FRESH && !histo) {                                                      // (block-uniform) nothing to add: the slots stay as they are
+            uint32_t any = nrec;
+            for (uint32_t x = 1; x < nsl; ++x) any |= cnt[(uint64_t)region * nsl + x];
+            if (!any) continue;
+        }
+        // the first records of the region's first slice (normally its only one) are requested before the image is set up
+        uint64_t recs[RI_PF];
+#pragma unroll
+        for (int u = 0; u < RI_PF; ++u) { const uint32_t i = (uint32_t)u * RI_TH + t; recs[u] = i < nrec ? src[i] : 0ull; }
+        if (FRESH) {
+            for (uint32_t i = t; i < R; i += RI_TH) { s_tag[i] = 0ull; s_cnt[i] = 0; }
+        } else {
+            for (uint32_t i = t; i < R; i += RI_TH) {
+                const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * (first + i));
+                s_tag[i] = e.x;
+                s_cnt[i] = (cnt_t)e.y;
+            }
+        }
+        lds_barrier();
+        // the probe loop of the lanes that did not find their key in its home slot (cur = what the home slot held)
+        auto probe_on = [&](uint64_t rec, uint32_t idx, unsigned long long want, unsigned long long cur) {
+            for (;;) {
+                if (cur == 0ull) {
+                    cur = atomicCAS(&s_tag[idx], 0ull, want);                        // LDS compare-and-swap
+                    if (cur == 0ull) { ++fresh; cur = want; }
+                }
+                if (cur == want) { atomicAdd(&s_cnt[idx], (cnt_t)1); return; }       // LDS add
+                ++idx;
+                ++want;                                                              // tag_of(rem, off + 1): the offset is the tag's low bits
+                if (whole) idx &= R - 1;
+                if (idx >= R || (want & (unsigned long long)(MAXPROBE - 1)) == 0ull) {   // leaves the region (or the probe limit): direct path, later
+                    defer_record(T, hash_of(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
+                    return;
+                }
+                cur = s_tag[idx];
+            }
+        };
+        auto insert_batch = [&](uint32_t i0, uint32_t n) {                           // recs[u] = record i0 + u * RI_TH + t of a slice of n
+            uint32_t idx[RI_PF];
+            unsigned long long want[RI_PF], cur[RI_PF];
+#pragma unroll
+            for (int u = 0; u < RI_PF; ++u) {
+                // the record holds the low recbits hash bits; the bits above the slot index of this region are implied by the
+                // list it is in, so slot and remainder come from the record alone
+                idx[u] = (uint32_t)(recs[u] >> rs) & (R - 1);
+                want[u] = OCC | ((recs[u] & rmask) << OFFBITS);
+                cur[u] = s_tag[idx[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < RI_PF; ++u) {
+                if (i0 + (uint32_t)u * RI_TH + t < n) {
+                    if (cur[u] == want[u]) atomicAdd(&s_cnt[idx[u]], (cnt_t)1);
+                    else probe_on(recs[u], idx[u], want[u], cur[u]);
+                }
+            }
+        };
+        for (uint32_t x = 0; x < nsl; ++x) {
+            if (x) { nrec = cnt[(uint64_t)region * nsl + x]; src += cap; }
+            for (uint32_t i0 = 0; i0 < nrec; i0 += RI_PF * RI_TH) {
+                if (x || i0) {
+#pragma unroll
+                    for (int u = 0; u < RI_PF; ++u) { const uint32_t i = i0 + (uint32_t)u * RI_TH + t; recs[u] = i < nrec ? src[i] : 0ull; }
+                }
+                insert_batch(i0, nrec);
+            }
+        }
+        lds_barrier();
+        for (uint32_t i = t; i < R; i += RI_TH) {
+            const unsigned long long tag = s_tag[i];
+            const unsigned long long c64 = (unsigned long long)s_cnt[i];
+            *reinterpret_cast<ulonglong2 *>(T.slots + 2 * (first + i)) = make_ulonglong2(tag, c64);
+            if (histo) {
+                const bool occ = tag != 0ull && c64 != 0ull;
+                const uint32_t c = clamp32(c64);
+                const uint32_t b = c > 10001u ? 10001u : c;
+                // most occupied slots of a read set hold 1 (read errors): those are counted per wave, not by 64 same-address atomics
+                const unsigned long long ones = __ballot(occ && b == 1u);
+                if (ones && (t & 63) == (int)__builtin_ctzll(ones)) atomicAdd(&s_bins[1], (unsigned int)__popcll(ones));
+                if (occ && b != 1u) {
+                    if (b < (uint32_t)LDS_HBINS) atomicAdd(&s_bins[b], 1u);
+                    else atomicAdd(&histo[b], 1ull);
+                }
+            }
+        }
+        lds_barrier();
+    }
+    if (histo) {
+        for (int i = t; i < LDS_HBINS; i += RI_TH)
+            if (s_bins[i]) atomicAdd(&histo[i], (unsigned long long)s_bins[i]);
+    }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+}
+
+// the deferred records through the direct path, with the fused histogram kept exact: a key whose count goes from c to c + inc
+// leaves bin(c) and enters bin(c + inc) (every add returns the count it found, so concurrent adds to one key move it bin by bin)
+__device__ __forceinline__ uint32_t histo_bin(unsigned long long c) { const uint32_t v = clamp32(c); return v > 10001u ? 10001u : v; }
+__global__ __launch_bounds__(256) void import3h_kernel(const unsigned long long *__restrict__ entries, const unsigned long long *__restrict__ n_ptr, uint64_t cap,
+                                                       TableDev T, unsigned long long *__restrict__ histo) {
+    const uint64_t n = *n_ptr < cap ? *n_ptr : cap;
+    unsigned long long fresh = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const u128 h = mk(entries[3 * i], entries[3 * i + 1]);
+        const unsigned long long inc = entries[3 * i + 2];
+        const uint64_t home = home_of(h, T.B, T.s);
+        const uint64_t rem = rem_of(h, T.B, T.s);
+        bool done = false;
+        for (uint32_t off = 0; off < MAXPROBE && !done; ++off) {
+            const uint64_t slot = (home + off) & T.mask;
+            const unsigned long long want = tag_of(rem, off);
+            unsigned long long *p = T.slots + 2 * slot;
+            unsigned long long cur = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == 0ull) {
+                cur = atomicCAS(p, 0ull, want);
+                if (cur == 0ull) { ++fresh; cur = want; }
+            }
+            if (cur == want) {
+                const unsigned long long old = __hip_atomic_fetch_add(p + 1, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t b0 = histo_bin(old), b1 = histo_bin(old + inc);
+                if (histo && (old == 0ull || b0 != b1)) {
+                    if (old) atomicAdd(&histo[b0], ~0ull);                            // (minus one)
+                    atomicAdd(&histo[b1], 1ull);
+                }
+                done = true;
+            }
+        }
+        if (!done) {                                                                 // no room within the probe limit: spill list, the table grows
+            table_spill(T, h, inc);
+            if (histo) histo[10002] = 1ull;                                           // "not complete": the re-insertion after growth does not know the bins
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+}
+
 __global__ __launch_bounds__(256) void import3_kernel(const unsigned long long *__restrict__ entries, const unsigned long long *__restrict__ n_ptr,
                                                       uint64_t cap, TableDev T, unsigned long long *__restrict__ histo_incomplete) {
     const uint64_t n = *n_ptr < cap ? *n_ptr : cap;
@@ -585,20 +839,26 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     if (piece_bases < (8u << 20)) return false;          // small pieces: the direct kernel is already latency-hidden
     const int B = d.B, s = d.s;
     const int need_p1 = B > 64 ? B - 64 : 0;              // records are 8 bytes
-    int p1 = std::max(need_p1, (s - RG_MAXBITS + 1) / 2);
-    if (p1 < 1) p1 = 1;
-    if (p1 > 10 || p1 > s - 8) return false;              // (k >= 38, or a table too small to be worth it)
-    int p2 = s - RG_MAXBITS - p1;
-    if (p2 < 0) p2 = 0;
-    if (p2 > 11) return false;
+    // regions of 2^12 slots (three region_insert workgroups per CU); 2^13 only where the two list levels cannot split finer
+    int p1 = 0, p2 = 0;
+    bool ok = false;
+    for (int rg = RG_MAXBITS; rg <= RG_MAXBITS + 1 && !ok; ++rg) {
+        p1 = std::max(need_p1, (s - rg + 1) / 2);
+        if (p1 < 1) p1 = 1;
+        if (p1 > 10 || p1 > s - 8) continue;              // (k >= 38, or a table too small to be worth it)
+        p2 = s - rg - p1;
+        if (p2 < 0) p2 = 0;
+        ok = p2 <= 11;
+    }
+    if (!ok) return false;
     G.p1 = p1; G.p2 = p2; G.rbits = s - p1 - p2; G.recbits = B - p1;
+    static const int exp_env = getenv("JASPER_EXPERIMENT_P1") ? atoi(getenv("JASPER_EXPERIMENT_P1")) : 0;
+    G.exp = exp_env;
     // slices should hold >= ~512 records on average so that their 1.25x + 8 sigma capacity wastes little
-    static const int th1_env = getenv("JASPER_EXPERIMENT_P1THREADS") ? atoi(getenv("JASPER_EXPERIMENT_P1THREADS")) : 0;   // tuning experiments only
-    G.th1 = th1_env == 512 ? 512 : 1024;
-    const uint64_t tile1 = (uint64_t)G.th1 * PT_GROUP;
+    const uint64_t tile1 = (uint64_t)PT_TILE;
     const uint64_t ntiles = (piece_bases + tile1 - 1) / tile1;
     uint64_t nblk1 = piece_bases / ((uint64_t)(1u << p1) * 512);
-    nblk1 = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(nblk1, ntiles), 256 * (1024 / G.th1)));   // one 1024-thread block (152 KB of LDS) per CU, or two of 512
+    nblk1 = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(nblk1, ntiles), 256));   // one 1024-thread block (159 KB of LDS) per CU
     G.nblk1 = (uint32_t)nblk1;
     G.cap1 = list_cap((double)piece_bases / ((double)(1u << p1) * (double)nblk1));
     // one slice per region list: part2 runs one 1024-thread block per CU, and 2^p1 >= 256 buckets already fill the chip;
@@ -623,25 +883,13 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     unsigned long long *defer_n = defer;                    // first 8 bytes: counter; entries start 64 bytes in
     unsigned long long *defer_e = defer + 8;
     HIPCHK(hipMemsetAsync(defer_n, 0, 64, stream));
-    const uint64_t ntiles = (len + (uint64_t)G.th1 * PT_GROUP - 1) / ((uint64_t)G.th1 * PT_GROUP);
+    const uint64_t ntiles = (len + (uint64_t)PT_TILE - 1) / (uint64_t)PT_TILE;
     for (int i = 0; i < 6; ++i) if (!ev_stage_t[i]) HIPCHK(hipEventCreate(&ev_stage_t[i]));
-    part_stage_n = 5;
+    part_stage_n = 4;
     count_path = 1;
     HIPCHK(hipEventRecord(ev_k0, stream));
     HIPCHK(hipEventRecord(ev_stage_t[0], stream));
-    static bool attr1_set = false;
-    if (!attr1_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr1_set = true;
-    }
-#define JK_P1_LAUNCH(W, TH_) hipLaunchKernelGGL((part1_kernel<W, TH_>), dim3(G.nblk1), dim3(TH_), p1_lds(TH_), stream, d_piece, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, deferred_cap)
-    if (G.th1 == 512) { if (k > 32) JK_P1_LAUNCH(true, 512); else JK_P1_LAUNCH(false, 512); }
-    else { if (k > 32) JK_P1_LAUNCH(true, 1024); else JK_P1_LAUNCH(false, 1024); }
-#undef JK_P1_LAUNCH
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_part1(stream, k, d_piece, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, deferred_cap));
     HIPCHK(hipEventRecord(ev_stage_t[1], stream));
     const uint64_t *lists = out1;
     const unsigned int *lcnt = cnt1;
@@ -661,30 +909,32 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     // fused histogram: asked for by count_device when this piece is the whole input going into an empty table
     unsigned long long *histo = histo_request ? d_histo : nullptr;
     if (histo) HIPCHK(hipMemsetAsync(histo, 0, HISTO_WORDS * sizeof(unsigned long long), stream));
-    const size_t lds = ((size_t)(1u << G.rbits) + RG_HALO) * 16 + (histo ? LDS_HBINS * 4 : 0);
-    // lazily cleared table: part1/part2 overflow fallbacks and the deferred list use the direct path on the slot array,
-    // so they need real zeros -- they are rare; when the lists show none, the LDS pass does the clearing for free
-    if (slots_dirty && nregions <= 1) { if (materialize(err)) return -1; }
-    const int fresh = slots_dirty ? 1 : 0;
+    // A table that is logically empty is not read: the images start from zeros and every slot is written (a lazily cleared table
+    // is never zeroed in HBM).  Its LDS image counts in 32 bits -- a piece below 2^32 bases cannot overflow them.
+    const bool empty_tbl = slots_dirty || histo != nullptr;
+    const bool fresh32 = empty_tbl && len < (1ull << 32);
+    if (slots_dirty && !fresh32) { if (materialize(err)) return -1; }
+    const uint32_t R = 1u << G.rbits;
+    const size_t lds = (size_t)R * (fresh32 ? 12 : 16) + (histo ? LDS_HBINS * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_insert_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(region_insert_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(region_insert_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    for (uint32_t parity = 0; parity < 2; ++parity) {
-        if (!(nregions == 1 && parity == 1)) {
-            const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
-            hipLaunchKernelGGL(lds_insert_kernel<false>, dim3(nblk), dim3(PT_THREADS), lds, stream, (const void *)lists, lcnt, lcap, nsl, d, G, nregions, parity, fresh, defer_e,
-                               defer_n, deferred_cap, histo, 1u);
-            HIPCHK(hipGetLastError());
-        }
-        HIPCHK(hipEventRecord(ev_stage_t[3 + parity], stream));
+    {
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(lds, 1)));
+        const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>(nregions, 256 * per_cu * 4));
+        if (fresh32) hipLaunchKernelGGL(region_insert_kernel<true>, dim3(nblk), dim3(RI_TH), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap, histo);
+        else hipLaunchKernelGGL(region_insert_kernel<false>, dim3(nblk), dim3(RI_TH), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap, histo);
+        HIPCHK(hipGetLastError());
     }
-    slots_dirty = false;   // every region has been written by the two launches above
-    hipLaunchKernelGGL(import3_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, deferred_cap, d, histo ? histo + 10002 : nullptr);
+    HIPCHK(hipEventRecord(ev_stage_t[3], stream));
+    slots_dirty = false;   // every region has been written by the launch above
+    hipLaunchKernelGGL(import3h_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, deferred_cap, d, histo);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_k1, stream));
-    HIPCHK(hipEventRecord(ev_stage_t[5], stream));
+    HIPCHK(hipEventRecord(ev_stage_t[4], stream));
     part_stage_pending = true;
     if (getenv("JASPER_COUNT_DEBUG") && atoi(getenv("JASPER_COUNT_DEBUG")) >= 2) {
         HIPCHK(jk_stream_wait(stream));
@@ -768,7 +1018,6 @@ static bool xchg_geometry(const Table &t, uint64_t piece_max, uint64_t records_m
     while (((uint64_t)nown << (G.p2 - p2b)) > (uint64_t)xchg_max_lists() && p2b < G.p2) ++p2b;
     if (((uint64_t)nown << (G.p2 - p2b)) > (uint64_t)PT_MAXBUCKETS) return false;
     G.p2 -= p2b;
-    if (G.th1 != 1024) return false;
     const uint32_t nb1 = 1u << G.p1;
     G.nblk2 = nb1 >= 256 ? 1u : std::min<uint32_t>(G.nblk1, 8u);
     if (nown * G.nblk2 > (uint32_t)LI_MAXSL) return false;
@@ -830,15 +1079,7 @@ int Table::xchg_scan(const uint8_t *d_bases, uint64_t n, uint64_t pos, uint64_t 
     start = start >= a ? start - a : 0;
     const uint64_t len = end - start, emit_from = pos - start;
     const uint64_t ntiles = (len + (uint64_t)PT_TILE - 1) / (uint64_t)PT_TILE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    if (k > 32) hipLaunchKernelGGL((part1_kernel<true, 1024>), dim3(G.nblk1), dim3(1024), p1_lds(1024), stream, d_bases + start, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, defer_cap);
-    else hipLaunchKernelGGL((part1_kernel<false, 1024>), dim3(G.nblk1), dim3(1024), p1_lds(1024), stream, d_bases + start, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, defer_cap);
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_part1(stream, k, d_bases + start, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, defer_cap));
     HIPCHK(hipEventRecord(ev_stage_t[1], stream));
     if (read_stats(err)) return -1;                            // (waits for the kernel)
     if (records) *records = h_stats[ST_OCCURRENCES] - occ_before;
