@@ -69,10 +69,13 @@ __device__ __forceinline__ uint64_t rec_of(u128 h, int recbits) { return recbits
 __device__ __forceinline__ u128 hash_of(uint64_t b1, uint64_t rec, int recbits) { return bor(shl(mk(0, b1), recbits), mk(0, rec)); }
 
 // a record that found no room in its list waits for the direct path until every LDS image has been written back
-__device__ __forceinline__ void defer_record(const TableDev &T, u128 h, unsigned long long *deferred, unsigned long long *deferred_n, uint64_t deferred_cap) {
+__device__ __forceinline__ void defer_record(unsigned long long *stats, u128 h, unsigned long long *deferred, unsigned long long *deferred_n, uint64_t deferred_cap) {
     const unsigned long long di = atomicAdd(deferred_n, 1ull);
     if (di < deferred_cap) { deferred[3 * di] = h.hi; deferred[3 * di + 1] = h.lo; deferred[3 * di + 2] = 1ull; }
-    else atomicExch(&T.stats[ST_FATAL], 1ull);
+    else atomicExch(&stats[ST_FATAL], 1ull);
+}
+__device__ __forceinline__ void defer_record(const TableDev &T, u128 h, unsigned long long *deferred, unsigned long long *deferred_n, uint64_t deferred_cap) {
+    defer_record(T.stats, h, deferred, deferred_n, deferred_cap);
 }
 
 // ---- level 1: bases -> records in 2^p1 bucket lists --------------------------------------------------------
@@ -110,8 +113,13 @@ __device__ __forceinline__ unsigned int wave_scan_incl(unsigned int v) {
     return v;
 }
 
+struct P1Args {              // what part1_kernel needs of the table and the geometry (few scalar registers: the kernel is short of them)
+    int k, p1, recbits, exp;
+    uint32_t nblk1, cap1;
+    unsigned long long *stats;
+};
 template <int NW>
-__global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t ntiles, uint64_t emit_from, TableDev T, PartGeom G,
+__global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t ntiles, uint64_t emit_from, P1Args P,
                                                       uint64_t *__restrict__ out1, unsigned int *__restrict__ cnt1, unsigned long long *__restrict__ deferred,
                                                       unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
     extern __shared__ __align__(16) unsigned char s_raw[];
@@ -126,46 +134,59 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
     unsigned short *s_bkt = reinterpret_cast<unsigned short *>(s_base + P1_MAXB);            // bucket of each staged record
     uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_bkt + P1_STAGE);                      // P1_STAGE records, bucket order
     const int t = threadIdx.x;
-    const int k = T.k;
-    const int nb = 1 << G.p1;
+    const int k = P.k;
+    const int nb = 1 << P.p1;
     // word-level constants: the k-mer's 2k bits fill words 0 .. NW-1, `topbits` of them in word NW-1
     const int topbits = 2 * k - 32 * (NW - 1);                                  // 2..32
     const uint32_t topmask = topbits >= 32 ? ~0u : ((1u << topbits) - 1u);
     const int rsh = topbits - 2;                                                // where the complement of a new base enters rc's top word
     const int hb = NW > 2 ? 2 * k - 64 : 0;                                     // hash bits above the low 64 (2k > 64)
-    const uint64_t himask = NW > 2 ? (hb >= 64 ? ~0ull : ((1ull << hb) - 1ull)) : 0ull;
+    const uint32_t himask = NW > 2 ? (hb >= 32 ? ~0u : ((1u << hb) - 1u)) : 0u;
     const uint64_t lomask = NW > 2 || 2 * k >= 64 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const int hh = k;                                                           // (2k <= 64) xor-shift by half the width
-    const int e = NW > 2 ? G.p1 - hb : 0;                                       // bucket bits taken from the low 64 hash bits (2k > 64: p1 >= hb)
-    const uint64_t recmask = G.recbits >= 64 ? ~0ull : ((1ull << G.recbits) - 1ull);
+    const int e = NW > 2 ? P.p1 - hb : 0;                                       // bucket bits taken from the low 64 hash bits (2k > 64: p1 >= hb)
+    const uint64_t recmask = P.recbits >= 64 ? ~0ull : ((1ull << P.recbits) - 1ull);
     unsigned int cur = 0;                                                       // cursor of bucket t's slice
-    unsigned long long added = 0;
+    unsigned long long added = 0, added_run = 0;
     s_cnt[t] = 0;
     if (t == 0) s_wsum[16] = 0;
-    const uint64_t slice0 = reinterpret_cast<uint64_t>(out1 + ((uint64_t)t * G.nblk1 + blockIdx.x) * G.cap1);     // my slice of bucket t's list
-    // my 16 bases of the NEXT tile are requested while the current one is processed (one block per CU: nothing else
-    // would hide that latency)
-    Raw16 raw = load16(bases, (int64_t)(blockIdx.x * (uint64_t)PT_TILE) + (int64_t)t * PT_GROUP, (int64_t)n);
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // a block takes a run of consecutive tiles: the 64 bases before a tile are then the tail of the tile before it, still in LDS
+    const uint64_t per_block = (ntiles + gridDim.x - 1) / gridDim.x;
+    const uint64_t tile_first = blockIdx.x * per_block, tile_end = tile_first + per_block < ntiles ? tile_first + per_block : ntiles;
+    // My 16 bases of the NEXT tile are requested at the top of a tile and turned into codes right BEFORE this tile's copy-out
+    // stores are issued.  Vector-memory operations of a wave retire in order, so a load that is waited for after the stores makes
+    // the wave wait for the stores as well -- at the top of every tile, for the whole write latency of its copy-out (measured:
+    // 1.7 of 5.7 ms).  This way the stores of tile i drain under the hashing of tile i+1.
+    uint32_t c = 0, iv = 0xFFFFu, hc = 0, hiv = 0xFFFFu;
+    if (tile_first < tile_end) {
+        const int64_t b0 = (int64_t)(tile_first * PT_TILE);
+        stage16(bases, b0 + (int64_t)t * PT_GROUP, (int64_t)n, c, iv);
+        if (t < PT_HALO) stage16(bases, b0 - (int64_t)(PT_HALO - t) * PT_GROUP, (int64_t)n, hc, hiv);
+    }
+    for (uint64_t tile = tile_first; tile < tile_end; ++tile) {
         const int64_t base0 = (int64_t)(tile * PT_TILE);
-        uint32_t c, iv;
-        encode16(raw.w, c, iv);
-        if (tile + gridDim.x < ntiles) raw = load16(bases, (int64_t)((tile + gridDim.x) * PT_TILE) + (int64_t)t * PT_GROUP, (int64_t)n);
-        s_code[t + PT_HALO] = c;
-        s_inv[t + PT_HALO] = iv;
-        if (t < PT_HALO) {
-            uint32_t hc, hiv;
-            stage16(bases, base0 - (int64_t)(PT_HALO - t) * PT_GROUP, (int64_t)n, hc, hiv);
-            s_code[t] = hc;
-            s_inv[t] = hiv;
+        const bool has_next = tile + 1 < tile_end;
+        int ta = t;
+        asm volatile("" : "+v"(ta));
+        // (only a next tile that lies inside the text as a whole: ONE load instruction, no branch with a slow side whose merge
+        //  would make the compiler wait for the load right here; the piece's last tile is read at its own top instead)
+        const bool prefetch = has_next && (uint64_t)(base0 + 2 * (int64_t)PT_TILE) <= n;
+        Raw16 raw;
+        {   // (unconditional: without a next tile to fetch, the first 16 bytes of the text are read and ignored)
+            struct __attribute__((packed, aligned(1))) V16 { uint32_t w[4]; };
+            const V16 v = *reinterpret_cast<const V16 *>(bases + (prefetch ? base0 + (int64_t)PT_TILE + (int64_t)ta * PT_GROUP : (int64_t)0));
+            raw.w[0] = v.w[0]; raw.w[1] = v.w[1]; raw.w[2] = v.w[2]; raw.w[3] = v.w[3];
         }
+        s_code[ta + PT_HALO] = c;
+        s_inv[ta + PT_HALO] = iv;
+        if (ta < PT_HALO) { s_code[ta] = hc; s_inv[ta] = hiv; }
         lds_barrier();
         // A. hash my 16 windows, take a rank in the tile's bucket histogram
         uint32_t f[NW], r[NW];
         int run;
         {
-            const uint32_t w4 = s_code[t], w3 = s_code[t + 1], w2 = s_code[t + 2], w1 = s_code[t + 3];
-            const uint64_t ivprev = ((uint64_t)s_inv[t] << 48) | ((uint64_t)s_inv[t + 1] << 32) | ((uint64_t)s_inv[t + 2] << 16) | (uint64_t)s_inv[t + 3];
+            const uint32_t w4 = s_code[ta], w3 = s_code[ta + 1], w2 = s_code[ta + 2], w1 = s_code[ta + 3];
+            const uint64_t ivprev = ((uint64_t)s_inv[ta] << 48) | ((uint64_t)s_inv[ta + 1] << 32) | ((uint64_t)s_inv[ta + 2] << 16) | (uint64_t)s_inv[ta + 3];
             const u128 fwd0 = band(mk(((uint64_t)w4 << 32) | w3, ((uint64_t)w2 << 32) | w1), maskbits(2 * k));
             const u128 rc0 = revcomp(fwd0, k);
             const uint32_t fw[4] = {(uint32_t)fwd0.lo, (uint32_t)(fwd0.lo >> 32), (uint32_t)fwd0.hi, (uint32_t)(fwd0.hi >> 32)};
@@ -175,12 +196,12 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
             run = ivprev ? (int)__builtin_ctzll(ivprev) : 64;
         }
         // k-mers that END before emit_from belong to the piece before this one
-        const int64_t mine = base0 + (int64_t)t * PT_GROUP;
+        const int64_t mine = base0 + (int64_t)ta * PT_GROUP;
         int jfirst = (int64_t)emit_from > mine ? (int)((int64_t)emit_from - mine < PT_GROUP ? (int64_t)emit_from - mine : PT_GROUP) : 0;
         asm volatile("" : "+v"(jfirst));                                            // (keeps the 16 tests below 32-bit compares with a register)
         uint64_t rec[PT_GROUP];
-        uint32_t bkt[PT_GROUP];    // bucket, or 0xFFFF = no record
-        uint32_t rnk[PT_GROUP];    // rank among the tile's records of that bucket
+        uint32_t br[PT_GROUP];     // bucket (0xFFFF = no record) << 16 | rank among the tile's records of that bucket
+        uint32_t bprev = 0xFFFFu, rprev = 0;      // (a record's two halves are put together one iteration later: the atomic's latency is covered)
 #pragma unroll
         for (int j = 0; j < PT_GROUP; ++j) {
             const uint32_t cj = (c >> (30 - 2 * j)) & 3u;
@@ -214,7 +235,7 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
             if constexpr (NW > 2) {                                                 // 64 < 2k <= 74 (p1 <= 10 bucket bits cover the bits above 64): kmer.hpp mix()
                 const uint64_t lo = mix64(((uint64_t)m[1] << 32) | m[0]);
                 const uint32_t lo_hi = (uint32_t)(lo >> 32);
-                const uint32_t hi = (m[2] ^ __builtin_amdgcn_alignbit(lo_hi, (uint32_t)lo, 30)) & (uint32_t)himask;
+                const uint32_t hi = (m[2] ^ __builtin_amdgcn_alignbit(lo_hi, (uint32_t)lo, 30)) & himask;
                 // bucket = top p1 bits of the 2k-bit hash (hi: hb bits, lo: 64 bits), p1 >= hb; record = the rest
                 b = (hi << e) | ((lo_hi >> 1) >> (31 - e));
                 rec[j] = lo & recmask;
@@ -224,60 +245,80 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                 v ^= v >> hh;
                 v = (v * JK_C1) & lomask;
                 v ^= v >> hh;
-                b = (uint32_t)(v >> G.recbits);
+                b = (uint32_t)(v >> P.recbits);
                 rec[j] = v & recmask;
             }
-            bkt[j] = valid ? b : 0xFFFFu;
-            rnk[j] = 0;
-            if (valid) rnk[j] = atomicAdd(&s_cnt[b], 1u);                           // LDS returning atomic
+            if (j > 0) br[j - 1] = (bprev << 16) | rprev;
+            bprev = valid ? b : 0xFFFFu;
+            rprev = 0;
+            if (valid) rprev = atomicAdd(&s_cnt[b], 1u);                            // LDS returning atomic
+        }
+        br[PT_GROUP - 1] = (bprev << 16) | rprev;
+        if (has_next) {
+            int tb = t;
+            asm volatile("" : "+v"(tb));
+            if (tb < PT_HALO) { hc = s_code[P1_TH + tb]; hiv = s_inv[P1_TH + tb]; }   // the tail of this tile = the 64 bases before the next
         }
         lds_barrier();
         // B. exclusive prefix of the bucket counts: thread t owns bucket t (wave scan + wave totals); the counter is zeroed
         //    for the next tile and the slice cursor advanced here
         unsigned int total;
         {
-            const unsigned int v = t < nb ? s_cnt[t] : 0u;
-            s_cnt[t] = 0;
+            // (the thread number through an opaque copy: what is derived from it here is recomputed per tile -- hoisted out of the
+            //  tile loop as loop invariants these addresses and masks end up spilled to scratch, and every reload waits for vmcnt(0))
+            int tb = t;
+            asm volatile("" : "+v"(tb));
+            const unsigned int v = tb < nb ? s_cnt[tb] : 0u;
+            s_cnt[tb] = 0;
             const unsigned int inc = wave_scan_incl(v);
-            if ((t & 63) == 63) s_wsum[t >> 6] = inc;
+            if ((tb & 63) == 63) s_wsum[tb >> 6] = inc;
             lds_barrier();
             // the 16 wave totals: scanned again by every wave (lanes 0..15), base of my wave and tile total by lane reads
-            const unsigned int ws = wave_scan_incl((t & 63) < P1_TH / 64 ? s_wsum[t & 63] : 0u);
-            const unsigned int wbase = (t >> 6) ? (unsigned int)__builtin_amdgcn_readlane((int)ws, (t >> 6) - 1) : 0u;
+            const unsigned int ws = wave_scan_incl((tb & 63) < P1_TH / 64 ? s_wsum[tb & 63] : 0u);
+            const unsigned int wbase = (tb >> 6) ? (unsigned int)__builtin_amdgcn_readlane((int)ws, (tb >> 6) - 1) : 0u;
             total = (unsigned int)__builtin_amdgcn_readlane((int)ws, P1_TH / 64 - 1);
             const unsigned int ex = wbase + inc - v;
-            s_off[t] = ex;
-            s_base[t] = slice0 + ((uint64_t)cur - (uint64_t)ex) * 8ull;
+            s_off[tb] = ex;
+            const uint64_t slice0 = reinterpret_cast<uint64_t>(out1 + ((uint64_t)tb * P.nblk1 + blockIdx.x) * P.cap1);     // my slice of bucket t's list
+            s_base[tb] = slice0 + ((uint64_t)cur - (uint64_t)ex) * 8ull;
             cur += v;
-            if (cur > G.cap1 && v) s_wsum[16] = 1;                                   // (stays set: the slice stays full)
+            if (cur > P.cap1 && v) s_wsum[16] = 1;                                   // (stays set: the slice stays full)
         }
         if (t == 0) added += total;
+        const unsigned long long added_all = added_run;
+        added_run += total;
         lds_barrier();
-        if (G.exp & 2) continue;                                                    // (timing experiment: hashing and ranking only)
+        if (P.exp & 2) total = 0;                                                   // (timing experiment: hashing and ranking only)
         for (unsigned int r0 = 0; r0 < total; r0 += P1_STAGE) {
             if (r0) lds_barrier();                                                  // the previous round has been copied out
             // C. records into LDS in bucket order
             if (total <= (unsigned int)P1_STAGE) {                                  // (block-uniform) the usual case: one round holds the tile
 #pragma unroll
                 for (int j = 0; j < PT_GROUP; ++j) {
-                    if (bkt[j] != 0xFFFFu) {
-                        const unsigned int pos = s_off[bkt[j]] + rnk[j];
+                    const uint32_t b = br[j] >> 16;
+                    if (b != 0xFFFFu) {
+                        const unsigned int pos = s_off[b] + (br[j] & 0xFFFFu);
                         unsigned int pos2 = pos;
                         asm("" : "+v"(pos2));                                       // (its own shift: derived from pos * 8 it becomes a 64-bit multiply-add)
                         s_stage[pos] = rec[j];
-                        s_bkt[pos2] = (unsigned short)bkt[j];
+                        s_bkt[pos2] = (unsigned short)b;
                     }
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < PT_GROUP; ++j) {
-                    if (bkt[j] != 0xFFFFu) {
-                        const unsigned int pos = s_off[bkt[j]] + rnk[j] - r0;
-                        if (pos < (unsigned int)P1_STAGE) { s_stage[pos] = rec[j]; s_bkt[pos] = (unsigned short)bkt[j]; }
+                    const uint32_t b = br[j] >> 16;
+                    if (b != 0xFFFFu) {
+                        const unsigned int pos = s_off[b] + (br[j] & 0xFFFFu) - r0;
+                        if (pos < (unsigned int)P1_STAGE) { s_stage[pos] = rec[j]; s_bkt[pos] = (unsigned short)b; }
                     }
                 }
             }
             lds_barrier();
+            if (r0 == 0 && prefetch) {                                              // the next tile's text has long arrived (see above)
+                asm volatile("" : "+v"(raw.w[0]), "+v"(raw.w[1]), "+v"(raw.w[2]), "+v"(raw.w[3]));     // (not before this point)
+                encode16(raw.w, c, iv);
+            }
             // D. copy out: lane i takes staged record i -- consecutive lanes, consecutive records of one slice
             const unsigned int nr = total - r0 < (unsigned int)P1_STAGE ? total - r0 : (unsigned int)P1_STAGE;
             if (!s_wsum[16]) {                                                      // (block-uniform) no slice of mine is full
@@ -285,24 +326,27 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                 for (unsigned int i = t; i < nr; i += P1_TH) {
                     const uint64_t rr = s_stage[i];
                     const uint32_t b = s_bkt[i];
-                    if (G.exp & 1) reinterpret_cast<global_u64 *>(s_base[b & 7])[(r0 + i) & 1023] = rr;     // (timing experiment: stores that stay in cache)
+                    if (P.exp & 1) reinterpret_cast<global_u64 *>(s_base[b & 7])[(r0 + i) & 1023] = rr;     // (timing experiment: stores that stay in cache)
+                    else if (P.exp & 4) out1[(uint64_t)blockIdx.x * 1024ull * P.cap1 + (added_all + r0 + i) % (1024ull * P.cap1)] = rr;     // (timing experiment: the same bytes as one sequential stream per block)
                     else reinterpret_cast<global_u64 *>(s_base[b])[r0 + i] = rr;
                 }
             } else {
                 for (unsigned int i = t; i < nr; i += P1_TH) {
                     const uint64_t rr = s_stage[i];
                     const uint32_t b = s_bkt[i];
-                    const uint64_t first = reinterpret_cast<uint64_t>(out1 + ((uint64_t)b * G.nblk1 + blockIdx.x) * G.cap1);
+                    const uint64_t first = reinterpret_cast<uint64_t>(out1 + ((uint64_t)b * P.nblk1 + blockIdx.x) * P.cap1);
                     const uint64_t pos = (uint64_t)(((int64_t)(s_base[b] - first) >> 3) + (int64_t)(r0 + i));   // position in the bucket's slice (s_base may lie below it)
-                    if (pos < G.cap1) reinterpret_cast<global_u64 *>(first)[pos] = rr;
-                    else defer_record(T, hash_of((uint64_t)b, rr, G.recbits), deferred, deferred_n, deferred_cap);   // slice full
+                    if (pos < P.cap1) reinterpret_cast<global_u64 *>(first)[pos] = rr;
+                    else defer_record(P.stats, hash_of((uint64_t)b, rr, P.recbits), deferred, deferred_n, deferred_cap);   // slice full
                 }
             }
         }
+        if ((P.exp & 2) && prefetch) encode16(raw.w, c, iv);
+        if (has_next && !prefetch) stage16(bases, base0 + (int64_t)PT_TILE + (int64_t)t * PT_GROUP, (int64_t)n, c, iv);      // (the piece's last tile)
         // (the next tile's barriers order its writes to the stage, s_off and s_base against this copy-out)
     }
-    if (t < nb) cnt1[(uint64_t)t * G.nblk1 + blockIdx.x] = G.exp ? 0u : (cur < G.cap1 ? cur : G.cap1);
-    if (t == 0 && added) atomicAdd(&T.stats[ST_OCCURRENCES], added);
+    if (t < nb) cnt1[(uint64_t)t * P.nblk1 + blockIdx.x] = P.exp ? 0u : (cur < P.cap1 ? cur : P.cap1);
+    if (t == 0 && added) atomicAdd(&P.stats[ST_OCCURRENCES], added);
 }
 // one launch site for the three word counts: k <= 16, 17..32, 33..37
 static hipError_t launch_part1(hipStream_t stream, int k, const uint8_t *d_piece, uint64_t len, uint64_t ntiles, uint64_t emit_from, const TableDev &d, const PartGeom &G,
@@ -315,7 +359,9 @@ static hipError_t launch_part1(hipStream_t stream, int k, const uint8_t *d_piece
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
         attr_set = true;
     }
-#define JK_P1_LAUNCH(NW_) hipLaunchKernelGGL((part1_kernel<NW_>), dim3(G.nblk1), dim3(P1_TH), P1_LDS, stream, d_piece, len, ntiles, emit_from, d, G, out1, cnt1, defer_e, defer_n, deferred_cap)
+    P1Args P;
+    P.k = k; P.p1 = G.p1; P.recbits = G.recbits; P.exp = G.exp; P.nblk1 = G.nblk1; P.cap1 = G.cap1; P.stats = d.stats;
+#define JK_P1_LAUNCH(NW_) hipLaunchKernelGGL((part1_kernel<NW_>), dim3(G.nblk1), dim3(P1_TH), P1_LDS, stream, d_piece, len, ntiles, emit_from, P, out1, cnt1, defer_e, defer_n, deferred_cap)
     if (k <= 16) JK_P1_LAUNCH(1);
     else if (k <= 32) JK_P1_LAUNCH(2);
     else JK_P1_LAUNCH(3);                     // (k <= 37: partition_geometry gives 8-byte records only while 2k - 64 <= p1 <= 10)
