@@ -328,6 +328,7 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                     const uint32_t b = s_bkt[i];
                     if (P.exp & 1) reinterpret_cast<global_u64 *>(s_base[b & 7])[(r0 + i) & 1023] = rr;     // (timing experiment: stores that stay in cache)
                     else if (P.exp & 4) out1[(uint64_t)blockIdx.x * 1024ull * P.cap1 + (added_all + r0 + i) % (1024ull * P.cap1)] = rr;     // (timing experiment: the same bytes as one sequential stream per block)
+                    else if (P.exp & 8) __builtin_nontemporal_store(rr, reinterpret_cast<global_u64 *>(s_base[b]) + (r0 + i));     // (timing experiment: streaming stores)
                     else reinterpret_cast<global_u64 *>(s_base[b])[r0 + i] = rr;
                 }
             } else {

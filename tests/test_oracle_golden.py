@@ -111,3 +111,22 @@ def test_multithreaded_driver_equals_plain_oracle():
         assert a.polish_batch(names, seqs, 3, 2) == b.polish_batch(names, seqs, 3, 2)
         qs = [asm[i:i + k] for i in range(0, 3000, 7)] + ["", "ACGTN"]
         assert [a.query(q) for q in qs] == [b.query(q) for q in qs]
+
+
+@pytest.mark.skipif(not (os.path.exists("/tmp/jf_install/bin/jellyfish") and os.path.exists("/root/reference/src/jasper.py")),
+                    reason="needs the reference built in the build container (SURVEY.md Appendix C)")
+def test_generator_reproduces_committed_cases(tmp_path):
+    """tests/golden/make_golden.py, run against the REAL reference, must regenerate the committed fixtures byte for byte
+    (seeds are kept per case NAME; a seed taken from a case's position changes whenever a case is inserted)"""
+    import filecmp
+    import subprocess
+    import sys
+    gen = os.path.join(os.path.dirname(GOLDEN), "make_golden.py")
+    for name in ("cluster_k37", "edges_k25"):
+        env = dict(os.environ, GOLDEN_KATS="0", GOLDEN_E2E="0")
+        subprocess.run([sys.executable, gen, "--out", str(tmp_path), "--only", name], check=True, capture_output=True, env=env, timeout=600)
+        new, old = os.path.join(str(tmp_path), name), os.path.join(GOLDEN, name)
+        files = sorted(os.listdir(old))
+        assert sorted(os.listdir(new)) == files, name
+        same, diff, errs = filecmp.cmpfiles(old, new, files, shallow=False)
+        assert not diff and not errs, (name, diff, errs)
