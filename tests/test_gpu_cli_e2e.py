@@ -55,10 +55,13 @@ def test_cli_matches_jasper_sh(hip, tmp_path, fixture):
             got[fn] = [ln.strip() for ln in open(tmp_path / fn) if ln.startswith(">")]
     assert got == meta["batches"]
     assert sorted(fn for fn in os.listdir(tmp_path) if re.match(r"jasper\..*\.success$", fn)) == meta["sentinels"]
-    # log lines: same messages in the same order (the reference's Q values read "Inf" there only because bc is missing)
+    # log lines: same messages in the same order.  The reference's own Q values read "Inf" (bc is missing where it ran), so the
+    # digits are compared with the internal known answers: the oracle's (bad, total) for this fixture through jasper_amd.qv
     mine = [re.sub(r"^\[[^\]]*\]", "[DATE]", ln) for ln in p.stdout.splitlines()]
     strip_q = lambda ls: [re.sub(r"Q value = .*", "Q value =", ln) for ln in ls]
     assert strip_q(mine) == strip_q(meta["stdout"])
+    kat = json.load(open(os.path.join(HERE, "golden", "qv_kats.json")))["fixtures"][fixture]
+    assert [ln.split("] ", 1)[1] for ln in mine if "Q value" in ln] == ["Before Polishing: Q value = " + kat["before"][2], "After Polishing: Q value = " + kat["after"][2]]
     # src/jasper.sh:177 leaves the database behind (`tee $JF_DB`); ours is a Jellyfish binary/sorted file too
     assert os.path.getsize(tmp_path / ("mer_counts%d.jf" % K)) > 1000
     # a second run in the same directory resumes from the sentinels and leaves the result untouched
@@ -134,6 +137,8 @@ def test_cli_two_ranks_matches_jasper_sh(hip, tmp_path):
     mine = [re.sub(r"^\[[^\]]*\]", "[DATE]", ln) for ln in p.stdout.splitlines() if re.match(r"^\[\w{3} \w{3} +\d", ln)]   # (gloo prints its own "[Gloo] ..." lines)
     strip_q = lambda ls: [re.sub(r"Q value = .*", "Q value =", ln) for ln in ls]
     assert strip_q(mine) == strip_q(meta["stdout"])                       # only rank 0 talks, same lines as one process
+    kat = json.load(open(os.path.join(HERE, "golden", "qv_kats.json")))["fixtures"]["e2e"]      # the Q digits: internal known answers
+    assert [ln.split("] ", 1)[1] for ln in mine if "Q value" in ln] == ["Before Polishing: Q value = " + kat["before"][2], "After Polishing: Q value = " + kat["after"][2]]
     # src/jasper.sh:177 leaves the database behind: written by both ranks together, one consecutive sorted piece each.
     # The reader's ordering rule (test_gpu_jf.py restates it from binary_dumper.hpp) holds across the seam, the content is
     # what one GPU writes, and the file goes back to the build container for the real jellyfish to read (gpurun_out)

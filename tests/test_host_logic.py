@@ -109,6 +109,47 @@ def test_qv_formatting():
     assert abs(float(qv.q_value(112, 46999349, 37)) - (-10 * math.log10(1 - (1 - 112 / 46999349) ** (1 / 37)))) < 1e-2
 
 
+def test_bc_emulation_known_answers():
+    """jasper_amd/qv.py restates GNU bc's number arithmetic and libmath's l() / e() (src/jasper.sh:239-256 runs them at scale
+    10 / 50 / 5): what every GNU bc prints for a few expressions, and the internal known-answer table of Q strings"""
+    import json
+    kats = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qv_kats.json")))
+    bc = qv._Bc(20)
+    got = {"scale=20; l(2)": bc.l((2, 0)), "scale=20; e(1)": bc.e((1, 0)), "scale=20; sqrt(2)": bc.sqrt((2, 0)), "scale=20; l(10)": bc.l((10, 0))}
+    for expr, want in kats["bc_constants"].items():
+        assert qv._Bc.show(got[expr]) == want, expr
+    assert bc.scale == 20                                   # l() and e() restore the caller's scale
+    # the scale rules of * and / (bc manual): 2 decimals x 3 decimals at scale 4 -> 4 decimals, truncated
+    b4 = qv._Bc(4)
+    assert qv._Bc.show(b4.mul(qv._Bc.lit("1.25"), qv._Bc.lit("-.333"))) == "-.4162"
+    assert qv._Bc.show(b4.div((2, 0), (3, 0))) == ".6666" and qv._Bc.show(b4.div((-2, 0), (3, 0))) == "-.6666"
+    assert qv._Bc.show(qv._Bc.add(qv._Bc.lit("1.5"), qv._Bc.lit(".25"))) == "1.75"
+    for bad, total, k, want in kats["triples"]:
+        assert qv.q_value(bad, total, k) == want, (bad, total, k)
+    for fx in kats["fixtures"].values():
+        for bad, total, want in (fx["before"], fx["after"]):
+            assert qv.q_value(bad, total, fx["k"]) == want
+
+
+def test_bc_emulation_against_the_independent_restatement():
+    """the series-based emulation against correctly rounded ln / exp truncated where bc truncates: the two may differ in the
+    LAST printed decimal only (-10 x a logarithm cut to 5 decimals, divided by l(10) = 2.30258: at most a few units of 1e-5);
+    tools/qv_compare.py runs 10^5 triples (docs/experiments.md has the counts)"""
+    import random
+    rng = random.Random(7)
+    n = differ = 0
+    for _ in range(1500):
+        total = rng.randint(1000, 4 * 10 ** 9)
+        bad = int(total * 10 ** rng.uniform(-7.5, -0.3))
+        k = rng.choice([17, 21, 25, 31, 37, 45, 63])
+        a, b = qv.q_value(bad, total, k), qv.q_value_exact(bad, total, k)
+        n += 1
+        if a != b:
+            differ += 1
+            assert a != "Inf" and b != "Inf" and abs(float(a) - float(b)) < 6e-5, (bad, total, k, a, b)
+    assert differ <= n // 100
+
+
 def test_cli_parser_quirks():
     o = cli.parse_args(["-a", "x/asm.fa", "-k", "25", "-p", "1", "-t", "8", "-b", "123"])
     assert (o.query_fn, o.kmer, o.passes, o.num_threads, o.batch_size) == ("asm.fa", "25", "1", "8", "123")
