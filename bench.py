@@ -310,8 +310,8 @@ def main():
         try:
             try:
                 return one_step(torch, local, loc, reads, d_chunks, world, timers, shard)
-            except RuntimeError as e:           # (count_sharded raises on every rank together)
-                if isinstance(e, jdist.ShardAttachError) or not loc["exchange"] or "count_sharded" not in str(e) or a.count == "exchange":
+            except jdist.CollectiveCountError as e:      # (count_sharded raises it on every rank together; nothing else is answered with a fallback)
+                if not loc["exchange"] or a.count == "exchange":
                     raise
                 if rank == 0:
                     sys.stderr.write("bench.py: %s -- counting into a table per GPU instead\n" % e)

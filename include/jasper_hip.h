@@ -71,6 +71,9 @@ int jasper_table_load_jf_part(const char *path, int device, uint32_t part, uint3
 int jasper_table_write_jf(jasper_table *t, const char *path, const char *const *cmdline, int n_cmdline);
 /* test hook (host arithmetic only, no GPU): the table's bijective k-mer hash (inverse = 0) or its inverse (1) */
 int jasper_debug_mix(int k, int inverse, uint64_t hi, uint64_t lo, uint64_t out2[2]);
+/* distinct = keys in this table; occurrences = k-mer occurrences this table's counting calls have SCANNED.  For an owner shard
+ * filled by the exchange (jasper_count_exchange_*) that is what this GPU read and sent to all owners, not the occurrences of the
+ * keys the shard holds (those are the sum of its counts: jasper_histogram). */
 int jasper_table_info(jasper_table *t, int *k, uint64_t *slots, uint64_t *distinct, uint64_t *occurrences);
 int jasper_table_sync(jasper_table *t);
 /* forget every k-mer (slots and counters zeroed in place; capacity kept) */

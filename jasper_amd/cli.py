@@ -450,7 +450,8 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
                 except jdist.ShardAttachError as e:         # (raised on every rank together, after all lists were inserted)
                     sharded._attach_failed = str(e)
                     info = dict(rounds=-1)
-                except RuntimeError as e:                   # (raised on every rank together: e.g. shards sized from a hint that was far too small)
+                except jdist.CollectiveCountError as e:     # (raised on every rank together: e.g. shards sized from a hint that was far too small;
+                                                            #  anything else is this rank's own failure and ends it -- no fallback the peers do not take)
                     if is0:
                         sys.stderr.write("jasper_amd: %s -- counting into a table per GPU instead\n" % e)
                     info = None
@@ -603,6 +604,11 @@ class _EarlyTable:
 
         self.th = threading.Thread(target=work, daemon=True)
         self.th.start()
+        # an exit taken while the thread is still inside the GPU driver (the split stage that runs beside it calls error_exit ->
+        # sys.exit on an unreadable assembly or a full disk) must wait for it: tearing the interpreter down under a thread that
+        # initialises HIP can hang or crash instead of giving the reference's clean "Splitting files failed" exit code
+        import atexit
+        atexit.register(self.th.join)
 
     def get(self):
         self.th.join()

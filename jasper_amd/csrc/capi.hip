@@ -332,6 +332,7 @@ int jasper_table_attach_tables(jasper_table *t, jasper_table *const *shards, uin
 // Can this process map these slot arrays at all?  Meant to be called from a THROW-AWAY process with a time limit: a mapping
 // call that never returns (seen on this stack for one allocation size) then costs a killed helper, not a hung rank.
 int jasper_table_release_retired(jasper_table *t) {
+    if (!t) { g_err = "bad argument"; return JASPER_ERR; }
     t->t.release_retired();
     return JASPER_OK;
 }

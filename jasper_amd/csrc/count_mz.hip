@@ -780,6 +780,7 @@ bool Table::minimizer_geometry(uint64_t piece_bases, void *geom_out) const {
     G.capC = slice_cap(ents / ((double)(1u << G.pe1) * G.nblkC), 1.6);      // (blocks take buckets from a queue: uneven shares)
     G.nsubE = 2;
     G.exp = getenv("JASPER_MZ_EXP") ? atoi(getenv("JASPER_MZ_EXP")) : 0;
+    G.capE = slice_cap(ents / ((double)(1ull << (G.pe1 + G.pe2)) * G.nsubE), 1.3);
     if (const char *e = getenv("JASPER_MZ_TEST_CAPS")) {      // tests: "a:c:e" = factors on the three slice capacities, so that slices overflow
         double fa = 1, fc = 1, fe = 1;
         if (sscanf(e, "%lf:%lf:%lf", &fa, &fc, &fe) == 3) {
@@ -788,7 +789,6 @@ bool Table::minimizer_geometry(uint64_t piece_bases, void *geom_out) const {
             G.capE = std::max<uint32_t>(8, (uint32_t)(G.capE * fe));
         }
     }
-    G.capE = slice_cap(ents / ((double)(1ull << (G.pe1 + G.pe2)) * G.nsubE), 1.3);
     return true;
 }
 

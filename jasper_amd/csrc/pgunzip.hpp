@@ -263,6 +263,8 @@ class ParallelGunzip {
     // dict: the 32 KB to use as the window (null: the window is empty, the start is a member's first block)
     struct RunOut { std::vector<uint8_t> out; uint64_t end_bit = 0; bool eof = false, ok = false;
                     std::vector<size_t> member_ends; std::vector<std::pair<uint32_t, uint32_t>> trailers; };
+    size_t run_in_max() const { return (size_t)(threads_ + 2) * chunk_; }                  // compressed bytes one run may consume ...
+    size_t run_out_max() const { return std::max<size_t>(32 * chunk_, 64u << 20); }        // ... and text it may produce, before it ends at a block end
     void inflate_run(uint64_t start_bit, const uint8_t *dict, const std::vector<uint64_t> &stops, RunOut &R) const {
         R.ok = false;
         z_stream s;
@@ -316,6 +318,11 @@ class ParallelGunzip {
                 const uint64_t posb = 8ull * (uint64_t)(s.next_in - data_) - (uint64_t)(s.data_type & 63);
                 while (stop_i < stops.size() && stops[stop_i] < posb) ++stop_i;
                 if (stop_i < stops.size() && stops[stop_i] == posb) { R.end_bit = posb; R.ok = true; break; }
+                // A run is bounded: with no usable boundary ahead (streams of stored or fixed-Huffman blocks, every candidate a false
+                // positive) it would otherwise inflate to the end of the file into ONE growing vector.  It ends at the first block
+                // end past the bound -- a real block start, so the next wave carries on from there (the chunks of this wave that
+                // started beyond it are dropped by the stitch like any chunk whose predecessor did not end on its start).
+                if (produced >= run_out_max() || posb - start_bit >= 8ull * run_in_max()) { R.end_bit = posb; R.ok = true; break; }
             }
         }
         R.out.resize(produced);

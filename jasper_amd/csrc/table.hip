@@ -751,15 +751,26 @@ int Table::fit(double max_load, std::string &err) {
 int Table::resize(int new_s, std::string &err) {
     if (new_s == d.s) return 0;
     detach_shards();      // the slot array moves and its geometry changes: the owners have to agree and attach again
-    unsigned long long *new_ext = nullptr;      // the new geometry may or may not need the second remainder word
-    if (wide_rem(d.B, new_s)) HIPCHK(hipMalloc((void **)&new_ext, (size_t)(1ull << new_s) * 8));
+    // what this call allocates is freed again on every error path (the old arrays stay the table's until the very end)
+    unsigned long long *new_ext = nullptr, *ns = nullptr;      // the new geometry may or may not need the second remainder word
+    auto fail = [&](hipError_t e, const char *what) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        if (new_ext) (void)hipFree(new_ext);
+        if (ns) (void)hipFree(ns);
+        return -1;
+    };
+    hipError_t e;
+    if (wide_rem(d.B, new_s) && (e = hipMalloc((void **)&new_ext, (size_t)(1ull << new_s) * 8)) != hipSuccess) return fail(e, "resize: hipMalloc(ext)");
+    if ((e = hipMalloc((void **)&ns, slot_alloc_bytes(1ull << new_s))) != hipSuccess) return fail(e, "resize: hipMalloc(slots)");
+    // an exported slot array may still be mapped by peers: not freed but retired until they have said so (release_retired)
+    auto drop_old = [&]() {
+        if (exported) { retired.push_back(d.slots); exported = false; }
+        else (void)hipFree(d.slots);
+        if (d.ext) (void)hipFree(d.ext);
+    };
     if (slots_dirty) {   // logically empty: nothing to rehash, the new slot array stays lazily cleared as well
-        unsigned long long *ns = nullptr;
-        HIPCHK(hipMalloc((void **)&ns, slot_alloc_bytes(1ull << new_s)));
-        HIPCHK(jk_stream_wait(stream));
-        if (exported && n_retired < 8) { retired[n_retired++] = d.slots; exported = false; }
-        else HIPCHK(hipFree(d.slots));
-        if (d.ext) HIPCHK(hipFree(d.ext));
+        if ((e = jk_stream_wait(stream)) != hipSuccess) return fail(e, "resize: stream");
+        drop_old();
         d.slots = ns; d.ext = new_ext; d.s = new_s; d.mask = (1ull << new_s) - 1; nslots = 1ull << new_s;
         return 0;
     }
@@ -767,16 +778,14 @@ int Table::resize(int new_s, std::string &err) {
     nt.s = new_s;
     nt.mask = (1ull << new_s) - 1;
     nt.ext = new_ext;
-    HIPCHK(hipMalloc((void **)&nt.slots, slot_alloc_bytes(1ull << new_s)));
-    if (zero_slots(nt.slots, 1ull << new_s, err)) return -1;
+    nt.slots = ns;
+    if (zero_slots(nt.slots, 1ull << new_s, err)) { (void)fail(hipSuccess, "resize"); return -1; }
     // distinct is recounted by the re-insertion
-    HIPCHK(hipMemsetAsync(d.stats + ST_DISTINCT, 0, sizeof(unsigned long long), stream));
+    if ((e = hipMemsetAsync(d.stats + ST_DISTINCT, 0, sizeof(unsigned long long), stream)) != hipSuccess) return fail(e, "resize: memset");
     hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(nslots, 256)), dim3(256), 0, stream, d, nt);
-    HIPCHK(hipGetLastError());
-    HIPCHK(jk_stream_wait(stream));
-    if (exported && n_retired < 8) { retired[n_retired++] = d.slots; exported = false; }      // peers may still have it mapped
-    else HIPCHK(hipFree(d.slots));
-    if (d.ext) HIPCHK(hipFree(d.ext));
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e, "resize: rehash launch");
+    if ((e = jk_stream_wait(stream)) != hipSuccess) return fail(e, "resize: rehash");
+    drop_old();
     d = nt;
     nslots = 1ull << new_s;
     return 0;
@@ -1278,8 +1287,8 @@ int Table::ipc_handle(void *out64, std::string &err) {
 }
 
 void Table::release_retired() {
-    for (int i = 0; i < n_retired; ++i) if (retired[i]) (void)hipFree(retired[i]);
-    n_retired = 0;
+    for (void *p : retired) if (p) (void)hipFree(p);
+    retired.clear();
 }
 
 // handles64: n handles of 64 bytes, one per owner in owner order (entry `self` is ignored: that is this table).  Every

@@ -9,6 +9,7 @@
 #include "kmer.hpp"
 #include <functional>
 #include <string>
+#include <vector>
 
 namespace jk {
 
@@ -407,8 +408,7 @@ struct Table {
     // A slot array whose IPC handle has been given out may still be mapped by peers when this table outgrows it: it is not
     // freed then but retired, until the ranks have attached to the new one and said so (release_retired), or the table goes
     bool exported = false;
-    void *retired[8] = {};
-    int n_retired = 0;
+    std::vector<void *> retired;
     void release_retired();
     void *ipc_mapped[MAX_SHARDS] = {};   // peers' slot arrays opened with hipIpcOpenMemHandle (closed by detach_shards)
     // the table as a Jellyfish binary/sorted database (jfwrite.hip); cmdline goes into the header like jellyfish's own

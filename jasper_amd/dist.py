@@ -308,6 +308,13 @@ def _ipc_probe_ok(shard, handles, rank, seconds=None):
     return ok
 
 
+class CollectiveCountError(RuntimeError):
+    """count_sharded failed and EVERY rank of the group raises this at the same point of the protocol (the failure of one
+    rank -- a reader error, a device allocation, a list overflow -- is agreed on with a reduction before anybody leaves), so
+    the callers may fall back together.  Any other exception out of count_sharded is one rank's alone: it must end that rank,
+    never be answered with a fallback that the other ranks do not take."""
+
+
 class ShardAttachError(RuntimeError):
     """the owners' slot arrays could not be mapped into this process (no IPC / no peer access between the GPUs)"""
 
@@ -512,14 +519,22 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
     dist.all_reduce(agree, op=dist.ReduceOp.MAX, group=group)
     slots, any_filled = (int(v) for v in agree.tolist())
     # (every rank is here: none of them still reads the shards of the last step through its peer mappings)
-    shard.reserve(slots)
-    plan = shard.exchange_plan(1 << 26, world)          # (whether there is a geometry does not depend on the piece size)
-    okt = torch.tensor([1 if plan is not None else 0], dtype=torch.int64, device=device)
+    # Every step below that can fail on ONE rank (a device allocation of reserve(), a library call) reports into the next
+    # reduction instead of raising: a rank that left through an exception while its peers wait in a collective hangs the job.
+    ok, why, plan = 1, "", None
+    try:
+        shard.reserve(slots)
+        plan = shard.exchange_plan(1 << 26, world)      # (whether there is a geometry does not depend on the piece size)
+        if clear and plan is not None:
+            shard.clear()
+    except RuntimeError as e:
+        ok, why = 0, str(e)
+    okt = torch.tensor([1 if plan is not None else 0, ok], dtype=torch.int64, device=device)
     dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
-    if not int(okt.item()):
+    if not int(okt[1].item()):
+        raise CollectiveCountError("count_sharded: preparing the shards failed on some rank" + (": " + why if why else ""))
+    if not int(okt[0].item()):
         return None
-    if clear:
-        shard.clear()
     # a round holds its send and receive lists (~10 bytes per base each) next to the shard: at most 2^31 bases, fewer when the
     # memory is short (one value for all ranks: the buffers are sized by the longest piece of the round).  The gloo rehearsal
     # gathers every rank's send buffer on every rank, and its ranks may share one GPU.
@@ -549,21 +564,28 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
         dist.all_reduce(st, op=dist.ReduceOp.MAX, group=group)
         piece_max, slots, any_more, bad = (int(v) for v in st.tolist())
         if bad:
-            raise RuntimeError("count_sharded: reading the reads failed on some rank" + (": " + why if why else ""))
+            raise CollectiveCountError("count_sharded: reading the reads failed on some rank" + (": " + why if why else ""))
         if piece_max == 0:
             break
-        shard.reserve(slots)                            # a shard that grew in the last round changes the geometry for all
-        plan = shard.exchange_plan(piece_max, world)
-        okt = torch.tensor([1 if plan is not None else 0], dtype=torch.int64, device=device)
+        plan = None
+        try:
+            shard.reserve(slots)                        # a shard that grew in the last round changes the geometry for all
+            plan = shard.exchange_plan(piece_max, world)
+        except RuntimeError as e:
+            ok, why = 0, str(e)
+        okt = torch.tensor([1 if plan is not None else 0, ok], dtype=torch.int64, device=device)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
-        if not int(okt.item()):
-            raise RuntimeError("count_sharded: the shards outgrew the exchange geometry between rounds")
+        if not int(okt[1].item()):
+            raise CollectiveCountError("count_sharded: growing the shards failed on some rank" + (": " + why if why else ""))
+        if not int(okt[0].item()):
+            raise CollectiveCountError("count_sharded: the shards outgrew the exchange geometry between rounds")
         dcap = plan["deferred_cap"]
-        # (libjasper_hip works on its own stream: torch memory must be idle before it is handed over -- empty(), never zeros())
-        deferred = torch.empty(8 + 3 * dcap, dtype=torch.int64, device=device)
-        _sync(device)
         found = 0
+        deferred = None
         try:                                            # first pass: my reads -> level-1 lists inside the library; how many records?
+            # (libjasper_hip works on its own stream: torch memory must be idle before it is handed over -- empty(), never zeros())
+            deferred = torch.empty(8 + 3 * dcap, dtype=torch.int64, device=device)
+            _sync(device)
             if mine:
                 found = shard.exchange_scan(mine[0], mine[1], mine[2], mine[3], piece_max, world, deferred.data_ptr(), dcap)
                 source.scanned()
@@ -574,17 +596,19 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
         st = torch.tensor([found, 1 - ok], dtype=torch.int64, device=device)
         dist.all_reduce(st, op=dist.ReduceOp.MAX, group=group)
         if int(st[1].item()):
-            raise RuntimeError("count_sharded: the first partition pass failed on some rank" + (": " + why if why else ""))
+            raise CollectiveCountError("count_sharded: the first partition pass failed on some rank" + (": " + why if why else ""))
         records_max = max(int(st[0].item()), 1)         # the send lists are sized from the records that are really there
-        plan = shard.exchange_plan(piece_max, world, records_max)
-        nrec, ncnt = plan["records_per_owner"], plan["counts_per_owner"]
-        send = torch.empty((world, nrec), dtype=torch.int64, device=device)
-        send_cnt = torch.empty((world, ncnt), dtype=torch.int32, device=device)
-        _sync(device)
+        send = send_cnt = None
+        nrec = ncnt = 0
         try:                                            # second pass: level-1 lists -> region lists grouped by owner
+            plan = shard.exchange_plan(piece_max, world, records_max)
+            nrec, ncnt = plan["records_per_owner"], plan["counts_per_owner"]
+            send = torch.empty((world, nrec), dtype=torch.int64, device=device)
+            send_cnt = torch.empty((world, ncnt), dtype=torch.int32, device=device)
+            _sync(device)
             shard.exchange_partition(piece_max, records_max, world, send.data_ptr(), send_cnt.data_ptr(), deferred.data_ptr(), dcap)
             shard.sync()
-        except RuntimeError as e:
+        except (RuntimeError, TypeError) as e:          # (TypeError: no plan for these sizes -- exchange_plan returned None)
             ok, why = 0, str(e)
         ndef = int(deferred[0].item()) if ok else 0
         if ndef > dcap:
@@ -605,7 +629,7 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
         dist.all_gather(parts, nd, group=group)
         parts = [p.tolist() for p in parts]
         if any(p[1] for p in parts):
-            raise RuntimeError("count_sharded: partitioning failed on some rank" + (": " + why if why else ""))
+            raise CollectiveCountError("count_sharded: partitioning failed on some rank" + (": " + why if why else ""))
         slice_cap = 0
         if cbits:
             slice_cap = max(max(p[2] for p in parts), 1)
@@ -633,7 +657,7 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
         okt = torch.tensor([ok], dtype=torch.int64, device=device)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
         if not int(okt.item()):
-            raise RuntimeError("count_sharded: inserting the received lists failed on some rank" + (": " + why if why else ""))
+            raise CollectiveCountError("count_sharded: inserting the received lists failed on some rank" + (": " + why if why else ""))
         del recv, recv_cnt, deferred, d_all
         rounds += 1
     if device.type == "cuda" and rounds > 1:

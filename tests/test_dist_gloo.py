@@ -208,9 +208,9 @@ class FakeExchangeTable(FakeTable):
     """the methods dist.count_sharded calls.  The "reads" are bytes, every byte one record whose key is its value; owner =
     key % n; a send list holds `cap` records, what does not fit is deferred -- like the real lists, only tiny."""
 
-    def __init__(self, geometry=True, fail_scan=False, **kw):
+    def __init__(self, geometry=True, fail_scan=False, fail_reserve=False, fail_plan_after=None, **kw):
         super().__init__(**kw)
-        self.geometry, self.fail_scan = geometry, fail_scan
+        self.geometry, self.fail_scan, self.fail_reserve, self.fail_plan_after = geometry, fail_scan, fail_reserve, fail_plan_after
         self.scanned = None
         self.whole = []
         self.plans = []
@@ -224,7 +224,14 @@ class FakeExchangeTable(FakeTable):
     def _cap(self, piece_max, records_max, n):
         return max(2, (records_max or piece_max) // n)            # the mean fill of the fullest sender: skewed keys overflow
 
+    def reserve(self, slots):
+        if self.fail_reserve:
+            raise RuntimeError("HIP out of memory (on purpose)")         # what torch.cuda.OutOfMemoryError is: a RuntimeError of ONE rank
+        return super().reserve(slots)
+
     def exchange_plan(self, piece_max, n, records_max=0):
+        if self.fail_plan_after is not None and len(self.plans) >= self.fail_plan_after:
+            raise RuntimeError("plan failed on purpose")
         if not self.geometry:
             return None
         cap = self._cap(piece_max, records_max, n)
@@ -298,14 +305,15 @@ def _count_worker(rank, world, port, q, mode):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cpu")
-        shard = FakeExchangeTable(geometry=(mode != "nogeom" or rank == 0), fail_scan=(mode == "fail" and rank == 1), tag=rank + 1)
+        shard = FakeExchangeTable(geometry=(mode != "nogeom" or rank == 0), fail_scan=(mode == "fail" and rank == 1),
+                                  fail_reserve=(mode == "fail_reserve" and rank == 1), fail_plan_after=(2 if mode == "fail_plan" and rank == 0 else None), tag=rank + 1)
         out = []
         for step in range(4):
             reads = torch.from_numpy(_reads_of(rank, step % 3).copy())
             try:
                 info = jd.count_sharded(shard, reads.data_ptr() if reads.numel() else 0, reads.numel(), dev, clear=(step < 3),
                                         piece_limit=(None if step != 0 else 128))
-            except RuntimeError as e:
+            except jd.CollectiveCountError as e:          # (only what EVERY rank raises: another exception fails this worker)
                 out.append("raised: " + str(e)[:40])
                 continue
             if info is None:
@@ -359,3 +367,9 @@ def test_count_sharded_failures_are_collective():
     assert all(isinstance(x, str) and x.startswith("raised") for r in range(2) for x in res[r])      # both ranks raise together, nobody hangs
     res = _run_count("nogeom")
     assert res[0] == [None] * 4 and res[1] == [None] * 4          # one rank without a geometry: nobody consumes anything
+    # what only ONE rank can run into -- a device allocation while growing its shard, a library call between two reductions --
+    # is agreed on before anybody leaves: both ranks raise CollectiveCountError at the same point, nobody hangs or falls back alone
+    res = _run_count("fail_reserve")
+    assert all(isinstance(x, str) and x.startswith("raised") for r in range(2) for x in res[r])
+    res = _run_count("fail_plan")
+    assert all(isinstance(x, str) and x.startswith("raised") for r in range(2) for x in res[r])

@@ -662,6 +662,9 @@ def test_minimizer_path_overflowing_slices_take_the_direct_path(KT, capfd):
     tm, log = run("%.4f:%.4f:%.4f" % tuple(f))
     m = re.search(r"deferred (\d+), overflow records (\d+)", log)
     assert m and int(m.group(1)) > 10 and int(m.group(2)) > 10, "the capacities were not cut far enough to overflow: " + log[-400:]
+    # ... and the entry slices themselves reached their cut capacity (the third factor: entries that find their region list full)
+    m = re.search(r"sliceE (\d+) / (\d+)", log)
+    assert m and int(m.group(1)) >= int(m.group(2)), log[-400:]
     os.environ["JASPER_COUNT_DIRECT"] = "1"
     try:
         td = KT(k, min_slots=slots)
