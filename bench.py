@@ -26,6 +26,7 @@ a step with its results compared with the GPU's; rank 0 at N=1 only) ride along.
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -211,6 +212,56 @@ def cpu_baseline(seed, reads_np, names, seqs, gpu):
     return out
 
 
+def e2e_cli():
+    """UNTIMED leg (never part of `value`): the drop-in as a user runs it -- BASELINE configs[1] as FILES on local disk (2.9 GB of
+    FASTQ + 47 Mb of FASTA, the deterministic inputs of tests/golden/fullsize_cfg2_t16.json), `python -m jasper_amd.cli` with
+    jasper.sh's flags in a child process, files out.  Reports the wall time of that process, its own stage marks, the rate at
+    which the read text became a table, and whether the outputs have the digests of the REAL reference's run on the same files
+    (src/jasper.sh with Jellyfish 2.3.0: 113.6 s on the 8 vCPU of the build container)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from jasper_amd import synth
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_cfg2_t16.json")))
+    d = tempfile.mkdtemp(prefix="jasper_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        t0 = time.perf_counter()
+        nreads, asm_len = synth.write_cli_inputs(d, ref["genome_mb"], ref["seed"], coverage=ref["coverage"])
+        t_gen = time.perf_counter() - t0
+        fastq = os.path.getsize(os.path.join(d, "reads.fq"))
+        args = [sys.executable, "-m", "jasper_amd.cli", "-r", "reads.fq", "-a", "asm.fa", "-k", str(ref["k"]), "-t", str(ref["threads"]), "-p", str(ref["passes"])]
+        runs = {}
+        for label, extra in (("with_database_file", {}), ("no_database_file", {"JASPER_AMD_NO_JF": "1"})):
+            for fn in os.listdir(d):
+                if fn not in ("reads.fq", "asm.fa"):
+                    os.remove(os.path.join(d, fn))
+            t0 = time.perf_counter()
+            p = subprocess.run(args, cwd=d, env=dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_TIMING="1", **extra), capture_output=True, text=True, timeout=600)
+            wall = time.perf_counter() - t0
+            if p.returncode:
+                raise RuntimeError("jasper_amd.cli exit %d: %s" % (p.returncode, p.stderr[-400:]))
+            marks = {}
+            for ln in p.stderr.splitlines():
+                m = re.match(r"\[timing\] (.*?)\s+([0-9.]+) s$", ln)
+                if m:
+                    marks[m.group(1)] = float(m.group(2))
+            got = synth.output_digests(d, k=ref["k"])
+            keys = ("threshold", "jfhisto_sha256", "polished_bases", "polished_fasta_sha256", "fixes_csv_lines", "fixes_csv_sha256")
+            runs[label] = {"seconds": round(wall, 3), "stage_seconds": marks, "outputs_equal_reference": all(got[k] == ref[k] for k in keys)}
+        best = runs["no_database_file"]
+        count_s = next((v for k, v in best["stage_seconds"].items() if k.startswith("count reads")), None)
+        return {"seconds": best["seconds"], "seconds_with_database_file": runs["with_database_file"]["seconds"],
+                "outputs_equal_reference": all(r["outputs_equal_reference"] for r in runs.values()),
+                "ingest_text_GBps": round(fastq / 1e9 / count_s, 2) if count_s else None, "stage_seconds": best["stage_seconds"],
+                "stage_seconds_with_database_file": runs["with_database_file"]["stage_seconds"],
+                "input": "%.2f GB FASTQ (%d reads) + %.1f Mb FASTA on %s (page cache warm: written %.0f s before), flags -k %d -t %d -p %d" % (
+                    fastq / 1e9, nreads, asm_len / 1e6, d.rsplit("/", 1)[0], t_gen, ref["k"], ref["threads"], ref["passes"]),
+                "reference_seconds_build_container_8_vcpu": ref["reference_wall_seconds"],
+                "note": "untimed leg; wall time of the child process: interpreter start, split, count (files -> table), histogram, threshold, polish of the batch files, join, QV"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +270,7 @@ def main():
     ap.add_argument("--genome-mb", type=float, default=47.0, help="assembly size per GPU in Mb (47 = chr21-sized, BASELINE configs[1])")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the untimed files-in / files-out run of the drop-in CLI (e2e_cli)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: all ranks share GPU 0")
     ap.add_argument("--count", choices=("auto", "exchange", "local"), default="auto",
@@ -247,6 +299,14 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         sys.exit(subprocess.call(cmd, env=env))
+    # the files-in / files-out run of the drop-in (untimed, N = 1 only) comes FIRST: its child process then has the GPU to itself,
+    # as a user's run has (beside this process's tables and streams the same child took 2.1 s instead of 0.8)
+    e2e = None
+    if a.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.genome_mb == 47.0 and not a.no_e2e:
+        try:
+            e2e = e2e_cli()
+        except Exception as e:      # a report, like the CPU baseline: never a reason to lose the measurement
+            e2e = {"seconds": None, "failed": "%r" % (e,)}
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -379,9 +439,14 @@ def main():
     # collect FETCH_SIZE / WRITE_SIZE inside this process); null when that file is absent
     traffic, traffic_src = None, None
     pol_traffic, pol_traffic_src = None, None
-    for rnd in (("round2", "round1") if (world == 1 and a.genome_mb == 47.0) else ()):      # (the committed counters are those of the N=1 configs[1] run)
+    from jasper_amd._lib import kernel_source_digest
+    for rnd in (("round3",) if (world == 1 and a.genome_mb == 47.0) else ()):      # (the committed counters are those of the N=1 configs[1] run)
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", rnd, "bench_hbm_counters.json")))
+            if pj.get("kernel_source_sha256") != kernel_source_digest():
+                # counters of OTHER kernels are not evidence: nothing is cited (tools/prof_bench.sh + tools/summarize_prof.py re-collect them)
+                traffic_src = pol_traffic_src = "profiles/%s/bench_hbm_counters.json was taken from other kernel sources than this build's: not cited" % rnd
+                continue
             try:    # the polishing kernels of one polish call (scan_batch runs once per call): FETCH_SIZE + WRITE_SIZE as reported
                 pk = ("scan_batch", "classify_batch", "find_sync_batch", "find_clean_batch", "seg_init", "seg_walk", "seg_gather", "seg_stitch", "rescan_batch")
                 calls = pj["FETCH_SIZE"]["jk::scan_batch_kernel"]["dispatches"]
@@ -471,6 +536,8 @@ def main():
                 raise               # a result that differs from the oracle voids the measurement
             except Exception as e:  # anything else: the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "Mbp/s", "cores": host_cpu()[0], "kind": "port", "sample": "failed: %r" % (e,)}
+        if e2e is not None:
+            out["e2e_cli"] = e2e
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()           # nobody unmaps or frees a shard that a peer may still be reading

@@ -148,3 +148,20 @@ def lib():
 def check(rc):
     if rc != 0:
         raise JasperHipError(rc, lib().jasper_last_error().decode(errors="replace"))
+
+
+def kernel_source_digest():
+    """sha256 over the native sources (jasper_amd/csrc/*.hip|hpp|cpp, include/*.h), file names and contents in sorted order:
+    what a set of hardware counters under profiles/ was taken from.  bench.py cites committed counters only when this digest is
+    the one stored with them (tools/summarize_prof.py) -- counters of other kernels are not evidence."""
+    import glob
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, "jasper_amd", "csrc", "*.h*")) + glob.glob(os.path.join(root, "jasper_amd", "csrc", "*.cpp")) +
+                   glob.glob(os.path.join(root, "include", "*.h")))
+    for fn in files:
+        h.update(os.path.basename(fn).encode() + b"\0")
+        with open(fn, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()

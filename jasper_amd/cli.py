@@ -589,16 +589,19 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
 
 
 class _EarlyTable:
-    """KmerTable(k, min_slots) created by a thread (the library call releases the GIL); get() hands it over, or raises what
-    the creation raised"""
+    """KmerTable(k, min_slots) created -- and the read files counted into it -- by a thread (the library calls release the GIL)
+    while the caller splits the assembly; get() hands the table over, or raises what the thread raised"""
 
-    def __init__(self, k, min_slots, device):
+    def __init__(self, k, min_slots, device, reads=None):
         import threading
         self.out, self.err = None, None
 
         def work():
             try:
-                self.out = KmerTable(k, min_slots=min_slots, device=device)
+                t = KmerTable(k, min_slots=min_slots, device=device)
+                if reads:
+                    t.count_files(reads)
+                self.out = t
             except BaseException as e:          # noqa: BLE001 -- handed to the caller of get()
                 self.err = e
 
@@ -713,11 +716,13 @@ def run(argv):
     if multi:
         return _run_multi(o, rank, world, dev, batch_size, passes, kmer)
 
-    # the counting table (its allocation, and the start of the GPU runtime: 0.2-0.8 s) is set up by a thread while this one splits
+    # the counting stage -- the start of the GPU runtime, the table's allocation and reads -> table: everything of src/jasper.sh:177
+    # but the database file -- is the work of a thread while this one splits the assembly (the two do not depend on each other;
+    # the log lines keep the reference's order)
     early = None
     if (o.jf_db is None and not (os.path.isfile("mer_counts%d.jf" % kmer) and os.path.getsize("mer_counts%d.jf" % kmer) > 0)
             and not os.environ.get("JASPER_AMD_NO_EARLY_TABLE") and o.reads.split() and all(os.path.isfile(fn) and os.path.getsize(fn) > 0 for fn in o.reads.split())):   # (only when counting WILL happen: no exit while the thread is in the driver)
-        early = _EarlyTable(kmer, max(1 << 20, int(1.25 * o.jf_size)), o.device)
+        early = _EarlyTable(kmer, max(1 << 20, int(1.25 * o.jf_size)), o.device, reads=o.reads.split())
 
     if not os.path.exists("jasper.split.success"):                      # :152-159
         log("Splitting query into batches for parallel execution")
@@ -748,9 +753,12 @@ def run(argv):
         else:
             _timing("split")
             log("Creating jellyfish database mer_counts%d.jf" % kmer)
-            table = early.get() if early is not None else KmerTable(kmer, min_slots=max(1 << 20, int(1.25 * o.jf_size)), device=o.device)
-            early = None
-            table.count_files(reads)
+            if early is not None:
+                table = early.get()                     # (counted while the assembly was split)
+                early = None
+            else:
+                table = KmerTable(kmer, min_slots=max(1 << 20, int(1.25 * o.jf_size)), device=o.device)
+                table.count_files(reads)
             _timing("count reads (files -> table)")
             if os.environ.get("JASPER_AMD_NO_JF", "") not in ("1", "true", "yes"):
                 # :177 `... | tee $JF_DB | ...`: leave the database behind for reruns and for other Jellyfish tools

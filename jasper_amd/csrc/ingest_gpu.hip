@@ -283,7 +283,7 @@ struct Reader {           // the concatenation of all input files as one byte st
     int fd = -1;          // ... anything else is read as it is (what `zcat -f` does): pread by a few threads, because one
     off_t off = 0, size = 0;   // thread copies out of the page cache at only ~7 GB/s
     std::string err;
-    static constexpr int READ_THREADS = 4;
+    static constexpr int READ_THREADS = 8;
     // fills buf with up to want bytes; returns bytes read, 0 at the end of the last file, -1 on error
     long read(char *buf, size_t want) {
         size_t got = 0;
@@ -431,7 +431,7 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
             est += (uint64_t)st.st_size * ((L > 3 && !strcmp(paths[i] + L - 3, ".gz")) ? 5 : 1);
         } else est += 1ull << 32;
     }
-    size_t CHUNK = 128u << 20;
+    size_t CHUNK = 64u << 20;
     while (CHUNK > (4u << 20) && CHUNK / 2 >= est) CHUNK /= 2;
     if (const char *e = getenv("JASPER_INGEST_CHUNK")) CHUNK = std::max<size_t>(4096, strtoull(e, nullptr, 10));   // tests: many small chunks
     else if (ingest_chunk > CHUNK) CHUNK = ingest_chunk;  // the pinned buffer of an earlier call is kept
@@ -445,10 +445,19 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
     if (!h_ingest || ingest_chunk < CHUNK) {              // kept with the table between calls
         if (h_ingest) (void)hipHostFree(h_ingest);
         h_ingest = nullptr;
-        HIPCHK(hipHostMalloc((void **)&h_ingest, 2 * CHUNK + 64, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&h_ingest, 2 * (2 * CHUNK + 64), hipHostMallocDefault));
         ingest_chunk = CHUNK;
     }
-    char *h_buf = h_ingest;
+    // Two text buffers: while the GPU parses one, a thread reads the next CHUNK of the stream into the other (file -> pinned memory
+    // is a copy out of the page cache at ~10 GB/s: as long as the whole GPU side of a chunk, and until round 3 the two took turns).
+    // A chunk's bytes go to offset CHUNK of its buffer; what the chunk before left over (an incomplete record, <= CHUNK) is put
+    // right in front of them.
+    char *h_two[2] = {h_ingest, h_ingest + ingest_chunk * 2 + 64};
+    int cur_buf = 0;
+    char *h_buf = h_two[0] + CHUNK;
+    std::thread pf;                       // the read ahead
+    long pf_got = 0;
+    bool pf_active = false;
     uint8_t *d_text = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 0, 2 * CHUNK + 64, err));
     uint8_t *d_bases = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 1, BASES_CAP + 2 * CHUNK + 64, err));
     const size_t max_blocks = (2 * CHUNK + IG_BYTES - 1) / IG_BYTES + 1;
@@ -512,11 +521,18 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
         hp.resume(mode);
         int rc = hp.feed(first, first_n);
         n_host += first_n;
+        if (pf_active) {                                       // the chunk a thread has been reading ahead comes next in the stream
+            pf.join();
+            pf_active = false;
+            if (pf_got < 0) { err = rd.err; return -1; }
+            if (!rc && pf_got > 0) { rc = hp.feed(h_two[1 - cur_buf] + CHUNK, (size_t)pf_got); n_host += (uint64_t)pf_got; }
+        }
+        char *rb = h_two[cur_buf];                             // (`first` and the read-ahead have been consumed: the buffer is free)
         while (!rc) {
-            const long got = rd.read(h_buf, CHUNK);
+            const long got = rd.read(rb, CHUNK);
             if (got < 0) { err = rd.err; return -1; }
             if (got == 0) break;
-            rc = hp.feed(h_buf, (size_t)got);
+            rc = hp.feed(rb, (size_t)got);
             n_host += (uint64_t)got;
         }
         if (!rc) rc = hp.finish();
@@ -527,9 +543,24 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
 
     int mode = 0;                 // 0 unknown, 1 FASTA, 2 FASTQ (FastxParser's numbering)
     size_t carry = 0;             // bytes at the start of h_buf left over from the previous chunk (an incomplete record / line)
+    struct JoinOnExit { std::thread &t; bool &active; ~JoinOnExit() { if (active && t.joinable()) t.join(); } } join_on_exit{pf, pf_active};
     for (;;) {
         if (carry > CHUNK) return host_rest(mode, h_buf, carry);                  // a line / record longer than a chunk
-        const long got = rd.read(h_buf + carry, CHUNK);
+        long got;
+        if (pf_active) {                                                          // the chunk read while the last one was parsed
+            pf.join();
+            pf_active = false;
+            got = pf_got;
+            char *nb = h_two[1 - cur_buf] + CHUNK - carry;
+            if (carry) memcpy(nb, h_buf, carry);                                  // (h_buf: where the loop below left the incomplete record)
+            h_buf = nb;
+            cur_buf = 1 - cur_buf;
+        } else {
+            char *nb = h_two[cur_buf] + CHUNK - carry;
+            if (carry && nb != h_buf) memmove(nb, h_buf, carry);
+            h_buf = nb;
+            got = rd.read(h_buf + carry, CHUNK);
+        }
         if (got < 0) { err = rd.err; return -1; }
         size_t n = carry + (size_t)got;
         const bool eof = got == 0;
@@ -541,6 +572,11 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
             else return host_rest(0, h_buf, n);                                   // (the host parser words the error)
         }
         if (eof) return host_rest(mode, h_buf, n);                                // the tail: at most one incomplete record / line
+        {   // read ahead: the next CHUNK of the stream into the other buffer while this one is parsed
+            char *dst = h_two[1 - cur_buf] + CHUNK;
+            pf_active = true;
+            pf = std::thread([&rd, &pf_got, dst, CHUNK] { pf_got = rd.read(dst, CHUNK); });
+        }
         HIPCHK(hipMemcpyAsync(d_text, h_buf, n, hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemsetAsync(d_flags, 0, 8, stream));
         const uint32_t nblk = (uint32_t)((n + IG_BYTES - 1) / IG_BYTES);
@@ -583,7 +619,7 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
         n_gpu += n_use;
         if (bases_len >= BASES_CAP) { if (int rc = flush_bases()) return rc; }
         carry = n - (size_t)n_use;
-        if (carry) memmove(h_buf, h_buf + n_use, carry);
+        h_buf += n_use;                                                           // (moved in front of the next chunk at the top of the loop)
     }
     return flush_bases();
 }

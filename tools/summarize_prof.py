@@ -45,9 +45,10 @@ for ctr, pat in (("FETCH_SIZE", "pmc_fetch/*/*counter_collection.csv"), ("WRITE_
         a[0] += 1
         a[1] += float(r["Counter_Value"])
     out[ctr] = {k: {"dispatches": v[0], "sum_KB": v[1], "KB_per_dispatch": v[1] / v[0]} for k, v in acc.items()}
-pipe = ("jk::part1_kernel", "jk::part2_kernel", "jk::lds_insert_kernel", "jk::import3_kernel", "jk::count_kernel")
+pipe = ("jk::part1_kernel", "jk::part2_kernel", "jk::region_insert_kernel", "jk::lds_insert_kernel", "jk::import3", "jk::count_kernel")
 tot_kb = sum(v["sum_KB"] for c in ("FETCH_SIZE", "WRITE_SIZE") for k, v in out[c].items() if k.startswith(pipe))
-launches = max(1, out["FETCH_SIZE"].get("jk::part1_kernel<true>", out["FETCH_SIZE"].get("jk::part1_kernel", {"dispatches": steps}))["dispatches"] // steps)
+p1 = [v for k, v in out["FETCH_SIZE"].items() if k.startswith("jk::part1_kernel")]
+launches = max(1, (p1[0]["dispatches"] if p1 else steps) // steps)
 fetch_kb = sum(v["sum_KB"] for k, v in out["FETCH_SIZE"].items() if k.startswith(pipe))
 write_kb = sum(v["sum_KB"] for k, v in out["WRITE_SIZE"].items() if k.startswith(pipe))
 out["counting_pipeline"] = {"steps_profiled": steps, "hbm_bytes_per_step": tot_kb * 1024.0 / steps, "launches_per_step": launches,
@@ -57,8 +58,11 @@ out["counting_pipeline"] = {"steps_profiled": steps, "hbm_bytes_per_step": tot_k
                             # doubled before it is compared with a byte count; WRITE_SIZE is exact for streaming stores
                             "hbm_bytes_per_step_corrected": (2.0 * fetch_kb + write_kb) * 1024.0 / steps,
                             "fetch_bytes_per_step_as_reported": fetch_kb * 1024.0 / steps, "write_bytes_per_step": write_kb * 1024.0 / steps,
-                            "note": "part1 + part2 + lds_insert (+ deferred import): FETCH_SIZE + WRITE_SIZE as reported by rocprofv3, and the "
+                            "note": "part1 + part2 + region_insert (+ deferred import): FETCH_SIZE + WRITE_SIZE as reported by rocprofv3, and the "
                                     "corrected figure 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B read requests at 64 B)"}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from jasper_amd._lib import kernel_source_digest
+out["kernel_source_sha256"] = kernel_source_digest()      # bench.py cites these counters only while the sources are the same
 json.dump(out, open(os.path.join(dst, "bench_hbm_counters.json"), "w"), indent=1)
 for r in rows[:14]:
     print("%-34s calls %4s avg %10.1f us" % (short(r["Name"])[:34], r["Calls"], float(r["AverageNs"]) / 1e3))
