@@ -270,6 +270,7 @@ def main():
     ap.add_argument("--genome-mb", type=float, default=47.0, help="assembly size per GPU in Mb (47 = chr21-sized, BASELINE configs[1])")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-selftest", action="store_true", help="N > 1: skip the transport self-test in throw-away processes")
     ap.add_argument("--no-e2e", action="store_true", help="skip the untimed files-in / files-out run of the drop-in CLI (e2e_cli)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: all ranks share GPU 0")
@@ -315,6 +316,23 @@ def main():
     if a.gpus != world:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (a.gpus, world))
         sys.exit(2)
+    # N > 1 over RCCL: first contact with the transport happens in throw-away processes under a time limit (dist.transport_selftest)
+    # BEFORE this rank touches its GPU.  Rank 0 runs it, a gloo group (TCP, host memory) tells everybody the verdict, and a
+    # transport that hangs or delivers wrong words makes the whole job use gloo for its collectives instead of never returning.
+    selftest = None
+    if world > 1 and a.backend == "nccl" and not a.no_selftest:
+        from jasper_amd import dist as jdist0
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        box = [jdist0.transport_selftest(world, "nccl", a.one_gpu) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        dist.barrier()
+        dist.destroy_process_group()
+        selftest = box[0]
+        if not selftest["ok"]:
+            if rank == 0:
+                sys.stderr.write("bench.py: RCCL self-test failed (%s) -- collectives over gloo instead\n" % selftest.get("error"))
+            a.backend = "gloo"
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible; the product has no CPU path\n")
         sys.exit(2)
@@ -472,6 +490,7 @@ def main():
         "value": round(asm_total / 1e6 / (dt / steps), 3),
         "unit": "Mbp/s",
         "n_gpus": world, "rccl_world_size": (dist.get_world_size() if world > 1 else 1), "backend": (a.backend if world > 1 else None),
+        "rccl_selftest": selftest,      # N > 1: the transport's first contact, made in throw-away processes under a time limit (null at N = 1)
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%s: %.0f Mb synthetic genome x %d GPU(s) + %dx %d-bp reads, k=%d, %d passes, "

@@ -308,6 +308,67 @@ def _ipc_probe_ok(shard, handles, rank, seconds=None):
     return ok
 
 
+def transport_selftest(world, backend="nccl", one_gpu=False, seconds=240, mb=64):
+    """First contact with the transport in throw-away processes (jasper_amd/_selftest.py): `world` ranks, one per GPU, set up a
+    process group and run one all_to_all_single of `mb` megabytes, an all_reduce, an all_gather and a barrier -- as a CHILD job
+    under a time limit.  A collective that never returns then costs a killed child (its own process group, nothing else) and a
+    fall-back to the gloo transport, not a hung job.  Call it before this process touches the GPU; returns a dict for the logs:
+    {"ok", "seconds", "ms": {...}, "error"}."""
+    import json
+    import signal
+    import socket
+    import subprocess
+    import sys
+    import tempfile
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tempfile.mkdtemp(prefix="jasper_selftest_")
+    out = os.path.join(d, "result.json")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "-m", "jasper_amd._selftest", "--out", out, "--backend", backend, "--mb", str(mb)] + (["--one-gpu"] if one_gpu else [])
+    # (the child job makes its own rendezvous: nothing of the parent's, which may itself be a rank of a running job)
+    env = {k: v for k, v in os.environ.items() if not (k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                                                             "MASTER_ADDR", "MASTER_PORT", "GROUP_WORLD_SIZE", "ROLE_NAME") or k.startswith("TORCHELASTIC_"))}
+    env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = {"ok": False, "world": world, "backend": backend, "ms": {}, "error": None}
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            _, errtxt = p.communicate(timeout=seconds)
+            files = [out] + [out + ".rank%d" % r for r in range(1, world)]
+            parts = []
+            for fn in files:
+                try:
+                    parts.append(json.load(open(fn)))
+                except (OSError, ValueError):
+                    parts.append(None)
+            if parts[0]:
+                res.update(parts[0])
+            res["ok"] = p.returncode == 0 and all(q and q.get("ok") for q in parts)
+            if not res["ok"] and not res.get("error"):
+                bad = [q["error"] for q in parts if q and q.get("error")]
+                res["error"] = bad[0] if bad else "self-test exit code %s: %s" % (p.returncode, (errtxt or "")[-300:])
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)            # exactly the process group started above
+            except OSError:
+                pass
+            p.communicate()
+            res["error"] = "no answer within %d s: killed" % seconds
+    except OSError as e:
+        res["error"] = "could not start the self-test: %r" % (e,)
+    res["seconds"] = round(time.perf_counter() - t0, 2)
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
 class CollectiveCountError(RuntimeError):
     """count_sharded failed and EVERY rank of the group raises this at the same point of the protocol (the failure of one
     rank -- a reader error, a device allocation, a list overflow -- is agreed on with a reduction before anybody leaves), so

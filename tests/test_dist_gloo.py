@@ -326,12 +326,12 @@ def _count_worker(rank, world, port, q, mode):
         dist.destroy_process_group()
 
 
-def _run_count(mode):
+def _run_count(mode, world=2):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_count_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    ps = [ctx.Process(target=_count_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in ps:
         p.start()
     res = dict(q.get(timeout=180) for _ in ps)
@@ -360,6 +360,24 @@ def test_count_sharded_protocol_world2():
     assert res[0][1][1] == 1 and res[0][1][3] == [True]          # step 1: one round although rank 1 has nothing
     assert res[0][2][2] > 0                      # step 2: the heavy key overflowed its list and arrived as deferred entries
     assert res[0][3][3] == [False]               # step 3: one round, but the shard was not empty
+
+
+def test_count_sharded_protocol_world8():
+    """the same protocol with the 8 ranks of one node (gloo, host memory): every owner ends up with exactly its keys, summed over
+    all ranks and rounds; rounds, deferred records and the geometry are the same on every rank"""
+    W = 8
+    res = _run_count("ok", world=W)
+    carried = {}
+    for step in range(4):
+        exp = dict(carried) if step == 3 else {}
+        for r in range(W):
+            for key in _reads_of(r, step % 3):
+                exp[int(key)] = exp.get(int(key), 0) + 1
+        carried = exp
+        for r in range(W):
+            assert res[r][step][0] == {k: c for k, c in exp.items() if k % W == r}
+            assert res[r][step][1:3] == res[0][step][1:3] and res[r][step][4:6] == res[0][step][4:6]
+    assert res[0][0][1] == 4 and res[0][2][2] > 0          # four rounds in step 0; the heavy key of step 2 travelled as deferred records
 
 
 def test_count_sharded_failures_are_collective():

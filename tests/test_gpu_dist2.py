@@ -95,3 +95,35 @@ def test_two_ranks_one_gpu(hip):
     assert got == full.seqs                                       # chunk shards together == unsharded run
     assert tuple(res[0][6]) == tuple(res[1][6]) == full.qv        # QV counters all-reduced
     t.close()
+
+
+def test_transport_selftest_in_throwaway_processes(hip):
+    """dist.transport_selftest: what `bench.py --gpus N` does before it commits to RCCL -- the process group, one all_to_all of
+    64 MB checked word by word, all_reduce / all_gather / barrier -- in a child job under a time limit.  On the one GPU of the
+    test box the transport is gloo (RCCL refuses two ranks on one device); with two GPUs, test_gpu_nccl.py runs bench.py over
+    RCCL with the self-test in front.  A job that does not answer in time is killed and reported, never waited for."""
+    sys.path.insert(0, ROOT)
+    from jasper_amd import dist as jd
+    res = jd.transport_selftest(2, backend="gloo", one_gpu=True, seconds=240, mb=16)
+    assert res["ok"], res
+    assert res["world"] == 2 and res["ms"]["all_to_all_single"] > 0 and res["bytes_all_to_all"] >= (15 << 20)
+    res = jd.transport_selftest(2, backend="gloo", one_gpu=True, seconds=1, mb=16)      # (two interpreters do not even start in 1 s)
+    assert not res["ok"] and "killed" in res["error"], res
+
+
+def test_bench_four_ranks_rehearsed_on_one_gpu(hip):
+    """`bench.py --gpus 4 --backend gloo --one-gpu` at small size: the N-rank driver path (read shards, list exchange or entries,
+    owner-sharded table over hipIpc, chunk shards, max-over-ranks timing, ONE json line) with four processes on the one GPU of the
+    test box (it lets six processes use its card at once, this test runner being one of them); the 8-rank protocol runs on the
+    CPU in test_dist_gloo.py"""
+    import json
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--genome-mb", "2", "--backend", "gloo", "--one-gpu"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["rccl_world_size"] == 4 and out["backend"] == "gloo" and out["value"] > 0
+    assert out["rccl_selftest"] is None                        # (the self-test is RCCL's: not run for the gloo rehearsal)

@@ -183,6 +183,7 @@ def test_bench_two_gpus_self_launch(hip, count):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_world_size"] == 2 and out["backend"] == "nccl"
+    assert out["rccl_selftest"] and out["rccl_selftest"]["ok"] and out["rccl_selftest"]["world"] == 2      # first contact made in throw-away processes
     assert "table" in out["config"] and out["value"] > 0
     if count == "exchange":
         assert out["count_exchange"] is not None
