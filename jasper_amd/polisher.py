@@ -100,23 +100,22 @@ def rows_from_record(seqname, r):
     if kind == "d":
         return [[seqname, r["index"], r["newc"] * r["rep"], "d-"]]
     if kind == "x":
-        fixed_seq_rep, original_rep = globalms_first(r["patch"], r["orig"])
-        fixed_ind, fixed_base, original = [], [], []
-        for index in range(len(fixed_seq_rep)):                      # :313-329
-            ori = original_rep[index]
-            changed = fixed_seq_rep[index]
-            if changed == ori:
-                continue
-            elif changed == "-":
-                fixed_base.append('-'); original.append("i" + ori); fixed_ind.append(index + r["index"])
-            elif ori == "-":
-                original.append("d-"); fixed_ind.append(index + r["index"]); fixed_base.append(changed)
-            else:
-                original.append("s" + ori); fixed_base.append(changed); fixed_ind.append(index + r["index"])
-        if len(fixed_ind) == 1:                                       # :218-219 (python lists end up in the row)
-            return [[seqname, fixed_ind[0], fixed_base, original]]
-        # :221-222 -- IndexError on an empty list makes the reference print and sys.exit(1)
-        return [[seqname, fixed_ind[0], fixed_base[0], original[0]], [seqname, fixed_ind[1], fixed_base[1], original[1]]]
+        # the ">k bad k-mers" branch: the patch aligned against the text it replaced, one (coordinate, new, tag + old) triple per
+        # column where the two differ -- a gap in the patch is a removed base ("i" + base, new = '-'), a gap in the old text a
+        # restored one ("d-"), anything else a substitution ("s" + base); coordinates are alignment columns counted from the
+        # segment's start (src/jasper.py:309-329).  handle_bad_kmers then writes ONE row: with a single difference the three
+        # python LISTS go into the row as they are, otherwise the first two differences (src/jasper.py:218-222).
+        new_row, old_row = globalms_first(r["patch"], r["orig"])
+        diffs = []
+        for col, (b_new, b_old) in enumerate(zip(new_row, old_row)):
+            if b_new != b_old:
+                tag = ("i" + b_old) if b_new == "-" else "d-" if b_old == "-" else ("s" + b_old)
+                diffs.append((col + r["index"], b_new, tag))
+        if len(diffs) == 1:
+            at, b_new, tag = diffs[0]
+            return [[seqname, at, [b_new], [tag]]]
+        # (fewer than two differences left after that: the reference indexes an empty list, prints and exits 1 -- so does this)
+        return [[seqname, at, b_new, tag] for at, b_new, tag in (diffs[0], diffs[1])]
     raise ValueError("unknown fix record kind %r" % kind)
 
 
@@ -186,9 +185,11 @@ def main(contigs, query_path, k, test, fix, fout, fixedout, db, thre, num_iter):
     except SystemExit:
         raise
     except BaseException:
-        exception_type, exception_object, exception_traceback = sys.exc_info()
-        print(exception_traceback.tb_lineno)
-        print(sys.exc_info())
+        # what the reference's bare `except` leaves on stdout -- the line number, then the exc_info triple -- and exit status 1
+        # (src/jasper.py:27-32; jasper.sh only looks at the status)
+        info = sys.exc_info()
+        print(info[2].tb_lineno)
+        print(info)
         sys.exit(1)
 
 
@@ -246,9 +247,11 @@ def main_many(query_paths, k, test, fix, db, thre, num_iter):
     except SystemExit:
         raise
     except BaseException:
-        exception_type, exception_object, exception_traceback = sys.exc_info()
-        print(exception_traceback.tb_lineno)
-        print(sys.exc_info())
+        # what the reference's bare `except` leaves on stdout -- the line number, then the exc_info triple -- and exit status 1
+        # (src/jasper.py:27-32; jasper.sh only looks at the status)
+        info = sys.exc_info()
+        print(info[2].tb_lineno)
+        print(info)
         sys.exit(1)
 
 
