@@ -1208,6 +1208,74 @@ __global__ __launch_bounds__(64) void seg_gather_kernel(const SegDev *segs, int 
     for (uint32_t q = threadIdx.x; q < S.naux; q += blockDim.x) out_aux[aux_off[s] + q] = S.aux[q];
 }
 
+// ---- after the walks: what the host's bookkeeping loop did, on the device -----------------------------------------------
+// One wave per chunk record, 64 of its segments at a time (running sums by wave prefix scans); then lane 0 of block 0's last
+// arriver would have to scan the chunks -- instead every wave adds up the chunks BEFORE its own (n_chunks is small: the chunk
+// records of one polish call), which needs the other chunks' totals only: phase 1 writes them, a second launch adds the bases.
+__device__ __forceinline__ long long wave_scan_incl64(long long v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const long long u = __shfl_up(v, o); if (lane >= o) v += u; }
+    return v;
+}
+__global__ __launch_bounds__(64) void seg_summary_kernel(SegDev *segs, const int32_t *first_seg, int n_chunks, int64_t *idx_base, uint32_t *seq_base,
+                                                         uint32_t *rec_off, uint32_t *aux_off, ChunkSummary *out) {
+    const int c = blockIdx.x;
+    if (c >= n_chunks) return;
+    const int lane = threadIdx.x;
+    const int s0 = first_seg[c], s1 = first_seg[c + 1];
+    long long newlen = 0, shift = 0, seqc = 0, recc = 0, auxc = 0, wrong = 0, lookups = 0;
+    int bad = -1, spec = 0;
+    for (int base = s0; base < s1; base += 64) {
+        const int s = base + lane;
+        const bool in = s < s1;
+        long long d = 0, own = 0, nrec = 0, naux = 0, seg_lo = 0, own_hi = 0;
+        if (in) {
+            SegDev &S = segs[s];
+            d = S.len - S.len0;
+            own_hi = S.last ? S.len : S.own_hi0 + d;
+            own = own_hi - S.own_lo;
+            nrec = S.nrec; naux = S.naux; seg_lo = S.seg_lo;
+            wrong += S.wrong; lookups += (long long)S.lookups;
+            if (S.status != PS_OK && (bad < 0 || s < bad)) bad = s;
+            if (S.spec_fail && S.status == PS_OK) spec = 1;
+        }
+        const long long i_own = wave_scan_incl64(own), i_d = wave_scan_incl64(d), i_rec = wave_scan_incl64(nrec), i_aux = wave_scan_incl64(naux);
+        if (in) {
+            SegDev &S = segs[s];
+            S.own_hi = own_hi;
+            S.out_off = newlen + i_own - own;
+            idx_base[s] = seg_lo + shift + i_d - d;
+            seq_base[s] = (uint32_t)(seqc + i_rec - nrec);
+            rec_off[s] = (uint32_t)(recc + i_rec - nrec);          // (relative to the chunk: seg_offsets_kernel adds the chunks before it)
+            aux_off[s] = (uint32_t)(auxc + i_aux - naux);
+        }
+        newlen += __shfl(i_own, 63); shift += __shfl(i_d, 63);
+        seqc += __shfl(i_rec, 63); recc += __shfl(i_rec, 63); auxc += __shfl(i_aux, 63);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        wrong += __shfl_xor(wrong, o); lookups += __shfl_xor(lookups, o);
+        const int b2 = __shfl_xor(bad, o);
+        bad = bad < 0 ? b2 : (b2 < 0 ? bad : (b2 < bad ? b2 : bad));
+        spec |= __shfl_xor(spec, o);
+    }
+    if (lane == 0) {
+        ChunkSummary R;
+        R.newlen = newlen; R.wrong = wrong; R.lookups = (uint64_t)lookups; R.nrec = (uint32_t)recc; R.naux = (uint32_t)auxc; R.bad_seg = bad; R.spec_fail = spec;
+        out[c] = R;
+    }
+}
+// rec_off / aux_off of a chunk's segments become offsets into the pass's record / aux arrays: plus the totals of the chunks before
+__global__ __launch_bounds__(64) void seg_offsets_kernel(const int32_t *first_seg, int n_chunks, uint32_t *rec_off, uint32_t *aux_off, const ChunkSummary *sum) {
+    const int c = blockIdx.x;
+    if (c >= n_chunks || c == 0) return;
+    const int lane = threadIdx.x;
+    unsigned long long rb = 0, ab = 0;
+    for (int q = lane; q < c; q += 64) { rb += sum[q].nrec; ab += sum[q].naux; }
+    for (int o = 32; o > 0; o >>= 1) { rb += __shfl_xor(rb, o); ab += __shfl_xor(ab, o); }
+    for (int s = first_seg[c] + lane; s < first_seg[c + 1]; s += 64) { rec_off[s] += (uint32_t)rb; aux_off[s] += (uint32_t)ab; }
+}
+
 // ---- batched variants: blockIdx.y walks the chunks of the batch ---------------------------------------------------
 __global__ __launch_bounds__(SC_THREADS) void scan_batch_kernel(const ScanChunk *__restrict__ chunks, int n_chunks, TableDev T) {
     __shared__ uint32_t s_code[SC_THREADS + SC_HALO];
@@ -1469,6 +1537,12 @@ void launch_seg_walk(const TableDev &T, SegDev *d_segs, int n_segs, PolishParams
     if (n_segs <= 0) return;
     (void)hipMemsetAsync(d_ticket, 0, sizeof(unsigned int), stream);
     hipLaunchKernelGGL(seg_walk_kernel, dim3(n_segs), dim3(64), 0, stream, T, d_segs, n_segs, pp, pass, pool, d_ticket);
+}
+void launch_seg_summary(SegDev *d_segs, int n_segs, const int32_t *d_first_seg, int n_chunks, int64_t *idx_base, uint32_t *seq_base, uint32_t *rec_off,
+                        uint32_t *aux_off, ChunkSummary *d_out, hipStream_t stream) {
+    if (n_segs <= 0 || n_chunks <= 0) return;
+    hipLaunchKernelGGL(seg_summary_kernel, dim3(n_chunks), dim3(64), 0, stream, d_segs, d_first_seg, n_chunks, idx_base, seq_base, rec_off, aux_off, d_out);
+    hipLaunchKernelGGL(seg_offsets_kernel, dim3(n_chunks), dim3(64), 0, stream, d_first_seg, n_chunks, rec_off, aux_off, d_out);
 }
 void launch_seg_gather(const SegDev *d_segs, int n_segs, const int64_t *idx_base, const uint32_t *seq_base, const uint32_t *rec_off,
                        const uint32_t *aux_off, FixRec *out_recs, uint8_t *out_aux, hipStream_t stream) {

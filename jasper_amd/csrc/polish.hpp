@@ -94,9 +94,20 @@ struct SegDev {
     uint64_t tk[12];     // of which: [0] skipping good k-mers, [1] finding the bad run, [2] choosing a fix, [3] splicing the text;
                          // [4..10] inside [2]: fix_k_case_sub, fix_insert, fix_del, fixdiploid, fix_same_base_del,
                          // fix_same_base_insertion, base_extension
-    // filled by the host before stitching
+    // filled before stitching (seg_summary_kernel, or the host on the slow path)
     int64_t own_lo, own_hi;   // local range of the polished text this segment contributes
+    int64_t own_hi0;          // own_hi before this segment's own change of length is added (set when the segment is built)
     int64_t out_off;          // where it goes in the chunk's new text
+};
+
+// what the host needs of a pass's walks, per chunk record (seg_summary_kernel): everything else stays on the device
+struct ChunkSummary {
+    int64_t newlen;           // length of the chunk's stitched text
+    int64_t wrong;            // bad k-mers counted (src/jasper.py:207)
+    uint64_t lookups;
+    uint32_t nrec, naux;      // fix records / aux bytes of the chunk's segments
+    int32_t bad_seg;          // index of the first segment whose status is not PS_OK, or -1
+    int32_t spec_fail;        // some segment's speculation failed
 };
 
 constexpr long long ARRIVE_PENDING = (long long)0x8080808080808080ull;   // what hipMemset(0x80) leaves
@@ -138,6 +149,11 @@ void launch_seg_walk(const TableDev &T, SegDev *d_segs, int n_segs, PolishParams
 // d_cls_out / d_flags may be null (last pass): then only the text is stitched
 void launch_seg_stitch(const SegDev *d_segs, int n_segs, uint8_t *const *d_chunk_out, uint8_t *const *d_cls_out, uint8_t *const *d_flags,
                        hipStream_t stream);
+// After the walks: per chunk (its segments are consecutive, in text order) the stitched coordinates -- own_hi / out_off of every
+// segment written back into d_segs -- the coordinate bases the gather needs (idx_base, seq_base, rec_off, aux_off: n_segs each)
+// and one ChunkSummary per chunk.  first_seg[c] .. first_seg[c+1] = the chunk's segments.
+void launch_seg_summary(SegDev *d_segs, int n_segs, const int32_t *d_first_seg, int n_chunks, int64_t *idx_base, uint32_t *seq_base, uint32_t *rec_off,
+                        uint32_t *aux_off, ChunkSummary *d_out, hipStream_t stream);
 void launch_seg_gather(const SegDev *d_segs, int n_segs, const int64_t *idx_base, const uint32_t *seq_base, const uint32_t *rec_off,
                        const uint32_t *aux_off, FixRec *out_recs, uint8_t *out_aux, hipStream_t stream);
 

@@ -114,6 +114,23 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     pool.stride = pool.off_patch + al256(pool.patch_cap);
     if (!dmalloc(b_pool, pool.stride * pool.nslots) || !dmalloc(b_locks, pool.nslots * 4) || !dmalloc(b_scan, sizeof(ScanChunk) * n_chunks) ||
         !dmalloc(b_ticket, 256)) return -2;
+    // the bookkeeping after a pass's walks happens on the device (seg_summary_kernel); the host gets one ChunkSummary per chunk
+    DevBuf b_first, b_sum, b_idx, b_seq, b_ro, b_ao;
+    if (!dmalloc(b_first, ((size_t)n_chunks + 1) * 4) || !dmalloc(b_sum, (size_t)n_chunks * sizeof(ChunkSummary)) || !dmalloc(b_idx, (size_t)max_segs * 8) ||
+        !dmalloc(b_seq, (size_t)max_segs * 4) || !dmalloc(b_ro, (size_t)max_segs * 4) || !dmalloc(b_ao, (size_t)max_segs * 4)) return -2;
+    // pinned host memory for everything that crosses PCIe inside the pass loop (kept with the table)
+    const size_t PIN_RECS = 1u << 18, PIN_AUX = 8u << 20;            // records / aux bytes of ALL passes that travel without a host wait
+    SegDev *segs_p = reinterpret_cast<SegDev *>(T.pinned(0, (size_t)max_segs * sizeof(SegDev), err));
+    int32_t *first_p = reinterpret_cast<int32_t *>(T.pinned(1, ((size_t)n_chunks + 1) * 4, err));
+    ChunkSummary *sum_p = reinterpret_cast<ChunkSummary *>(T.pinned(2, (size_t)n_chunks * sizeof(ChunkSummary), err));
+    int64_t *cand_p = reinterpret_cast<int64_t *>(T.pinned(3, (std::min<size_t>(cand_items, 32768) + cell_items + 8) * 8, err));
+    FixRec *recs_p = reinterpret_cast<FixRec *>(T.pinned(4, PIN_RECS * sizeof(FixRec), err));
+    uint8_t *aux_p = reinterpret_cast<uint8_t *>(T.pinned(5, PIN_AUX, err));
+    ScanChunk *sc_p = reinterpret_cast<ScanChunk *>(T.pinned(6, sizeof(ScanChunk) * (size_t)n_chunks, err));
+    if (!segs_p || !first_p || !sum_p || !cand_p || !recs_p || !aux_p || !sc_p) return -2;
+    size_t pin_recs_used = 0, pin_aux_used = 0;
+    struct PinnedPass { size_t rec_at, nrec, aux_at, naux, r0, pass_i; };      // what a pass left in the pinned record buffers: copied out after the last pass
+    std::vector<PinnedPass> pinned_passes;
     pool.base = b_pool.as<uint8_t>();
     pool.locks = b_locks.as<unsigned int>();
     HIPCHK(hipMemsetAsync(pool.locks, 0, pool.nslots * 4, st));
@@ -184,7 +201,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                 S.clean_cand = b_cells.as<int64_t>() + off_cell[c];
                 S.n_cells = (uint32_t)std::min<int64_t>(n_cells[c], std::max<int64_t>(0, len[c] - k + 1) / CLEAN_CELL + 1);
             }
-            HIPCHK(hipMemcpyAsync(b_scan.p, sc.data(), sizeof(ScanChunk) * n_chunks, hipMemcpyHostToDevice, st));
+            memcpy(sc_p, sc.data(), sizeof(ScanChunk) * n_chunks);
+            HIPCHK(hipMemcpyAsync(b_scan.p, sc_p, sizeof(ScanChunk) * n_chunks, hipMemcpyHostToDevice, st));
             if (pass == 0) launch_scan_batch(T.d, b_scan.as<ScanChunk>(), n_chunks, k, pp.solid, st);
             else launch_rescan_batch(T.d, b_scan.as<ScanChunk>(), n_chunks, k, pp.solid, st);
         }
@@ -192,10 +210,15 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         // the candidate list is fetched optimistically: its count and its first CAND_PRE entries in one round trip
         const size_t CAND_PRE = std::min<size_t>(cand_items, 32768);
         unsigned int n_cand = 0;
-        HIPCHK(hipMemcpyAsync(&n_cand, b_ccount.p, 4, hipMemcpyDeviceToHost, st));
-        if (CAND_PRE) HIPCHK(hipMemcpyAsync(all_cands.data(), b_cand.p, CAND_PRE * 8, hipMemcpyDeviceToHost, st));
-        if (cell_items) HIPCHK(hipMemcpyAsync(all_cells.data(), b_cells.p, cell_items * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(jk_stream_wait(st));
+        {   // (pinned: [0] the count, [1 ..] the first CAND_PRE candidates, then the clean-zone cells)
+            HIPCHK(hipMemcpyAsync(cand_p, b_ccount.p, 4, hipMemcpyDeviceToHost, st));
+            if (CAND_PRE) HIPCHK(hipMemcpyAsync(cand_p + 1, b_cand.p, CAND_PRE * 8, hipMemcpyDeviceToHost, st));
+            if (cell_items) HIPCHK(hipMemcpyAsync(cand_p + 1 + CAND_PRE, b_cells.p, cell_items * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(jk_stream_wait(st));
+            n_cand = *reinterpret_cast<const unsigned int *>(cand_p);
+            if (CAND_PRE) memcpy(all_cands.data(), cand_p + 1, std::min<size_t>(n_cand, CAND_PRE) * 8);
+            if (cell_items) memcpy(all_cells.data(), cand_p + 1 + CAND_PRE, cell_items * 8);
+        }
         n_cand = (unsigned int)std::min<size_t>(n_cand, cand_items);
         if (n_cand > CAND_PRE) {
             HIPCHK(hipMemcpyAsync(all_cands.data() + CAND_PRE, b_cand.as<int64_t>() + CAND_PRE, (n_cand - CAND_PRE) * 8, hipMemcpyDeviceToHost, st));
@@ -209,11 +232,12 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         }
 
         // ---- 2. segments
-        auto build_segments = [&](const std::vector<int> &chunks, bool speculate, std::vector<SegDev> &out, std::string &e2) -> int {
-            out.clear();
-            if (speculate) out.reserve((size_t)std::min<int64_t>(max_segs, 1 << 16));   // (kept across passes: no regrowth in the loop)
-            size_t tpos = 0, rpos = 0, apos = 0;
+        // segments of `chunks` into out[0 .. n_out) (room for max_segs); first_of (optional): first_of[i] = index of chunks[i]'s first segment
+        auto build_segments = [&](const std::vector<int> &chunks, bool speculate, SegDev *out, size_t &n_out, int32_t *first_of, std::string &e2) -> int {
+            n_out = 0;
+            size_t tpos = 0, rpos = 0, apos = 0, ci = 0;
             for (int c : chunks) {
+                if (first_of) first_of[ci++] = (int32_t)n_out;
                 std::vector<int64_t> sync;
                 if (speculate && !chunk_cands[c].empty()) {
                     cands = chunk_cands[c];
@@ -242,16 +266,17 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                     chained.swap(mtype);
                 }
                 const int m = (int)sync.size();
+                if ((int64_t)n_out + m + 1 > max_segs) { e2 = "polish: internal segment arena bound exceeded"; return -2; }
                 for (int j = 0; j <= m; ++j) {
-                    out.emplace_back();                      // value-initialised in place: zeros, no copy of the ~400-byte struct
-                    SegDev &S = out.back();
+                    SegDev &S = out[n_out++];
+                    memset(&S, 0, sizeof S);
                     S.chunk = (uint32_t)c;
                     S.first = (j == 0);
                     S.last = (j == m);
                     S.seg_lo = j == 0 ? 0 : sync[j - 1] - W;
                     S.start_i = j == 0 ? 0 : W;
                     S.chain_in = j > 0 && chained[j - 1];
-                    S.arrive = b_arrive.as<long long>() + out.size();         // (= 1 + its index; slot 0 is never read: a first segment is not chained)
+                    S.arrive = b_arrive.as<long long>() + n_out;             // (= 1 + its index; slot 0 is never read: a first segment is not chained)
                     S.stop_orig = j == m ? INT64_MAX : sync[j];
                     const int64_t seg_hi = j == m ? len[c] : std::min<int64_t>(len[c], sync[j] + M);
                     S.len0 = seg_hi - S.seg_lo;
@@ -271,41 +296,77 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                     // owned part of the text: chunk coordinates [B_j, B_{j+1}), B = sync - 2k
                     S.own_lo = j == 0 ? 0 : 2ll * k;                   // local (no edit can precede it)
                     S.own_hi = j == m ? -1 : (sync[j] - 2ll * k) - S.seg_lo;   // local, before adding this segment's delta
+                    S.own_hi0 = S.own_hi;
                 }
             }
-            if (tpos > seg_text_bound || rpos > seg_rec_bound || apos > seg_aux_bound || (int64_t)out.size() > max_segs) {
+            if (first_of) first_of[ci] = (int32_t)n_out;
+            if (tpos > seg_text_bound || rpos > seg_rec_bound || apos > seg_aux_bound || (int64_t)n_out > max_segs) {
                 e2 = "polish: internal segment arena bound exceeded"; return -2;
             }
             return 0;
         };
-        auto run_segments = [&](std::vector<SegDev> &sv, std::string &e2) -> int {
-            if (sv.empty()) return 0;
+        // upload, walk; then either the whole table comes back (sv is overwritten) or -- `summary` -- the bookkeeping is done on
+        // the device and one ChunkSummary per chunk comes back (sum_p)
+        auto run_segments = [&](SegDev *sv, size_t nsv, bool summary, std::string &e2) -> int {
+            if (!nsv) return 0;
             const bool fine = dbg && getenv("JASPER_POLISH_DEBUG") && atoi(getenv("JASPER_POLISH_DEBUG")) >= 2;   // (waits between the steps: their times, not the pass's)
             double tf[5] = {fine ? now() : 0, 0, 0, 0, 0};
-            if (hipMemcpyAsync(b_segs.p, sv.data(), sv.size() * sizeof(SegDev), hipMemcpyHostToDevice, st) != hipSuccess) { e2 = "polish: H2D segs"; return -1; }
+            if (hipMemcpyAsync(b_segs.p, sv, nsv * sizeof(SegDev), hipMemcpyHostToDevice, st) != hipSuccess) { e2 = "polish: H2D segs"; return -1; }
+            if (summary && hipMemcpyAsync(b_first.p, first_p, ((size_t)n_chunks + 1) * 4, hipMemcpyHostToDevice, st) != hipSuccess) { e2 = "polish: H2D first"; return -1; }
             if (fine) { (void)jk_stream_wait(st); tf[1] = now(); }
-            launch_seg_init(b_segs.as<SegDev>(), (int)sv.size(), (const uint8_t *const *)dIn, st);
-            if (hipMemsetAsync(b_arrive.p, 0x80, (sv.size() + 2) * 8, st) != hipSuccess) { e2 = "polish: memset"; return -1; }   // ARRIVE_PENDING
+            launch_seg_init(b_segs.as<SegDev>(), (int)nsv, (const uint8_t *const *)dIn, st);
+            if (hipMemsetAsync(b_arrive.p, 0x80, (nsv + 2) * 8, st) != hipSuccess) { e2 = "polish: memset"; return -1; }   // ARRIVE_PENDING
             if (fine) { (void)jk_stream_wait(st); tf[2] = now(); }
-            launch_seg_walk(T.d, b_segs.as<SegDev>(), (int)sv.size(), pp, pass, pool, b_ticket.as<unsigned int>(), st);
+            launch_seg_walk(T.d, b_segs.as<SegDev>(), (int)nsv, pp, pass, pool, b_ticket.as<unsigned int>(), st);
             if (hipGetLastError() != hipSuccess) { e2 = "polish: kernel launch failed"; return -1; }
             if (fine) { (void)jk_stream_wait(st); tf[3] = now(); }
-            if (hipMemcpyAsync(sv.data(), b_segs.p, sv.size() * sizeof(SegDev), hipMemcpyDeviceToHost, st) != hipSuccess) { e2 = "polish: D2H segs"; return -1; }
+            if (summary) {
+                launch_seg_summary(b_segs.as<SegDev>(), (int)nsv, b_first.as<int32_t>(), n_chunks, b_idx.as<int64_t>(), b_seq.as<uint32_t>(), b_ro.as<uint32_t>(),
+                                   b_ao.as<uint32_t>(), b_sum.as<ChunkSummary>(), st);
+                if (hipMemcpyAsync(sum_p, b_sum.p, (size_t)n_chunks * sizeof(ChunkSummary), hipMemcpyDeviceToHost, st) != hipSuccess) { e2 = "polish: D2H summary"; return -1; }
+            } else if (hipMemcpyAsync(sv, b_segs.p, nsv * sizeof(SegDev), hipMemcpyDeviceToHost, st) != hipSuccess) { e2 = "polish: D2H segs"; return -1; }
             if (jk_stream_wait(st) != hipSuccess) { e2 = "polish: kernel execution failed"; return -1; }
             if (fine) {
                 tf[4] = now();
-                fprintf(stderr, "[polish]     %zu segments x %zu B: H2D %.3f ms, init + memset %.3f ms, walk %.3f ms, D2H %.3f ms\n", sv.size(), sizeof(SegDev), tf[1] - tf[0], tf[2] - tf[1],
-                        tf[3] - tf[2], tf[4] - tf[3]);
+                fprintf(stderr, "[polish]     %zu segments x %zu B: H2D %.3f ms, init + memset %.3f ms, walk %.3f ms, %s %.3f ms\n", nsv, sizeof(SegDev), tf[1] - tf[0], tf[2] - tf[1],
+                        tf[3] - tf[2], summary ? "summary + D2H" : "D2H", tf[4] - tf[3]);
             }
             return 0;
         };
         std::vector<int> all(n_chunks);
         for (int c = 0; c < n_chunks; ++c) all[c] = c;
         const double tb0 = dbg ? now() : 0;
-        if ((rc = build_segments(all, true, segs, err))) break;
+        size_t ns = 0;
+        if ((rc = build_segments(all, true, segs_p, ns, first_p, err))) break;
         const double tb1 = dbg ? now() : 0;
-        if ((rc = run_segments(segs, err))) break;
-        if (dbg) fprintf(stderr, "[polish]   host: build %zu segments %.3f ms, upload + walk + download %.3f ms\n", segs.size(), tb1 - tb0, now() - tb1);
+        if ((rc = run_segments(segs_p, ns, true, err))) break;
+        if (dbg) fprintf(stderr, "[polish]   host: build %zu segments %.3f ms, upload + walk + summary %.3f ms\n", ns, tb1 - tb0, now() - tb1);
+
+        // ---- 3. + 4. the bookkeeping per chunk came back as summaries.  Anything out of the ordinary -- a segment that ran out of
+        //         room, the reference's own IndexError, a speculation that failed -- takes the host's own bookkeeping (below),
+        //         on the whole segment table; so does the debug output, which wants every segment's counters.
+        bool ordinary = !getenv("JASPER_POLISH_DEBUG");
+        for (int c = 0; c < n_chunks && ordinary; ++c) ordinary = sum_p[c].bad_seg < 0 && !sum_p[c].spec_fail;
+        std::vector<int64_t> idx_base;
+        std::vector<uint32_t> seq_base, rec_off, aux_off;
+        std::vector<int64_t> newlen(n_chunks, 0), shift(n_chunks, 0);
+        std::vector<uint32_t> seqc(n_chunks, 0);
+        size_t nrec_pass = 0, naux_pass = 0;
+        if (ordinary) {
+            R.n_segments += ns;
+            for (int c = 0; c < n_chunks; ++c) {
+                const ChunkSummary &S = sum_p[c];
+                newlen[c] = S.newlen;
+                nrec_pass += S.nrec;
+                naux_pass += S.naux;
+                R.lookups += S.lookups;
+                if (pass == 0) { R.qv[0] += S.wrong; R.qv_chunk[4 * (size_t)c + 0] += S.wrong; }
+                if (pass == passes) { R.qv[2] += S.wrong; R.qv_chunk[4 * (size_t)c + 2] += S.wrong; }
+            }
+        } else {
+        segs.resize(ns);
+        HIPCHK(hipMemcpyAsync(segs.data(), b_segs.p, ns * sizeof(SegDev), hipMemcpyDeviceToHost, st));
+        HIPCHK(jk_stream_wait(st));
         R.n_segments += segs.size();
 
         // ---- 3. chunks whose speculation failed are redone as a single segment (= the plain sequential walk)
@@ -324,8 +385,10 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             // only writes through the SegDev table it uploads -- so place the redo segments BEHIND the good ones)
             size_t tpos = 0, rpos = 0, apos = 0;
             for (const SegDev &S : segs) { tpos += al256((size_t)S.cap); rpos += S.rec_cap; apos += al256(S.aux_cap); }
-            std::vector<SegDev> redo_segs;
-            if ((rc = build_segments(redo, false, redo_segs, err))) break;
+            std::vector<SegDev> redo_segs((size_t)max_segs);
+            size_t nredo = 0;
+            if ((rc = build_segments(redo, false, redo_segs.data(), nredo, nullptr, err))) break;
+            redo_segs.resize(nredo);
             size_t t2 = tpos, r2 = rpos, a2 = apos;
             for (SegDev &S : redo_segs) {
                 S.buf = b_segtext.as<uint8_t>() + t2;  t2 += al256((size_t)S.cap);
@@ -335,10 +398,13 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             }
             if (t2 > seg_text_bound || r2 > seg_rec_bound || a2 > seg_aux_bound) {
                 // not enough spare room: fall back to redoing EVERYTHING unsegmented (always fits)
-                if ((rc = build_segments(all, false, segs, err))) break;
-                if ((rc = run_segments(segs, err))) break;
+                segs.assign((size_t)max_segs, SegDev{});
+                size_t nall = 0;
+                if ((rc = build_segments(all, false, segs.data(), nall, nullptr, err))) break;
+                segs.resize(nall);
+                if ((rc = run_segments(segs.data(), segs.size(), false, err))) break;
             } else {
-                if ((rc = run_segments(redo_segs, err))) break;
+                if ((rc = run_segments(redo_segs.data(), redo_segs.size(), false, err))) break;
                 segs = good;
                 segs.insert(segs.end(), redo_segs.begin(), redo_segs.end());
                 std::stable_sort(segs.begin(), segs.end(), [](const SegDev &a, const SegDev &b) {
@@ -346,7 +412,6 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                 });
             }
         }
-
         if (getenv("JASPER_POLISH_DEBUG")) {
             uint64_t mx = 0, sum = 0, mxl = 0; int64_t mxlen = 0; size_t nrecs = 0, mxrec = 0;
             uint64_t tks[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mxtk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -374,12 +439,9 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         }
 
         // ---- 4. bookkeeping per chunk: status, counters, coordinates of the stitched text
-        const size_t ns = segs.size();
-        std::vector<int64_t> idx_base(ns);
-        std::vector<uint32_t> seq_base(ns), rec_off(ns), aux_off(ns);
-        std::vector<int64_t> newlen(n_chunks, 0), shift(n_chunks, 0);
-        std::vector<uint32_t> seqc(n_chunks, 0);
-        size_t nrec_pass = 0, naux_pass = 0;
+        ns = segs.size();
+        idx_base.assign(ns, 0);
+        seq_base.assign(ns, 0); rec_off.assign(ns, 0); aux_off.assign(ns, 0);
         for (size_t s = 0; s < ns && rc == 0; ++s) {
             SegDev &S = segs[s];
             const int c = (int)S.chunk;
@@ -392,7 +454,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
                 break;
             }
             const int64_t d = S.len - S.len0;
-            if (S.last) S.own_hi = S.len; else S.own_hi += d;
+            S.own_hi = S.last ? S.len : S.own_hi0 + d;        // (from own_hi0: the device's summary pass may have written own_hi already)
             S.out_off = newlen[c];
             newlen[c] += S.own_hi - S.own_lo;
             idx_base[s] = S.seg_lo + shift[c];
@@ -408,6 +470,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
             if (pass == passes) { R.qv[2] += S.wrong; R.qv_chunk[4 * (size_t)c + 2] += S.wrong; }
         }
         if (rc) break;
+        }       // (the host's own bookkeeping)
+        if (rc) break;
         for (int c = 0; c < n_chunks; ++c) {
             if (pass == 0) { R.qv[1] += len[c] - k + 1; R.qv_chunk[4 * (size_t)c + 1] += len[c] - k + 1; }   // src/jasper.py:51,107-111
             if (pass == passes) { R.qv[3] += len[c] - k + 1; R.qv_chunk[4 * (size_t)c + 3] += len[c] - k + 1; }
@@ -416,28 +480,39 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         if (rc) break;
 
         // ---- 5. gather records / aux, stitch the new text
-        HIPCHK(hipMemcpyAsync(b_segs.p, segs.data(), ns * sizeof(SegDev), hipMemcpyHostToDevice, st));
         rec_pass_begin.push_back(R.recs.size());
         aux_pass.emplace_back();
+        const int64_t *g_idx = b_idx.as<int64_t>();
+        const uint32_t *g_seq = b_seq.as<uint32_t>(), *g_ro = b_ro.as<uint32_t>(), *g_ao = b_ao.as<uint32_t>();
+        if (!ordinary) {                            // the host's bookkeeping goes up: the segment table and the four coordinate bases
+            HIPCHK(hipMemcpyAsync(b_segs.p, segs.data(), ns * sizeof(SegDev), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(b_idx.p, idx_base.data(), ns * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(b_seq.p, seq_base.data(), ns * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(b_ro.p, rec_off.data(), ns * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(b_ao.p, aux_off.data(), ns * 4, hipMemcpyHostToDevice, st));
+        }
         if (nrec_pass) {
-            DevBuf d_idx, d_seq, d_ro, d_ao, d_recs, d_aux;
-            int ws_save = ws_next;          // the same six workspace slots every pass
-            if (!dmalloc(d_idx, ns * 8) || !dmalloc(d_seq, ns * 4) || !dmalloc(d_ro, ns * 4) || !dmalloc(d_ao, ns * 4) ||
-                !dmalloc(d_recs, nrec_pass * sizeof(FixRec)) || !dmalloc(d_aux, naux_pass)) { rc = -2; break; }
+            DevBuf d_recs, d_aux;
+            int ws_save = ws_next;          // the same two workspace slots every pass
+            if (!dmalloc(d_recs, nrec_pass * sizeof(FixRec)) || !dmalloc(d_aux, naux_pass)) { rc = -2; break; }
             ws_next = ws_save;
-            HIPCHK(hipMemcpyAsync(d_idx.p, idx_base.data(), ns * 8, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(d_seq.p, seq_base.data(), ns * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(d_ro.p, rec_off.data(), ns * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(d_ao.p, aux_off.data(), ns * 4, hipMemcpyHostToDevice, st));
-            launch_seg_gather(b_segs.as<SegDev>(), (int)ns, d_idx.as<int64_t>(), d_seq.as<uint32_t>(), d_ro.as<uint32_t>(),
-                              d_ao.as<uint32_t>(), d_recs.as<FixRec>(), d_aux.as<uint8_t>(), st);
+            launch_seg_gather(b_segs.as<SegDev>(), (int)ns, g_idx, g_seq, g_ro, g_ao, d_recs.as<FixRec>(), d_aux.as<uint8_t>(), st);
             HIPCHK(hipGetLastError());
             const size_t r0 = R.recs.size();
             R.recs.resize(r0 + nrec_pass);
-            HIPCHK(hipMemcpyAsync(&R.recs[r0], d_recs.p, nrec_pass * sizeof(FixRec), hipMemcpyDeviceToHost, st));
             aux_pass.back().resize(naux_pass);
-            if (naux_pass) HIPCHK(hipMemcpyAsync(aux_pass.back().data(), d_aux.p, naux_pass, hipMemcpyDeviceToHost, st));
-            HIPCHK(jk_stream_wait(st));
+            if (pin_recs_used + nrec_pass <= PIN_RECS && pin_aux_used + naux_pass <= PIN_AUX) {
+                // through pinned memory, without waiting: the stream orders the copy before the next pass's gather reuses d_recs
+                HIPCHK(hipMemcpyAsync(recs_p + pin_recs_used, d_recs.p, nrec_pass * sizeof(FixRec), hipMemcpyDeviceToHost, st));
+                if (naux_pass) HIPCHK(hipMemcpyAsync(aux_p + pin_aux_used, d_aux.p, naux_pass, hipMemcpyDeviceToHost, st));
+                pinned_passes.push_back(PinnedPass{pin_recs_used, nrec_pass, pin_aux_used, naux_pass, r0, aux_pass.size() - 1});
+                pin_recs_used += nrec_pass;
+                pin_aux_used += naux_pass;
+            } else {
+                HIPCHK(hipMemcpyAsync(&R.recs[r0], d_recs.p, nrec_pass * sizeof(FixRec), hipMemcpyDeviceToHost, st));
+                if (naux_pass) HIPCHK(hipMemcpyAsync(aux_pass.back().data(), d_aux.p, naux_pass, hipMemcpyDeviceToHost, st));
+                HIPCHK(jk_stream_wait(st));
+            }
         }
         const bool carry = pass < passes;           // another pass follows: carry the classes over, flag changed text
         if (carry) HIPCHK(hipMemsetAsync(b_flags.p, 0, flag_items, st));
@@ -470,6 +545,10 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
         R.seconds = ms * 1e-3;
+        for (const PinnedPass &P : pinned_passes) {                                             // what travelled through pinned memory
+            memcpy(&R.recs[P.r0], recs_p + P.rec_at, P.nrec * sizeof(FixRec));
+            if (P.naux) memcpy(aux_pass[P.pass_i].data(), aux_p + P.aux_at, P.naux);
+        }
         // records: order by chunk, pass, emission; regroup the aux bytes of 'x' records per chunk
         for (size_t p = 0; p < rec_pass_begin.size(); ++p) {
             const size_t b = rec_pass_begin[p], e = p + 1 < rec_pass_begin.size() ? rec_pass_begin[p + 1] : R.recs.size();

@@ -663,12 +663,24 @@ void *Table::workspace(int id, size_t bytes, std::string &err) {
     return b.p;
 }
 
+void *Table::pinned(int id, size_t bytes, std::string &err) {
+    if (bytes == 0) bytes = 256;
+    WsBuf &b = pin[id];
+    if (b.bytes >= bytes) return b.p;
+    if (b.p) { (void)jk_stream_wait(stream); (void)hipHostFree(b.p); b.p = nullptr; b.bytes = 0; }
+    const size_t want = bytes + bytes / 4;
+    if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { err = "pinned host buffer allocation failed"; b.p = nullptr; return nullptr; }
+    b.bytes = want;
+    return b.p;
+}
+
 void Table::destroy() {
     feed_stop();
     (void)hipSetDevice(device);
     if (stream) (void)jk_stream_wait(stream);
     detach_shards();
     for (WsBuf &b : ws) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    for (WsBuf &b : pin) { if (b.p) (void)hipHostFree(b.p); b.p = nullptr; b.bytes = 0; }
     for (int i = 0; i < 2; ++i) {
         if (d_stage[i]) (void)hipFree(d_stage[i]);
         if (h_stage[i]) (void)hipHostFree(h_stage[i]);

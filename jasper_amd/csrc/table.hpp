@@ -339,6 +339,11 @@ struct Table {
     static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_INGEST = 44, WS_MZ = 50, WS_HOSTBASES = 54, WS_SLOTS = 55;
     WsBuf ws[WS_SLOTS];   // 0..WS_POLISH_MAX-1: polisher (polish_host.hip, in allocation order); WS_COUNT..+3: partitioned counting
     void *workspace(int id, size_t bytes, std::string &err);
+    // grow-only PINNED host buffers kept with the table (the polisher's segment tables, candidate lists and records travel through
+    // them: a copy to or from pageable memory is staged by the runtime and makes the caller wait)
+    static constexpr int PIN_SLOTS = 8;
+    WsBuf pin[PIN_SLOTS];
+    void *pinned(int id, size_t bytes, std::string &err);
 
     static int min_log2_slots(int k);
     int init(int k, uint64_t min_slots, int device, std::string &err);
