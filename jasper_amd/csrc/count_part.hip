@@ -118,7 +118,11 @@ struct P1Args {              // what part1_kernel needs of the table and the geo
     uint32_t nblk1, cap1;
     unsigned long long *stats;
 };
-template <int NW>
+// KFIX: 0 = k, p1 and the record width are read from P; 37 = the reference's default k (src/jasper.sh:11) with the geometry that
+// k implies (2k - 64 = 10 = p1 bucket bits above a 64-bit record): the masks and shift amounts of the per-base loop are then
+// immediates instead of scalar registers (the kernel has more loop constants than scalar registers: they were spilled to vector
+// lanes and read back by v_readlane in every iteration).
+template <int NW, int KFIX = 0>
 __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t ntiles, uint64_t emit_from, P1Args P,
                                                       uint64_t *__restrict__ out1, unsigned int *__restrict__ cnt1, unsigned long long *__restrict__ deferred,
                                                       unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
@@ -134,8 +138,10 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
     unsigned short *s_bkt = reinterpret_cast<unsigned short *>(s_base + P1_MAXB);            // bucket of each staged record
     uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_bkt + P1_STAGE);                      // P1_STAGE records, bucket order
     const int t = threadIdx.x;
-    const int k = P.k;
-    const int nb = 1 << P.p1;
+    const int k = KFIX ? KFIX : P.k;
+    const int p1 = KFIX ? 2 * KFIX - 64 : P.p1;
+    const int recbits = KFIX ? 64 : P.recbits;
+    const int nb = 1 << p1;
     // word-level constants: the k-mer's 2k bits fill words 0 .. NW-1, `topbits` of them in word NW-1
     const int topbits = 2 * k - 32 * (NW - 1);                                  // 2..32
     const uint32_t topmask = topbits >= 32 ? ~0u : ((1u << topbits) - 1u);
@@ -144,8 +150,12 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
     const uint32_t himask = NW > 2 ? (hb >= 32 ? ~0u : ((1u << hb) - 1u)) : 0u;
     const uint64_t lomask = NW > 2 || 2 * k >= 64 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const int hh = k;                                                           // (2k <= 64) xor-shift by half the width
-    const int e = NW > 2 ? P.p1 - hb : 0;                                       // bucket bits taken from the low 64 hash bits (2k > 64: p1 >= hb)
-    const uint64_t recmask = P.recbits >= 64 ? ~0ull : ((1ull << P.recbits) - 1ull);
+    const int e = NW > 2 ? p1 - hb : 0;                                         // bucket bits taken from the low 64 hash bits (2k > 64: p1 >= hb)
+    const uint64_t recmask = recbits >= 64 ? ~0ull : ((1ull << recbits) - 1ull);
+    // a window is a k-mer iff none of its k bases is "no base": OR of the invalid-base bits over every window of k positions,
+    // for the tile's 16 windows at once (the largest power of two <= k by doubling, then two such windows that overlap)
+    int wlog = 0;
+    while ((2 << wlog) <= k) ++wlog;                                            // 2^wlog <= k < 2^(wlog+1)
     unsigned int cur = 0;                                                       // cursor of bucket t's slice
     unsigned long long added = 0, added_run = 0;
     s_cnt[t] = 0;
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
         lds_barrier();
         // A. hash my 16 windows, take a rank in the tile's bucket histogram
         uint32_t f[NW], r[NW];
-        int run;
+        uint32_t vmask;                    // bit 15 - j: the window ending at my base j is a k-mer
         {
             const uint32_t w4 = s_code[ta], w3 = s_code[ta + 1], w2 = s_code[ta + 2], w1 = s_code[ta + 3];
             const uint64_t ivprev = ((uint64_t)s_inv[ta] << 48) | ((uint64_t)s_inv[ta + 1] << 32) | ((uint64_t)s_inv[ta + 2] << 16) | (uint64_t)s_inv[ta + 3];
@@ -193,12 +203,18 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
             const uint32_t rw[4] = {(uint32_t)rc0.lo, (uint32_t)(rc0.lo >> 32), (uint32_t)rc0.hi, (uint32_t)(rc0.hi >> 32)};
 #pragma unroll
             for (int w = 0; w < NW; ++w) { f[w] = fw[w]; r[w] = rw[w]; }
-            run = ivprev ? (int)__builtin_ctzll(ivprev) : 64;
+            // bit q of z: my base 15 - q (q < 16), or the base q - 15 positions before my first (k <= 37: bits up to 15 + 36 matter)
+            uint64_t z = (uint64_t)iv | (ivprev << 16);
+            uint64_t sm = z;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) if (b < wlog) sm |= sm >> (1 << b);         // windows of 2^wlog positions
+            sm |= sm >> (k - (1 << wlog));                                          // windows of k positions
+            vmask = ~(uint32_t)sm & 0xFFFFu;
         }
         // k-mers that END before emit_from belong to the piece before this one
         const int64_t mine = base0 + (int64_t)ta * PT_GROUP;
-        int jfirst = (int64_t)emit_from > mine ? (int)((int64_t)emit_from - mine < PT_GROUP ? (int64_t)emit_from - mine : PT_GROUP) : 0;
-        asm volatile("" : "+v"(jfirst));                                            // (keeps the 16 tests below 32-bit compares with a register)
+        const int jfirst = (int64_t)emit_from > mine ? (int)((int64_t)emit_from - mine < PT_GROUP ? (int64_t)emit_from - mine : PT_GROUP) : 0;
+        vmask &= 0xFFFFu >> jfirst;
         uint64_t rec[PT_GROUP];
         uint32_t br[PT_GROUP];     // bucket (0xFFFF = no record) << 16 | rank among the tile's records of that bucket
         uint32_t bprev = 0xFFFFu, rprev = 0;      // (a record's two halves are put together one iteration later: the atomic's latency is covered)
@@ -213,8 +229,7 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
 #pragma unroll
             for (int w = 0; w < NW - 1; ++w) r[w] = __builtin_amdgcn_alignbit(r[w + 1], r[w], 2);
             r[NW - 1] = (r[NW - 1] >> 2) | ((cj ^ 3u) << rsh);
-            run = ((iv >> (15 - j)) & 1u) ? 0 : run + 1;
-            const bool valid = run >= k && j >= jfirst;
+            const bool valid = (vmask >> (15 - j)) & 1u;
             // canonical = numeric min of the two strands: borrow chain of r - f from the low word up, then one select per word
             // (written out: the compiler turns the same chain into 2 compares per word plus scalar mask logic)
             uint32_t m[NW];
@@ -245,7 +260,7 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                 v ^= v >> hh;
                 v = (v * JK_C1) & lomask;
                 v ^= v >> hh;
-                b = (uint32_t)(v >> P.recbits);
+                b = (uint32_t)(v >> recbits);
                 rec[j] = v & recmask;
             }
             if (j > 0) br[j - 1] = (bprev << 16) | rprev;
@@ -328,7 +343,6 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                     const uint32_t b = s_bkt[i];
                     if (P.exp & 1) reinterpret_cast<global_u64 *>(s_base[b & 7])[(r0 + i) & 1023] = rr;     // (timing experiment: stores that stay in cache)
                     else if (P.exp & 4) out1[(uint64_t)blockIdx.x * 1024ull * P.cap1 + (added_all + r0 + i) % (1024ull * P.cap1)] = rr;     // (timing experiment: the same bytes as one sequential stream per block)
-                    else if (P.exp & 8) __builtin_nontemporal_store(rr, reinterpret_cast<global_u64 *>(s_base[b]) + (r0 + i));     // (timing experiment: streaming stores)
                     else reinterpret_cast<global_u64 *>(s_base[b])[r0 + i] = rr;
                 }
             } else {
@@ -358,12 +372,14 @@ static hipError_t launch_part1(hipStream_t stream, int k, const uint8_t *d_piece
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(part1_kernel<3, 37>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
         attr_set = true;
     }
     P1Args P;
     P.k = k; P.p1 = G.p1; P.recbits = G.recbits; P.exp = G.exp; P.nblk1 = G.nblk1; P.cap1 = G.cap1; P.stats = d.stats;
-#define JK_P1_LAUNCH(NW_) hipLaunchKernelGGL((part1_kernel<NW_>), dim3(G.nblk1), dim3(P1_TH), P1_LDS, stream, d_piece, len, ntiles, emit_from, P, out1, cnt1, defer_e, defer_n, deferred_cap)
-    if (k <= 16) JK_P1_LAUNCH(1);
+#define JK_P1_LAUNCH(...) hipLaunchKernelGGL((part1_kernel<__VA_ARGS__>), dim3(G.nblk1), dim3(P1_TH), P1_LDS, stream, d_piece, len, ntiles, emit_from, P, out1, cnt1, defer_e, defer_n, deferred_cap)
+    if (k == 37 && G.p1 == 10 && G.recbits == 64 && !getenv("JASPER_EXPERIMENT_NO_KFIX")) JK_P1_LAUNCH(3, 37);
+    else if (k <= 16) JK_P1_LAUNCH(1);
     else if (k <= 32) JK_P1_LAUNCH(2);
     else JK_P1_LAUNCH(3);                     // (k <= 37: partition_geometry gives 8-byte records only while 2k - 64 <= p1 <= 10)
 #undef JK_P1_LAUNCH
