@@ -532,6 +532,190 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
 }
 constexpr size_t P2_LDS = (size_t)PT_TILE * 8 + (size_t)(3 * PT_MAXBUCKETS + 1 + 16 + P2_MAXSL + 1) * 4;
 
+// ---- level 2, single-GPU form: whole 128-byte lines only ---------------------------------------------------------------------
+// The same job as part2_kernel<false> for the plain case with at most P2F_MAXB lists per bucket.  Two things differ:
+//  * A list's slice is only ever written in whole, aligned 128-byte lines.  What a round leaves over of a list (< 16 records)
+//    waits in LDS (s_carry) and leaves in front of the next round's records; the last round's rest closes the slice.  Measured on
+//    part1's copy-out: runs that begin and end inside a line cost twice -- the line is written by two rounds, and
+//    between the two the half-written line has to survive in an L2 that the open lines of all blocks fill completely.
+//  * few instructions per record: a WAVE streams whole input slices (slice, position and length are scalars: a record's address
+//    is one add), a row that does not exist counts as a record of one extra list that sorts behind all others (no per-record
+//    branch), the copy-out is one lane per staged record, and the loads of the next round are in flight during this one --
+//    waited for before this round's copy-out stores are issued (see part1_kernel).
+constexpr int P2F_MAXB = 128;
+constexpr int P2F_LINE = 16;           // records per 128-byte line
+constexpr int P2F_ROWS = 7;            // rows of 1024 records per round: 56 KB of stage, TWO workgroups per CU (one's loads and stores
+constexpr int P2F_TILE = PT_THREADS * P2F_ROWS;      // run under the other's LDS work; 64 registers per lane: no room for a prefetch)
+// per list and round: stage record i leaves to gbase + 8 i if i < lim, else waits in carry slot i + cadd
+struct P2Meta { uint64_t gbase; uint32_t lim; int32_t cadd; };
+constexpr size_t P2F_LDS = (size_t)P2F_TILE * 8 + (size_t)(3 * (P2F_MAXB + 4) + 32) * 4 + (size_t)P2F_MAXB * sizeof(P2Meta) + (size_t)P2F_MAXB * P2F_LINE * 8;
+struct P2Args {
+    int p1, p2, recbits;
+    uint32_t nblk1, nblk2, cap1, cap2;     // cap2: a multiple of P2F_LINE
+    unsigned long long *stats;
+};
+__global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *__restrict__ out1, const unsigned int *__restrict__ cnt1, P2Args P, uint64_t *__restrict__ out2,
+                                                            unsigned int *__restrict__ cnt2, unsigned long long *__restrict__ deferred,
+                                                            unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    P2Meta *s_meta = reinterpret_cast<P2Meta *>(s_raw);                                      // P2F_MAXB
+    uint64_t *s_carry = reinterpret_cast<uint64_t *>(s_meta + P2F_MAXB);                      // P2F_MAXB x P2F_LINE: what a list has waiting
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_carry + P2F_MAXB * P2F_LINE);    // P2F_MAXB+4  records of this round per list ([nb2] = the padding)
+    unsigned int *s_off = s_cnt + P2F_MAXB + 4;                                              // P2F_MAXB+4  exclusive prefix of s_cnt
+    unsigned int *s_have = s_off + P2F_MAXB + 4;                                             // P2F_MAXB+4  records waiting per list, bit 31: they leave this round
+    unsigned int *s_wsum = s_have + P2F_MAXB + 4;                                            // [0], [1] wave totals, [16] = "a slice overflows", [17] = rounds
+    uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_wsum + 32);                           // P2F_TILE records, list order
+    const int t = threadIdx.x;
+    const int nb2 = 1 << P.p2;
+    const int shift2 = P.recbits - P.p2;               // the p2 bits right below the level-1 bucket bits
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6), lane = (uint32_t)t & 63u;
+    for (uint32_t b1 = blockIdx.y; b1 < (1u << P.p1); b1 += gridDim.y) {
+        auto slice_of = [&](uint32_t b2) { return reinterpret_cast<uint64_t>(out2 + ((((uint64_t)b1 << P.p2) + (uint64_t)b2) * P.nblk2 + blockIdx.x) * P.cap2); };
+        // my wave's input slices: x + (wave + 16 m) * nblk2 of this bucket, m = 0, 1, ...; rounds = the most any wave needs
+        if (t < P2F_MAXB + 4) s_cnt[t] = 0;
+        if (t == 0) { s_wsum[16] = 0; s_wsum[17] = 0; }
+        lds_barrier();
+        const uint32_t sl_step = 16u * P.nblk2;
+        uint32_t sl = blockIdx.x + wave * P.nblk2;                                           // (scalar) current input slice of my wave
+        {
+            uint32_t rounds = 0;
+            for (uint32_t j = sl + lane * sl_step; j < P.nblk1; j += 64u * sl_step) rounds += (cnt1[(uint64_t)b1 * P.nblk1 + j] + 64u * P2F_ROWS - 1u) / (64u * P2F_ROWS);
+            for (int o = 32; o > 0; o >>= 1) rounds += __shfl_xor(rounds, o);
+            if (lane == 0) atomicMax(&s_wsum[17], rounds);
+        }
+        lds_barrier();
+        const uint32_t rounds = s_wsum[17];
+        uint32_t pos = 0;                                                                    // (scalar) position in that slice
+        uint32_t slen = sl < P.nblk1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt1[(uint64_t)b1 * P.nblk1 + sl]) : 0u;
+        const uint64_t *src = out1 + ((uint64_t)b1 * P.nblk1 + sl) * P.cap1;
+        unsigned int cur = 0, have = 0;                    // thread t < nb2, list t: records written to its slice so far (whole lines) / waiting in s_carry
+        uint64_t rec[P2F_ROWS];
+        auto fetch = [&](uint64_t (&dst)[P2F_ROWS], uint32_t &valid) {                       // up to 64 x P2F_ROWS records of my wave's stream; valid = rows that exist (bit j: row j)
+            while (pos >= slen && sl < P.nblk1) {                                            // (scalar) next slice
+                sl += sl_step;
+                pos = 0;
+                slen = sl < P.nblk1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt1[(uint64_t)b1 * P.nblk1 + sl]) : 0u;
+                src = out1 + ((uint64_t)b1 * P.nblk1 + sl) * P.cap1;
+            }
+            valid = 0;
+#pragma unroll
+            for (int j = 0; j < P2F_ROWS; ++j) {
+                const uint32_t i = pos + (uint32_t)j * 64u + lane;
+                dst[j] = ~0ull;
+                if (i < slen) { dst[j] = src[i]; valid |= 1u << j; }
+            }
+            pos += 64u * P2F_ROWS;
+        };
+        uint32_t vmask = 0;
+        for (uint32_t round = 0; round < rounds; ++round) {
+            fetch(rec, vmask);
+            // A. the list of each record, a rank in the round's list histogram (a row that does not exist: the padding list nb2)
+            uint32_t br[P2F_ROWS];
+#pragma unroll
+            for (int j = 0; j < P2F_ROWS; ++j) {
+                const uint32_t b2 = (vmask >> j) & 1u ? (uint32_t)(rec[j] >> shift2) & (uint32_t)(nb2 - 1) : (uint32_t)nb2;
+                br[j] = (b2 << 16) | (atomicAdd(&s_cnt[b2], 1u) & 0xFFFFu);                  // LDS returning atomic; a round holds 2^14 rows
+            }
+            lds_barrier();
+            // B. exclusive prefix of the list counts: thread t owns list t (nb2 <= 128: the first two waves)
+            unsigned int v = 0, inc = 0;
+            if (t < P2F_MAXB) {
+                v = t < nb2 ? s_cnt[t] : 0u;
+                inc = wave_scan_incl(v);
+                if (lane == 63) s_wsum[wave] = inc;
+                s_cnt[t] = 0;
+                if (t == 0) s_cnt[nb2] = 0;
+            }
+            lds_barrier();
+            const unsigned int total = s_wsum[0] + s_wsum[1];
+            unsigned int F = 0;                                                              // records of my list that leave now (whole lines)
+            if (t < nb2) {
+                const unsigned int ex = inc - v + (wave ? s_wsum[0] : 0u);
+                const unsigned int T = have + v;
+                F = T & ~(unsigned int)(P2F_LINE - 1);
+                const unsigned int L = F ? F - have : 0u;                                     // of the new records
+                s_off[t] = ex;
+                P2Meta M;
+                M.gbase = slice_of((uint32_t)t) + ((uint64_t)cur + (uint64_t)have - (uint64_t)ex) * 8ull;      // stage index i -> slice position cur + have + (i - ex)
+                M.lim = ex + L;
+                M.cadd = F ? -(int32_t)(ex + L) : (int32_t)have - (int32_t)ex;                // carry slot of a record that stays: i + cadd
+                s_meta[t] = M;
+                s_have[t] = have | (F ? 0x80000000u : 0u);
+                if (cur + F > P.cap2) s_wsum[16] = 1;                                         // (stays set: the slice stays full)
+            }
+            if (t == 0) s_off[nb2] = total;                                                  // the padding sorts behind every record
+            lds_barrier();
+            // C. rows into LDS in list order
+#pragma unroll
+            for (int j = 0; j < P2F_ROWS; ++j) s_stage[s_off[br[j] >> 16] + (br[j] & 0xFFFFu)] = rec[j];
+            // D1. what waited goes first: lane q of a list's 16 lanes takes waiting record q (read now, stored after the barrier:
+            //     the records that stay this round go into the same slots)
+            int td = t;                                           // (an opaque copy: what is derived from it is recomputed here, not kept live -- and spilled -- across the round)
+            asm volatile("" : "+v"(td));
+            uint64_t cw[2] = {0ull, 0ull};
+            uint32_t cat[2] = {~0u, ~0u};                                                    // its position in the list's slice, ~0 = nothing
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t b2 = ((uint32_t)td >> 4) + (uint32_t)u * 64u, q = (uint32_t)td & 15u;
+                if (b2 < (uint32_t)nb2) {
+                    const unsigned int hv = s_have[b2];
+                    if ((hv >> 31) && q < (hv & 0xFFFFu)) {
+                        cw[u] = s_carry[b2 * P2F_LINE + q];
+                        const P2Meta M = s_meta[b2];
+                        cat[u] = (uint32_t)((int64_t)(M.gbase - slice_of(b2)) / 8 + (int64_t)s_off[b2]) - (hv & 0xFFFFu) + q;      // cur + q
+                    }
+                }
+            }
+            const bool overflow = s_wsum[16] != 0;
+            lds_barrier();
+            if (!overflow) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (cat[u] != ~0u) reinterpret_cast<global_u64 *>(slice_of(((uint32_t)td >> 4) + (uint32_t)u * 64u))[cat[u]] = cw[u];
+                // D2. one lane per staged record: into the slice, or into the list's carry
+#pragma unroll 2
+                for (unsigned int i = (unsigned int)td; i < total; i += PT_THREADS) {
+                    const uint64_t rr = s_stage[i];
+                    const uint32_t b2 = (uint32_t)(rr >> shift2) & (uint32_t)(nb2 - 1);
+                    const P2Meta M = s_meta[b2];
+                    if (i < M.lim) reinterpret_cast<global_u64 *>(M.gbase)[i] = rr;
+                    else s_carry[b2 * P2F_LINE + (uint32_t)((int32_t)i + M.cadd)] = rr;
+                }
+            } else {
+                // a slice is full: record by record, with the bound (what does not fit takes the deferred list)
+                auto put = [&](uint32_t b2, uint64_t at, uint64_t rr) {
+                    if (at < P.cap2) reinterpret_cast<global_u64 *>(slice_of(b2))[at] = rr;
+                    else defer_record(P.stats, hash_of(b1, rr, P.recbits), deferred, deferred_n, deferred_cap);
+                };
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (cat[u] != ~0u) put(((uint32_t)td >> 4) + (uint32_t)u * 64u, cat[u], cw[u]);
+                for (unsigned int i = (unsigned int)td; i < total; i += PT_THREADS) {
+                    const uint64_t rr = s_stage[i];
+                    const uint32_t b2 = (uint32_t)(rr >> shift2) & (uint32_t)(nb2 - 1);
+                    const P2Meta M = s_meta[b2];
+                    if (i < M.lim) put(b2, (uint64_t)((int64_t)(M.gbase - slice_of(b2)) / 8 + (int64_t)i), rr);
+                    else s_carry[b2 * P2F_LINE + (uint32_t)((int32_t)i + M.cadd)] = rr;
+                }
+            }
+            if (t < nb2) { cur += F; have = have + v - F; }
+            // (the next round's barriers order its writes to the stage, s_meta and s_carry against this copy-out)
+        }
+        lds_barrier();
+        // the rest of every list closes its slice (the one line of a slice that is not written whole)
+        if (t < nb2) {
+            for (unsigned int q = 0; q < have; ++q) {
+                const uint64_t rr = s_carry[(uint32_t)t * P2F_LINE + q];
+                if (cur + q < P.cap2) reinterpret_cast<global_u64 *>(slice_of((uint32_t)t))[cur + q] = rr;
+                else defer_record(P.stats, hash_of(b1, rr, P.recbits), deferred, deferred_n, deferred_cap);
+            }
+            const unsigned int n = cur + have;
+            cnt2[(((uint64_t)b1 << P.p2) + (uint64_t)t) * P.nblk2 + blockIdx.x] = n < P.cap2 ? n : P.cap2;
+        }
+        lds_barrier();
+    }
+}
+
 // ---- final: region lists -> LDS image of the region -> table ------------------------------------------------------
 // lists: slices  lists[(region * nsl + x) * cap + i], i < cnt[region * nsl + x].  `parity`: regions with (region & 1) == parity.
 constexpr int LDS_HBINS = 1024;        // histogram bins kept in LDS by lds_insert_kernel (higher multiplicities are rare: global atomics)
@@ -928,7 +1112,7 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     // lds_insert_kernel then reads a region's records as one contiguous list
     static const int nblk2_exp = getenv("JASPER_EXPERIMENT_NBLK2") ? atoi(getenv("JASPER_EXPERIMENT_NBLK2")) : 0;   // tuning experiments only
     G.nblk2 = p2 ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nblk1, nblk2_exp > 0 ? nblk2_exp : ((1u << p1) >= 256 ? 1 : 8))) : 1;
-    G.cap2 = p2 ? list_cap((double)piece_bases / ((double)(1ull << (p1 + p2)) * (double)G.nblk2)) : 0;
+    G.cap2 = p2 ? (list_cap((double)piece_bases / ((double)(1ull << (p1 + p2)) * (double)G.nblk2)) + 15u) & ~15u : 0;      // whole 128-byte lines (part2f_kernel)
     return true;
 }
 
@@ -964,7 +1148,17 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr2_set = true;
         }
-        hipLaunchKernelGGL(part2_kernel<false>, grid, dim3(PT_THREADS), P2_LDS, stream, out1, cnt1, d, G, out2, cnt2, defer_e, defer_n, deferred_cap, 1u);
+        if ((1 << G.p2) <= P2F_MAXB && G.cap2 % P2F_LINE == 0 && !getenv("JASPER_EXPERIMENT_OLDP2")) {
+            static bool attr2f_set = false;
+            if (!attr2f_set) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr2f_set = true;
+            }
+            P2Args P;
+            P.p1 = G.p1; P.p2 = G.p2; P.recbits = G.recbits; P.nblk1 = G.nblk1; P.nblk2 = G.nblk2; P.cap1 = G.cap1; P.cap2 = G.cap2; P.stats = d.stats;
+            hipLaunchKernelGGL(part2f_kernel, grid, dim3(PT_THREADS), P2F_LDS, stream, out1, cnt1, P, out2, cnt2, defer_e, defer_n, deferred_cap);
+        } else
+            hipLaunchKernelGGL(part2_kernel<false>, grid, dim3(PT_THREADS), P2_LDS, stream, out1, cnt1, d, G, out2, cnt2, defer_e, defer_n, deferred_cap, 1u);
         HIPCHK(hipGetLastError());
         lists = out2; lcnt = cnt2; lcap = G.cap2; nsl = G.nblk2;
     }
