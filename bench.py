@@ -519,7 +519,7 @@ def main():
         "roofline": {"bound": "hbm",
                      "kernel": {3: "k-mer counting = part1_kernel + part2_kernel<by owner> on the sender, lds_insert_kernel (even, odd) on the owner, per round",
                                 2: "k-mer counting = mz_part + mz_split + mz_count + split16 (entries) + lds_insert (even, odd) per piece (minimizer super-k-mers)",
-                                1: "k-mer counting = part1_kernel + part2_kernel + region_insert_kernel per piece",
+                                1: "k-mer counting = part1_kernel + part2f_kernel + region_insert_kernel (+ import3h_kernel for deferred records) per piece",
                                 0: "count_kernel"}[T["path"]],
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
