@@ -308,6 +308,42 @@ def _ipc_probe_ok(shard, handles, rank, seconds=None):
     return ok
 
 
+def _job_processes(token):
+    """pids of the processes that carry `token` (a path made by mkdtemp for one job) as a whole command-line argument"""
+    me = os.getpid()
+    found = []
+    for name in os.listdir("/proc"):
+        if not name.isdigit() or int(name) == me:
+            continue
+        try:
+            with open("/proc/%s/cmdline" % name, "rb") as f:
+                args = f.read().split(b"\0")
+        except OSError:
+            continue
+        if token.encode() in args:
+            found.append(int(name))
+    return found
+
+
+def _kill_job_processes(token, seconds=10.0):
+    """SIGKILL to exactly the processes of _job_processes(token); returns how many were still there after `seconds`"""
+    import signal
+    import time
+    t_end = time.monotonic() + seconds
+    while True:
+        pids = _job_processes(token)
+        if not pids:
+            return 0
+        for pid in pids:
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except OSError:
+                pass
+        if time.monotonic() > t_end:
+            return len(pids)
+        time.sleep(0.2)
+
+
 def transport_selftest(world, backend="nccl", one_gpu=False, seconds=240, mb=64):
     """First contact with the transport in throw-away processes (jasper_amd/_selftest.py): `world` ranks, one per GPU, set up a
     process group and run one all_to_all_single of `mb` megabytes, an all_reduce, an all_gather and a barrier -- as a CHILD job
@@ -355,12 +391,21 @@ def transport_selftest(world, backend="nccl", one_gpu=False, seconds=240, mb=64)
                 bad = [q["error"] for q in parts if q and q.get("error")]
                 res["error"] = bad[0] if bad else "self-test exit code %s: %s" % (p.returncode, (errtxt or "")[-300:])
         except subprocess.TimeoutExpired:
+            # the launcher puts every rank into a session of its own: killing the launcher's process group alone would leave
+            # the ranks behind, on the GPUs.  Ask the launcher to end them (it forwards SIGTERM), then kill it, then kill
+            # whatever still carries this job's result path on its command line (the path is unique to this call)
+            try:
+                p.send_signal(signal.SIGTERM)
+                p.communicate(timeout=10)
+            except (OSError, subprocess.TimeoutExpired):
+                pass
             try:
                 os.killpg(p.pid, signal.SIGKILL)            # exactly the process group started above
             except OSError:
                 pass
             p.communicate()
-            res["error"] = "no answer within %d s: killed" % seconds
+            left = _kill_job_processes(out)
+            res["error"] = "no answer within %d s: killed" % seconds + (" (%d rank processes did not go away)" % left if left else "")
     except OSError as e:
         res["error"] = "could not start the self-test: %r" % (e,)
     res["seconds"] = round(time.perf_counter() - t0, 2)
