@@ -57,12 +57,12 @@ constexpr int RG_HALO = 128;                     // slots of the next region a p
 struct PartGeom {
     int p1, p2, rbits;       // p1 + p2 + rbits == s
     int recbits;             // 2k - p1  (<= 64): bits kept in a record
-    uint32_t nblk1;          // part1 grid: every block owns one SLICE of every level-1 list
+    uint32_t nblk1;          // slices per level-1 list: the part1 blocks b, b + nblk1, b + 2 nblk1, ... append to slice b % nblk1 of every list
+    uint32_t grid1;          // part1 blocks
     uint32_t nblk2;          // part2 blocks per level-1 bucket: every one owns a slice of each of the bucket's region lists
     uint32_t cap1, cap2;     // slice capacities (records)
-    int exp;                 // tuning experiments only (JASPER_EXPERIMENT_P1): 0 = the product
 };
-// level-1 list of bucket b = slices  out1[(b * nblk1 + blk) * cap1 ...], filled counts cnt1[b * nblk1 + blk]
+// level-1 list of bucket b = slices  out1[(b * nblk1 + g) * cap1 ...], filled counts cnt1[b * nblk1 + g]
 // region list of region r  = slices  out2[(r * nblk2 + x) * cap2 ...],   filled counts cnt2[r * nblk2 + x]
 
 __device__ __forceinline__ uint64_t rec_of(u128 h, int recbits) { return recbits >= 64 ? h.lo : (h.lo & ((1ull << recbits) - 1ull)); }
@@ -79,11 +79,17 @@ __device__ __forceinline__ void defer_record(const TableDev &T, u128 h, unsigned
 }
 
 // ---- level 1: bases -> records in 2^p1 bucket lists --------------------------------------------------------
-// Every block owns one slice of every bucket list; thread t keeps the cursor of bucket t's slice in a register, so there is
-// no global atomic.  A tile's records are first sorted by bucket inside LDS (rank from a returning LDS atomic, offsets from
-// a block scan) and then copied out in bucket order: consecutive lanes write consecutive records of one slice, i.e. whole
-// 128-B runs.  (Writing each 8-B record straight from the thread that produced it cost 3.9x the bytes in WRITE_SIZE:
-// 1024 open lines per block x 2 blocks per CU do not stay in the 4 MiB L2 until they are full.)
+// A tile's records are first sorted by bucket inside LDS (rank from a returning LDS atomic, offsets from a block scan) and then
+// copied out in bucket order: consecutive lanes write consecutive records of one slice.  (Writing each 8-B record straight from
+// the thread that produced it cost 3.9x the bytes in WRITE_SIZE.)
+// A tile's run in one bucket is ~13 records = 108 bytes: it begins and ends inside 128-byte lines.  With a slice per BLOCK every
+// line is written by two consecutive tiles of its block, 16 us apart, and the open lines of all blocks (256 x 1024 lists x 128 B)
+// are as large as the L2s together: the half-written lines are evicted and written twice (+1.9 ms of 5.7).  So the blocks SHARE
+// their slices: block b appends to slice b % nblk1 of every list (nblk1 = 2), a tile's run gets its place by ONE returning
+// agent-scope atomic add per bucket on the slice's fill count (thread t: bucket t; 16 wave instructions per tile), and a line
+// that one block leaves open is completed by the next tile of any of the other blocks, within a microsecond.  (Sharing among the
+// blocks of one XCD only -- 8 slices, b and b + 8 share an L2 -- is no better than sharing among all: 5.1 against 4.9 ms.)  The
+// atomic's result is not needed before the copy-out: it is in flight during the scan and the staging.
 //
 // The kernel is bound by instruction ISSUE, not by bytes (round 2: 196 wave instructions per record at 4 waves per SIMD), so it
 // is written for few instructions per base:
@@ -94,7 +100,7 @@ __device__ __forceinline__ void defer_record(const TableDev &T, u128 h, unsigned
 //   * the copy-out is per RECORD, not per bucket: a second LDS array holds the bucket of every staged record, so a lane needs
 //     three LDS reads and one multiply-add for its destination (the per-bucket loop of round 2 spent ~35 instructions per
 //     record on 16-lane groups that were 3/4 full);
-//   * five barriers per tile: thread t zeroes bucket t's counter in the scan, cursors live in registers.
+//   * five barriers per tile.
 // The stage holds P1_STAGE records; a tile with more (only input without read boundaries: a genome) is staged in two rounds.
 constexpr int P1_MAXB = 1024;          // part1 handles p1 <= 10; larger p1 falls back to the direct kernel
 constexpr int P1_TH = 1024;
@@ -114,7 +120,7 @@ __device__ __forceinline__ unsigned int wave_scan_incl(unsigned int v) {
 }
 
 struct P1Args {              // what part1_kernel needs of the table and the geometry (few scalar registers: the kernel is short of them)
-    int k, p1, recbits, exp;
+    int k, p1, recbits;
     uint32_t nblk1, cap1;
     unsigned long long *stats;
 };
@@ -156,8 +162,8 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
     // for the tile's 16 windows at once (the largest power of two <= k by doubling, then two such windows that overlap)
     int wlog = 0;
     while ((2 << wlog) <= k) ++wlog;                                            // 2^wlog <= k < 2^(wlog+1)
-    unsigned int cur = 0;                                                       // cursor of bucket t's slice
-    unsigned long long added = 0, added_run = 0;
+    unsigned long long added = 0;
+    const uint32_t grp = blockIdx.x % P.nblk1;                                  // my slice of every list, shared with the blocks grp + j * nblk1
     s_cnt[t] = 0;
     if (t == 0) s_wsum[16] = 0;
     // a block takes a run of consecutive tiles: the 64 bases before a tile are then the tail of the tile before it, still in LDS
@@ -275,16 +281,17 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
             if (tb < PT_HALO) { hc = s_code[P1_TH + tb]; hiv = s_inv[P1_TH + tb]; }   // the tail of this tile = the 64 bases before the next
         }
         lds_barrier();
-        // B. exclusive prefix of the bucket counts: thread t owns bucket t (wave scan + wave totals); the counter is zeroed
-        //    for the next tile and the slice cursor advanced here
+        // B. exclusive prefix of the bucket counts: thread t owns bucket t (wave scan + wave totals); the place of the tile's run
+        //    in the slice is asked for here and looked at after the staging
         unsigned int total;
+        unsigned int apos = 0;
         {
             // (the thread number through an opaque copy: what is derived from it here is recomputed per tile -- hoisted out of the
             //  tile loop as loop invariants these addresses and masks end up spilled to scratch, and every reload waits for vmcnt(0))
             int tb = t;
             asm volatile("" : "+v"(tb));
             const unsigned int v = tb < nb ? s_cnt[tb] : 0u;
-            s_cnt[tb] = 0;
+            if (v) apos = __hip_atomic_fetch_add(&cnt1[(uint64_t)tb * P.nblk1 + grp], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned int inc = wave_scan_incl(v);
             if ((tb & 63) == 63) s_wsum[tb >> 6] = inc;
             lds_barrier();
@@ -294,16 +301,9 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
             total = (unsigned int)__builtin_amdgcn_readlane((int)ws, P1_TH / 64 - 1);
             const unsigned int ex = wbase + inc - v;
             s_off[tb] = ex;
-            const uint64_t slice0 = reinterpret_cast<uint64_t>(out1 + ((uint64_t)tb * P.nblk1 + blockIdx.x) * P.cap1);     // my slice of bucket t's list
-            s_base[tb] = slice0 + ((uint64_t)cur - (uint64_t)ex) * 8ull;
-            cur += v;
-            if (cur > P.cap1 && v) s_wsum[16] = 1;                                   // (stays set: the slice stays full)
         }
         if (t == 0) added += total;
-        const unsigned long long added_all = added_run;
-        added_run += total;
         lds_barrier();
-        if (P.exp & 2) total = 0;                                                   // (timing experiment: hashing and ranking only)
         for (unsigned int r0 = 0; r0 < total; r0 += P1_STAGE) {
             if (r0) lds_barrier();                                                  // the previous round has been copied out
             // C. records into LDS in bucket order
@@ -329,6 +329,17 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                     }
                 }
             }
+            if (r0 == 0) {
+                // where stage index 0 would go in the slice: the run's place has arrived by now; the bucket's counter is zeroed for
+                // the next tile
+                int tc = t;
+                asm volatile("" : "+v"(tc), "+v"(apos));
+                const unsigned int v = s_cnt[tc];
+                s_cnt[tc] = 0;
+                const uint64_t slice0 = reinterpret_cast<uint64_t>(out1 + ((uint64_t)tc * P.nblk1 + grp) * P.cap1);
+                s_base[tc] = slice0 + ((uint64_t)apos - (uint64_t)s_off[tc]) * 8ull;
+                if (v && apos + v > P.cap1) s_wsum[16] = 1;                          // (stays set: the slice stays full)
+            }
             lds_barrier();
             if (r0 == 0 && prefetch) {                                              // the next tile's text has long arrived (see above)
                 asm volatile("" : "+v"(raw.w[0]), "+v"(raw.w[1]), "+v"(raw.w[2]), "+v"(raw.w[3]));     // (not before this point)
@@ -341,27 +352,32 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                 for (unsigned int i = t; i < nr; i += P1_TH) {
                     const uint64_t rr = s_stage[i];
                     const uint32_t b = s_bkt[i];
-                    if (P.exp & 1) reinterpret_cast<global_u64 *>(s_base[b & 7])[(r0 + i) & 1023] = rr;     // (timing experiment: stores that stay in cache)
-                    else if (P.exp & 4) out1[(uint64_t)blockIdx.x * 1024ull * P.cap1 + (added_all + r0 + i) % (1024ull * P.cap1)] = rr;     // (timing experiment: the same bytes as one sequential stream per block)
-                    else reinterpret_cast<global_u64 *>(s_base[b])[r0 + i] = rr;
+                    reinterpret_cast<global_u64 *>(s_base[b])[r0 + i] = rr;
                 }
             } else {
                 for (unsigned int i = t; i < nr; i += P1_TH) {
                     const uint64_t rr = s_stage[i];
                     const uint32_t b = s_bkt[i];
-                    const uint64_t first = reinterpret_cast<uint64_t>(out1 + ((uint64_t)b * P.nblk1 + blockIdx.x) * P.cap1);
+                    const uint64_t first = reinterpret_cast<uint64_t>(out1 + ((uint64_t)b * P.nblk1 + grp) * P.cap1);
                     const uint64_t pos = (uint64_t)(((int64_t)(s_base[b] - first) >> 3) + (int64_t)(r0 + i));   // position in the bucket's slice (s_base may lie below it)
                     if (pos < P.cap1) reinterpret_cast<global_u64 *>(first)[pos] = rr;
                     else defer_record(P.stats, hash_of((uint64_t)b, rr, P.recbits), deferred, deferred_n, deferred_cap);   // slice full
                 }
             }
         }
-        if ((P.exp & 2) && prefetch) encode16(raw.w, c, iv);
+        if (total == 0) {                                                           // (block-uniform) a tile without a k-mer
+            s_cnt[t] = 0;
+            if (prefetch) encode16(raw.w, c, iv);
+        }
         if (has_next && !prefetch) stage16(bases, base0 + (int64_t)PT_TILE + (int64_t)t * PT_GROUP, (int64_t)n, c, iv);      // (the piece's last tile)
         // (the next tile's barriers order its writes to the stage, s_off and s_base against this copy-out)
     }
-    if (t < nb) cnt1[(uint64_t)t * P.nblk1 + blockIdx.x] = P.exp ? 0u : (cur < P.cap1 ? cur : P.cap1);
     if (t == 0 && added) atomicAdd(&P.stats[ST_OCCURRENCES], added);
+}
+// the fill counts were the slices' cursors: one that ran past its slice's end becomes "full" (what did not fit was deferred)
+__global__ __launch_bounds__(256) void clamp_counts_kernel(unsigned int *__restrict__ cnt, uint32_t n, uint32_t cap) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n && cnt[i] > cap) cnt[i] = cap;
 }
 // one launch site for the three word counts: k <= 16, 17..32, 33..37
 static hipError_t launch_part1(hipStream_t stream, int k, const uint8_t *d_piece, uint64_t len, uint64_t ntiles, uint64_t emit_from, const TableDev &d, const PartGeom &G,
@@ -376,13 +392,19 @@ static hipError_t launch_part1(hipStream_t stream, int k, const uint8_t *d_piece
         attr_set = true;
     }
     P1Args P;
-    P.k = k; P.p1 = G.p1; P.recbits = G.recbits; P.exp = G.exp; P.nblk1 = G.nblk1; P.cap1 = G.cap1; P.stats = d.stats;
-#define JK_P1_LAUNCH(...) hipLaunchKernelGGL((part1_kernel<__VA_ARGS__>), dim3(G.nblk1), dim3(P1_TH), P1_LDS, stream, d_piece, len, ntiles, emit_from, P, out1, cnt1, defer_e, defer_n, deferred_cap)
+    P.k = k; P.p1 = G.p1; P.recbits = G.recbits; P.nblk1 = G.nblk1; P.cap1 = G.cap1; P.stats = d.stats;
+    const uint32_t n_cnt1 = (1u << G.p1) * G.nblk1;
+    {
+        hipError_t e = hipMemsetAsync(cnt1, 0, (size_t)n_cnt1 * 4, stream);
+        if (e != hipSuccess) return e;
+    }
+#define JK_P1_LAUNCH(...) hipLaunchKernelGGL((part1_kernel<__VA_ARGS__>), dim3(G.grid1), dim3(P1_TH), P1_LDS, stream, d_piece, len, ntiles, emit_from, P, out1, cnt1, defer_e, defer_n, deferred_cap)
     if (k == 37 && G.p1 == 10 && G.recbits == 64 && !getenv("JASPER_EXPERIMENT_NO_KFIX")) JK_P1_LAUNCH(3, 37);
     else if (k <= 16) JK_P1_LAUNCH(1);
     else if (k <= 32) JK_P1_LAUNCH(2);
     else JK_P1_LAUNCH(3);                     // (k <= 37: partition_geometry gives 8-byte records only while 2k - 64 <= p1 <= 10)
 #undef JK_P1_LAUNCH
+    hipLaunchKernelGGL(clamp_counts_kernel, dim3((n_cnt1 + 255) / 256), dim3(256), 0, stream, cnt1, n_cnt1, G.cap1);
     return hipGetLastError();
 }
 
@@ -549,9 +571,10 @@ constexpr int P2F_TILE = PT_THREADS * P2F_ROWS;      // run under the other's LD
 // per list and round: stage record i leaves to gbase + 8 i if i < lim, else waits in carry slot i + cadd
 struct P2Meta { uint64_t gbase; uint32_t lim; int32_t cadd; };
 constexpr size_t P2F_LDS = (size_t)P2F_TILE * 8 + (size_t)(3 * (P2F_MAXB + 4) + 32) * 4 + (size_t)P2F_MAXB * sizeof(P2Meta) + (size_t)P2F_MAXB * P2F_LINE * 8;
+constexpr int P2F_PIECE = 64 * P2F_ROWS * 9;         // records per input piece: nine full wave rounds (4032 records, 252 lines)
 struct P2Args {
     int p1, p2, recbits;
-    uint32_t nblk1, nblk2, cap1, cap2;     // cap2: a multiple of P2F_LINE
+    uint32_t nblk1, vper, nblk2, cap1, cap2;     // vper = pieces per level-1 slice; cap2: a multiple of P2F_LINE
     unsigned long long *stats;
 };
 __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *__restrict__ out1, const unsigned int *__restrict__ cnt1, P2Args P, uint64_t *__restrict__ out2,
@@ -571,31 +594,48 @@ __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *_
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6), lane = (uint32_t)t & 63u;
     for (uint32_t b1 = blockIdx.y; b1 < (1u << P.p1); b1 += gridDim.y) {
         auto slice_of = [&](uint32_t b2) { return reinterpret_cast<uint64_t>(out2 + ((((uint64_t)b1 << P.p2) + (uint64_t)b2) * P.nblk2 + blockIdx.x) * P.cap2); };
-        // my wave's input slices: x + (wave + 16 m) * nblk2 of this bucket, m = 0, 1, ...; rounds = the most any wave needs
+        // The bucket's few long slices are read in PIECES of P2F_PIECE records (P.vper pieces per slice, by its capacity): piece
+        // x + (wave + 16 m) * nblk2, m = 0, 1, ... is my wave's input; rounds = the most any wave needs
         if (t < P2F_MAXB + 4) s_cnt[t] = 0;
         if (t == 0) { s_wsum[16] = 0; s_wsum[17] = 0; }
         lds_barrier();
         const uint32_t sl_step = 16u * P.nblk2;
-        uint32_t sl = blockIdx.x + wave * P.nblk2;                                           // (scalar) current input slice of my wave
+        const uint32_t npieces = P.nblk1 * P.vper;
+        auto piece_len = [&](uint32_t j) -> uint32_t {                                       // records of piece j (j < npieces)
+            const uint32_t c = cnt1[(uint64_t)b1 * P.nblk1 + j / P.vper], first = (j % P.vper) * (uint32_t)P2F_PIECE;
+            return c > first ? (c - first < (uint32_t)P2F_PIECE ? c - first : (uint32_t)P2F_PIECE) : 0u;
+        };
+        uint32_t sl = blockIdx.x + wave * P.nblk2;                                           // (scalar) current input piece of my wave
         {
             uint32_t rounds = 0;
-            for (uint32_t j = sl + lane * sl_step; j < P.nblk1; j += 64u * sl_step) rounds += (cnt1[(uint64_t)b1 * P.nblk1 + j] + 64u * P2F_ROWS - 1u) / (64u * P2F_ROWS);
+            for (uint32_t j = sl + lane * sl_step; j < npieces; j += 64u * sl_step) rounds += (piece_len(j) + 64u * P2F_ROWS - 1u) / (64u * P2F_ROWS);
             for (int o = 32; o > 0; o >>= 1) rounds += __shfl_xor(rounds, o);
             if (lane == 0) atomicMax(&s_wsum[17], rounds);
         }
         lds_barrier();
         const uint32_t rounds = s_wsum[17];
-        uint32_t pos = 0;                                                                    // (scalar) position in that slice
-        uint32_t slen = sl < P.nblk1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt1[(uint64_t)b1 * P.nblk1 + sl]) : 0u;
-        const uint64_t *src = out1 + ((uint64_t)b1 * P.nblk1 + sl) * P.cap1;
+        uint32_t pos = 0;                                                                    // (scalar) position in that piece
+        uint32_t ph = sl / P.vper, sub = sl % P.vper;                                        // (scalar) piece sl = piece `sub` of slice `ph`
+        auto open_piece = [&](uint32_t &len_out, const uint64_t *&src_out) {
+            len_out = 0;
+            if (sl < npieces) {
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt1[(uint64_t)b1 * P.nblk1 + ph]), first = sub * (uint32_t)P2F_PIECE;
+                len_out = c > first ? (c - first < (uint32_t)P2F_PIECE ? c - first : (uint32_t)P2F_PIECE) : 0u;
+            }
+            src_out = out1 + ((uint64_t)b1 * P.nblk1 + ph) * P.cap1 + (uint64_t)sub * P2F_PIECE;
+        };
+        uint32_t slen;
+        const uint64_t *src;
+        open_piece(slen, src);
         unsigned int cur = 0, have = 0;                    // thread t < nb2, list t: records written to its slice so far (whole lines) / waiting in s_carry
         uint64_t rec[P2F_ROWS];
         auto fetch = [&](uint64_t (&dst)[P2F_ROWS], uint32_t &valid) {                       // up to 64 x P2F_ROWS records of my wave's stream; valid = rows that exist (bit j: row j)
-            while (pos >= slen && sl < P.nblk1) {                                            // (scalar) next slice
+            while (pos >= slen && sl < npieces) {                                            // (scalar) next piece
                 sl += sl_step;
+                sub += sl_step;
+                while (sub >= P.vper) { sub -= P.vper; ++ph; }
                 pos = 0;
-                slen = sl < P.nblk1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt1[(uint64_t)b1 * P.nblk1 + sl]) : 0u;
-                src = out1 + ((uint64_t)b1 * P.nblk1 + sl) * P.cap1;
+                open_piece(slen, src);
             }
             valid = 0;
 #pragma unroll
@@ -1099,15 +1139,20 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     }
     if (!ok) return false;
     G.p1 = p1; G.p2 = p2; G.rbits = s - p1 - p2; G.recbits = B - p1;
-    static const int exp_env = getenv("JASPER_EXPERIMENT_P1") ? atoi(getenv("JASPER_EXPERIMENT_P1")) : 0;
-    G.exp = exp_env;
-    // slices should hold >= ~512 records on average so that their 1.25x + 8 sigma capacity wastes little
+    // one 1024-thread block (159 KB of LDS) per CU; the blocks of an XCD (b, b + 8, ...) share their slices (part1_kernel)
     const uint64_t tile1 = (uint64_t)PT_TILE;
     const uint64_t ntiles = (piece_bases + tile1 - 1) / tile1;
-    uint64_t nblk1 = piece_bases / ((uint64_t)(1u << p1) * 512);
-    nblk1 = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(nblk1, ntiles), 256));   // one 1024-thread block (159 KB of LDS) per CU
+    uint64_t grid1 = piece_bases / ((uint64_t)(1u << p1) * 512);
+    grid1 = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(grid1, ntiles), 256));
+    static const int ngrp_exp = getenv("JASPER_EXPERIMENT_NGRP") ? atoi(getenv("JASPER_EXPERIMENT_NGRP")) : 0;     // tuning experiments only
+    // (measured, 47 Mb workload: 1, 2 or 4 slices per list 4.9-5.0 ms, 8 slices 5.1, a slice per block 5.6-5.7 without and 6.2 with
+    //  the atomics; few buckets: 8 slices, so that part2's blocks per bucket each find slices of their own)
+    const uint64_t nblk1 = std::min<uint64_t>(grid1, ngrp_exp > 0 ? (uint64_t)ngrp_exp : ((1u << p1) >= 256 ? 2 : 8));
+    G.grid1 = (uint32_t)grid1;
     G.nblk1 = (uint32_t)nblk1;
-    G.cap1 = list_cap((double)piece_bases / ((double)(1u << p1) * (double)nblk1));
+    // (a slice takes the tiles of ceil(grid1 / nblk1) blocks of ceil(ntiles / grid1) tiles each)
+    const uint64_t tiles_per_slice = ((grid1 + nblk1 - 1) / nblk1) * ((ntiles + grid1 - 1) / grid1);
+    G.cap1 = list_cap((double)std::min<uint64_t>(piece_bases, tiles_per_slice * tile1) / (double)(1u << p1));
     // one slice per region list: part2 runs one 1024-thread block per CU, and 2^p1 >= 256 buckets already fill the chip;
     // lds_insert_kernel then reads a region's records as one contiguous list
     static const int nblk2_exp = getenv("JASPER_EXPERIMENT_NBLK2") ? atoi(getenv("JASPER_EXPERIMENT_NBLK2")) : 0;   // tuning experiments only
@@ -1156,6 +1201,7 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
             }
             P2Args P;
             P.p1 = G.p1; P.p2 = G.p2; P.recbits = G.recbits; P.nblk1 = G.nblk1; P.nblk2 = G.nblk2; P.cap1 = G.cap1; P.cap2 = G.cap2; P.stats = d.stats;
+            P.vper = (G.cap1 + (uint32_t)P2F_PIECE - 1u) / (uint32_t)P2F_PIECE;
             hipLaunchKernelGGL(part2f_kernel, grid, dim3(PT_THREADS), P2F_LDS, stream, out1, cnt1, P, out2, cnt2, defer_e, defer_n, deferred_cap);
         } else
             hipLaunchKernelGGL(part2_kernel<false>, grid, dim3(PT_THREADS), P2_LDS, stream, out1, cnt1, d, G, out2, cnt2, defer_e, defer_n, deferred_cap, 1u);

@@ -577,6 +577,7 @@ def test_atomic_free_counting_paths_equal_direct_counting(KT, k):
     reads[1000:1600] = ord("A")
     reads[5000:5400] = torch.tensor(list(b"ACACACACACACACACACAC" * 20), dtype=torch.uint8, device=dev)
     reads[9000:9300] = ord("N")
+    reads[2_000_000:2_050_000] = ord("N")         # whole 16384-base tiles of the partition pass without a single k-mer
     torch.cuda.synchronize()
     slots = int(1.25 * nreads * 150 * 2.1 / 10)
     os.environ["JASPER_COUNT_PATH"] = "2"
