@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace jk {
 
@@ -32,8 +33,9 @@ struct DevBuf {  // a slot of the table's grow-only workspace (not owned) or a t
 };
 }  // namespace
 
-int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *lens, int solid_thre, int passes, int fix,
-               PolishOut &R, std::string &err, bool device_in, bool keep_on_device, int roomy) {
+// one lane: these chunk records through all passes, on stream `st`, in the lane's own workspace slots and pinned buffers
+static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunks, const char *const *seqs, const int64_t *lens, int solid_thre, int passes, int fix,
+                           PolishOut &R, std::string &err, bool device_in, bool keep_on_device, int roomy) {
     // `roomy`: every slack / bound below is a guess about how much a pass can add; the default guesses are generous for
     // real polishing (edits are ~0.1 % of the text).  If one is exceeded the call fails cleanly with -2 and the caller
     // repeats it with roomy = 1: 8x the slack (nothing of a failed call is kept, so the repeat is exact).
@@ -44,9 +46,8 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     const int64_t M = 3ll * k;        // text kept right of the next sync point
     const int64_t TMIN = 1024;        // minimum distance between sync points
     const int64_t CMIN = 32768;       // minimum distance between a clean-zone boundary and its neighbours
-    hipStream_t st = T.stream;
     HIPCHK(hipSetDevice(T.device));
-    if (T.materialize(err)) return -1;
+    const int ws_base = lane ? Table::WS_LANE0 + (lane - 1) * Table::WS_POLISH_MAX : 0, pin_base = lane * Table::PIN_PER_LANE;
     R.seqs.assign(n_chunks, std::string());
     R.d_seqs.clear();
     R.d_lens.clear();
@@ -91,7 +92,7 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     int ws_next = 0;
     auto dmalloc = [&](DevBuf &b, size_t bytes) -> bool {      // persistent: slot of the table's workspace
         if (ws_next >= Table::WS_POLISH_MAX) { err = "polish: workspace slots exhausted"; return false; }
-        b.p = T.workspace(ws_next++, bytes, err);
+        b.p = T.workspace(ws_base + ws_next++, bytes, err);
         b.owned = false;
         return b.p != nullptr;
     };
@@ -120,13 +121,13 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
         !dmalloc(b_seq, (size_t)max_segs * 4) || !dmalloc(b_ro, (size_t)max_segs * 4) || !dmalloc(b_ao, (size_t)max_segs * 4)) return -2;
     // pinned host memory for everything that crosses PCIe inside the pass loop (kept with the table)
     const size_t PIN_RECS = 1u << 18, PIN_AUX = 8u << 20;            // records / aux bytes of ALL passes that travel without a host wait
-    SegDev *segs_p = reinterpret_cast<SegDev *>(T.pinned(0, (size_t)max_segs * sizeof(SegDev), err));
-    int32_t *first_p = reinterpret_cast<int32_t *>(T.pinned(1, ((size_t)n_chunks + 1) * 4, err));
-    ChunkSummary *sum_p = reinterpret_cast<ChunkSummary *>(T.pinned(2, (size_t)n_chunks * sizeof(ChunkSummary), err));
-    int64_t *cand_p = reinterpret_cast<int64_t *>(T.pinned(3, (std::min<size_t>(cand_items, 32768) + cell_items + 8) * 8, err));
-    FixRec *recs_p = reinterpret_cast<FixRec *>(T.pinned(4, PIN_RECS * sizeof(FixRec), err));
-    uint8_t *aux_p = reinterpret_cast<uint8_t *>(T.pinned(5, PIN_AUX, err));
-    ScanChunk *sc_p = reinterpret_cast<ScanChunk *>(T.pinned(6, sizeof(ScanChunk) * (size_t)n_chunks, err));
+    SegDev *segs_p = reinterpret_cast<SegDev *>(T.pinned(pin_base + 0, (size_t)max_segs * sizeof(SegDev), err));
+    int32_t *first_p = reinterpret_cast<int32_t *>(T.pinned(pin_base + 1, ((size_t)n_chunks + 1) * 4, err));
+    ChunkSummary *sum_p = reinterpret_cast<ChunkSummary *>(T.pinned(pin_base + 2, (size_t)n_chunks * sizeof(ChunkSummary), err));
+    int64_t *cand_p = reinterpret_cast<int64_t *>(T.pinned(pin_base + 3, (std::min<size_t>(cand_items, 32768) + cell_items + 8) * 8, err));
+    FixRec *recs_p = reinterpret_cast<FixRec *>(T.pinned(pin_base + 4, PIN_RECS * sizeof(FixRec), err));
+    uint8_t *aux_p = reinterpret_cast<uint8_t *>(T.pinned(pin_base + 5, PIN_AUX, err));
+    ScanChunk *sc_p = reinterpret_cast<ScanChunk *>(T.pinned(pin_base + 6, sizeof(ScanChunk) * (size_t)n_chunks, err));
     if (!segs_p || !first_p || !sum_p || !cand_p || !recs_p || !aux_p || !sc_p) return -2;
     size_t pin_recs_used = 0, pin_aux_used = 0;
     struct PinnedPass { size_t rec_at, nrec, aux_at, naux, r0, pass_i; };      // what a pass left in the pinned record buffers: copied out after the last pass
@@ -574,6 +575,102 @@ int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *l
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     return rc;
+}
+
+// A batch as several lanes.  Chunk records are independent (the reference runs one process per batch file, src/jasper.sh:207-212),
+// and one lane leaves most of the chip idle most of the time: its walks are chains of dependent lookups on a few thousand waves,
+// the slowest segment of a pass (a path search: 0.6 ms) or the chain through a chunk's clean zones (0.6 ms in the later passes)
+// sets the pass's length whatever the number of chunks, and between the passes the host cuts the next segments.  Groups of
+// chunks, each with its own stream, host thread and workspace, fill each other's gaps: one's walk tail and host work run under
+// another's kernels.  Measured (47 Mb in 18 chunk records): 4.7 ms in one lane, 4.55-4.7 in two, 4.35-4.65 in three, worse in
+// four -- the HBM-bound scans only share the bandwidth and every lane still has its own chain of walks -- while the first
+// call pays the workspace allocations once per lane (the drop-in end to end: 0.80 -> 0.97 s).  So ONE lane is the default and
+// JASPER_POLISH_LANES=n asks for more.  Results are per chunk, the same in any number of lanes -- only the records have to
+// be merged back into batch order (tests/test_gpu_parity.py).
+int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *lens, int solid_thre, int passes, int fix,
+               PolishOut &R, std::string &err, bool device_in, bool keep_on_device, int roomy) {
+    HIPCHK(hipSetDevice(T.device));
+    if (T.materialize(err)) return -1;
+    int lanes = 1;                                                                        // (measured: too little gained to be the default)
+    if (const char *e = getenv("JASPER_POLISH_LANES")) lanes = atoi(e);                   // (tests, tuning)
+    if (getenv("JASPER_POLISH_DEBUG")) lanes = 1;                                         // (its statistics are one lane's)
+    lanes = std::max(1, std::min(std::min(lanes, (int)Table::POLISH_LANES_MAX), n_chunks / 2));
+    if (lanes == 1) return run_polish_lane(T, 0, T.stream, n_chunks, seqs, lens, solid_thre, passes, fix, R, err, device_in, keep_on_device, roomy);
+
+    // groups of about the same length: longest first to the lightest lane; inside a lane, batch order
+    std::vector<int> order(n_chunks);
+    for (int c = 0; c < n_chunks; ++c) order[c] = c;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+    std::vector<std::vector<int>> mine(lanes);
+    std::vector<int64_t> load(lanes, 0);
+    for (int c : order) {
+        int l = 0;
+        for (int j = 1; j < lanes; ++j) if (load[j] < load[l]) l = j;
+        mine[l].push_back(c);
+        load[l] += lens[c];
+    }
+    for (auto &m : mine) std::sort(m.begin(), m.end());
+    // the lanes' streams start behind what the table's stream has been given so far (the counting)
+    if (!T.polish_ev) HIPCHK(hipEventCreateWithFlags(&T.polish_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(T.polish_ev, T.stream));
+    for (int l = 1; l < lanes; ++l) {
+        if (!T.polish_stream[l]) HIPCHK(hipStreamCreateWithFlags(&T.polish_stream[l], hipStreamNonBlocking));
+        HIPCHK(hipStreamWaitEvent(T.polish_stream[l], T.polish_ev, 0));
+    }
+    std::vector<PolishOut> out(lanes);
+    std::vector<std::string> errs(lanes);
+    std::vector<int> rcs(lanes, 0);
+    std::vector<std::vector<const char *>> lseqs(lanes);
+    std::vector<std::vector<int64_t>> llens(lanes);
+    for (int l = 0; l < lanes; ++l)
+        for (int c : mine[l]) { lseqs[l].push_back(seqs[c]); llens[l].push_back(lens[c]); }
+    auto run = [&](int l) {
+        rcs[l] = run_polish_lane(T, l, l ? T.polish_stream[l] : T.stream, (int)mine[l].size(), lseqs[l].data(), llens[l].data(), solid_thre, passes, fix, out[l],
+                                 errs[l], device_in, keep_on_device, roomy);
+    };
+    {
+        std::vector<std::thread> th;
+        for (int l = 1; l < lanes; ++l) th.emplace_back(run, l);
+        run(0);
+        for (auto &t : th) t.join();
+    }
+    // (every lane has waited for its stream; a failure of any lane fails the call: HIP error, then "the reference exits 1", then capacity)
+    for (int want : {-1, -4, -2})
+        for (int l = 0; l < lanes; ++l)
+            if (rcs[l] == want) { err = errs[l]; return want; }
+    for (int l = 0; l < lanes; ++l)
+        if (rcs[l]) { err = errs[l]; return rcs[l]; }
+    R.seqs.assign(n_chunks, std::string());
+    R.aux.assign(n_chunks, std::string());
+    R.d_seqs.clear();
+    R.d_lens.clear();
+    if (keep_on_device) { R.d_seqs.assign(n_chunks, nullptr); R.d_lens.assign(n_chunks, 0); }
+    R.recs.clear();
+    R.qv[0] = R.qv[1] = R.qv[2] = R.qv[3] = 0;
+    R.qv_chunk.assign((size_t)4 * n_chunks, 0);
+    R.lookups = 0; R.seconds = 0; R.n_segments = 0; R.n_respeculated = 0;
+    for (int l = 0; l < lanes; ++l) {
+        PolishOut &O = out[l];
+        for (size_t j = 0; j < mine[l].size(); ++j) {
+            const int c = mine[l][j];
+            R.seqs[c].swap(O.seqs[j]);
+            R.aux[c].swap(O.aux[j]);
+            if (keep_on_device) { R.d_seqs[c] = O.d_seqs[j]; R.d_lens[c] = O.d_lens[j]; }
+            for (int q = 0; q < 4; ++q) R.qv_chunk[4 * (size_t)c + q] = O.qv_chunk[4 * j + q];
+        }
+        for (FixRec f : O.recs) { f.chunk = (uint32_t)mine[l][f.chunk]; R.recs.push_back(f); }
+        for (int q = 0; q < 4; ++q) R.qv[q] += O.qv[q];
+        R.lookups += O.lookups;
+        R.n_segments += O.n_segments;
+        R.n_respeculated += O.n_respeculated;
+        R.seconds = std::max(R.seconds, O.seconds);
+    }
+    std::stable_sort(R.recs.begin(), R.recs.end(), [](const FixRec &a, const FixRec &b) {
+        if (a.chunk != b.chunk) return a.chunk < b.chunk;
+        if (a.pass != b.pass) return a.pass < b.pass;
+        return a.seqno < b.seqno;
+    });
+    return 0;
 }
 
 }  // namespace jk

@@ -336,12 +336,19 @@ struct Table {
     uint64_t size_hint = 0;   // caller's expected number of distinct k-mers (`jellyfish count -s`); 0 = none given
     // grow-only device workspace reused by the polisher across calls (hipMalloc of GBs costs far more than the kernels)
     struct WsBuf { void *p = nullptr; size_t bytes = 0; };
-    static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_INGEST = 44, WS_MZ = 50, WS_HOSTBASES = 54, WS_SLOTS = 55;
+    // The polisher may run a batch as several LANES at once (groups of chunk records, each with a stream, a host thread and a
+    // workspace of its own: polish_host.hip): lane 0 uses the table's stream and the first WS_POLISH_MAX slots, lane l > 0
+    // polish_stream[l] and the slots from WS_LANE0 + (l - 1) * WS_POLISH_MAX on.
+    static constexpr int POLISH_LANES_MAX = 4;
+    static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_INGEST = 44, WS_MZ = 50, WS_HOSTBASES = 54, WS_LANE0 = 55,
+                         WS_SLOTS = WS_LANE0 + (POLISH_LANES_MAX - 1) * WS_POLISH_MAX;
     WsBuf ws[WS_SLOTS];   // 0..WS_POLISH_MAX-1: polisher (polish_host.hip, in allocation order); WS_COUNT..+3: partitioned counting
+    hipStream_t polish_stream[POLISH_LANES_MAX] = {nullptr, nullptr, nullptr, nullptr};      // [0] unused (= stream); created on first use
+    hipEvent_t polish_ev = nullptr;
     void *workspace(int id, size_t bytes, std::string &err);
     // grow-only PINNED host buffers kept with the table (the polisher's segment tables, candidate lists and records travel through
     // them: a copy to or from pageable memory is staged by the runtime and makes the caller wait)
-    static constexpr int PIN_SLOTS = 8;
+    static constexpr int PIN_PER_LANE = 8, PIN_SLOTS = PIN_PER_LANE * POLISH_LANES_MAX;
     WsBuf pin[PIN_SLOTS];
     void *pinned(int id, size_t bytes, std::string &err);
 

@@ -165,6 +165,42 @@ def test_polish_vs_oracle(KT, O, k, G, seed, thre, passes):
     t.close()
 
 
+@pytest.mark.parametrize("lanes,tight", [(2, False), (3, False), (4, False), (3, True)])
+def test_polish_in_lanes_equals_one_lane_and_oracle(KT, O, lanes, tight):
+    """a batch run as several lanes (groups of chunk records with a stream, a host thread and a workspace each; the default for
+    batches of 4 MB and more) gives what one lane gives: text, every fix row in batch order, QV counters per chunk -- also when
+    a lane's first attempt runs out of room and the whole call is repeated with more (JASPER_POLISH_TIGHT)"""
+    from jasper_amd import polisher
+    k, G, thre, passes = 37, 900_000, 3, 2
+    genome, reads, asm = workload(31, G, k, asm_err=2e-3)
+    t = KT(k, min_slots=1 << 20)
+    t.count_bases(reads)
+    db = O.OracleDB(k)
+    db.count_bases(reads)
+    # ragged chunk lengths, a tiny and an empty record in the middle of the batch
+    cuts = [0, 40_000, 41_000, 250_000, 250_050, 250_050, 600_000, 820_000, len(asm)]
+    seqs = [asm[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    names = ["c:%d" % a for a in cuts[:-1]]
+    fixed_o, rows_o, qv_o, _ = db.polish_batch(names, seqs, thre, passes)
+    os.environ["JASPER_POLISH_LANES"] = "1"
+    try:
+        one = t.polish_batch(seqs, thre, passes)
+        os.environ["JASPER_POLISH_LANES"] = str(lanes)
+        if tight:
+            os.environ["JASPER_POLISH_TIGHT"] = "1"
+        fixed, rows, qv, res = polisher.polish_batch(t, names, seqs, thre, passes)
+    finally:
+        del os.environ["JASPER_POLISH_LANES"]
+        os.environ.pop("JASPER_POLISH_TIGHT", None)
+    assert fixed == fixed_o == one.seqs and qv == qv_o == one.qv
+    for it in range(passes):
+        assert polisher.fix_csv_text(rows[it]) == "Contig Base_coord Original Mutation\r\n" + rows_o[it]
+    assert res.records == one.records and res.segments == one.segments and res.lookups == one.lookups
+    assert [res.qv_chunk(i) for i in range(len(seqs))] == [one.qv_chunk(i) for i in range(len(seqs))]
+    assert bool(res.retried) == tight
+    t.close()
+
+
 def test_reads_files_formats_and_gzip(KT, O, tmp_path):
     """`zcat -f R1 R2 | jellyfish count`: one stream, format from the first byte, plain and gzip mixed"""
     k = 21
