@@ -913,35 +913,10 @@ struct Walker {
                     }
                 }
             }
-            // the classes of the next three blocks of 64 stride positions were asked for together with this block's: where the
-            // text is still pass-start text (long clean stretches, later passes) a step costs one class byte, and the loop is a
-            // chain of load latencies -- four blocks per latency instead of one
-            constexpr int AHEAD = 3;
-            bool evn[AHEAD], usable[AHEAD];
-#pragma unroll
-            for (int j = 0; j < AHEAD; ++j) {
-                const int64_t pj = p + (int64_t)(j + 1) * 64ll * (k - 1);
-                evn[j] = true;
-                usable[j] = false;
-                if (pj >= end) { usable[j] = true; evn[j] = true; }                 // (past the end: an event, like in the block loop above)
-                else if (cls != nullptr && pj >= dirty_end + k) {
-                    const int64_t o = pj - delta + seg_lo;
-                    if (!is_last && o >= stop_orig) usable[j] = true;
-                    else if (o >= 0 && o < cls_n) { usable[j] = true; evn[j] = cls[o] != PC_CLEAN; }
-                }
-            }
             const uint64_t mask = __ballot(ev);
             nlook += 128;
             if (mask) return i + (int64_t)__builtin_ctzll(mask) * (k - 1);
             i += 64ll * (k - 1);
-#pragma unroll
-            for (int j = 0; j < AHEAD; ++j) {
-                if (i >= end || __ballot(!usable[j])) break;                         // (wave-uniform) a lane of this block needs the full evaluation
-                const uint64_t mj = __ballot(evn[j]);
-                nlook += 128;
-                if (mj) return i + (int64_t)__builtin_ctzll(mj) * (k - 1);
-                i += 64ll * (k - 1);
-            }
         }
     }
 
