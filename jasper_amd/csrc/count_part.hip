@@ -6,18 +6,20 @@
 // DESIGN.md 4.1).  Here the table is updated with LDS atomics instead:
 //
 //   part1_kernel   bases -> mixed hash -> bucket = top p1 hash bits; the remaining (2k-p1 <= 64) bits go, as one
-//                  8-byte record, into the bucket's list.  Per 16 K-record tile: LDS histogram (returning LDS
-//                  atomics give every record its rank), block scan, records sorted by bucket inside LDS, copied out in
-//                  bucket order: whole 128-B runs into the block's own slice of every bucket list (no global atomic).
-//   part2_kernel   same scheme on each bucket, by the next p2 hash bits  ->  2^(p1+p2) lists, one per table REGION
-//                  of 2^rbits <= 8192 consecutive slots (home slot = top hash bits, so a region is a hash range).
-//   lds_insert_kernel  one workgroup per region: region (+128-slot halo so a probe may run past the region end) is
-//                  loaded into LDS (130 KB; started from zeros on a lazily cleared table), records are inserted with
-//                  LDS compare-and-swap / add, image written back -- and, when this pass produces the final counts
-//                  of the whole table, binned into the multiplicity histogram on the way out.
-//                  Even and odd regions run in two launches, so no two resident images overlap.
-//   A record that finds no room (slice full, probe beyond the halo) goes to a deferred list that import3_kernel drains
-//   through the direct path after the last lds_insert.
+//                  8-byte record, into the bucket's list.  Per 16 K-base tile: LDS histogram (returning LDS atomics give
+//                  every record its rank), block scan, records sorted by bucket inside LDS, copied out in bucket order
+//                  into the list's slice, at a place taken by one returning atomic per bucket and tile.
+//   part2f_kernel  same scheme on each bucket, by the next p2 hash bits  ->  2^(p1+p2) lists, one per table REGION
+//                  of 2^rbits <= 8192 consecutive slots (home slot = top hash bits, so a region is a hash range); slices
+//                  written in whole 128-byte lines.  (part2_kernel: the general form -- more than 128 lists per bucket,
+//                  lists laid out by key owner for the exchange between GPUs, an owner's extra split pass.)
+//   region_insert_kernel  one workgroup per region: an LDS image of the region's slots (started from zeros on a table
+//                  that is logically empty), records inserted with LDS compare-and-swap / add, image written back --
+//                  and, when this pass produces the final counts of the whole table, binned into the multiplicity
+//                  histogram on the way out.  One launch; the owner's side of the exchange reads N senders' slices.
+//   A record that finds no room (slice full, probe past the region's end) goes to a deferred list that import3h_kernel
+//   drains through the direct path afterwards.
+//   (lds_insert_kernel: round 2's form of the last pass, kept for the 16-byte entries of count_mz.hip.)
 //
 // The table layout, tags and probe order are exactly those of the direct path, so lookups, histogram, export, growth
 // and the polisher do not know which path filled the table.  HBM traffic per k-mer: 1 B base + 8 B x 2 (part1 list)
@@ -418,7 +420,7 @@ static hipError_t launch_part1(hipStream_t stream, int k, const uint8_t *d_piece
 constexpr int P2_MAXSL = 512;          // level-1 slices per bucket (= nblk1 <= 512)
 // OWN (the multi-GPU exchange, count_exchange below): a bucket is split 2^p2 * nown ways, by (owner_of(hash), next p2
 // hash bits), and the lists are laid out owner-major -- list ((o * 2^p1 + b1) << p2) + b2 -- so that everything owner o
-// is to receive is ONE contiguous block of out2 / cnt2: the region lists of o's own table, ready for lds_insert_kernel.
+// is to receive is ONE contiguous block of out2 / cnt2: the region lists of o's own table, ready for region_insert_kernel<., XCHG>.
 // MIN (the owner's extra pass when the senders could not split finely enough, count_exchange below): the input slices of a
 // bucket come from nsrc senders, each of which laid out ITS lists of all buckets as one block -- slice j of bucket b =
 // sender j / (nblk1/nsrc), its slice j % (nblk1/nsrc): list index ((sender * buckets + b) * (nblk1/nsrc) + that).
@@ -756,26 +758,19 @@ __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *_
     }
 }
 
-// ---- final: region lists -> LDS image of the region -> table ------------------------------------------------------
-// lists: slices  lists[(region * nsl + x) * cap + i], i < cnt[region * nsl + x].  `parity`: regions with (region & 1) == parity.
-constexpr int LDS_HBINS = 1024;        // histogram bins kept in LDS by lds_insert_kernel (higher multiplicities are rare: global atomics)
-// ENT = false: lists of 8-byte records (count_part.hip: low hash bits, one occurrence each);  ENT = true: lists of 16-byte
-// (hash, count) entries { hash.lo, hash.hi | count << 32 } (count_mz.hip) -- the whole hash is there, the count is added.
-// MULTI (count_exchange below): the region's slices come from nsrc senders, each of which laid out ITS lists of all my
-// regions as one block -- slice x of region r = sender x / (nsl/nsrc), its slice x % (nsl/nsrc): list index
-// ((sender * nregions + r) * (nsl/nsrc) + that).  The slices are short (1/nsrc of a region's records each), so they are
-// read as ONE concatenated list (prefix of their lengths in LDS) to keep every lane busy.
-constexpr int LI_MAXSL = 64;           // slices per region in the MULTI form
-template <bool ENT, bool MULTI = false>
+// ---- final, entry form (count_mz.hip): lists of (hash, count) entries -> LDS image of the region -> table ---------------------
+// lists: slices  lists[(region * nsl + x) * cap + i], i < cnt[region * nsl + x], of 16-byte entries { hash.lo, hash.hi | count << 32 }
+// -- the whole hash is there, the count is added.  Round 2's form of the final pass: 16-byte LDS slots, a halo of RG_HALO slots of
+// the next region (a probe may run into it), so the regions with (region & 1) == parity go in one launch and the others in a
+// second.  (The 8-byte-record lists of this file go through region_insert_kernel below.)
+constexpr int LDS_HBINS = 1024;        // histogram bins kept in LDS (higher multiplicities are rare: global atomics)
+constexpr int LI_MAXSL = 64;           // slices per region an owner reads (region_insert_kernel<., XCHG>)
 __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__restrict__ lists_v, const unsigned int *__restrict__ cnt, uint32_t cap,
                                                                  uint32_t nsl, TableDev T, PartGeom G, uint32_t nregions, uint32_t parity, int fresh_table,
                                                                  unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
-                                                                 uint64_t deferred_cap, unsigned long long *__restrict__ histo, uint32_t nsrc, int cbits = 0,
-                                                                 int fbits = 0) {
-    // cbits > 0 (lists deduplicated by the sender, list_dedupe_kernel): the top fbits of a record's p2 field -- the second-level
-    // bits the SENDER resolved, implied by the list it made -- hold (occurrences - 1) in their low cbits
+                                                                 uint64_t deferred_cap, unsigned long long *__restrict__ histo) {
     extern __shared__ __align__(16) unsigned long long s_img[];    // 2 words per slot: (R + halo) slots
-    using rec_t = typename std::conditional<ENT, ulonglong2, uint64_t>::type;
+    using rec_t = ulonglong2;
     const rec_t *lists = reinterpret_cast<const rec_t *>(lists_v);
     const int t = threadIdx.x;
     const uint32_t R = 1u << G.rbits;
@@ -792,44 +787,16 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__re
         for (int i = t; i < LDS_HBINS; i += PT_THREADS) s_bins[i] = 0;
         lds_barrier();
     }
-    unsigned int *s_pref = s_bins + LDS_HBINS;                     // MULTI (LI_MAXSL + 1 words): exclusive prefix of the region's slice lengths
-    const uint32_t per_src = MULTI ? nsl / nsrc : nsl;
-    auto slice_of = [&](uint32_t region, uint32_t x) -> uint64_t {
-        if constexpr (MULTI) return ((uint64_t)(x / per_src) * nregions + region) * per_src + x % per_src;
-        else return (uint64_t)region * nsl + x;
-    };
     for (uint32_t region = blockIdx.x * 2 + parity; region < nregions; region += gridDim.x * 2) {
         uint32_t total = 0;
-        for (uint32_t x = 0; x < nsl; ++x) total += cnt[slice_of(region, x)];
+        for (uint32_t x = 0; x < nsl; ++x) total += cnt[(uint64_t)region * nsl + x];
         if (total == 0 && !fresh_table && !histo) continue;                  // block-uniform (a fresh table must still be zeroed here)
-        if constexpr (MULTI) {
-            if (t == 0) {
-                unsigned int run = 0;
-                for (uint32_t x = 0; x < nsl; ++x) { s_pref[x] = run; run += cnt[slice_of(region, x)]; }
-                s_pref[nsl] = run;
-            }
-            // (the barrier after the image set-up below orders this before the first use)
-        }
         const uint64_t first = (uint64_t)region << G.rbits;        // first slot of the region
-        const uint64_t b1 = region >> G.p2;
         auto insert = [&](rec_t recv) {
-            // the record holds the low recbits hash bits; the bits above the slot index of this region are implied
-            // by the list it is in, so slot and remainder come from the record alone (no 128-bit arithmetic here)
-            uint64_t rec, inc;
-            u128 hfull = mk(0, 0);
-            if constexpr (ENT) { rec = recv.x; inc = recv.y >> 32; hfull = mk(recv.y & 0xFFFFFFFFull, recv.x); }
-            else {
-                rec = recv; inc = 1ull;
-                if (cbits) {                                   // (uniform) the count, and the record as it was before the sender put it there
-                    const int csh = G.recbits - fbits;
-                    const uint64_t fmask = ((1ull << fbits) - 1ull) << csh;
-                    inc = ((rec >> csh) & ((1ull << cbits) - 1ull)) + 1ull;
-                    rec = (rec & ~fmask) | ((uint64_t)((region >> (G.p2 - fbits)) & ((1u << fbits) - 1u)) << csh);
-                }
-            }
-            uint64_t rem = rec & rmask;
-            uint32_t local = (uint32_t)(rec >> rs) & (R - 1);
-            if constexpr (ENT) { local = (uint32_t)shr(hfull, rs).lo & (R - 1); }      // (rs may exceed the low word's reach)
+            const uint64_t rec = recv.x, inc = recv.y >> 32;
+            const u128 hfull = mk(recv.y & 0xFFFFFFFFull, recv.x);
+            const uint64_t rem = rec & rmask;
+            const uint32_t local = (uint32_t)shr(hfull, rs).lo & (R - 1);     // (rs may exceed the low word's reach)
             bool done = false;
             for (uint32_t off = 0; off < MAXPROBE && !done; ++off) {
                 uint32_t idx = local + off;
@@ -847,24 +814,15 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__re
                 }
             }
             if (!done) {
-                if constexpr (ENT) {
-                    const unsigned long long di = atomicAdd(deferred_n, 1ull);
-                    if (di < deferred_cap) { deferred[3 * di] = hfull.hi; deferred[3 * di + 1] = hfull.lo; deferred[3 * di + 2] = inc; }
-                    else atomicExch(&T.stats[ST_FATAL], 1ull);
-                } else if (cbits) {
-                    const u128 hh = hash_of(b1, rec, G.recbits);
-                    const unsigned long long di = atomicAdd(deferred_n, 1ull);
-                    if (di < deferred_cap) { deferred[3 * di] = hh.hi; deferred[3 * di + 1] = hh.lo; deferred[3 * di + 2] = inc; }
-                    else atomicExch(&T.stats[ST_FATAL], 1ull);
-                } else {
-                    defer_record(T, hash_of(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
-                }
+                const unsigned long long di = atomicAdd(deferred_n, 1ull);
+                if (di < deferred_cap) { deferred[3 * di] = hfull.hi; deferred[3 * di + 1] = hfull.lo; deferred[3 * di + 2] = inc; }
+                else atomicExch(&T.stats[ST_FATAL], 1ull);
             }
         };
-        // the first 16 records per lane of the region's first slice (a region holds ~16 K, and normally in ONE slice) are
-        // requested before the image is set up: one latency instead of four, overlapped with the set-up
+        // the first 4 entries per lane of the region's first slice are requested before the image is set up: one latency
+        // instead of four, overlapped with the set-up
         constexpr int PF = 4;
-        const uint32_t nrec0 = MULTI ? 0u : cnt[(uint64_t)region * nsl];
+        const uint32_t nrec0 = cnt[(uint64_t)region * nsl];
         const rec_t *src0 = lists + (uint64_t)region * nsl * cap;
         rec_t pre[PF];
 #pragma unroll
@@ -883,24 +841,6 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__re
 #pragma unroll
         for (int u = 0; u < PF; ++u)
             if ((uint32_t)u * PT_THREADS + t < nrec0) insert(pre[u]);
-        if constexpr (MULTI) {
-            uint32_t x = 0;                                                       // slice of my current record: my indices only grow
-            for (uint32_t i0 = 0; i0 < total; i0 += 4 * PT_THREADS) {
-                rec_t recs[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t i = i0 + u * PT_THREADS + t;
-                    recs[u] = rec_t{};
-                    if (i < total) {
-                        while (s_pref[x + 1] <= i) ++x;                           // (a handful of slices)
-                        recs[u] = lists[slice_of(region, x) * cap + (i - s_pref[x])];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (i0 + u * PT_THREADS + t < total) insert(recs[u]);
-            }
-        } else
         for (uint32_t x = 0; x < nsl; ++x) {
             const uint32_t nrec = x == 0 ? nrec0 : cnt[(uint64_t)region * nsl + x];
             const rec_t *src = src0 + (uint64_t)x * cap;
@@ -946,16 +886,24 @@ __global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__re
 // loop; here the first probe of four records is straight-line code and only the lanes that miss it loop.
 constexpr int RI_TH = 512;
 constexpr int RI_PF = 8;              // records per lane in flight
-template <bool FRESH>
+// XCHG (the owner's side of the list exchange, several GPUs): the region's slices come from nsrc senders, each of which laid out
+// ITS lists of all my regions as one block -- slice x of region r = sender x / (nsl/nsrc), its slice x % (nsl/nsrc): list index
+// ((sender * nregions + r) * (nsl/nsrc) + that).  They are short (1/nsrc of a region's records each) and are read as ONE
+// concatenated list (prefix of their lengths in LDS).  cbits > 0 (lists deduplicated by the sender, list_dedupe_kernel): the top
+// fbits of a record's p2 field -- the second-level bits the SENDER resolved, implied by the list it made -- hold
+// (occurrences - 1) in their low cbits.
+template <bool FRESH, bool XCHG = false>
 __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__restrict__ lists, const unsigned int *__restrict__ cnt, uint32_t cap, uint32_t nsl,
                                                               TableDev T, PartGeom G, uint32_t nregions, unsigned long long *__restrict__ deferred,
                                                               unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap,
-                                                              unsigned long long *__restrict__ histo) {
-    using cnt_t = typename std::conditional<FRESH, unsigned int, unsigned long long>::type;
-    extern __shared__ __align__(16) unsigned long long s_tag[];                      // R tags, R counts, LDS_HBINS bins
+                                                              unsigned long long *__restrict__ histo, uint32_t nsrc = 1, int cbits = 0, int fbits = 0) {
+    // (an owner adds up what several senders counted in pieces of up to 2^31 bases each: 64-bit counts there)
+    using cnt_t = typename std::conditional<FRESH && !XCHG, unsigned int, unsigned long long>::type;
+    extern __shared__ __align__(16) unsigned long long s_tag[];                      // R tags, R counts, LDS_HBINS bins (, LI_MAXSL + 1 slice offsets)
     const uint32_t R = 1u << G.rbits;
     cnt_t *s_cnt = reinterpret_cast<cnt_t *>(s_tag + R);
     unsigned int *s_bins = reinterpret_cast<unsigned int *>(s_cnt + R);
+    unsigned int *s_pref = s_bins + LDS_HBINS;                                       // XCHG: exclusive prefix of the region's slice lengths
     const int t = threadIdx.x;
     const int rs = T.B - T.s;                                                        // remainder bits (<= 53 by the tag format)
     const uint64_t rmask = (1ull << rs) - 1ull;
@@ -967,17 +915,34 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__
     for (uint32_t region = blockIdx.x; region < nregions; region += gridDim.x) {
         const uint64_t first = (uint64_t)region << G.rbits;                          // first slot of the region
         const uint64_t b1 = region >> G.p2;
+        const uint32_t per_src = XCHG ? nsl / nsrc : nsl;
+        auto slice_of = [&](uint32_t x) -> uint64_t {
+            if constexpr (XCHG) return ((uint64_t)(x / per_src) * nregions + region) * per_src + x % per_src;
+            else return (uint64_t)region * nsl + x;
+        };
         const uint64_t *src = lists + (uint64_t)region * nsl * cap;
-        uint32_t nrec = cnt[(uint64_t)region * nsl];
-        if (!FRESH && !histo) {                                                      // (block-uniform) nothing to add: the slots stay as they are
+        uint32_t nrec = XCHG ? 0u : cnt[(uint64_t)region * nsl];
+        uint32_t total = 0;                                                          // XCHG: records of all the region's slices
+        if constexpr (XCHG) {
+            for (uint32_t x = 0; x < nsl; ++x) total += cnt[slice_of(x)];
+            if (!FRESH && !histo && !total) continue;                                // (block-uniform)
+            if (t == 0) {
+                unsigned int run = 0;
+                for (uint32_t x = 0; x < nsl; ++x) { s_pref[x] = run; run += cnt[slice_of(x)]; }
+                s_pref[nsl] = run;
+            }
+            // (the barrier after the image set-up below orders this before the first use)
+        } else if (!FRESH && !histo) {                                               // (block-uniform) nothing to add: the slots stay as they are
             uint32_t any = nrec;
             for (uint32_t x = 1; x < nsl; ++x) any |= cnt[(uint64_t)region * nsl + x];
             if (!any) continue;
         }
         // the first records of the region's first slice (normally its only one) are requested before the image is set up
         uint64_t recs[RI_PF];
+        if constexpr (!XCHG) {
 #pragma unroll
-        for (int u = 0; u < RI_PF; ++u) { const uint32_t i = (uint32_t)u * RI_TH + t; recs[u] = i < nrec ? src[i] : 0ull; }
+            for (int u = 0; u < RI_PF; ++u) { const uint32_t i = (uint32_t)u * RI_TH + t; recs[u] = i < nrec ? src[i] : 0ull; }
+        }
         if (FRESH) {
             for (uint32_t i = t; i < R; i += RI_TH) { s_tag[i] = 0ull; s_cnt[i] = 0; }
         } else {
@@ -989,18 +954,23 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__
         }
         lds_barrier();
         // the probe loop of the lanes that did not find their key in its home slot (cur = what the home slot held)
-        auto probe_on = [&](uint64_t rec, uint32_t idx, unsigned long long want, unsigned long long cur) {
+        auto probe_on = [&](uint64_t rec, uint32_t idx, unsigned long long want, unsigned long long cur, cnt_t inc) {
             for (;;) {
                 if (cur == 0ull) {
                     cur = atomicCAS(&s_tag[idx], 0ull, want);                        // LDS compare-and-swap
                     if (cur == 0ull) { ++fresh; cur = want; }
                 }
-                if (cur == want) { atomicAdd(&s_cnt[idx], (cnt_t)1); return; }       // LDS add
+                if (cur == want) { atomicAdd(&s_cnt[idx], inc); return; }            // LDS add
                 ++idx;
                 ++want;                                                              // tag_of(rem, off + 1): the offset is the tag's low bits
                 if (whole) idx &= R - 1;
                 if (idx >= R || (want & (unsigned long long)(MAXPROBE - 1)) == 0ull) {   // leaves the region (or the probe limit): direct path, later
-                    defer_record(T, hash_of(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
+                    if constexpr (XCHG) {
+                        const u128 hh = hash_of(b1, rec, G.recbits);
+                        const unsigned long long di = atomicAdd(deferred_n, 1ull);
+                        if (di < deferred_cap) { deferred[3 * di] = hh.hi; deferred[3 * di + 1] = hh.lo; deferred[3 * di + 2] = (unsigned long long)inc; }
+                        else atomicExch(&T.stats[ST_FATAL], 1ull);
+                    } else defer_record(T, hash_of(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
                     return;
                 }
                 cur = s_tag[idx];
@@ -1009,8 +979,18 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__
         auto insert_batch = [&](uint32_t i0, uint32_t n) {                           // recs[u] = record i0 + u * RI_TH + t of a slice of n
             uint32_t idx[RI_PF];
             unsigned long long want[RI_PF], cur[RI_PF];
+            cnt_t inc[RI_PF];
 #pragma unroll
             for (int u = 0; u < RI_PF; ++u) {
+                inc[u] = (cnt_t)1;
+                if constexpr (XCHG) {
+                    if (cbits) {                                                     // (uniform) the count, and the record as it was before the sender put it there
+                        const int csh = G.recbits - fbits;
+                        const uint64_t fmask = ((1ull << fbits) - 1ull) << csh;
+                        inc[u] = (cnt_t)(((recs[u] >> csh) & ((1ull << cbits) - 1ull)) + 1ull);
+                        recs[u] = (recs[u] & ~fmask) | ((uint64_t)((region >> (G.p2 - fbits)) & ((1u << fbits) - 1u)) << csh);
+                    }
+                }
                 // the record holds the low recbits hash bits; the bits above the slot index of this region are implied by the
                 // list it is in, so slot and remainder come from the record alone
                 idx[u] = (uint32_t)(recs[u] >> rs) & (R - 1);
@@ -1020,11 +1000,26 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__
 #pragma unroll
             for (int u = 0; u < RI_PF; ++u) {
                 if (i0 + (uint32_t)u * RI_TH + t < n) {
-                    if (cur[u] == want[u]) atomicAdd(&s_cnt[idx[u]], (cnt_t)1);
-                    else probe_on(recs[u], idx[u], want[u], cur[u]);
+                    if (cur[u] == want[u]) atomicAdd(&s_cnt[idx[u]], inc[u]);
+                    else probe_on(recs[u], idx[u], want[u], cur[u], inc[u]);
                 }
             }
         };
+        if constexpr (XCHG) {
+            uint32_t x = 0;                                                          // slice of my current record: my indices only grow
+            for (uint32_t i0 = 0; i0 < total; i0 += RI_PF * RI_TH) {
+#pragma unroll
+                for (int u = 0; u < RI_PF; ++u) {
+                    const uint32_t i = i0 + (uint32_t)u * RI_TH + t;
+                    recs[u] = 0ull;
+                    if (i < total) {
+                        while (s_pref[x + 1] <= i) ++x;                              // (a handful of slices)
+                        recs[u] = lists[slice_of(x) * cap + (i - s_pref[x])];
+                    }
+                }
+                insert_batch(i0, total);
+            }
+        } else
         for (uint32_t x = 0; x < nsl; ++x) {
             if (x) { nrec = cnt[(uint64_t)region * nsl + x]; src += cap; }
             for (uint32_t i0 = 0; i0 < nrec; i0 += RI_PF * RI_TH) {
@@ -1154,7 +1149,7 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     const uint64_t tiles_per_slice = ((grid1 + nblk1 - 1) / nblk1) * ((ntiles + grid1 - 1) / grid1);
     G.cap1 = list_cap((double)std::min<uint64_t>(piece_bases, tiles_per_slice * tile1) / (double)(1u << p1));
     // one slice per region list: part2 runs one 1024-thread block per CU, and 2^p1 >= 256 buckets already fill the chip;
-    // lds_insert_kernel then reads a region's records as one contiguous list
+    // region_insert_kernel then reads a region's records as one contiguous list
     static const int nblk2_exp = getenv("JASPER_EXPERIMENT_NBLK2") ? atoi(getenv("JASPER_EXPERIMENT_NBLK2")) : 0;   // tuning experiments only
     G.nblk2 = p2 ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nblk1, nblk2_exp > 0 ? nblk2_exp : ((1u << p1) >= 256 ? 1 : 8))) : 1;
     G.cap2 = p2 ? (list_cap((double)piece_bases / ((double)(1ull << (p1 + p2)) * (double)G.nblk2)) + 15u) & ~15u : 0;      // whole 128-byte lines (part2f_kernel)
@@ -1267,14 +1262,14 @@ int Table::insert_entry_lists(const void *lists, const unsigned int *cnt, uint32
     const int fresh = slots_dirty ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_insert_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_insert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     for (uint32_t parity = 0; parity < 2; ++parity) {
         if (!(nregions == 1 && parity == 1)) {
             const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
-            hipLaunchKernelGGL(lds_insert_kernel<true>, dim3(nblk), dim3(PT_THREADS), lds, stream, lists, cnt, cap, nsl, d, G, nregions, parity, fresh, defer_e, defer_n,
-                               deferred_cap, histo, 1u);
+            hipLaunchKernelGGL(lds_insert_kernel, dim3(nblk), dim3(PT_THREADS), lds, stream, lists, cnt, cap, nsl, d, G, nregions, parity, fresh, defer_e, defer_n,
+                               deferred_cap, histo);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(ev[parity], stream));
@@ -1308,7 +1303,7 @@ int Table::finish_deferred(unsigned long long *defer_e, unsigned long long *defe
 static uint32_t xchg_cap(double avg, double mult) { return (uint32_t)std::min<double>(4.0e9, avg + 6.0 * std::sqrt(avg * (1.0 + mult)) + 16.0); }
 // G: what the senders and the wire use (G.p2 = the second-level bits the SENDER resolves); p2b: second-level bits left to the
 // owner -- a bucket can be split 2048 ways in one pass, and the senders also split by owner, so for very large shards (2^32
-// slots on 8 GPUs) the owner runs one more split pass over what it received (part2_kernel<false, MIN>) before lds_insert.
+// slots on 8 GPUs) the owner runs one more split pass over what it received (part2_kernel<false, MIN>) before its insert.
 static int xchg_max_lists() { const char *e = getenv("JASPER_XCHG_TEST_MAXLISTS"); return e ? std::max(2, atoi(e)) : PT_MAXBUCKETS; }   // (tests: force the extra pass on small tables)
 static bool xchg_geometry(const Table &t, uint64_t piece_max, uint64_t records_max, uint32_t nown, PartGeom &G, int &p2b) {
     if (nown < 2 || nown > MAX_SHARDS) return false;
@@ -1547,12 +1542,13 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
     histo_cached = false;
     unsigned long long *histo = whole_input && empty ? d_histo : nullptr;
     if (histo) HIPCHK(hipMemsetAsync(histo, 0, HISTO_WORDS * sizeof(unsigned long long), stream));
-    const size_t lds = ((size_t)(1u << G.rbits) + RG_HALO) * 16 + LDS_HBINS * 4 + (LI_MAXSL + 1) * 4;
-    if (slots_dirty && nregions <= 1) { if (materialize(err)) return -1; }
-    const int fresh = slots_dirty ? 1 : 0;
+    // (a table that is logically empty is not read: the images start from zeros and every slot is written)
+    const bool fresh = slots_dirty || histo != nullptr;
+    const size_t lds = (size_t)(1u << G.rbits) * 16 + LDS_HBINS * 4 + (LI_MAXSL + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_insert_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(region_insert_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(region_insert_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     // this rank's own deferred list lives in the caller's buffer; the kernel's own overflow (probe beyond the halo) goes to a list of its own
@@ -1585,7 +1581,6 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
         static bool attr2_set = false;
         if (!attr2_set) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_insert_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr2_set = true;
         }
         hipLaunchKernelGGL((part2_kernel<false, true>), dim3(1, std::min<uint32_t>(1u << G2.p1, 2048)), dim3(PT_THREADS), P2_LDS, stream, (const uint64_t *)d_recv,
@@ -1593,19 +1588,21 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
         HIPCHK(hipGetLastError());
         lists = out2; lcnt = cnt2; lcap = G2.cap2; nsl = 1;
     }
-    for (uint32_t parity = 0; parity < 2; ++parity) {
-        if (!(nregions == 1 && parity == 1)) {
-            const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
-            if (p2b) hipLaunchKernelGGL((lds_insert_kernel<false, false>), dim3(nblk), dim3(PT_THREADS), lds, stream, lists, lcnt, lcap, nsl, d, GI, nregions, parity, fresh,
-                                        defer_e, defer_n, own_cap, histo, 1u, cbits, G.p2);
-            else hipLaunchKernelGGL((lds_insert_kernel<false, true>), dim3(nblk), dim3(PT_THREADS), lds, stream, lists, lcnt, lcap, nsl, d, GI, nregions, parity, fresh,
-                                    defer_e, defer_n, own_cap, histo, nown, cbits, G.p2);
-            HIPCHK(hipGetLastError());
-        }
-        HIPCHK(hipEventRecord(ev_stage_t[4 + parity], stream));
+    {
+        // one launch over all regions (region_insert_kernel: a probe that leaves its region takes the direct path afterwards)
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
+        const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>(nregions, 256 * per_cu * 4));
+        const uint32_t nsrc = p2b ? 1u : nown;
+        if (fresh) hipLaunchKernelGGL((region_insert_kernel<true, true>), dim3(nblk), dim3(RI_TH), lds, stream, (const uint64_t *)lists, lcnt, lcap, nsl, d, GI, nregions, defer_e, defer_n,
+                                      own_cap, histo, nsrc, cbits, G.p2);
+        else hipLaunchKernelGGL((region_insert_kernel<false, true>), dim3(nblk), dim3(RI_TH), lds, stream, (const uint64_t *)lists, lcnt, lcap, nsl, d, GI, nregions, defer_e, defer_n,
+                                own_cap, histo, nsrc, cbits, G.p2);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ev_stage_t[4], stream));
+        HIPCHK(hipEventRecord(ev_stage_t[5], stream));
     }
-    slots_dirty = false;
-    hipLaunchKernelGGL(import3_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, own_cap, d, histo ? histo + 10002 : nullptr);
+    slots_dirty = false;      // every region has been written by the launch above
+    hipLaunchKernelGGL(import3h_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, own_cap, d, histo);      // (keeps the fused histogram exact)
     HIPCHK(hipGetLastError());
     if (n_defer_all) {
         hipLaunchKernelGGL(import3_owned_kernel, dim3(256), dim3(256), 0, stream, (const unsigned long long *)d_defer_all, n_defer_all, d, nown, self, histo ? histo + 10002 : nullptr);

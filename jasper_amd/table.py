@@ -223,7 +223,7 @@ class KmerTable:
     STAGE_NAMES = {2: ("mz_part_kernel", "mz_split_kernels", "mz_count_kernel", "split16_entries_kernel", "lds_insert_kernel_even", "lds_insert_kernel_odd",
                        "expand_and_deferred_kernels"),
                    1: ("part1_kernel", "part2_kernel", "region_insert_kernel", "deferred_import3h_kernel"),
-                   3: ("part1_kernel", "part2_by_owner_kernel", "lds_insert_kernel_even", "lds_insert_kernel_odd", "deferred_import3_kernels"),
+                   3: ("part1_kernel", "part2_by_owner_kernel", "region_insert_kernel", "(unused)", "deferred_import3h_kernels"),
                    0: ()}
 
     def count_stages(self):

@@ -2,7 +2,7 @@
 """The kernels of the multi-GPU counting exchange (dist.count_sharded) timed on ONE GPU, one virtual rank after the other:
 every rank's reads (bench.py's workload for a world of W ranks) are partitioned into region lists grouped by owner, the blocks
 meant for owner 0 are kept, and owner 0 inserts them into its shard.  Prints the stage times of a sender (part1, part2 by owner)
-and of an owner (lds_insert even / odd), and checks the shard against the keys owner 0 gets from a plain table of all reads'
+and of an owner (region_insert), and checks the shard against the keys owner 0 gets from a plain table of all reads'
 k-mers when W is small enough for that table to fit.
    python tools/bench_exchange_steps.py [W] [genome_mb] [reps]"""
 import os
@@ -83,7 +83,7 @@ for rep in range(reps):
     info = shard.info()
     used = int(rcnt.to(torch.int64).sum().item())
     print("rep %d (last sender deferred %d): owner 0 received %d records (%.3f of one rank's k-mers) in %d x %d slices of cap %d (mean fill %.0f, fullest %d): "
-          "lds_insert even %.2f odd %.2f deferred %.2f ms (wall %.2f); shard distinct %d in 2^%d slots"
+          "region_insert %.2f (+%.2f) deferred %.2f ms (wall %.2f); shard distinct %d in 2^%d slots"
           % (rep, ndef, used, used / kmers, W, ncnt, plan["slice_cap"], part[0][0], max(p[1] for p in part), st[2], st[3], st[4], (t1 - t0) * 1e3,
              info["distinct"], info["slots"].bit_length() - 1), flush=True)
 # a sender's stage times: the last partition call on `sender` followed by an (empty-handed) insert would mix tables; read the events through one more full cycle
