@@ -263,17 +263,28 @@ def split_batches(contigs, batch_size, query_fn):
     batch_index, output = 0, 0
     f = open("%s.batch.%d.fa" % (query_fn, batch_index), "w")
     files.append(f.name)
+    held = {}                                 # what polisher.parse_fasta would make of the file being written
+    plain = True
+
+    def close():
+        f.close()
+        if plain:
+            polisher.remember(f.name, "records", dict(held))
     for hdr, seq in records:
         if output > bs:
-            f.close()
+            close()
             batch_index += 1
             f = open("%s.batch.%d.fa" % (query_fn, batch_index), "w")
             files.append(f.name)
             output = 0
+            held, plain = {}, True
         f.write(hdr + "\n")
         f.write(seq + "\n")
         output += len(seq)
-    f.close()
+        # (parse_fasta: a line that starts with '>' names a record by its first token; other lines, '\n' taken off, are its text)
+        plain = plain and hdr.isascii() and seq.isascii() and hdr.startswith(">") and len(hdr.split()) == 1 and not seq.startswith(">") and "\n" not in seq and "\r" not in seq
+        held[hdr.split()[0][1:] if hdr.split() else ""] = seq
+    close()
     return files
 
 
@@ -285,7 +296,8 @@ def join_polished(fixed_files, batch_size, contig_order, fast=True):
     h = {}
     ctg, seq = "", ""                         # (perl's undef $ctg is the hash key "")
     for path in fixed_files:                  # (one stream: a sequence may go on in the next file, as for `cat`)
-        for kind, tok in _fasta_events(path, fast):
+        events = polisher.recall(path, "events") if fast else None        # (written by this very process a moment ago: polisher.main_many)
+        for kind, tok in (events if events is not None else _fasta_events(path, fast)):
             if kind == "h":
                 if seq:
                     h[ctg] = seq

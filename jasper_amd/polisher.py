@@ -14,6 +14,50 @@ from .table import KmerTable
 FIX_FIELDS = ['Contig', 'Base_coord', 'Original', 'Mutation']  # src/jasper.py:115
 
 
+# What this process has itself just written to a file, kept so that the next stage need not read and parse it again (the file
+# is still written: it is the stage's artefact and the restart point).  Valid only while the file's size and mtime are what they
+# were when it was written.
+_WRITTEN = {}
+
+
+def remember(path, kind, value, final_path=None):
+    """kind: "records" = what parse_fasta(path) returns, "events" = what cli._fasta_events(path) returns"""
+    try:
+        st = os.stat(path)
+    except OSError:
+        return
+    _WRITTEN[(os.path.abspath(final_path or path), kind)] = (st.st_size, st.st_mtime_ns, value)
+
+
+def recall(path, kind):
+    e = _WRITTEN.get((os.path.abspath(path), kind))
+    if e is None:
+        return None
+    try:
+        st = os.stat(path)
+    except OSError:
+        return None
+    return e[2] if (st.st_size, st.st_mtime_ns) == e[:2] else None
+
+
+def wrap_lines(seq, num_per_line=60):
+    """the text split_output's lines give when joined with and ended by a newline, for ASCII text; None otherwise"""
+    try:
+        raw = seq.encode("ascii") if isinstance(seq, str) else bytes(seq)
+    except UnicodeEncodeError:
+        return None
+    if not raw:
+        return b""
+    import numpy as np
+    a = np.frombuffer(raw, dtype=np.uint8)
+    full = len(raw) // num_per_line
+    out = np.empty((full, num_per_line + 1), dtype=np.uint8)
+    out[:, :num_per_line] = a[:full * num_per_line].reshape(full, num_per_line)
+    out[:, num_per_line] = 10
+    tail = raw[full * num_per_line:]
+    return out.tobytes() + (tail + b"\n" if tail else b"")
+
+
 def parse_fasta(query_file):
     """src/jasper.py:615-631 -- ordered dict name -> sequence; name = first token without '>', only '\\n' stripped"""
     seq = {}
@@ -203,7 +247,9 @@ def main_many(query_paths, k, test, fix, db, thre, num_iter):
         per_file = []
         names, seqs = [], []
         for qp in query_paths:
-            d = parse_fasta(qp)
+            d = recall(qp, "records")
+            if d is None:
+                d = parse_fasta(qp)
             per_file.append((qp, len(names), len(d)))
             names.extend(d.keys())
             seqs.extend(d.values())
@@ -236,12 +282,25 @@ def main_many(query_paths, k, test, fix, db, thre, num_iter):
                         csvf.write(fix_csv_text(flat))
                 ff = os.path.split(qp + ".fixed.fa.tmp")
                 out_path = ff[0] + "_iter" + str(num_iter - 1) + "_" + ff[1]
+                events = []
                 with open(out_path, 'w') as of:
                     for seqname, seq in zip(names[first:first + n], fixed[first:first + n]):
                         of.write(">{}\n".format(seqname))
-                        lines = split_output(seq, 60)
-                        if lines:
-                            of.write("\n".join(lines) + "\n")
+                        wrapped = wrap_lines(seq, 60)
+                        if wrapped is not None:
+                            of.flush()
+                            of.buffer.write(wrapped)
+                        else:
+                            lines = split_output(seq, 60)
+                            if lines:
+                                of.write("\n".join(lines) + "\n")
+                        events.append(("h", ">" + seqname))
+                        if seq:
+                            events.append(("s", seq if isinstance(seq, str) else bytes(seq).decode("ascii", "replace")))
+                # (what cli.join_polished would read back from the file under its final name)
+                if all(isinstance(q, str) and q.isascii() and not any(c.isspace() for c in nm) and nm.isascii()
+                       for nm, q in zip(names[first:first + n], fixed[first:first + n])):
+                    remember(out_path, "events", events, final_path=out_path[:-4] if out_path.endswith(".tmp") else out_path)
                 outs.append(out_path)
         return outs
     except SystemExit:

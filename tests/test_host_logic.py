@@ -58,6 +58,32 @@ def test_split_and_join_roundtrip(tmp_path, monkeypatch):
     assert text == "".join("%s\n%s\n" % c for c in contigs)
 
 
+def test_what_a_stage_remembers_of_its_own_files_is_what_reading_them_gives(tmp_path, monkeypatch):
+    """the batch files are written and then polished by the same process: their records are kept (polisher.remember) instead of
+    parsed again -- the same dict parse_fasta makes, for as long as the file is what was written; duplicate chunk names (two contigs
+    whose headers share the first token) included"""
+    import os
+    import time
+    monkeypatch.chdir(tmp_path)
+    contigs = [(">c0", "ACGT" * 1000), (">c0", "TTTT" * 300), (">c1", "G" * 2500), (">odd:name", "N" * 10)]
+    files = cli.split_batches(contigs, 1500, "asm.fa")
+    assert len(files) > 2
+    for f in files:
+        kept = polisher.recall(f, "records")
+        assert kept is not None and list(kept.items()) == list(polisher.parse_fasta(f).items())
+        assert polisher.recall(f, "events") is None
+    # a file that changed after it was written is read again
+    time.sleep(0.01)
+    with open(files[0], "a") as f:
+        f.write(">late\nAC\n")
+    assert polisher.recall(files[0], "records") is None
+    # 60-column wrapping through numpy == the reference's slicing (src/jasper.py:142-147)
+    for s in ["", "A", "ACGT" * 15, "ACGT" * 15 + "A", "ACGTN" * 1000]:
+        lines = polisher.split_output(s, 60)
+        assert polisher.wrap_lines(s, 60) == (("\n".join(lines) + "\n").encode() if lines else b"")
+    assert polisher.wrap_lines("ACG\u00e9T") is None
+
+
 def test_read_assembly_first_token_rules(tmp_path):
     p = tmp_path / "a.fa"
     p.write_text(">c0 desc here\nACGT extra\nTTTT\n\n>c1\nGG\n>empty\n>c2\nA\n")
