@@ -518,7 +518,6 @@ def main():
         "polish_segments": T["segments"], "polish_chunks_redone_unsegmented": T["respeculated"],
         "roofline": {"bound": "hbm",
                      "kernel": {3: "k-mer counting = part1_kernel + part2_kernel<by owner> (+ list_dedupe_kernel) on the sender, region_insert_kernel<exchange> on the owner, per round",
-                                2: "k-mer counting = mz_part + mz_split + mz_count + split16 (entries) + lds_insert (even, odd) per piece (minimizer super-k-mers)",
                                 1: "k-mer counting = part1_kernel + part2f_kernel + region_insert_kernel (+ import3h_kernel for deferred records) per piece",
                                 0: "count_kernel"}[T["path"]],
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -237,12 +237,10 @@ void jasper_result_free(jasper_result *r);
 /* kernel timing for bench.py: HIP-event time of the last counting call on this table, and its launch count */
 int jasper_last_count_timing(jasper_table *t, double *kernel_ms, uint64_t *launches);
 /* the same split by kernel stage of the atomic-free counting paths, and which path the last piece took (*path):
- *   2 = minimizer super-k-mers (count_mz.hip): mz_part, mz_split (count + scan + write), mz_count, split16 (entries),
- *       lds_insert (even regions), lds_insert (odd), expand + deferred direct inserts, (unused)
  *   1 = one record per occurrence (count_part.hip): part1, part2, region_insert, deferred, (unused x4)
  *   3 = the same with the region lists exchanged between GPUs: part1, part2 by owner (+ dedupe), region_insert, (unused), deferred
  *   0 = count_kernel (global atomics; small pieces)
- * *partitioned_launches of the counted launches took path 1 or 2 (the others ran count_kernel) */
+ * *partitioned_launches of the counted launches took path 1 or 3 (the others ran count_kernel) */
 int jasper_last_count_stages(jasper_table *t, double stage_ms[8], uint64_t *partitioned_launches, int *path);
 
 /* A slot array whose IPC handle was given out (jasper_table_ipc_handle) and that the table has outgrown since is kept until

@@ -19,7 +19,6 @@
 //                  histogram on the way out.  One launch; the owner's side of the exchange reads N senders' slices.
 //   A record that finds no room (slice full, probe past the region's end) goes to a deferred list that import3h_kernel
 //   drains through the direct path afterwards.
-//   (lds_insert_kernel: round 2's form of the last pass, kept for the 16-byte entries of count_mz.hip.)
 //
 // The table layout, tags and probe order are exactly those of the direct path, so lookups, histogram, export, growth
 // and the polisher do not know which path filled the table.  HBM traffic per k-mer: 1 B base + 8 B x 2 (part1 list)
@@ -54,7 +53,6 @@ constexpr int PT_TILE = PT_THREADS * PT_GROUP;   // 16384 records per block iter
 constexpr int PT_HALO = 4;
 constexpr int PT_MAXBUCKETS = 2048;              // p1, p2 <= 11
 constexpr int RG_MAXBITS = 12;                   // region = 4096 slots: 48 KB of LDS in region_insert_kernel, three workgroups per CU (8192 for the largest tables)
-constexpr int RG_HALO = 128;                     // slots of the next region a probe may run into
 
 struct PartGeom {
     int p1, p2, rbits;       // p1 + p2 + rbits == s
@@ -758,130 +756,16 @@ __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *_
     }
 }
 
-// ---- final, entry form (count_mz.hip): lists of (hash, count) entries -> LDS image of the region -> table ---------------------
-// lists: slices  lists[(region * nsl + x) * cap + i], i < cnt[region * nsl + x], of 16-byte entries { hash.lo, hash.hi | count << 32 }
-// -- the whole hash is there, the count is added.  Round 2's form of the final pass: 16-byte LDS slots, a halo of RG_HALO slots of
-// the next region (a probe may run into it), so the regions with (region & 1) == parity go in one launch and the others in a
-// second.  (The 8-byte-record lists of this file go through region_insert_kernel below.)
-constexpr int LDS_HBINS = 1024;        // histogram bins kept in LDS (higher multiplicities are rare: global atomics)
+constexpr int LDS_HBINS = 1024;        // histogram bins kept in LDS by region_insert_kernel (higher multiplicities are rare: global atomics)
 constexpr int LI_MAXSL = 64;           // slices per region an owner reads (region_insert_kernel<., XCHG>)
-__global__ __launch_bounds__(PT_THREADS) void lds_insert_kernel(const void *__restrict__ lists_v, const unsigned int *__restrict__ cnt, uint32_t cap,
-                                                                 uint32_t nsl, TableDev T, PartGeom G, uint32_t nregions, uint32_t parity, int fresh_table,
-                                                                 unsigned long long *__restrict__ deferred, unsigned long long *__restrict__ deferred_n,
-                                                                 uint64_t deferred_cap, unsigned long long *__restrict__ histo) {
-    extern __shared__ __align__(16) unsigned long long s_img[];    // 2 words per slot: (R + halo) slots
-    using rec_t = ulonglong2;
-    const rec_t *lists = reinterpret_cast<const rec_t *>(lists_v);
-    const int t = threadIdx.x;
-    const uint32_t R = 1u << G.rbits;
-    const uint32_t halo = nregions > 1 ? (uint32_t)RG_HALO : 0u;     // a single region is the whole table: probes wrap inside it
-    const uint32_t span = R + halo;
-    const int rs = T.B - T.s;                                        // remainder bits (<= 53 by the tag format)
-    const uint64_t rmask = (1ull << rs) - 1ull;
-    unsigned long long fresh = 0;
-    // fused multiplicity histogram (histo != null: this pass writes the FINAL counts of the whole table): every slot is
-    // binned exactly once, by the block that writes its final value -- an even region's body in the even launch; in the
-    // odd launch the odd region's head and body plus its halo, which is the head of the even region to its right.
-    unsigned int *s_bins = reinterpret_cast<unsigned int *>(s_img + 2 * (size_t)span);     // LDS_HBINS words, only with histo
-    if (histo) {
-        for (int i = t; i < LDS_HBINS; i += PT_THREADS) s_bins[i] = 0;
-        lds_barrier();
-    }
-    for (uint32_t region = blockIdx.x * 2 + parity; region < nregions; region += gridDim.x * 2) {
-        uint32_t total = 0;
-        for (uint32_t x = 0; x < nsl; ++x) total += cnt[(uint64_t)region * nsl + x];
-        if (total == 0 && !fresh_table && !histo) continue;                  // block-uniform (a fresh table must still be zeroed here)
-        const uint64_t first = (uint64_t)region << G.rbits;        // first slot of the region
-        auto insert = [&](rec_t recv) {
-            const uint64_t rec = recv.x, inc = recv.y >> 32;
-            const u128 hfull = mk(recv.y & 0xFFFFFFFFull, recv.x);
-            const uint64_t rem = rec & rmask;
-            const uint32_t local = (uint32_t)shr(hfull, rs).lo & (R - 1);     // (rs may exceed the low word's reach)
-            bool done = false;
-            for (uint32_t off = 0; off < MAXPROBE && !done; ++off) {
-                uint32_t idx = local + off;
-                if (nregions == 1) idx &= (R - 1);             // whole table in LDS: wrap like the global probe
-                else if (idx >= span) break;                   // beyond the halo: deferred to the direct path
-                const unsigned long long want = tag_of(rem, off);
-                unsigned long long cur = s_img[2 * idx];
-                if (cur == 0ull) {
-                    cur = atomicCAS(&s_img[2 * idx], 0ull, want);   // LDS compare-and-swap
-                    if (cur == 0ull) { ++fresh; cur = want; }
-                }
-                if (cur == want) {
-                    atomicAdd(&s_img[2 * idx + 1], (unsigned long long)inc);      // LDS add
-                    done = true;
-                }
-            }
-            if (!done) {
-                const unsigned long long di = atomicAdd(deferred_n, 1ull);
-                if (di < deferred_cap) { deferred[3 * di] = hfull.hi; deferred[3 * di + 1] = hfull.lo; deferred[3 * di + 2] = inc; }
-                else atomicExch(&T.stats[ST_FATAL], 1ull);
-            }
-        };
-        // the first 4 entries per lane of the region's first slice are requested before the image is set up: one latency
-        // instead of four, overlapped with the set-up
-        constexpr int PF = 4;
-        const uint32_t nrec0 = cnt[(uint64_t)region * nsl];
-        const rec_t *src0 = lists + (uint64_t)region * nsl * cap;
-        rec_t pre[PF];
-#pragma unroll
-        for (int u = 0; u < PF; ++u) { const uint32_t i = (uint32_t)u * PT_THREADS + t; pre[u] = i < nrec0 ? src0[i] : rec_t{}; }
-        // image in: coalesced 16-B loads (the halo wraps around the end of the table).  On a lazily cleared table the slot
-        // memory is garbage except for what this pass has already written: nothing yet in the even launch; in the odd
-        // launch the even regions, i.e. this region's own first `halo` slots (its left neighbour's halo) and its own halo.
-        for (uint32_t i = t; i < span; i += PT_THREADS) {
-            const bool have = !fresh_table || (parity == 1 && (i < halo || i >= R));
-            ulonglong2 e = make_ulonglong2(0ull, 0ull);
-            if (have) e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * ((first + i) & T.mask));
-            s_img[2 * i] = e.x;
-            s_img[2 * i + 1] = e.y;
-        }
-        lds_barrier();
-#pragma unroll
-        for (int u = 0; u < PF; ++u)
-            if ((uint32_t)u * PT_THREADS + t < nrec0) insert(pre[u]);
-        for (uint32_t x = 0; x < nsl; ++x) {
-            const uint32_t nrec = x == 0 ? nrec0 : cnt[(uint64_t)region * nsl + x];
-            const rec_t *src = src0 + (uint64_t)x * cap;
-            for (uint32_t i0 = x == 0 ? PF * PT_THREADS : 0; i0 < nrec; i0 += 4 * PT_THREADS) {
-                rec_t recs[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * PT_THREADS + t; recs[u] = i < nrec ? src[i] : rec_t{}; }   // 4 loads in flight
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (i0 + u * PT_THREADS + t < nrec) insert(recs[u]);
-            }
-        }
-        lds_barrier();
-        for (uint32_t i = t; i < span; i += PT_THREADS) {
-            const unsigned long long tag = s_img[2 * i], c64 = s_img[2 * i + 1];
-            *reinterpret_cast<ulonglong2 *>(T.slots + 2 * ((first + i) & T.mask)) = make_ulonglong2(tag, c64);
-            if (histo && tag != 0ull && c64 != 0ull && (parity == 1 || (i >= halo && i < R))) {
-                const uint32_t c = clamp32(c64);
-                const uint32_t b = c > 10001u ? 10001u : c;
-                if (b < (uint32_t)LDS_HBINS) atomicAdd(&s_bins[b], 1u);
-                else atomicAdd(&histo[b], 1ull);
-            }
-        }
-        lds_barrier();
-    }
-    if (histo) {
-        for (int i = t; i < LDS_HBINS; i += PT_THREADS)
-            if (s_bins[i]) atomicAdd(&histo[i], (unsigned long long)s_bins[i]);
-    }
-    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
-    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
-}
-
-// ---- final, single-GPU form: one launch, no halo, 12 bytes of LDS per slot ------------------------------------------------------
+// ---- final: region lists -> LDS image of the region -> table ---------------------------------------------------------------------
 // One workgroup per region of R = 2^rbits slots (R <= 4096 here: 48 KB of LDS, three workgroups of 512 threads per CU, so that
 // one's record loads and image write-out overlap another's insert loop).  The LDS image keeps the tag (8 bytes, the table's own
 // format) and -- on a table that starts empty (FRESH) -- a 32-bit count of what this pass adds; the slot's 16 bytes are put
 // together on the way out.  A region is exactly the block's own slots: a record whose probe sequence leaves the region (0.03 % of
 // them at load 0.3) goes to the deferred list and takes the direct path afterwards, so all regions run in ONE launch and every
 // slot is written, and binned into the multiplicity histogram, exactly once (import3h_kernel moves the bins of the few keys it
-// touches).  Round 2's form (lds_insert_kernel above: 16-byte LDS slots, a 128-slot halo, even and odd regions in two launches,
+// touches).  Round 2's form (lds_insert_kernel, gone: 16-byte LDS slots, a 128-slot halo, even and odd regions in two launches,
 // one 1024-thread workgroup per CU) spent 178 wave instructions per record, most of them scalar branch bookkeeping of the probe
 // loop; here the first probe of four records is straight-line code and only the lanes that miss it loop.
 constexpr int RI_TH = 512;
@@ -1099,18 +983,6 @@ __global__ __launch_bounds__(256) void import3h_kernel(const unsigned long long 
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
 }
 
-__global__ __launch_bounds__(256) void import3_kernel(const unsigned long long *__restrict__ entries, const unsigned long long *__restrict__ n_ptr,
-                                                      uint64_t cap, TableDev T, unsigned long long *__restrict__ histo_incomplete) {
-    const uint64_t n = *n_ptr < cap ? *n_ptr : cap;
-    if (histo_incomplete && *n_ptr != 0ull && blockIdx.x == 0 && threadIdx.x == 0) *histo_incomplete = 1ull;   // counts change after the fused histogram
-    unsigned long long fresh = 0;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        fresh += table_add_or_spill(T, mk(entries[3 * i], entries[3 * i + 1]), entries[3 * i + 2]);
-    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
-    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
-}
-
-// ==================================================================================================
 static uint32_t list_cap(double avg) { return (uint32_t)std::min<double>(4.0e9, avg * 1.25 + 8.0 * std::sqrt(avg) + 64.0); }
 
 // can this piece take the partitioned path, and with which geometry?
@@ -1249,42 +1121,6 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     return 0;
 }
 
-// ---- the entry form, used by count_mz.hip ----------------------------------------------------------------------------
-int Table::insert_entry_lists(const void *lists, const unsigned int *cnt, uint32_t cap, uint32_t nsl, int region_bits_total, int rbits, unsigned long long *defer_e,
-                              unsigned long long *defer_n, uint64_t deferred_cap, hipEvent_t *ev, std::string &err) {
-    PartGeom G{};
-    G.rbits = rbits; G.p1 = region_bits_total; G.p2 = 0; G.recbits = d.B;      // (only rbits is read by the entry form)
-    const uint32_t nregions = 1u << region_bits_total;
-    unsigned long long *histo = histo_request ? d_histo : nullptr;
-    if (histo) HIPCHK(hipMemsetAsync(histo, 0, HISTO_WORDS * sizeof(unsigned long long), stream));
-    const size_t lds = ((size_t)(1u << rbits) + RG_HALO) * 16 + (histo ? LDS_HBINS * 4 : 0);
-    if (slots_dirty && nregions <= 1) { if (materialize(err)) return -1; }
-    const int fresh = slots_dirty ? 1 : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_insert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    for (uint32_t parity = 0; parity < 2; ++parity) {
-        if (!(nregions == 1 && parity == 1)) {
-            const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((nregions + 1) / 2, 256 * 4));
-            hipLaunchKernelGGL(lds_insert_kernel, dim3(nblk), dim3(PT_THREADS), lds, stream, lists, cnt, cap, nsl, d, G, nregions, parity, fresh, defer_e, defer_n,
-                               deferred_cap, histo);
-            HIPCHK(hipGetLastError());
-        }
-        HIPCHK(hipEventRecord(ev[parity], stream));
-    }
-    slots_dirty = false;
-    return 0;
-}
-
-int Table::finish_deferred(unsigned long long *defer_e, unsigned long long *defer_n, uint64_t deferred_cap, std::string &err) {
-    unsigned long long *histo = histo_request ? d_histo : nullptr;
-    hipLaunchKernelGGL(import3_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, deferred_cap, d, histo ? histo + 10002 : nullptr);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
 // ==================================================================================================
 // count_exchange: the partition pipeline as the multi-GPU exchange (role: JF::jellyfish/merge_files.cc:44-96 -- there
 // every process counts into a table of its own and the tables are merged; here no rank ever builds a table of its own reads).
@@ -1292,7 +1128,7 @@ int Table::finish_deferred(unsigned long long *defer_e, unsigned long long *defe
 //                 xchg_partition   part2<OWN>: the level-1 lists become region lists grouped by the OWNER of the key;
 //                                  what owner o is to get is one contiguous block of the send buffers (records + slice counts)
 //   the caller    one all_to_all of the blocks (8 B per k-mer occurrence + slack), dist.count_sharded
-//   every owner   xchg_insert      lds_insert<MULTI> x 2 straight into its shard, fused histogram, deferred records
+//   every owner   xchg_insert      region_insert<., XCHG> straight into its shard, fused histogram, deferred records
 // All ranks must derive the same geometry: from the shard geometry (one for all owners), the number of owners, piece_max =
 // the longest piece any rank scans in this round, and records_max = the most records any rank's scan produced (0: not known,
 // piece_max stands in).  The slack of the send lists is what travels, so they are sized from the records actually there, not
@@ -1496,7 +1332,7 @@ int Table::xchg_dedupe(uint64_t piece_max, uint64_t records_max, uint32_t nown, 
     if (G.p2 < 1) return 1;                                    // (G.p2: the second-level bits the senders resolve)
     const int cbits = std::min(G.p2, 16);
     const uint64_t nlists = ((uint64_t)nown << (G.p1 + G.p2)) * G.nblk2;
-    unsigned int *d_max = (unsigned int *)workspace(WS_MZ + 3, 64, err);
+    unsigned int *d_max = (unsigned int *)workspace(WS_XCHG + 3, 64, err);
     if (!d_max) return -2;
     HIPCHK(hipMemsetAsync(d_max, 0, 4, stream));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nlists, 256u * 3u * 8u);
@@ -1575,8 +1411,8 @@ int Table::xchg_insert(const void *d_recv, const void *d_recv_cnt, uint64_t piec
         G2.p1 = G.p1 + G.p2; G2.p2 = p2b; G2.recbits = G.recbits - G.p2;
         G2.nblk1 = nown * G.nblk2; G2.cap1 = G.cap2; G2.nblk2 = 1;
         G2.cap2 = list_cap((double)std::max<uint64_t>(records_max, 1) / (double)nregions);
-        uint64_t *out2 = (uint64_t *)workspace(WS_MZ + 1, (size_t)nregions * G2.cap2 * 8, err);
-        unsigned int *cnt2 = (unsigned int *)workspace(WS_MZ + 2, ((size_t)nregions + 4) * 4, err);
+        uint64_t *out2 = (uint64_t *)workspace(WS_XCHG + 1, (size_t)nregions * G2.cap2 * 8, err);
+        unsigned int *cnt2 = (unsigned int *)workspace(WS_XCHG + 2, ((size_t)nregions + 4) * 4, err);
         if (!out2 || !cnt2) return -2;
         static bool attr2_set = false;
         if (!attr2_set) {

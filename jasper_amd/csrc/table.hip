@@ -854,11 +854,6 @@ int Table::launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from
     // break-even measured on MI355X: direct ~18 Gk-mers/s; partitioned ~55 Gk-mers/s for the two list passes plus one
     // streaming pass over the table (32 B/slot, 16 B/slot when the table is still lazily cleared)
     if (len >= (slots_dirty ? nslots / 6 : nslots / 4)) {
-        alignas(16) char mzgeom[128];
-        if (minimizer_geometry(len, mzgeom)) {
-            ++count_partitioned_launches;
-            return launch_count_minimizer(d_piece, len, emit_from, mzgeom, err);
-        }
         if (partition_geometry(len, geom)) {
             ++count_partitioned_launches;
             return launch_count_partitioned(d_piece, len, emit_from, geom, err);
@@ -953,18 +948,6 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err, ui
         int rc = after_batch(err);
         histo_cached = rc == 0 && fused_histo;
         if (dbg) fprintf(stderr, "[count] host: launch calls %.2f ms, wait + after_batch %.2f ms\n", t_l1 - t_l0, now_ms() - t_l1);
-        if (rc == -2 && count_path == 2 && started_empty && !mz_off) {
-            // The minimizer path sizes its lists from estimates (records per k-mer, entries per k-mer); an input that breaks
-            // them beyond what its fallbacks absorb (very short runs, no repeated k-mers at all) overflowed.  Nothing else was
-            // in the table when this call started: start over on the other paths.
-            if (dbg) fprintf(stderr, "[count] minimizer path overflowed its lists: restarting without it\n");
-            err.clear();
-            mz_off = true;
-            if (clear(err)) return -1;
-            if (read_stats(err)) return -1;
-            pos = std::min(first_new, n);
-            continue;
-        }
         if (rc == -2 && have_ratio && started_empty) {
             // The size hint promised a more repetitive input than this one: the piece sized from it overflowed the table.
             // Nothing else was in the table when this call started, so start over with worst-case piece sizes.

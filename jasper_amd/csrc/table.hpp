@@ -306,26 +306,16 @@ struct Table {
     bool partition_geometry(uint64_t piece_bases, void *geom_out) const;
     int launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, const void *geom, std::string &err);
     uint64_t count_partitioned_launches = 0;
-    // minimizer super-k-mer path, count_mz.hip; `geom` is an opaque MzGeom
-    bool minimizer_geometry(uint64_t piece_bases, void *geom_out) const;
-    int launch_count_minimizer(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, const void *geom, std::string &err);
-    // region lists of 16-byte (hash, count) entries -> LDS images -> table (the entry form of lds_insert_kernel, count_part.hip);
-    // records the two stage events ev[0], ev[1] after the even and the odd launch
-    int insert_entry_lists(const void *lists, const unsigned int *cnt, uint32_t cap, uint32_t nsl, int region_bits_total, int rbits, unsigned long long *defer_e,
-                           unsigned long long *defer_n, uint64_t deferred_cap, hipEvent_t *ev, std::string &err);
-    int finish_deferred(unsigned long long *defer_e, unsigned long long *defer_n, uint64_t deferred_cap, std::string &err);   // deferred list -> direct path
     static constexpr int N_STAGES = 8;
-    hipEvent_t ev_stage_t[N_STAGES + 1] = {};   // stage boundaries of the last partitioned / minimizer piece
-    // count_part.hip: part1, part2, lds even, lds odd, deferred;  count_mz.hip: mz_part, mz_split (count+scan+write), mz_count, split16 (entries),
-    // lds even, lds odd, expand + deferred
+    hipEvent_t ev_stage_t[N_STAGES + 1] = {};   // stage boundaries of the last partitioned piece
+    // count_part.hip: part1, part2, region_insert, deferred; with the lists exchanged: part1, part2 by owner (+ dedupe), region_insert, -, deferred
     double part_stage_ms[N_STAGES] = {};
     int part_stage_n = 5;          // stages the last piece recorded
-    int count_path = 0;            // path of the last piece: 0 direct kernel, 1 count_part.hip, 2 count_mz.hip
-    bool mz_off = false;           // count_mz.hip overflowed its lists on this table's input once: not tried again
+    int count_path = 0;            // path of the last piece: 0 direct kernel, 1 count_part.hip, 3 count_part.hip with the lists exchanged between GPUs
     bool part_stage_pending = false;
     bool xchg_partitioned = false;  // xchg_partition has recorded its stage events since the last xchg_insert
     bool xchg_deduped = false;      // ... and xchg_dedupe its own
-    // Multiplicity histogram taken for free while lds_insert_kernel writes the final region images back: valid when one
+    // Multiplicity histogram taken for free while region_insert_kernel writes the final region images back: valid when one
     // partitioned piece counted the whole input into an empty table and nothing had to take the deferred (direct) path.
     // d_histo: [0, HISTO_WORDS) fused histogram + "deferred records existed" flag, [HISTO_WORDS, 2*HISTO_WORDS) scratch of
     // histo_kernel.  Every other mutation of the table drops the cached histogram.
@@ -340,7 +330,7 @@ struct Table {
     // workspace of its own: polish_host.hip): lane 0 uses the table's stream and the first WS_POLISH_MAX slots, lane l > 0
     // polish_stream[l] and the slots from WS_LANE0 + (l - 1) * WS_POLISH_MAX on.
     static constexpr int POLISH_LANES_MAX = 4;
-    static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_INGEST = 44, WS_MZ = 50, WS_HOSTBASES = 54, WS_LANE0 = 55,
+    static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_INGEST = 44, WS_XCHG = 50, WS_HOSTBASES = 54, WS_LANE0 = 55,
                          WS_SLOTS = WS_LANE0 + (POLISH_LANES_MAX - 1) * WS_POLISH_MAX;
     WsBuf ws[WS_SLOTS];   // 0..WS_POLISH_MAX-1: polisher (polish_host.hip, in allocation order); WS_COUNT..+3: partitioned counting
     hipStream_t polish_stream[POLISH_LANES_MAX] = {nullptr, nullptr, nullptr, nullptr};      // [0] unused (= stream); created on first use

@@ -220,9 +220,7 @@ class KmerTable:
         check(self._L.jasper_last_count_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
-    STAGE_NAMES = {2: ("mz_part_kernel", "mz_split_kernels", "mz_count_kernel", "split16_entries_kernel", "lds_insert_kernel_even", "lds_insert_kernel_odd",
-                       "expand_and_deferred_kernels"),
-                   1: ("part1_kernel", "part2_kernel", "region_insert_kernel", "deferred_import3h_kernel"),
+    STAGE_NAMES = {1: ("part1_kernel", "part2_kernel", "region_insert_kernel", "deferred_import3h_kernel"),
                    3: ("part1_kernel", "part2_by_owner_kernel", "region_insert_kernel", "(unused)", "deferred_import3h_kernels"),
                    0: ()}
 
@@ -237,7 +235,7 @@ class KmerTable:
         return list(ms)[:len(self.STAGE_NAMES.get(path.value, ()))] or list(ms)[:5], n.value
 
     def count_path(self):
-        """3 = region lists exchanged between GPUs, 2 = minimizer super-k-mers, 1 = one record per occurrence, 0 = count_kernel"""
+        """3 = region lists exchanged between GPUs, 1 = one record per occurrence through partition passes and LDS images, 0 = count_kernel"""
         self.count_stages()
         return self._count_path
 

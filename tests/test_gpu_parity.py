@@ -598,10 +598,11 @@ def test_histogram_fused_into_counting_pass_equals_table_scan(KT):
 
 
 @pytest.mark.parametrize("k", [15, 21, 25, 27, 31, 32, 33, 35, 37, 41])
-def test_atomic_free_counting_paths_equal_direct_counting(KT, k):
-    """the three ways a table is filled must build the same table for every k they accept (one- and two-word k-mers):
-    minimizer super-k-mers (count_mz.hip: mz_part -> mz_split -> mz_count -> ent_split -> lds_insert), one record per
-    occurrence (count_part.hip: part1 -> part2 -> lds_insert; k <= 37) and the direct insert kernel (global atomics)"""
+def test_atomic_free_counting_equals_direct_counting(KT, k):
+    """the two ways a table is filled must build the same table for every k (one-, two- and three-word k-mers): one record per
+    occurrence through the partition passes and LDS images (count_part.hip: part1 -> part2 -> region_insert; k <= 37, where the
+    hash bits below the 2^10 first-level buckets fit an 8-byte record) and the direct insert kernel (global atomics), which
+    every other k takes"""
     import torch
     G = 1_500_000
     dev = torch.device("cuda", 0)
@@ -609,27 +610,19 @@ def test_atomic_free_counting_paths_equal_direct_counting(KT, k):
     genome = synth.torch_genome(gen, G, dev)
     nreads = G * 30 // 150
     reads = synth.torch_reads_stream(gen, genome, nreads, 150, 0.004)
-    # low-complexity stretches: long runs of one minimizer (records cut at nmax), and a read of all-N
+    # low-complexity stretches, a read of all-N
     reads[1000:1600] = ord("A")
     reads[5000:5400] = torch.tensor(list(b"ACACACACACACACACACAC" * 20), dtype=torch.uint8, device=dev)
     reads[9000:9300] = ord("N")
     reads[2_000_000:2_050_000] = ord("N")         # whole 16384-base tiles of the partition pass without a single k-mer
     torch.cuda.synchronize()
     slots = int(1.25 * nreads * 150 * 2.1 / 10)
-    os.environ["JASPER_COUNT_PATH"] = "2"
-    try:
-        tm = KT(k, min_slots=slots)
-        tm.count_bases_device(reads.data_ptr(), reads.numel())
-    finally:
-        del os.environ["JASPER_COUNT_PATH"]
-    if k <= 37:      # (k >= 38 needs >= 2^(2k-53) slots: this input is then small against the table and takes the direct kernel)
-        assert tm.count_stages()[1] >= 1 and tm.count_path() == 2, "minimizer path not taken"
-    tables = [tm]
+    tp = KT(k, min_slots=slots)
+    tp.count_bases_device(reads.data_ptr(), reads.numel())
     if k <= 37:
-        tp = KT(k, min_slots=slots)
-        tp.count_bases_device(reads.data_ptr(), reads.numel())
         assert tp.count_stages()[1] >= 1 and tp.count_path() == 1, "partitioned path not taken"
-        tables.append(tp)
+    else:
+        assert tp.count_stages()[1] == 0 and tp.count_path() == 0
     os.environ["JASPER_COUNT_DIRECT"] = "1"
     try:
         td = KT(k, min_slots=slots)
@@ -641,115 +634,17 @@ def test_atomic_free_counting_paths_equal_direct_counting(KT, k):
     g = genome[:200_000].cpu().numpy().tobytes().decode()
     qs = [g[i:i + k] for i in range(0, len(g) - k, 997)] + ["A" * k, "ACGT" * 16, "AC" * 32]
     hd, ld = td.histogram(), td.lookup(qs)
-    for tp in tables:
-        ip = tp.info()
-        assert ip["occurrences"] == idr["occurrences"] and ip["distinct"] == idr["distinct"], (tp.count_path(), ip, idr)
-        assert tp.histogram() == hd, tp.count_path()
-        assert tp.lookup(qs) == ld
-        tp.close()
+    ip = tp.info()
+    assert ip["occurrences"] == idr["occurrences"] and ip["distinct"] == idr["distinct"], (tp.count_path(), ip, idr)
+    assert tp.histogram() == hd and tp.lookup(qs) == ld
+    tp.close()
     # a second call adds to the table that is already there (images loaded, not started from zeros)
-    for path in ("1", "2"):
-        os.environ["JASPER_COUNT_PATH"] = path
-        try:
-            t2 = KT(k, min_slots=slots)
-            half = (reads.numel() // 2) // 151 * 151
-            t2.count_bases_device(reads.data_ptr(), half)
-            t2.count_bases_device(reads.data_ptr() + half, reads.numel() - half)
-        finally:
-            del os.environ["JASPER_COUNT_PATH"]
-        assert t2.info()["distinct"] == idr["distinct"] and t2.histogram() == hd and t2.lookup(qs) == ld
-        t2.close()
-    td.close()
-
-
-def test_minimizer_path_overflowing_slices_take_the_direct_path(KT, capfd):
-    """count_mz.hip sizes its lists from estimates: records that find their slice full are rolled out by mz_expand_kernel,
-    entries that find theirs full go to the deferred list -- both through the direct (atomic) path after the last region
-    image is written.  With the capacities cut (JASPER_MZ_TEST_CAPS) thousands of each overflow; the table must not differ."""
-    import torch
-    k = 31
-    G = 1_500_000
-    dev = torch.device("cuda", 0)
-    gen = torch.Generator(device=dev).manual_seed(777)
-    genome = synth.torch_genome(gen, G, dev)
-    nreads = G * 30 // 150
-    reads = synth.torch_reads_stream(gen, genome, nreads, 150, 0.004)
-    torch.cuda.synchronize()
-    slots = int(1.25 * nreads * 150 * 2.1 / 10)
-    import re
-
-    def run(caps):
-        os.environ.update(JASPER_COUNT_PATH="2", JASPER_COUNT_DEBUG="2")
-        if caps:
-            os.environ["JASPER_MZ_TEST_CAPS"] = caps
-        try:
-            t = KT(k, min_slots=slots)
-            t.count_bases_device(reads.data_ptr(), reads.numel())
-            assert t.count_path() == 2 or (caps and caps.startswith("0.02"))
-        finally:
-            for v in ("JASPER_COUNT_PATH", "JASPER_MZ_TEST_CAPS", "JASPER_COUNT_DEBUG"):
-                os.environ.pop(v, None)
-        return t, capfd.readouterr().err
-    # how full the slices get with the normal capacities, then capacities 30 % below that
-    t0, log = run(None)
-    t0.close()
-    m = re.search(r"fullest sliceA (\d+) / (\d+).*fullest sliceC (\d+) / (\d+), sliceE (\d+) / (\d+)", log)
-    assert m, log[-600:]
-    f = [0.7 * int(m.group(i)) / int(m.group(i + 1)) for i in (1, 3, 5)]
-    tm, log = run("%.4f:%.4f:%.4f" % tuple(f))
-    m = re.search(r"deferred (\d+), overflow records (\d+)", log)
-    assert m and int(m.group(1)) > 10 and int(m.group(2)) > 10, "the capacities were not cut far enough to overflow: " + log[-400:]
-    # ... and the entry slices themselves reached their cut capacity (the third factor: entries that find their region list full)
-    m = re.search(r"sliceE (\d+) / (\d+)", log)
-    assert m and int(m.group(1)) >= int(m.group(2)), log[-400:]
-    os.environ["JASPER_COUNT_DIRECT"] = "1"
-    try:
-        td = KT(k, min_slots=slots)
-        td.count_bases_device(reads.data_ptr(), reads.numel())
-    finally:
-        del os.environ["JASPER_COUNT_DIRECT"]
-    assert tm.info() == td.info() and tm.histogram() == td.histogram()
-    g = genome[:100_000].cpu().numpy().tobytes().decode()
-    qs = [g[i:i + k] for i in range(0, len(g) - k, 499)]
-    assert tm.lookup(qs) == td.lookup(qs)
-    tm.close()
-    # capacities far too small even for the fallbacks: the call notices, empties the table and starts over on the other path
-    tr, log = run("0.02:0.02:0.02")
-    assert "restarting without it" in log
-    assert tr.info() == td.info() and tr.histogram() == td.histogram()
-    tr.close()
-    td.close()
-
-
-def test_k41_takes_the_minimizer_path_and_equals_direct_counting(KT):
-    """38 <= k <= 43: keys of up to 86 bits do not fit count_part.hip's 8-byte records; with whole remainders in the tags
-    (2^29 slots at k = 41) an input of that size is counted through minimizer super-k-mers by default"""
-    import torch
-    k = 41
-    G = 3_600_000
-    dev = torch.device("cuda", 0)
-    gen = torch.Generator(device=dev).manual_seed(4100)
-    genome = synth.torch_genome(gen, G, dev)
-    nreads = G * 30 // 150
-    reads = synth.torch_reads_stream(gen, genome, nreads, 150, 0.004)
-    torch.cuda.synchronize()
-    tm = KT(k, min_slots=1 << 29)
-    tm.count_bases_device(reads.data_ptr(), reads.numel())
-    assert tm.count_stages()[1] >= 1 and tm.count_path() == 2, "minimizer path not taken"
-    os.environ["JASPER_COUNT_DIRECT"] = "1"
-    try:
-        td = KT(k, min_slots=1 << 29)
-        td.count_bases_device(reads.data_ptr(), reads.numel())
-        assert td.count_stages()[1] == 0
-    finally:
-        del os.environ["JASPER_COUNT_DIRECT"]
-    im, idr = tm.info(), td.info()
-    assert im["occurrences"] == idr["occurrences"] == nreads * (150 - k + 1) and im["distinct"] == idr["distinct"]
-    assert tm.histogram() == td.histogram()
-    g = genome[:100_000].cpu().numpy().tobytes().decode()
-    qs = [g[i:i + k] for i in range(0, len(g) - k, 499)]
-    assert tm.lookup(qs) == td.lookup(qs)
-    tm.close()
+    t2 = KT(k, min_slots=slots)
+    half = (reads.numel() // 2) // 151 * 151
+    t2.count_bases_device(reads.data_ptr(), half)
+    t2.count_bases_device(reads.data_ptr() + half, reads.numel() - half)
+    assert t2.info()["distinct"] == idr["distinct"] and t2.histogram() == hd and t2.lookup(qs) == ld
+    t2.close()
     td.close()
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """the counting phase of bench.py alone, repeated on one table (GPU box): stage times of the path taken.
-   python tools/bench_count_steps.py [genome_mb] [reps]      env JASPER_COUNT_PATH=1|2, JASPER_COUNT_DEBUG=2"""
+   python tools/bench_count_steps.py [genome_mb] [reps]      env JASPER_COUNT_DEBUG=2"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
