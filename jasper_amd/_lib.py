@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjasper_hip.so")
+# (JASPER_AMD_LIB: another build of the same library, for A/B timing of two builds in one run -- tools/ only)
+LIB_PATH = os.environ.get("JASPER_AMD_LIB") or os.path.join(_HERE, "libjasper_hip.so")
 
 JASPER_OK = 0
 JASPER_ERR = -1

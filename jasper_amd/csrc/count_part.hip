@@ -105,7 +105,7 @@ __device__ __forceinline__ void defer_record(const TableDev &T, u128 h, unsigned
 constexpr int P1_MAXB = 1024;          // part1 handles p1 <= 10; larger p1 falls back to the direct kernel
 constexpr int P1_TH = 1024;
 constexpr int P1_STAGE = 13824;        // records per staging round (a tile of 150-base reads holds ~12.4 K)
-constexpr size_t P1_LDS = (size_t)P1_STAGE * 10 + (size_t)(2 * P1_MAXB + 4 + 32) * 4 + (size_t)2 * (P1_TH + PT_HALO) * 4 + (size_t)P1_MAXB * 8;
+constexpr size_t P1_LDS = (size_t)P1_STAGE * 10 + (size_t)(P1_MAXB + 4 + 32) * 4 + (size_t)2 * (P1_TH + PT_HALO) * 4 + (size_t)P1_MAXB * 8;
 typedef __attribute__((address_space(1))) uint64_t global_u64;      // a pointer known to be global memory (kept as an integer in LDS)
 
 // inclusive prefix sum over the 64 lanes of a wave in six DPP adds (row shifts inside the rows of 16, then the two row broadcasts)
@@ -134,9 +134,10 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                                                       unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     // (the small arrays come first: their addresses fit the 16-bit offset field of the LDS instructions)
-    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_raw);                           // P1_MAXB   records of this tile per bucket
-    unsigned int *s_off = s_cnt + P1_MAXB;                                                   // P1_MAXB+4 exclusive prefix of s_cnt
-    unsigned int *s_wsum = s_off + P1_MAXB + 4;                                              // 16 wave totals, [16] = "a slice overflows in this tile"
+    // s_cnt: records of this tile per bucket while they are ranked (A), then, in place, the exclusive prefix of those counts (B..D)
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_raw);                           // P1_MAXB+4
+    unsigned int *s_off = s_cnt;
+    unsigned int *s_wsum = s_cnt + P1_MAXB + 4;                                              // 16 wave totals, [16] = "a slice overflows in this tile"
     uint32_t *s_code = reinterpret_cast<uint32_t *>(s_wsum + 32);                            // P1_TH + PT_HALO
     uint32_t *s_inv = s_code + (P1_TH + PT_HALO);
     // where stage index 0 of this tile would go in my slice of each bucket's list (slice base + (cursor - s_off) records), as an integer
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
             const unsigned int wbase = (tb >> 6) ? (unsigned int)__builtin_amdgcn_readlane((int)ws, (tb >> 6) - 1) : 0u;
             total = (unsigned int)__builtin_amdgcn_readlane((int)ws, P1_TH / 64 - 1);
             const unsigned int ex = wbase + inc - v;
-            s_off[tb] = ex;
+            s_off[tb] = ex;                                                          // (in place: nobody else looks at my bucket's count)
         }
         if (t == 0) added += total;
         lds_barrier();
@@ -330,14 +331,13 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                 }
             }
             if (r0 == 0) {
-                // where stage index 0 would go in the slice: the run's place has arrived by now; the bucket's counter is zeroed for
-                // the next tile
+                // where stage index 0 would go in the slice: the run's place has arrived by now
                 int tc = t;
                 asm volatile("" : "+v"(tc), "+v"(apos));
-                const unsigned int v = s_cnt[tc];
-                s_cnt[tc] = 0;
+                const unsigned int ex = s_off[tc];
+                const unsigned int v = (tc + 1 < P1_MAXB ? s_off[tc + 1] : total) - ex;      // (buckets past the last one hold the total)
                 const uint64_t slice0 = reinterpret_cast<uint64_t>(out1 + ((uint64_t)tc * P.nblk1 + grp) * P.cap1);
-                s_base[tc] = slice0 + ((uint64_t)apos - (uint64_t)s_off[tc]) * 8ull;
+                s_base[tc] = slice0 + ((uint64_t)apos - (uint64_t)ex) * 8ull;
                 if (v && apos + v > P.cap1) s_wsum[16] = 1;                          // (stays set: the slice stays full)
             }
             lds_barrier();
@@ -365,10 +365,8 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                 }
             }
         }
-        if (total == 0) {                                                           // (block-uniform) a tile without a k-mer
-            s_cnt[t] = 0;
-            if (prefetch) encode16(raw.w, c, iv);
-        }
+        if (total == 0 && prefetch) encode16(raw.w, c, iv);                          // (block-uniform) a tile without a k-mer
+        s_cnt[t] = 0;              // for the next tile (every staging round has read its offsets: a barrier lies behind each)
         if (has_next && !prefetch) stage16(bases, base0 + (int64_t)PT_TILE + (int64_t)t * PT_GROUP, (int64_t)n, c, iv);      // (the piece's last tile)
         // (the next tile's barriers order its writes to the stage, s_off and s_base against this copy-out)
     }
