@@ -632,6 +632,34 @@ class _EarlyTable:
         return self.out
 
 
+class _JfWriter:
+    """table.write_jf(tmp) + rename to `final`, by a thread, while the caller goes on to the histogram and the polishing (the
+    database file is `tee`'s by-product in the reference, src/jasper.sh:177: nothing in the same run reads it, and writing 14 bytes
+    per distinct k-mer takes longer than all the polishing).  finish() waits and raises what the thread raised; the file gets its
+    name only when it is complete."""
+
+    def __init__(self, table, tmp, final, cmdline):
+        import threading
+        self.err = None
+
+        def work():
+            try:
+                table.write_jf(tmp, cmdline)
+                os.replace(tmp, final)
+            except BaseException as e:          # noqa: BLE001 -- handed to the caller of finish()
+                self.err = e
+
+        self.th = threading.Thread(target=work, daemon=True)
+        self.th.start()
+        import atexit
+        atexit.register(self.th.join)          # (an exit taken meanwhile waits for the GPU work of the thread, as for _EarlyTable)
+
+    def finish(self):
+        self.th.join()
+        if self.err is not None:
+            raise self.err
+
+
 def _join_and_merge(o, qfn, batch_size, last_it, contigs):
     """src/jasper.sh:218-232"""
     fixed_files = sorted(glob.glob("_iter%d_%s.batch.*.fa.fixed.fa" % (last_it, glob.escape(qfn))))
@@ -732,6 +760,7 @@ def run(argv):
     # but the database file -- is the work of a thread while this one splits the assembly (the two do not depend on each other;
     # the log lines keep the reference's order)
     early = None
+    jf_writer = None
     if (o.jf_db is None and not (os.path.isfile("mer_counts%d.jf" % kmer) and os.path.getsize("mer_counts%d.jf" % kmer) > 0)
             and not os.environ.get("JASPER_AMD_NO_EARLY_TABLE") and o.reads.split() and all(os.path.isfile(fn) and os.path.getsize(fn) > 0 for fn in o.reads.split())):   # (only when counting WILL happen: no exit while the thread is in the driver)
         early = _EarlyTable(kmer, max(1 << 20, int(1.25 * o.jf_size)), o.device, reads=o.reads.split())
@@ -774,9 +803,8 @@ def run(argv):
             _timing("count reads (files -> table)")
             if os.environ.get("JASPER_AMD_NO_JF", "") not in ("1", "true", "yes"):
                 # :177 `... | tee $JF_DB | ...`: leave the database behind for reruns and for other Jellyfish tools
-                table.write_jf(jf_file + ".tmp", ["count", "-C", "-t", str(o.num_threads), "-s", str(o.jf_size), "-m", str(kmer), "-o", jf_file] + reads)
-                os.replace(jf_file + ".tmp", jf_file)
-                _timing("write mer_counts.jf")
+                jf_writer = _JfWriter(table, jf_file + ".tmp", jf_file,
+                                      ["count", "-C", "-t", str(o.num_threads), "-s", str(o.jf_size), "-m", str(kmer), "-o", jf_file] + reads)
             with open(histo_file + ".tmp", "w") as f:
                 for m, n in table.histo_rows():
                     f.write("%d %d\n" % (m, n))
@@ -875,6 +903,12 @@ def run(argv):
         for p in glob.glob("*qValCalcHelper.csv"):
             os.remove(p)
     _timing("join + QV")
+    if jf_writer is not None:
+        try:
+            jf_writer.finish()
+        except Exception as e:                 # noqa: BLE001 -- what `set -o pipefail` makes of a failing tee (src/jasper.sh:177-181)
+            error_exit("Creating jellyfish database mer_counts%d.jf failed (%s)" % (kmer, e))
+        _timing("mer_counts.jf complete (written beside the stages above)")
     log("Polished sequence is in %s.polished.fasta" % qfn)
     if table is not None:
         table.close()

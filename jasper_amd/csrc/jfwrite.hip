@@ -117,6 +117,7 @@ static std::string json_str(const char *s) {
 
 int Table::write_jf(const char *path, const char *const *cmdline, int n_cmd, std::string &err, int r_bits, int what) {
     int rc = 0;
+    hipStream_t stream = this->stream;       // (the table's own until the writer's is there: see below)
     FILE *f = nullptr;
     unsigned long long *d_klo[2] = {nullptr, nullptr}, *d_khi[2] = {nullptr, nullptr}, *d_counter = nullptr;
     HiCnt *d_hic[2] = {nullptr, nullptr};
@@ -131,6 +132,11 @@ int Table::write_jf(const char *path, const char *const *cmdline, int n_cmd, std
     if (hipSetDevice(device) != hipSuccess) { err = "hipSetDevice failed"; return -1; }
     if (materialize(err)) return -1;
     if (read_stats(err)) return -1;
+    // (a stream of its own: the table is only read from here on, and the caller may be polishing through the table's own stream
+    //  meanwhile -- jasper_amd/cli.py writes the database file beside the stages that follow the counting; read_stats has waited
+    //  for what the table's stream held)
+    if (!jf_stream) HIPCHK(hipStreamCreateWithFlags(&jf_stream, hipStreamNonBlocking));
+    stream = jf_stream;
     if (what != 2) {
         const uint64_t cap = h_stats[ST_DISTINCT] + 1;
         unsigned long long zero = 0, cnt = 0;

@@ -681,6 +681,7 @@ void Table::destroy() {
     detach_shards();
     for (hipStream_t &ps : polish_stream) { if (ps) { (void)jk_stream_wait(ps); (void)hipStreamDestroy(ps); ps = nullptr; } }
     if (polish_ev) { (void)hipEventDestroy(polish_ev); polish_ev = nullptr; }
+    if (jf_stream) { (void)jk_stream_wait(jf_stream); (void)hipStreamDestroy(jf_stream); jf_stream = nullptr; }
     for (WsBuf &b : ws) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
     for (WsBuf &b : pin) { if (b.p) (void)hipHostFree(b.p); b.p = nullptr; b.bytes = 0; }
     for (int i = 0; i < 2; ++i) {

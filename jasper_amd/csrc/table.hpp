@@ -335,6 +335,7 @@ struct Table {
     WsBuf ws[WS_SLOTS];   // 0..WS_POLISH_MAX-1: polisher (polish_host.hip, in allocation order); WS_COUNT..+3: partitioned counting
     hipStream_t polish_stream[POLISH_LANES_MAX] = {nullptr, nullptr, nullptr, nullptr};      // [0] unused (= stream); created on first use
     hipEvent_t polish_ev = nullptr;
+    hipStream_t jf_stream = nullptr;        // write_jf's own (jfwrite.hip)
     void *workspace(int id, size_t bytes, std::string &err);
     // grow-only PINNED host buffers kept with the table (the polisher's segment tables, candidate lists and records travel through
     // them: a copy to or from pageable memory is staged by the runtime and makes the caller wait)
