@@ -1276,10 +1276,11 @@ __global__ __launch_bounds__(DD_TH) void list_dedupe_kernel(uint64_t *__restrict
 #pragma unroll
             for (int u = 0; u < DD_PER; ++u) {
                 slot[u] = 0xFFFFu;
+                if ((unsigned int)u * DD_TH >= m) continue;                    // (block-uniform: a short chunk)
                 const unsigned int i = (unsigned int)u * DD_TH + t;
                 if (i >= m) continue;
                 if (r[u] == EMPTY) { atomicAdd(&s_all1, 1u); continue; }       // (the one value the set cannot hold)
-                uint32_t h = (uint32_t)((r[u] * 0x9E3779B97F4A7C15ull) >> 40) & (DD_SLOTS - 1);
+                uint32_t h = (uint32_t)(r[u] ^ (r[u] >> 13)) & (DD_SLOTS - 1);        // (the low record bits are hash bits already: kmer.hpp mix)
                 for (;;) {
                     unsigned long long cur = s_key[h];
                     if (cur == EMPTY) {
@@ -1293,8 +1294,20 @@ __global__ __launch_bounds__(DD_TH) void list_dedupe_kernel(uint64_t *__restrict
             __syncthreads();                                   // the chunk has been read: its place (and what lies before it) may be written
 #pragma unroll
             for (int u = 0; u < DD_PER; ++u) {
-                if (slot[u] == 0xFFFFu) continue;
+                // the claimants of a wave take their places in the output with ONE atomic (64 lanes adding to one LDS word are
+                // served one after the other); a key with more occurrences than a record holds takes its further places alone
+                if ((unsigned int)u * DD_TH >= m) continue;                    // (block-uniform)
+                const bool mine = slot[u] != 0xFFFFu;
+                const unsigned long long claim = __ballot(mine);
+                if (!claim) continue;
+                unsigned int base = 0;
+                if ((t & 63) == (int)__builtin_ctzll(claim)) base = atomicAdd(&s_out, (unsigned int)__popcll(claim));
+                base = (unsigned int)__shfl((int)base, (int)__builtin_ctzll(claim));
+                if (!mine) continue;
                 unsigned int left = s_cnt[slot[u]];
+                const unsigned int first = left < per ? left : per;
+                lst[base + (unsigned int)__popcll(claim & ((1ull << (t & 63)) - 1ull))] = (r[u] & ~fmask) | ((uint64_t)(first - 1u) << cshift);
+                left -= first;
                 while (left) {
                     const unsigned int take = left < per ? left : per;
                     lst[atomicAdd(&s_out, 1u)] = (r[u] & ~fmask) | ((uint64_t)(take - 1u) << cshift);
