@@ -791,6 +791,7 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__
     const uint64_t rmask = (1ull << rs) - 1ull;
     const bool whole = nregions == 1;                                                // the whole table is one region: probes wrap inside it
     unsigned long long fresh = 0;
+    if (!XCHG && deferred_n[1]) return;                                              // (uniform) the piece was abandoned: part_decide_kernel
     if (histo) {
         for (int i = t; i < LDS_HBINS; i += RI_TH) s_bins[i] = 0;
     }
@@ -940,16 +941,39 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
 }
 
+// Between the partition passes and the insert: lists that overflowed more than the deferred list holds (one k-mer that makes up
+// a tenth of the input: all its records go to ONE region list) cannot be inserted completely.  Nothing has touched the table yet,
+// so the piece is ABANDONED here -- word 1 of the deferred list's header tells region_insert_kernel and import3h_kernel to do
+// nothing -- and the host counts it again through the direct kernel (table.hip: count_device).
+__global__ void part_decide_kernel(unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap, const unsigned long long *__restrict__ stats) {
+    if (deferred_n[0] > deferred_cap || stats[ST_FATAL]) deferred_n[1] = 1ull;
+}
+
 // the deferred records through the direct path, with the fused histogram kept exact: a key whose count goes from c to c + inc
 // leaves bin(c) and enters bin(c + inc) (every add returns the count it found, so concurrent adds to one key move it bin by bin)
 __device__ __forceinline__ uint32_t histo_bin(unsigned long long c) { const uint32_t v = clamp32(c); return v > 10001u ? 10001u : v; }
 __global__ __launch_bounds__(256) void import3h_kernel(const unsigned long long *__restrict__ entries, const unsigned long long *__restrict__ n_ptr, uint64_t cap,
                                                        TableDev T, unsigned long long *__restrict__ histo) {
+    if (n_ptr[1]) return;                                                            // the piece was abandoned (part_decide_kernel)
     const uint64_t n = *n_ptr < cap ? *n_ptr : cap;
     unsigned long long fresh = 0;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const u128 h = mk(entries[3 * i], entries[3 * i + 1]);
-        const unsigned long long inc = entries[3 * i + 2];
+    for (uint64_t i0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) & ~63ull; i0 < n; i0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = i0 + (threadIdx.x & 63);
+        const bool have = i < n;
+        u128 h = mk(0, 0);
+        unsigned long long inc = 0;
+        if (have) { h = mk(entries[3 * i], entries[3 * i + 1]); inc = entries[3 * i + 2]; }
+        // a wave's 64 entries are often ONE key (what overflows a list is a k-mer far more frequent than the rest, and its records
+        // were deferred one after the other): the first lane adds for all of them -- 64 atomics on one address would queue up
+        {
+            const int lead = (int)__builtin_ctzll(__ballot(have));
+            const uint64_t lhi = (uint64_t)__shfl((long long)h.hi, lead), llo = (uint64_t)__shfl((long long)h.lo, lead);
+            const bool same = have && h.hi == lhi && h.lo == llo;
+            unsigned long long part = same ? inc : 0ull;
+            for (int o = 32; o > 0; o >>= 1) part += (unsigned long long)__shfl_xor((long long)part, o);
+            if (same) inc = (int)(threadIdx.x & 63) == lead ? part : 0ull;
+        }
+        if (!have || !inc) continue;
         const uint64_t home = home_of(h, T.B, T.s);
         const uint64_t rem = rem_of(h, T.B, T.s);
         bool done = false;
@@ -1073,6 +1097,10 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
         HIPCHK(hipGetLastError());
         lists = out2; lcnt = cnt2; lcap = G.cap2; nsl = G.nblk2;
     }
+    hipLaunchKernelGGL(part_decide_kernel, dim3(1), dim3(1), 0, stream, defer_n, deferred_cap, d.stats);
+    HIPCHK(hipGetLastError());
+    part_defer_header = defer_n;
+    part_slots_dirty_before = slots_dirty;
     HIPCHK(hipEventRecord(ev_stage_t[2], stream));
     // fused histogram: asked for by count_device when this piece is the whole input going into an empty table
     unsigned long long *histo = histo_request ? d_histo : nullptr;

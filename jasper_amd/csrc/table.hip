@@ -854,7 +854,7 @@ int Table::launch_count(const uint8_t *d_piece, uint64_t len, uint64_t emit_from
     // to the table (host-staged 64 MiB pieces stay on the direct kernel and are PCIe-bound anyway)
     // break-even measured on MI355X: direct ~18 Gk-mers/s; partitioned ~55 Gk-mers/s for the two list passes plus one
     // streaming pass over the table (32 B/slot, 16 B/slot when the table is still lazily cleared)
-    if (len >= (slots_dirty ? nslots / 6 : nslots / 4)) {
+    if (!part_off && len >= (slots_dirty ? nslots / 6 : nslots / 4)) {
         if (partition_geometry(len, geom)) {
             ++count_partitioned_launches;
             return launch_count_partitioned(d_piece, len, emit_from, geom, err);
@@ -945,9 +945,30 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err, ui
         histo_request = false;
         if (lrc) return -1;
         const double t_l1 = dbg ? now_ms() : 0;
+        const uint64_t pos_piece = pos;
         pos = end;
         int rc = after_batch(err);
         histo_cached = rc == 0 && fused_histo;
+        if (rc == -2 && count_path == 1 && part_defer_header) {
+            unsigned long long abandoned = 0;
+            HIPCHK(hipMemcpy(&abandoned, part_defer_header + 1, 8, hipMemcpyDeviceToHost));
+            if (abandoned) {
+                // One k-mer (or a few) so frequent that its region list overflowed beyond the deferred list: the piece stopped before
+                // it wrote to the table.  Counted again, like everything after it, by the direct kernel -- the k-mer's atomics
+                // queue up on one address there, but they all arrive.
+                if (dbg) fprintf(stderr, "[count] partitioned piece abandoned (lists overflowed the deferred list): direct kernel from here on\n");
+                err.clear();
+                part_off = true;
+                part_stage_pending = false;
+                slots_dirty = part_slots_dirty_before;
+                const unsigned long long zero = 0, occ = occ_before;
+                HIPCHK(hipMemcpy(d.stats + ST_FATAL, &zero, 8, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(d.stats + ST_OCCURRENCES, &occ, 8, hipMemcpyHostToDevice));
+                if (read_stats(err)) return -1;
+                pos = pos_piece;
+                continue;
+            }
+        }
         if (dbg) fprintf(stderr, "[count] host: launch calls %.2f ms, wait + after_batch %.2f ms\n", t_l1 - t_l0, now_ms() - t_l1);
         if (rc == -2 && have_ratio && started_empty) {
             // The size hint promised a more repetitive input than this one: the piece sized from it overflowed the table.

@@ -313,6 +313,10 @@ struct Table {
     int part_stage_n = 5;          // stages the last piece recorded
     int count_path = 0;            // path of the last piece: 0 direct kernel, 1 count_part.hip, 3 count_part.hip with the lists exchanged between GPUs
     bool part_stage_pending = false;
+    // a partitioned piece whose lists overflowed beyond the deferred list abandons itself before it touches the table
+    // (count_part.hip: part_decide_kernel); count_device then counts the piece through the direct kernel and stays with it
+    unsigned long long *part_defer_header = nullptr;
+    bool part_slots_dirty_before = false, part_off = false;
     bool xchg_partitioned = false;  // xchg_partition has recorded its stage events since the last xchg_insert
     bool xchg_deduped = false;      // ... and xchg_dedupe its own
     // Multiplicity histogram taken for free while region_insert_kernel writes the final region images back: valid when one

@@ -648,6 +648,48 @@ def test_atomic_free_counting_equals_direct_counting(KT, k):
     td.close()
 
 
+@pytest.mark.parametrize("frac", [0.02, 0.10, 0.5])
+def test_one_kmer_that_makes_up_much_of_the_input(KT, frac, capfd):
+    """reads of one repeated base: all their k-mers are ONE key, all its records go to one region list.  A few per cent of the
+    input overflow that list into the deferred list (and reach the table through the direct path, a wave's 64 equal entries as one
+    add); more than the deferred list holds makes the piece abandon itself before it touches the table, and the call counts it --
+    and what follows -- through the direct kernel.  Either way the table is the one direct counting builds."""
+    import torch
+    k = 37
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    genome = synth.torch_genome(gen, 1_500_000, dev)
+    nreads = 1_500_000 * 30 // 150
+    reads = synth.torch_reads_stream(gen, genome, nreads, 150, 0.004)
+    m = int(reads.numel() * frac) // 151 * 151
+    reads[:m].view(-1, 151)[:, :150] = ord("A")
+    torch.cuda.synchronize()
+    slots = int(1.25 * nreads * 150 * 2.1 / 10)
+    os.environ["JASPER_COUNT_DEBUG"] = "1"
+    try:
+        t = KT(k, min_slots=slots)
+        t.count_bases_device(reads.data_ptr(), reads.numel())
+    finally:
+        del os.environ["JASPER_COUNT_DEBUG"]
+    log = capfd.readouterr().err
+    assert ("piece abandoned" in log) == (frac >= 0.10), log[-500:]
+    assert t.count_path() == (1 if frac < 0.10 else 0)
+    os.environ["JASPER_COUNT_DIRECT"] = "1"
+    try:
+        td = KT(k, min_slots=slots)
+        td.count_bases_device(reads.data_ptr(), reads.numel())
+    finally:
+        del os.environ["JASPER_COUNT_DIRECT"]
+    assert t.info() == td.info() and t.histogram() == td.histogram()
+    assert t.lookup(["A" * k, "T" * k]) == td.lookup(["A" * k, "T" * k]) == [(m // 151) * (150 - k + 1)] * 2
+    # the table keeps counting (a second call adds to it), still equal to direct counting
+    t.count_bases_device(reads.data_ptr(), reads.numel())
+    td.count_bases_device(reads.data_ptr(), reads.numel())
+    assert t.info() == td.info() and t.histogram() == td.histogram()
+    t.close()
+    td.close()
+
+
 def _ingest_cases():
     rng = np.random.default_rng(77)
     genome = synth.make_genome(rng, 30000, repeat_frac=0)
