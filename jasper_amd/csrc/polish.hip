@@ -1527,6 +1527,23 @@ void launch_scan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunk
     launch_find_clean(d_chunks, n_chunks, k, stream);
 }
 
+// chunk texts <-> one packed buffer (text of chunk c at pack + offs[c]): a batch of very many small records crosses PCIe in one
+// transfer instead of one per record (polish_host.hip)
+__global__ __launch_bounds__(256) void copy_chunks_kernel(uint8_t *const *__restrict__ chunk_ptr, uint8_t *__restrict__ pack, const int64_t *__restrict__ offs, int n,
+                                                          int to_chunks) {
+    for (int c = blockIdx.x; c < n; c += gridDim.x) {
+        const int64_t len = offs[c + 1] - offs[c];
+        uint8_t *a = chunk_ptr[c], *b = pack + offs[c];
+        const uint8_t *src = to_chunks ? b : a;
+        uint8_t *dst = to_chunks ? a : b;
+        for (int64_t i = threadIdx.x; i < len; i += 256) dst[i] = src[i];
+    }
+}
+void launch_copy_chunks(uint8_t *const *d_chunk_ptr, uint8_t *d_pack, const int64_t *d_offs, int n, bool to_chunks, hipStream_t stream) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(copy_chunks_kernel, dim3((unsigned)std::min(n, 256 * 16)), dim3(256), 0, stream, d_chunk_ptr, d_pack, d_offs, n, to_chunks ? 1 : 0);
+}
+
 void launch_seg_init(SegDev *d_segs, int n_segs, const uint8_t *const *d_chunk_text, hipStream_t stream) {
     if (n_segs <= 0) return;
     dim3 grid(n_segs >= 512 ? 4 : 64, n_segs < 4096 ? n_segs : 4096);

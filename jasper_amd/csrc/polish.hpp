@@ -142,6 +142,7 @@ void launch_scan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunk
 // later passes: classes were carried over by the stitch; recompute the 64-window tiles next to changed text, then candidates
 void launch_rescan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunks, int k, uint32_t solid, hipStream_t stream);
 
+void launch_copy_chunks(uint8_t *const *d_chunk_ptr, uint8_t *d_pack, const int64_t *d_offs, int n, bool to_chunks, hipStream_t stream);
 void launch_seg_init(SegDev *d_segs, int n_segs, const uint8_t *const *d_chunk_text, hipStream_t stream);
 // d_ticket: one device word (zeroed by the call); d_segs[i].arrive must point into an array preset to ARRIVE_PENDING
 void launch_seg_walk(const TableDev &T, SegDev *d_segs, int n_segs, PolishParams pp, int pass, ScratchPool pool, unsigned int *d_ticket,

@@ -129,6 +129,21 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
     uint8_t *aux_p = reinterpret_cast<uint8_t *>(T.pinned(pin_base + 5, PIN_AUX, err));
     ScanChunk *sc_p = reinterpret_cast<ScanChunk *>(T.pinned(pin_base + 6, sizeof(ScanChunk) * (size_t)n_chunks, err));
     if (!segs_p || !first_p || !sum_p || !cand_p || !recs_p || !aux_p || !sc_p) return -2;
+    // very many small records in host memory: their texts cross PCIe packed, one transfer each way (a transfer per record costs
+    // ~10 us: 100 000 contigs of a fragmented assembly took 2.8 s for 70 ms of kernels)
+    int64_t total_len = 0;
+    for (int c = 0; c < n_chunks; ++c) total_len += len[c];
+    const bool packed_io = !device_in && n_chunks > 256 && total_len / n_chunks < 65536 && !getenv("JASPER_POLISH_NO_PACKED_IO");
+    DevBuf b_iooffs;
+    std::vector<int64_t> io_offs;
+    uint8_t *io_stage = nullptr;
+    if (packed_io) {
+        if (!dmalloc(b_iooffs, ((size_t)n_chunks + 1) * 8)) return -2;
+        io_offs.resize((size_t)n_chunks + 1);
+        // (the texts may grow on the way: the way back is sized like the arenas)
+        io_stage = reinterpret_cast<uint8_t *>(T.pinned(pin_base + 7, std::max<size_t>((size_t)total_len, 1) + (size_t)(RM * std::max<int64_t>(4096, total_len / 8)) + 64, err));
+        if (!io_stage) return -2;
+    }
     size_t pin_recs_used = 0, pin_aux_used = 0;
     struct PinnedPass { size_t rec_at, nrec, aux_at, naux, r0, pass_i; };      // what a pass left in the pinned record buffers: copied out after the last pass
     std::vector<PinnedPass> pinned_passes;
@@ -151,11 +166,23 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
         hCA[c] = b_cls.as<uint8_t>() + off_pos[c];
         hCB[c] = b_clsB.as<uint8_t>() + off_pos[c];
         hF[c] = b_flags.as<uint8_t>() + off_flag[c];
-        if (len[c] && !device_in) HIPCHK(hipMemcpyAsync(a, seqs[c], (size_t)len[c], hipMemcpyHostToDevice, st));
+        if (len[c] && !device_in && !packed_io) HIPCHK(hipMemcpyAsync(a, seqs[c], (size_t)len[c], hipMemcpyHostToDevice, st));
     }
     HIPCHK(hipMemcpyAsync(b_ptrA.p, tables.data(), tables.size() * sizeof(void *), hipMemcpyHostToDevice, st));
     uint8_t **dIn = b_ptrA.as<uint8_t *>(), **dOut = dIn + n_chunks, **dSpare = dOut + n_chunks;
     uint8_t **ptrClsIn = dSpare + n_chunks, **ptrClsOut = ptrClsIn + n_chunks, **ptrFlags = ptrClsOut + n_chunks;
+    if (packed_io) {
+        // all the texts in one transfer: packed on the host, spread to their arena places by a kernel (the count array, not yet in
+        // use, takes the packed copy)
+        int64_t at = 0;
+        for (int c = 0; c < n_chunks; ++c) { io_offs[c] = at; if (len[c]) memcpy(io_stage + at, seqs[c], (size_t)len[c]); at += len[c]; }
+        io_offs[n_chunks] = at;
+        HIPCHK(hipMemcpyAsync(b_iooffs.p, io_offs.data(), io_offs.size() * 8, hipMemcpyHostToDevice, st));
+        if (at) HIPCHK(hipMemcpyAsync(b_cnt.p, io_stage, (size_t)at, hipMemcpyHostToDevice, st));
+        launch_copy_chunks(dIn, b_cnt.as<uint8_t>(), b_iooffs.as<int64_t>(), n_chunks, true, st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(jk_stream_wait(st));                    // (io_offs and the stage are reused for the way back)
+    }
 
     if (dbg) { (void)jk_stream_wait(st); fprintf(stderr, "[polish] setup + H2D: %.2f ms\n", now() - t_begin); }
     const double t_loop = now();
@@ -538,11 +565,26 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
             R.d_lens.assign(len.begin(), len.end());
             for (int c = 0; c < n_chunks; ++c) R.d_seqs[c] = hIn[c];
         }
-        for (int c = 0; c < n_chunks && !keep_on_device; ++c) {
+        bool packed_back = false;
+        if (packed_io && !keep_on_device) {
+            int64_t at = 0;
+            for (int c = 0; c < n_chunks; ++c) { io_offs[c] = at; at += len[c]; }
+            io_offs[n_chunks] = at;
+            if ((size_t)at <= pos_items * 4 && (size_t)at <= (size_t)total_len + (size_t)(RM * std::max<int64_t>(4096, total_len / 8)) + 64) {
+                packed_back = true;
+                HIPCHK(hipMemcpyAsync(b_iooffs.p, io_offs.data(), io_offs.size() * 8, hipMemcpyHostToDevice, st));
+                launch_copy_chunks(dIn, b_cnt.as<uint8_t>(), b_iooffs.as<int64_t>(), n_chunks, false, st);
+                HIPCHK(hipGetLastError());
+                if (at) HIPCHK(hipMemcpyAsync(io_stage, b_cnt.p, (size_t)at, hipMemcpyDeviceToHost, st));
+            }
+        }
+        for (int c = 0; c < n_chunks && !keep_on_device && !packed_back; ++c) {
             R.seqs[c].resize((size_t)len[c]);
             if (len[c]) HIPCHK(hipMemcpyAsync(&R.seqs[c][0], hIn[c], (size_t)len[c], hipMemcpyDeviceToHost, st));
         }
         HIPCHK(jk_stream_wait(st));
+        if (packed_back)
+            for (int c = 0; c < n_chunks; ++c) R.seqs[c].assign(reinterpret_cast<const char *>(io_stage) + io_offs[c], (size_t)len[c]);
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
         R.seconds = ms * 1e-3;

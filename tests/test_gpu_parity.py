@@ -201,6 +201,36 @@ def test_polish_in_lanes_equals_one_lane_and_oracle(KT, O, lanes, tight):
     t.close()
 
 
+def test_very_many_small_chunk_records(KT, O):
+    """a fragmented assembly: thousands of short records in one batch (their texts cross PCIe packed, one transfer each way, above
+    256 records) -- the oracle's result, and the same as with a transfer per record"""
+    from jasper_amd import polisher
+    k, thre, passes = 37, 3, 2
+    genome, reads, asm = workload(41, 400_000, k, asm_err=3e-3)
+    t = KT(k, min_slots=1 << 20)
+    t.count_bases(reads)
+    db = O.OracleDB(k)
+    db.count_bases(reads)
+    rng = np.random.default_rng(9)
+    n = 3000
+    starts = rng.integers(0, len(asm) - 900, n)
+    lens = rng.integers(0, 800, n)                 # (empty and shorter-than-k records among them)
+    seqs = [asm[a:a + l] for a, l in zip(starts, lens)]
+    names = ["f%d:0" % i for i in range(n)]
+    fixed_o, rows_o, qv_o, _ = db.polish_batch(names, seqs, thre, passes)
+    fixed, rows, qv, res = polisher.polish_batch(t, names, seqs, thre, passes)
+    assert qv == qv_o and fixed == fixed_o
+    for it in range(passes):
+        assert polisher.fix_csv_text(rows[it]) == "Contig Base_coord Original Mutation\r\n" + rows_o[it]
+    os.environ["JASPER_POLISH_NO_PACKED_IO"] = "1"
+    try:
+        one = t.polish_batch(seqs, thre, passes)
+    finally:
+        del os.environ["JASPER_POLISH_NO_PACKED_IO"]
+    assert one.seqs == fixed and one.qv == qv and one.records == res.records
+    t.close()
+
+
 def test_reads_files_formats_and_gzip(KT, O, tmp_path):
     """`zcat -f R1 R2 | jellyfish count`: one stream, format from the first byte, plain and gzip mixed"""
     k = 21
