@@ -1041,7 +1041,11 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     G.nblk1 = (uint32_t)nblk1;
     // (a slice takes the tiles of ceil(grid1 / nblk1) blocks of ceil(ntiles / grid1) tiles each)
     const uint64_t tiles_per_slice = ((grid1 + nblk1 - 1) / nblk1) * ((ntiles + grid1 - 1) / grid1);
-    G.cap1 = list_cap((double)std::min<uint64_t>(piece_bases, tiles_per_slice * tile1) / (double)(1u << p1));
+    // (a level-1 slice holds half a million records and more: 10 % above the BASES that can fall into it -- records are ~3/4 of the
+    //  bases -- is slack for a bucket with a very frequent k-mer; what does not fit is deferred.  Device memory that has been used
+    //  before is cleared when it is allocated again, ~28 ms per GB on some boxes: every GB of slack shows in a first call.)
+    const double avg1 = (double)std::min<uint64_t>(piece_bases, tiles_per_slice * tile1) / (double)(1u << p1);
+    G.cap1 = avg1 >= 65536.0 ? (uint32_t)std::min<double>(4.0e9, avg1 * 1.10 + 8.0 * std::sqrt(avg1) + 64.0) : list_cap(avg1);
     // one slice per region list: part2 runs one 1024-thread block per CU, and 2^p1 >= 256 buckets already fill the chip;
     // region_insert_kernel then reads a region's records as one contiguous list
     static const int nblk2_exp = getenv("JASPER_EXPERIMENT_NBLK2") ? atoi(getenv("JASPER_EXPERIMENT_NBLK2")) : 0;   // tuning experiments only
@@ -1053,7 +1057,7 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
 int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64_t emit_from, const void *geom, std::string &err) {
     const PartGeom G = *reinterpret_cast<const PartGeom *>(geom);
     const uint32_t nb1 = 1u << G.p1, nregions = 1u << (G.p1 + G.p2);
-    const uint64_t deferred_cap = std::max<uint64_t>(1u << 16, len / 16);
+    const uint64_t deferred_cap = std::max<uint64_t>(1u << 16, len / 48);      // (24 bytes each; a piece that needs more abandons itself: part_decide_kernel)
     const size_t n_cnt1 = (size_t)nb1 * G.nblk1, n_cnt2 = G.p2 ? (size_t)nregions * G.nblk2 : 0;
     uint64_t *out1 = (uint64_t *)workspace(WS_COUNT + 0, n_cnt1 * G.cap1 * 8, err);
     uint64_t *out2 = G.p2 ? (uint64_t *)workspace(WS_COUNT + 1, n_cnt2 * G.cap2 * 8, err) : nullptr;

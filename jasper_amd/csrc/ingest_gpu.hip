@@ -435,7 +435,16 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
     while (CHUNK > (4u << 20) && CHUNK / 2 >= est) CHUNK /= 2;
     if (const char *e = getenv("JASPER_INGEST_CHUNK")) CHUNK = std::max<size_t>(4096, strtoull(e, nullptr, 10));   // tests: many small chunks
     else if (ingest_chunk > CHUNK) CHUNK = ingest_chunk;  // the pinned buffer of an earlier call is kept
-    const size_t BASES_CAP = (size_t)std::min<uint64_t>(3ull << 30, std::max<uint64_t>(est, 16u << 20));
+    // (the bases of a FASTQ file are less than half of its bytes; the buffer is counted and emptied whenever it is full anyway)
+    uint64_t est_bases = est;
+    {
+        struct stat st0;
+        if (n_paths > 0 && stat(paths[0], &st0) == 0 && S_ISREG(st0.st_mode)) {      // (a pipe can be read once: not looked at here)
+            FILE *f0 = fopen(paths[0], "rb");
+            if (f0) { const int c0 = fgetc(f0); fclose(f0); if (c0 == '@') est_bases = est / 2 + (16u << 20); }
+        }
+    }
+    const size_t BASES_CAP = (size_t)std::min<uint64_t>(3ull << 30, std::max<uint64_t>(est_bases, 16u << 20));
     uint64_t n_gpu = 0, n_host = 0;
     Reader rd;
     rd.paths = paths;

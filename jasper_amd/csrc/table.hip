@@ -13,6 +13,7 @@
 #include <cstring>
 #include <ctime>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 namespace jk {
@@ -651,8 +652,12 @@ void *Table::workspace(int id, size_t bytes, std::string &err) {
     WsBuf &b = ws[id];
     if (b.bytes >= bytes) return b.p;
     if (b.p) { (void)jk_stream_wait(stream); (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
-    const size_t want = bytes + bytes / 8;   // a little headroom so that slightly larger batches do not reallocate
+    const size_t want = bytes + std::min<size_t>(bytes / 8, (size_t)256 << 20);   // a little headroom so that slightly larger batches do not reallocate
+    const bool dbg = getenv("JASPER_COUNT_DEBUG") != nullptr && want >= (256u << 20);
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&b.p, want);
+    if (dbg) fprintf(stderr, "[workspace] slot %d: hipMalloc of %.2f GB took %.1f ms\n", id, (double)want / 1e9,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e != hipSuccess) {
         e = hipMalloc(&b.p, bytes);
         if (e != hipSuccess) { err = std::string("device workspace allocation failed: ") + hipGetErrorString(e); b.p = nullptr; return nullptr; }
