@@ -125,8 +125,6 @@ struct PolishParams {
 struct ScanChunk {
     const uint8_t *text;
     int64_t len;
-    uint32_t *cnt;
-    uint8_t *valid;
     uint8_t *cls;
     int64_t *cand;             // sync-point candidates of the WHOLE batch: (chunk << 40) | position, unordered
     unsigned int *cand_count;  // one counter for the batch
@@ -137,7 +135,7 @@ struct ScanChunk {
     uint32_t n_cells;
 };
 constexpr int64_t CLEAN_CELL = 65536;
-// pass 0: dense scan + classes + sync-point candidates of every chunk
+// pass 0: dense scan (counts stay in LDS) + classes + sync-point candidates of every chunk
 void launch_scan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunks, int k, uint32_t solid, hipStream_t stream);
 // later passes: classes were carried over by the stitch; recompute the 64-window tiles next to changed text, then candidates
 void launch_rescan_batch(const TableDev &T, const ScanChunk *d_chunks, int n_chunks, int k, uint32_t solid, hipStream_t stream);

@@ -88,7 +88,7 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
         seg_rec_bound += (size_t)(RM * (2 * tb / k + 16 * ms));
         seg_aux_bound += (size_t)(RM * (2 * tb + 1024 * ms));
     }
-    DevBuf b_textA, b_textB, b_cnt, b_valid, b_cls, b_clsB, b_flags, b_segedit, b_cells, b_arrive, b_cand, b_ccount, b_ptrA, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks, b_scan, b_ticket;
+    DevBuf b_textA, b_textB, b_pack, b_cls, b_clsB, b_flags, b_segedit, b_cells, b_arrive, b_cand, b_ccount, b_ptrA, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks, b_scan, b_ticket;
     int ws_next = 0;
     auto dmalloc = [&](DevBuf &b, size_t bytes) -> bool {      // persistent: slot of the table's workspace
         if (ws_next >= Table::WS_POLISH_MAX) { err = "polish: workspace slots exhausted"; return false; }
@@ -96,7 +96,7 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
         b.owned = false;
         return b.p != nullptr;
     };
-    if (!dmalloc(b_textA, text_bytes) || !dmalloc(b_textB, text_bytes) || !dmalloc(b_cnt, pos_items * 4) || !dmalloc(b_valid, pos_items) ||
+    if (!dmalloc(b_textA, text_bytes) || !dmalloc(b_textB, text_bytes) || 
         !dmalloc(b_cls, pos_items) || !dmalloc(b_clsB, pos_items) || !dmalloc(b_flags, flag_items) ||
         !dmalloc(b_segedit, seg_rec_bound * sizeof(EditRec)) || !dmalloc(b_cells, cell_items * 8) ||
         !dmalloc(b_arrive, ((size_t)max_segs + 4) * 8) || !dmalloc(b_cand, cand_items * 8) || !dmalloc(b_ccount, 256) ||
@@ -137,8 +137,9 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
     DevBuf b_iooffs;
     std::vector<int64_t> io_offs;
     uint8_t *io_stage = nullptr;
+    if (!packed_io) ws_next += 2;                    // (the two slots stay theirs: what follows keeps its slots from call to call)
     if (packed_io) {
-        if (!dmalloc(b_iooffs, ((size_t)n_chunks + 1) * 8)) return -2;
+        if (!dmalloc(b_iooffs, ((size_t)n_chunks + 1) * 8) || !dmalloc(b_pack, text_bytes)) return -2;
         io_offs.resize((size_t)n_chunks + 1);
         // (the texts may grow on the way: the way back is sized like the arenas)
         io_stage = reinterpret_cast<uint8_t *>(T.pinned(pin_base + 7, std::max<size_t>((size_t)total_len, 1) + (size_t)(RM * std::max<int64_t>(4096, total_len / 8)) + 64, err));
@@ -172,14 +173,13 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
     uint8_t **dIn = b_ptrA.as<uint8_t *>(), **dOut = dIn + n_chunks, **dSpare = dOut + n_chunks;
     uint8_t **ptrClsIn = dSpare + n_chunks, **ptrClsOut = ptrClsIn + n_chunks, **ptrFlags = ptrClsOut + n_chunks;
     if (packed_io) {
-        // all the texts in one transfer: packed on the host, spread to their arena places by a kernel (the count array, not yet in
-        // use, takes the packed copy)
+        // all the texts in one transfer: packed on the host, spread to their arena places by a kernel
         int64_t at = 0;
         for (int c = 0; c < n_chunks; ++c) { io_offs[c] = at; if (len[c]) memcpy(io_stage + at, seqs[c], (size_t)len[c]); at += len[c]; }
         io_offs[n_chunks] = at;
         HIPCHK(hipMemcpyAsync(b_iooffs.p, io_offs.data(), io_offs.size() * 8, hipMemcpyHostToDevice, st));
-        if (at) HIPCHK(hipMemcpyAsync(b_cnt.p, io_stage, (size_t)at, hipMemcpyHostToDevice, st));
-        launch_copy_chunks(dIn, b_cnt.as<uint8_t>(), b_iooffs.as<int64_t>(), n_chunks, true, st);
+        if (at) HIPCHK(hipMemcpyAsync(b_pack.p, io_stage, (size_t)at, hipMemcpyHostToDevice, st));
+        launch_copy_chunks(dIn, b_pack.as<uint8_t>(), b_iooffs.as<int64_t>(), n_chunks, true, st);
         HIPCHK(hipGetLastError());
         HIPCHK(jk_stream_wait(st));                    // (io_offs and the stage are reused for the way back)
     }
@@ -218,8 +218,6 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
                 ScanChunk &S = sc[c];
                 S.text = hIn[c];
                 S.len = len[c];
-                S.cnt = b_cnt.as<uint32_t>() + off_pos[c];
-                S.valid = b_valid.as<uint8_t>() + off_pos[c];
                 S.cls = clsIn + off_pos[c];
                 S.flags = b_flags.as<uint8_t>() + off_flag[c];
                 S.cand = b_cand.as<int64_t>();
@@ -570,12 +568,12 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
             int64_t at = 0;
             for (int c = 0; c < n_chunks; ++c) { io_offs[c] = at; at += len[c]; }
             io_offs[n_chunks] = at;
-            if ((size_t)at <= pos_items * 4 && (size_t)at <= (size_t)total_len + (size_t)(RM * std::max<int64_t>(4096, total_len / 8)) + 64) {
+            if ((size_t)at <= text_bytes && (size_t)at <= (size_t)total_len + (size_t)(RM * std::max<int64_t>(4096, total_len / 8)) + 64) {
                 packed_back = true;
                 HIPCHK(hipMemcpyAsync(b_iooffs.p, io_offs.data(), io_offs.size() * 8, hipMemcpyHostToDevice, st));
-                launch_copy_chunks(dIn, b_cnt.as<uint8_t>(), b_iooffs.as<int64_t>(), n_chunks, false, st);
+                launch_copy_chunks(dIn, b_pack.as<uint8_t>(), b_iooffs.as<int64_t>(), n_chunks, false, st);
                 HIPCHK(hipGetLastError());
-                if (at) HIPCHK(hipMemcpyAsync(io_stage, b_cnt.p, (size_t)at, hipMemcpyDeviceToHost, st));
+                if (at) HIPCHK(hipMemcpyAsync(io_stage, b_pack.p, (size_t)at, hipMemcpyDeviceToHost, st));
             }
         }
         for (int c = 0; c < n_chunks && !keep_on_device && !packed_back; ++c) {
