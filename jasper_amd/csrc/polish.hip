@@ -1420,6 +1420,7 @@ __global__ __launch_bounds__(256) void find_sync_batch_kernel(const ScanChunk *_
 __global__ __launch_bounds__(256) void rescan_batch_kernel(const ScanChunk *__restrict__ chunks, int n_chunks, TableDev T, uint32_t solid) {
     __shared__ uint32_t s_cnt[4][128];
     __shared__ uint8_t s_valid[4][128];
+    __shared__ uint8_t s_text[4][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = T.k;
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
@@ -1427,12 +1428,35 @@ __global__ __launch_bounds__(256) void rescan_batch_kernel(const ScanChunk *__re
         const int64_t nwin = C.len - k + 1;
         if (nwin <= 0) continue;
         const int64_t ntile = (nwin + 63) >> 6, nflag = (C.len >> 6) + 1;
-        for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
-            uint8_t f = C.flags[tile];
-            if (tile > 0) f |= C.flags[tile - 1];
-            if (tile + 1 < nflag) f |= C.flags[tile + 1];
-            if (!f) continue;
+        // (a wave looks at the flags of 64 tiles at once -- one per lane -- and then takes the flagged ones in turn: tile after tile
+        //  through one wave is a chain of flag-load latencies)
+        // (the 64 are a wave's next tiles of the round-robin over all waves, W apart: changed text comes in clusters -- a segment
+        //  flagged whole is 200 adjacent tiles -- and neighbours must not end up in one wave)
+        const int64_t W = (int64_t)gridDim.x * 4;
+        for (int64_t tile0 = (int64_t)blockIdx.x * 4 + wave; tile0 < ntile; tile0 += 64 * W) {
+            uint8_t f = 0;
+            {
+                const int64_t tl = tile0 + (int64_t)lane * W;
+                if (tl < ntile) {
+                    f = C.flags[tl];
+                    if (tl > 0) f |= C.flags[tl - 1];
+                    if (tl + 1 < nflag) f |= C.flags[tl + 1];
+                }
+            }
+            unsigned long long todo = __ballot(f != 0);
+          while (todo) {
+            const int64_t tile = tile0 + (int64_t)__builtin_ctzll(todo) * W;
+            todo &= todo - 1ull;
             const int64_t base = tile * 64 - 64;
+            // the text under the tile's 128 windows (128 + k - 1 <= 191 bytes) comes into LDS with one round of loads: a lane that
+            // read its window's k bytes itself, one after the other, spent ~100 us per tile waiting for them
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t pos = base + (int64_t)lane * 4 + q;
+                s_text[wave][lane * 4 + q] = (pos >= 0 && pos < C.len) ? C.text[pos] : (uint8_t)'N';
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int64_t p = base + r * 64 + lane;
@@ -1442,7 +1466,7 @@ __global__ __launch_bounds__(256) void rescan_batch_kernel(const ScanChunk *__re
                     u128 fwd = mk(0, 0);
                     bool ok = true;
                     for (int j = 0; j < k; ++j) {
-                        const int c = code(C.text[p + j]);
+                        const int c = code(s_text[wave][r * 64 + lane + j]);
                         ok = ok && c >= 0;
                         fwd = bor(shl(fwd, 2), mk(0, (uint64_t)(c & 3)));
                     }
@@ -1469,6 +1493,7 @@ __global__ __launch_bounds__(256) void rescan_batch_kernel(const ScanChunk *__re
                 C.cls[p] = c;
             }
             __builtin_amdgcn_wave_barrier();
+          }
         }
     }
 }
