@@ -1404,10 +1404,26 @@ __global__ __launch_bounds__(256) void find_sync_batch_kernel(const ScanChunk *_
             for (int64_t p = p0; p < pe; ++p) {
                 if (p < W || p + k - 1 > nwin) continue;
                 if (cls[p] != PC_BAD || cls[p - 1] != PC_CLEAN) continue;
-                bool ok = true;
-                for (int64_t q = 1; q < k - 1 && ok; ++q) ok = cls[p + q] == PC_BAD;
-                for (int64_t q = 2; q <= W && ok; ++q) ok = cls[p - q] == PC_CLEAN;
-                if (!ok) continue;
+                // cls[p+1 .. p+k-2] all BAD and cls[p-W .. p-2] all CLEAN: sixteen bytes per load, all loads independent (byte after
+                // byte with an early exit this was a chain of up to 4k + k load latencies per candidate)
+                uint32_t diff = 0;
+                {
+                    int64_t q = p + 1;
+                    const int64_t qe = p + k - 1;
+                    for (; q + 16 <= qe; q += 16) {
+                        const V16 v = *reinterpret_cast<const V16 *>(cls + q);
+                        diff |= (v.w[0] ^ 0x01010101u) | (v.w[1] ^ 0x01010101u) | (v.w[2] ^ 0x01010101u) | (v.w[3] ^ 0x01010101u);
+                    }
+                    for (; q < qe; ++q) diff |= (uint32_t)(cls[q] ^ (uint8_t)PC_BAD);
+                    q = p - W;
+                    const int64_t qf = p - 1;
+                    for (; q + 16 <= qf; q += 16) {
+                        const V16 v = *reinterpret_cast<const V16 *>(cls + q);
+                        diff |= v.w[0] | v.w[1] | v.w[2] | v.w[3];
+                    }
+                    for (; q < qf; ++q) diff |= (uint32_t)cls[q];
+                }
+                if (diff) continue;
                 const unsigned int idx = atomicAdd(C.cand_count, 1u);        // ONE list for the whole batch: (chunk << 40) | position
                 if (idx < C.cand_cap) C.cand[idx] = ((int64_t)ci << 40) | p;
             }
