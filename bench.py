@@ -539,7 +539,7 @@ def main():
     # so this figure says how the phase compares with a dense formulation at the HBM roofline, not how full the memory pipe is.
     polish_bytes = asm_len * ((PASSES + 1) * 17 + 1)
     pol_s = mean("polish_dev")
-    out["roofline_polish"] = {"bound": "hbm", "kernel": "scan_batch + classify + find_sync (pass 0), seg_walk x %d, seg_stitch, rescan" % (PASSES + 1),
+    out["roofline_polish"] = {"bound": "hbm", "kernel": "scan_classify + find_sync (pass 0), seg_walk x %d, seg_stitch, rescan" % (PASSES + 1),
                               "achieved": round(polish_bytes / pol_s / 1e9, 1) if pol_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(polish_bytes / pol_s / 1e9 / HBM_PEAK_GBS, 4) if pol_s > 0 else 0.0,
                               "algorithmic_bytes_per_step": int(polish_bytes), "device_ms": round(pol_s * 1e3, 3),
