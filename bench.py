@@ -235,6 +235,9 @@ def e2e_cli():
             for fn in os.listdir(d):
                 if fn not in ("reads.fq", "asm.fa"):
                     os.remove(os.path.join(d, fn))
+            # (device memory that a process frees is cleared in the background, and the next allocation of it waits for that:
+            #  ~28 ms per GB -- a run started right behind another one's 40 GB measures the other's clean-up; docs/experiments.md)
+            time.sleep(3.0)
             t0 = time.perf_counter()
             p = subprocess.run(args, cwd=d, env=dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_TIMING="1", **extra), capture_output=True, text=True, timeout=600)
             wall = time.perf_counter() - t0
