@@ -474,9 +474,9 @@ def main():
                 # counters of OTHER kernels are not evidence: nothing is cited (tools/prof_bench.sh + tools/summarize_prof.py re-collect them)
                 traffic_src = pol_traffic_src = "profiles/%s/bench_hbm_counters.json was taken from other kernel sources than this build's: not cited" % rnd
                 continue
-            try:    # the polishing kernels of one polish call (scan_batch runs once per call): FETCH_SIZE + WRITE_SIZE as reported
-                pk = ("scan_batch", "classify_batch", "find_sync_batch", "find_clean_batch", "seg_init", "seg_walk", "seg_gather", "seg_stitch", "rescan_batch")
-                calls = pj["FETCH_SIZE"]["jk::scan_batch_kernel"]["dispatches"]
+            try:    # the polishing kernels of one polish call (scan_classify_batch runs once per call): FETCH_SIZE + WRITE_SIZE as reported
+                pk = ("scan_classify_batch", "find_sync_batch", "find_clean_batch", "seg_init", "seg_walk", "seg_gather", "seg_stitch", "rescan_batch")
+                calls = pj["FETCH_SIZE"]["jk::scan_classify_batch_kernel"]["dispatches"]
                 kb = sum(pj[c]["jk::%s_kernel" % n]["sum_KB"] for c in ("FETCH_SIZE", "WRITE_SIZE") for n in pk if "jk::%s_kernel" % n in pj[c])
                 pol_traffic = int(kb * 1024 / calls)
                 pol_traffic_src = ("profiles/%s/bench_hbm_counters.json: FETCH_SIZE + WRITE_SIZE of the polishing kernels per polish call, as reported (their reads are "

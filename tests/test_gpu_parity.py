@@ -598,7 +598,7 @@ def test_polish_device_resident_equals_host_call(KT, O):
 
 def test_histogram_fused_into_counting_pass_equals_table_scan(KT):
     """one partitioned counting pass over the whole input into an empty table bins the final counts while it writes
-    them (lds_insert_kernel); that histogram must equal the one histo_kernel reads back from the table"""
+    them (region_insert_kernel); that histogram must equal the one histo_kernel reads back from the table"""
     import torch
     k = 37
     G = 12_000_000

@@ -4,7 +4,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-scans = [i for i, r in enumerate(rows) if 'scan_batch_kernel' in r['Kernel_Name'] and 'rescan' not in r['Kernel_Name']]
+scans = [i for i, r in enumerate(rows) if 'scan_classify_batch_kernel' in r['Kernel_Name']]
 nl = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 i0 = scans[-nl]
 t0 = int(rows[i0]['Start_Timestamp'])

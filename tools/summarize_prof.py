@@ -45,7 +45,7 @@ for ctr, pat in (("FETCH_SIZE", "pmc_fetch/*/*counter_collection.csv"), ("WRITE_
         a[0] += 1
         a[1] += float(r["Counter_Value"])
     out[ctr] = {k: {"dispatches": v[0], "sum_KB": v[1], "KB_per_dispatch": v[1] / v[0]} for k, v in acc.items()}
-pipe = ("jk::part1_kernel", "jk::clamp_counts_kernel", "jk::part2_kernel", "jk::part2f_kernel", "jk::region_insert_kernel", "jk::lds_insert_kernel", "jk::import3", "jk::count_kernel")
+pipe = ("jk::part1_kernel", "jk::clamp_counts_kernel", "jk::part2_kernel", "jk::part2f_kernel", "jk::region_insert_kernel", "jk::import3", "jk::count_kernel")
 tot_kb = sum(v["sum_KB"] for c in ("FETCH_SIZE", "WRITE_SIZE") for k, v in out[c].items() if k.startswith(pipe))
 p1 = [v for k, v in out["FETCH_SIZE"].items() if k.startswith("jk::part1_kernel")]
 launches = max(1, (p1[0]["dispatches"] if p1 else steps) // steps)
