@@ -448,7 +448,7 @@ static int polish_common(jasper_table *t, int n_chunks, const char *const *seqs,
     jasper_result *R = new jasper_result();
     *out = R;
     PolishOut po;
-    int rc = run_polish(T, n_chunks, seqs, lens, solid_thre, passes, fix, po, g_err, device_io, device_io);
+    int rc = run_polish(T, n_chunks, seqs, lens, solid_thre, passes, fix, po, g_err, device_io, device_io, getenv("JASPER_POLISH_ROOMY") ? 1 : 0);      // (tests: the roomy sizes at once)
     if (rc == -2) {                      // a slack / record / scratch bound was too small for this input: once more with 8x the room
         R->retried = 1;
         po = PolishOut();

@@ -532,6 +532,8 @@ struct Walker {
             __builtin_amdgcn_s_sleep(16);
         }
         bfs_slot = (int)slot;
+        // (the slot's last user may have run on another CU: nothing of its bytes that this CU's L1 still holds may be read)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         uint8_t *sb = pool.base + (size_t)slot * pool.stride;
         bfs_nodes = reinterpret_cast<uint32_t *>(sb);
         bfs_front = sb + pool.off_front;
@@ -542,7 +544,11 @@ struct Walker {
     }
     __device__ void release_scratch() {
         if (bfs_slot < 0) return;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // Every store of this wave into the slot must have ARRIVED before the slot is given up: a workgroup-scope fence does not
+        // wait for that, and a store still on its way landed in the arrays of the slot's next user (another CU) now and then --
+        // found as a path search that returned different patches from run to run once slots were few and the memory busy
+        // (several lanes, 64 slots; 16 slots: 118 of 150 runs).  Searches are rare: the agent-scope release costs nothing.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (lane == 0) atomicExch(&pool.locks[bfs_slot], 0u);
         bfs_slot = -1;
     }
@@ -1609,7 +1615,9 @@ void launch_seg_gather(const SegDev *d_segs, int n_segs, const int64_t *idx_base
 void launch_seg_stitch(const SegDev *d_segs, int n_segs, uint8_t *const *d_chunk_out, uint8_t *const *d_cls_out, uint8_t *const *d_flags,
                        hipStream_t stream) {
     if (n_segs <= 0) return;
-    dim3 grid(n_segs >= 512 ? 4 : 64, n_segs < 4096 ? n_segs : 4096);
+    // (blocks per segment: measured 116 / 158 / 434 us with 2 / 4 / 16 for the 3 800 segments of a 47 Mb batch's pass 0, 45 / 40 with 2 / 4
+    //  for the 700 of its later passes)
+    dim3 grid(n_segs >= 2048 ? 2 : n_segs >= 512 ? 4 : 64, n_segs < 4096 ? n_segs : 4096);
     hipLaunchKernelGGL(seg_stitch_kernel, grid, dim3(256), 0, stream, d_segs, n_segs, d_chunk_out, d_cls_out, d_flags);
 }
 

@@ -201,6 +201,30 @@ def test_polish_in_lanes_equals_one_lane_and_oracle(KT, O, lanes, tight):
     t.close()
 
 
+def test_path_search_scratch_slots_handed_from_wave_to_wave(KT):
+    """the scratch of a path search (src/jasper.py:527-583 base_extension) is one of a pool of slots in device memory, taken and
+    given back by the searching wave.  With few slots and busy memory (several lanes) a slot changes hands all the time; a
+    store of the wave that gave it back must never arrive in the arrays of the wave that took it (found in round 3: the release
+    was a workgroup-scope fence, and a path search returned different patches now and then -- 118 of 150 runs with 16 slots)."""
+    k, thre, passes = 37, 3, 2
+    genome, reads, asm = workload(31, 900_000, k, asm_err=2e-3)
+    t = KT(k, min_slots=1 << 20)
+    t.count_bases(reads)
+    cuts = [0, 40_000, 41_000, 250_000, 250_050, 250_050, 600_000, 820_000, len(asm)]
+    seqs = [asm[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    one = t.polish_batch(seqs, thre, passes)
+    want = (one.seqs, one.qv, one.records, one.segments, one.lookups)
+    os.environ.update(JASPER_POLISH_LANES="3", JASPER_POLISH_ROOMY="1", JASPER_POLISH_TEST_NSLOTS="8")
+    try:
+        for it in range(25):
+            r = t.polish_batch(seqs, thre, passes)
+            assert (r.seqs, r.qv, r.records, r.segments, r.lookups) == want, it
+    finally:
+        for v in ("JASPER_POLISH_LANES", "JASPER_POLISH_ROOMY", "JASPER_POLISH_TEST_NSLOTS"):
+            os.environ.pop(v, None)
+    t.close()
+
+
 def test_very_many_small_chunk_records(KT, O):
     """a fragmented assembly: thousands of short records in one batch (their texts cross PCIe packed, one transfer each way, above
     256 records) -- the oracle's result, and the same as with a transfer per record"""
