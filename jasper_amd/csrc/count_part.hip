@@ -62,7 +62,8 @@ struct PartGeom {
     uint32_t nblk2;          // part2 blocks per level-1 bucket: every one owns a slice of each of the bucket's region lists
     uint32_t cap1, cap2;     // slice capacities (records)
 };
-// level-1 list of bucket b = slices  out1[(b * nblk1 + g) * cap1 ...], filled counts cnt1[b * nblk1 + g]
+// level-1 list of bucket b = slices  out1[(b * nblk1 + g) * cap1 ...], filled counts cnt1[g * 2^p1 + b]  (slice-major: a wave's 64
+// fill-count atomics in part1 -- lane = bucket -- are then 256 contiguous bytes, four requests to the memory side instead of 8 x nblk1)
 // region list of region r  = slices  out2[(r * nblk2 + x) * cap2 ...],   filled counts cnt2[r * nblk2 + x]
 
 __device__ __forceinline__ uint64_t rec_of(u128 h, int recbits) { return recbits >= 64 ? h.lo : (h.lo & ((1ull << recbits) - 1ull)); }
@@ -105,8 +106,27 @@ __device__ __forceinline__ void defer_record(const TableDev &T, u128 h, unsigned
 constexpr int P1_MAXB = 1024;          // part1 handles p1 <= 10; larger p1 falls back to the direct kernel
 constexpr int P1_TH = 1024;
 constexpr int P1_STAGE = 13824;        // records per staging round (a tile of 150-base reads holds ~12.4 K)
-constexpr size_t P1_LDS = (size_t)P1_STAGE * 10 + (size_t)(P1_MAXB + 4 + 32) * 4 + (size_t)2 * (P1_TH + PT_HALO) * 4 + (size_t)P1_MAXB * 8;
+constexpr size_t P1_LDS = (size_t)P1_STAGE * 10 + (size_t)(2 * (P1_MAXB + 4) + 32 + 64) * 4 + (size_t)2 * (P1_TH + PT_HALO) * 4 + (size_t)P1_MAXB * 8;
 typedef __attribute__((address_space(1))) uint64_t global_u64;      // a pointer known to be global memory (kept as an integer in LDS)
+// Timing experiments on part1's copy-out (builds under ab/ only, `make EXTRA=-DJK_P1_EXP=n`; the lists they leave are garbage):
+//   1 = the stores go to a 16-MB window (cache-resident: everything but the HBM writes), 2 = no stores at all,
+//   4 = the same bytes as one sequential stream per block
+#ifndef JK_P1_EXP
+#define JK_P1_EXP 0
+#endif
+__device__ __forceinline__ void p1_store(uint64_t base, uint32_t idx, uint64_t rr, const uint64_t *out1, uint64_t seq) {
+#if JK_P1_EXP == 1
+    const uint64_t off = (base + (uint64_t)idx * 8ull - reinterpret_cast<uint64_t>(out1)) & ((16ull << 20) - 8ull);
+    *reinterpret_cast<global_u64 *>(reinterpret_cast<uint64_t>(out1) + off) = rr;
+#elif JK_P1_EXP == 2
+    asm volatile("" :: "v"(base), "v"(idx), "v"(rr));
+#elif JK_P1_EXP == 4
+    asm volatile("" :: "v"(base));
+    reinterpret_cast<global_u64 *>(reinterpret_cast<uint64_t>(out1))[seq + idx] = rr;
+#else
+    reinterpret_cast<global_u64 *>(base)[idx] = rr;
+#endif
+}
 
 // inclusive prefix sum over the 64 lanes of a wave in six DPP adds (row shifts inside the rows of 16, then the two row broadcasts)
 __device__ __forceinline__ unsigned int wave_scan_incl(unsigned int v) {
@@ -134,13 +154,14 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                                                       unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     // (the small arrays come first: their addresses fit the 16-bit offset field of the LDS instructions)
-    // s_cnt: records of this tile per bucket while they are ranked (A), then, in place, the exclusive prefix of those counts (B..D)
-    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_raw);                           // P1_MAXB+4
-    unsigned int *s_off = s_cnt;
-    unsigned int *s_wsum = s_cnt + P1_MAXB + 4;                                              // 16 wave totals, [16] = "a slice overflows in this tile"
-    uint32_t *s_code = reinterpret_cast<uint32_t *>(s_wsum + 32);                            // P1_TH + PT_HALO
+    // s_cnt2: two copies, used by alternate tiles -- records of the tile per bucket while they are ranked (A), then, in place, the
+    // exclusive prefix of those counts (B, C); the copy of the tile before is cleared meanwhile
+    unsigned int *s_cnt2 = reinterpret_cast<unsigned int *>(s_raw);                          // 2 x (P1_MAXB+4)
+    unsigned int *s_wsum = s_cnt2 + 2 * (P1_MAXB + 4);                                       // 16 wave totals, [16] = "a slice overflows", [24..31] the tile's last 64 bases
+    unsigned int *s_dummy = s_wsum + 32;                                                     // 64: what the rank atomics of windows that are no k-mer add to (one word per lane)
+    uint32_t *s_code = reinterpret_cast<uint32_t *>(s_dummy + 64);                           // P1_TH + PT_HALO
     uint32_t *s_inv = s_code + (P1_TH + PT_HALO);
-    // where stage index 0 of this tile would go in my slice of each bucket's list (slice base + (cursor - s_off) records), as an integer
+    // where stage index 0 of the staged tile goes in my slice of each bucket's list (slice base + (cursor - offset) records), as an integer
     uint64_t *s_base = reinterpret_cast<uint64_t *>(s_inv + (P1_TH + PT_HALO));              // P1_MAXB
     unsigned short *s_bkt = reinterpret_cast<unsigned short *>(s_base + P1_MAXB);            // bucket of each staged record
     uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_bkt + P1_STAGE);                      // P1_STAGE records, bucket order
@@ -165,39 +186,75 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
     while ((2 << wlog) <= k) ++wlog;                                            // 2^wlog <= k < 2^(wlog+1)
     unsigned long long added = 0;
     const uint32_t grp = blockIdx.x % P.nblk1;                                  // my slice of every list, shared with the blocks grp + j * nblk1
-    s_cnt[t] = 0;
+    s_cnt2[t] = 0;
+    s_cnt2[P1_MAXB + 4 + t] = 0;
+    for (int i = t; i < P1_STAGE; i += P1_TH) s_bkt[i] = 0;                     // (the copy-out reads the bucket of stage entries that hold nothing: any bucket will do)
     if (t == 0) s_wsum[16] = 0;
     // a block takes a run of consecutive tiles: the 64 bases before a tile are then the tail of the tile before it, still in LDS
-    const uint64_t per_block = (ntiles + gridDim.x - 1) / gridDim.x;
-    const uint64_t tile_first = blockIdx.x * per_block, tile_end = tile_first + per_block < ntiles ? tile_first + per_block : ntiles;
-    // My 16 bases of the NEXT tile are requested at the top of a tile and turned into codes right BEFORE this tile's copy-out
-    // stores are issued.  Vector-memory operations of a wave retire in order, so a load that is waited for after the stores makes
-    // the wave wait for the stores as well -- at the top of every tile, for the whole write latency of its copy-out (measured:
-    // 1.7 of 5.7 ms).  This way the stores of tile i drain under the hashing of tile i+1.
-    uint32_t c = 0, iv = 0xFFFFu, hc = 0, hiv = 0xFFFFu;
+    // (tile numbers are block-uniform 32-bit scalars: a piece has at most 2^31 bases)
+    const uint32_t nt32 = (uint32_t)ntiles;
+    const uint32_t per_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)((nt32 + gridDim.x - 1) / gridDim.x));
+    const uint32_t tile_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * per_block));
+    const uint32_t tile_end = tile_first + per_block < nt32 ? tile_first + per_block : nt32;
+    // THE TILE LOOP IS A PIPELINE OF TWO TILES.  Hashing (phase A) is vector-ALU work, the copy-out (phase D) is LDS reads and
+    // global stores: run one after the other by all 16 waves, each leaves the other's units idle (round 3: 15 us per tile, of which
+    // the ALU was busy 6).  So the copy-out of tile i is issued INSIDE the hash loop of tile i + 1, one staged record per hashed
+    // base: the stage, the bucket ids and the slice places of tile i are not touched by phase A, and the prefix sums of tile
+    // i + 1 (B) and its staging (C) come after a barrier behind both.
+    // Vector-memory operations of a wave retire in order: the text of tile i + 1 is requested at the top of tile i, BEFORE the
+    // stores of D(i - 1) are issued, and turned into codes at the end of tile i together with the slice places (a returning
+    // atomic issued in B) -- by then those stores are one scan and one staging phase old.
+    uint32_t c = 0, iv = 0xFFFFu;
     if (tile_first < tile_end) {
-        const int64_t b0 = (int64_t)(tile_first * PT_TILE);
+        uint32_t hc = 0, hiv = 0xFFFFu;
+        const int64_t b0 = (int64_t)tile_first * PT_TILE;
         stage16(bases, b0 + (int64_t)t * PT_GROUP, (int64_t)n, c, iv);
         if (t < PT_HALO) stage16(bases, b0 - (int64_t)(PT_HALO - t) * PT_GROUP, (int64_t)n, hc, hiv);
+        s_code[t + PT_HALO] = c;
+        s_inv[t + PT_HALO] = iv;
+        if (t < PT_HALO) { s_code[t] = hc; s_inv[t] = hiv; }
     }
-    for (uint64_t tile = tile_first; tile < tile_end; ++tile) {
-        const int64_t base0 = (int64_t)(tile * PT_TILE);
+    lds_barrier();
+    // staged records [0, pend_nr) wait to be copied out: stage index i goes to position pend_r0 + i behind s_base[bucket]  (block-uniform)
+    unsigned int pend_nr = 0, pend_r0 = 0;
+    uint64_t exp_seq = (uint64_t)blockIdx.x * per_block * PT_TILE;      // (JK_P1_EXP == 4: where this block's stream stands)
+    // the copy-out by itself: a staging round that is not a tile's last, the last tile's, and whenever a slice is full
+    auto copy_out = [&](unsigned int r0, unsigned int nr) {
+        if (!s_wsum[16]) {                                                          // (block-uniform) no slice of mine is full
+#pragma unroll 2
+            for (unsigned int i = t; i < nr; i += P1_TH) {
+                const uint64_t rr = s_stage[i];
+                const uint32_t b = s_bkt[i];
+                p1_store(s_base[b], r0 + i, rr, out1, exp_seq);
+            }
+        } else {
+            for (unsigned int i = t; i < nr; i += P1_TH) {
+                const uint64_t rr = s_stage[i];
+                const uint32_t b = s_bkt[i];
+                const uint64_t first = reinterpret_cast<uint64_t>(out1 + ((uint64_t)b * P.nblk1 + grp) * P.cap1);
+                const uint64_t pos = (uint64_t)(((int64_t)(s_base[b] - first) >> 3) + (int64_t)(r0 + i));   // position in the bucket's slice (s_base may lie below it)
+                if (pos < P.cap1) reinterpret_cast<global_u64 *>(first)[pos] = rr;
+                else defer_record(P.stats, hash_of((uint64_t)b, rr, P.recbits), deferred, deferred_n, deferred_cap);   // slice full
+            }
+        }
+    };
+    constexpr int NCO = (P1_STAGE + P1_TH - 1) / P1_TH;                             // staged records per thread (14)
+    static_assert(NCO + 2 <= PT_GROUP, "the copy-out pipeline must fit the hash loop");
+    for (uint32_t tile = tile_first; tile < tile_end; ++tile) {
+        const int64_t base0 = (int64_t)tile * PT_TILE;
         const bool has_next = tile + 1 < tile_end;
+        unsigned int *s_cnt = s_cnt2 + ((tile - tile_first) & 1u) * (P1_MAXB + 4);
+        unsigned int *s_off = s_cnt;
+        unsigned int *s_nxt = s_cnt2 + (((tile - tile_first) & 1u) ^ 1) * (P1_MAXB + 4);
         int ta = t;
         asm volatile("" : "+v"(ta));
         // (only a next tile that lies inside the text as a whole: ONE load instruction, no branch with a slow side whose merge
-        //  would make the compiler wait for the load right here; the piece's last tile is read at its own top instead)
+        //  would make the compiler wait for the load right here; the piece's last tile is read at the end of this one instead)
         const bool prefetch = has_next && (uint64_t)(base0 + 2 * (int64_t)PT_TILE) <= n;
-        Raw16 raw;
-        {   // (unconditional: without a next tile to fetch, the first 16 bytes of the text are read and ignored)
-            struct __attribute__((packed, aligned(1))) V16 { uint32_t w[4]; };
-            const V16 v = *reinterpret_cast<const V16 *>(bases + (prefetch ? base0 + (int64_t)PT_TILE + (int64_t)ta * PT_GROUP : (int64_t)0));
-            raw.w[0] = v.w[0]; raw.w[1] = v.w[1]; raw.w[2] = v.w[2]; raw.w[3] = v.w[3];
+        if (pend_nr && s_wsum[16]) {                                                // (block-uniform) a slice is full: record by record, with the bound
+            copy_out(pend_r0, pend_nr);
+            pend_nr = 0;
         }
-        s_code[ta + PT_HALO] = c;
-        s_inv[ta + PT_HALO] = iv;
-        if (ta < PT_HALO) { s_code[ta] = hc; s_inv[ta] = hiv; }
-        lds_barrier();
         // A. hash my 16 windows, take a rank in the tile's bucket histogram
         uint32_t f[NW], r[NW];
         uint32_t vmask;                    // bit 15 - j: the window ending at my base j is a k-mer
@@ -219,14 +276,25 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
             vmask = ~(uint32_t)sm & 0xFFFFu;
         }
         // k-mers that END before emit_from belong to the piece before this one
-        const int64_t mine = base0 + (int64_t)ta * PT_GROUP;
-        const int jfirst = (int64_t)emit_from > mine ? (int)((int64_t)emit_from - mine < PT_GROUP ? (int64_t)emit_from - mine : PT_GROUP) : 0;
-        vmask &= 0xFFFFu >> jfirst;
+        if ((uint64_t)base0 < emit_from) {                                          // (block-uniform: the piece's first tiles only)
+            const int64_t mine = base0 + (int64_t)ta * PT_GROUP;
+            const int jfirst = (int64_t)emit_from > mine ? (int)((int64_t)emit_from - mine < PT_GROUP ? (int64_t)emit_from - mine : PT_GROUP) : 0;
+            vmask &= 0xFFFFu >> jfirst;
+        }
         uint64_t rec[PT_GROUP];
         uint32_t br[PT_GROUP];     // bucket (0xFFFF = no record) << 16 | rank among the tile's records of that bucket
         uint32_t bprev = 0xFFFFu, rprev = 0;      // (a record's two halves are put together one iteration later: the atomic's latency is covered)
+        // D of the tile before, in three steps that are one iteration apart: a staged record's bucket (LDS) -> the record and the
+        // bucket's place (LDS) -> the store
+        uint64_t co_rr[NCO], co_base[NCO];
+        uint32_t co_b[NCO];
 #pragma unroll
         for (int j = 0; j < PT_GROUP; ++j) {
+            if (j < NCO) {
+                unsigned int i = (unsigned int)ta + (unsigned int)j * P1_TH;
+                if ((j + 1) * P1_TH > P1_STAGE) i = i < (unsigned int)P1_STAGE ? i : (unsigned int)P1_STAGE - 1u;     // (the stage's last, partial row)
+                co_b[j] = s_bkt[i];
+            }
             const uint32_t cj = (c >> (30 - 2 * j)) & 3u;
             // forward strand: shift left by one base; reverse complement: shift right, the complement enters on top
 #pragma unroll
@@ -272,14 +340,33 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
             }
             if (j > 0) br[j - 1] = (bprev << 16) | rprev;
             bprev = valid ? b : 0xFFFFu;
-            rprev = 0;
-            if (valid) rprev = atomicAdd(&s_cnt[b], 1u);                            // LDS returning atomic
+            // LDS returning atomic, no branch around it: a window that is no k-mer takes a "rank" nobody looks at from a word of its lane
+            rprev = atomicAdd(valid ? &s_cnt[b] : &s_dummy[ta & 63], 1u);
+            if (j >= 1 && j - 1 < NCO) {
+                unsigned int i = (unsigned int)ta + (unsigned int)(j - 1) * P1_TH;
+                if (j * P1_TH > P1_STAGE) i = i < (unsigned int)P1_STAGE ? i : (unsigned int)P1_STAGE - 1u;
+                co_rr[j - 1] = s_stage[i];
+                co_base[j - 1] = s_base[co_b[j - 1]];
+            }
+            if (j >= 2 && j - 2 < NCO) {
+                const unsigned int i = (unsigned int)ta + (unsigned int)(j - 2) * P1_TH;
+                if (i < pend_nr) p1_store(co_base[j - 2], pend_r0 + i, co_rr[j - 2], out1, exp_seq);
+            }
         }
         br[PT_GROUP - 1] = (bprev << 16) | rprev;
-        if (has_next) {
+        if (JK_P1_EXP == 4) exp_seq += pend_nr;
+        pend_nr = 0;
+        // the next tile's text: asked for behind the copy-out stores and looked at after the staging, together with the slice
+        // places (asked for in B) -- what is waited for there is the stores and both of these
+        Raw16 raw;
+        {   // (unconditional: without a next tile to fetch, the first 16 bytes of the text are read and ignored)
             int tb = t;
             asm volatile("" : "+v"(tb));
-            if (tb < PT_HALO) { hc = s_code[P1_TH + tb]; hiv = s_inv[P1_TH + tb]; }   // the tail of this tile = the 64 bases before the next
+            struct __attribute__((packed, aligned(1))) V16 { uint32_t w[4]; };
+            const V16 v = *reinterpret_cast<const V16 *>(bases + (prefetch ? base0 + (int64_t)PT_TILE + (int64_t)tb * PT_GROUP : (int64_t)0));
+            raw.w[0] = v.w[0]; raw.w[1] = v.w[1]; raw.w[2] = v.w[2]; raw.w[3] = v.w[3];
+            // the tail of this tile = the 64 bases before the next (parked in spare words: the head of s_code is still being read)
+            if (has_next && tb < PT_HALO) { s_wsum[24 + tb] = s_code[P1_TH + tb]; s_wsum[28 + tb] = s_inv[P1_TH + tb]; }
         }
         lds_barrier();
         // B. exclusive prefix of the bucket counts: thread t owns bucket t (wave scan + wave totals); the place of the tile's run
@@ -292,7 +379,7 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
             int tb = t;
             asm volatile("" : "+v"(tb));
             const unsigned int v = tb < nb ? s_cnt[tb] : 0u;
-            if (v) apos = __hip_atomic_fetch_add(&cnt1[(uint64_t)tb * P.nblk1 + grp], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v) apos = __hip_atomic_fetch_add(&cnt1[((uint32_t)grp << p1) + (uint32_t)tb], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned int inc = wave_scan_incl(v);
             if ((tb & 63) == 63) s_wsum[tb >> 6] = inc;
             lds_barrier();
@@ -305,10 +392,21 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
         }
         if (t == 0) added += total;
         lds_barrier();
-        for (unsigned int r0 = 0; r0 < total; r0 += P1_STAGE) {
-            if (r0) lds_barrier();                                                  // the previous round has been copied out
-            // C. records into LDS in bucket order
-            if (total <= (unsigned int)P1_STAGE) {                                  // (block-uniform) the usual case: one round holds the tile
+        // C. records into LDS in bucket order; a tile with more records than the stage holds leaves in several rounds, all but the
+        //    last of them copied out right away
+        unsigned int r0 = 0;
+        auto slice_places = [&]() {
+            // where stage index 0 would go in the slice: the run's place has arrived by now
+            int tc = t;
+            asm volatile("" : "+v"(tc), "+v"(apos));
+            const unsigned int ex = s_off[tc];
+            const unsigned int v = (tc + 1 < P1_MAXB ? s_off[tc + 1] : total) - ex;      // (buckets past the last one hold the total)
+            const uint64_t slice0 = reinterpret_cast<uint64_t>(out1 + ((uint64_t)tc * P.nblk1 + grp) * P.cap1);
+            s_base[tc] = slice0 + ((uint64_t)apos - (uint64_t)ex) * 8ull;
+            if (v && apos + v > P.cap1) s_wsum[16] = 1;                              // (stays set: the slice stays full)
+        };
+        if (total <= (unsigned int)P1_STAGE) {                                      // (block-uniform) the usual case: one round holds the tile
+            if (total) {
 #pragma unroll
                 for (int j = 0; j < PT_GROUP; ++j) {
                     const uint32_t b = br[j] >> 16;
@@ -320,7 +418,10 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                         s_bkt[pos2] = (unsigned short)b;
                     }
                 }
-            } else {
+                slice_places();
+            }
+        } else {
+            for (;;) {
 #pragma unroll
                 for (int j = 0; j < PT_GROUP; ++j) {
                     const uint32_t b = br[j] >> 16;
@@ -329,53 +430,42 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                         if (pos < (unsigned int)P1_STAGE) { s_stage[pos] = rec[j]; s_bkt[pos] = (unsigned short)b; }
                     }
                 }
-            }
-            if (r0 == 0) {
-                // where stage index 0 would go in the slice: the run's place has arrived by now
-                int tc = t;
-                asm volatile("" : "+v"(tc), "+v"(apos));
-                const unsigned int ex = s_off[tc];
-                const unsigned int v = (tc + 1 < P1_MAXB ? s_off[tc + 1] : total) - ex;      // (buckets past the last one hold the total)
-                const uint64_t slice0 = reinterpret_cast<uint64_t>(out1 + ((uint64_t)tc * P.nblk1 + grp) * P.cap1);
-                s_base[tc] = slice0 + ((uint64_t)apos - (uint64_t)ex) * 8ull;
-                if (v && apos + v > P.cap1) s_wsum[16] = 1;                          // (stays set: the slice stays full)
-            }
-            lds_barrier();
-            if (r0 == 0 && prefetch) {                                              // the next tile's text has long arrived (see above)
-                asm volatile("" : "+v"(raw.w[0]), "+v"(raw.w[1]), "+v"(raw.w[2]), "+v"(raw.w[3]));     // (not before this point)
-                encode16(raw.w, c, iv);
-            }
-            // D. copy out: lane i takes staged record i -- consecutive lanes, consecutive records of one slice
-            const unsigned int nr = total - r0 < (unsigned int)P1_STAGE ? total - r0 : (unsigned int)P1_STAGE;
-            if (!s_wsum[16]) {                                                      // (block-uniform) no slice of mine is full
-#pragma unroll 2
-                for (unsigned int i = t; i < nr; i += P1_TH) {
-                    const uint64_t rr = s_stage[i];
-                    const uint32_t b = s_bkt[i];
-                    reinterpret_cast<global_u64 *>(s_base[b])[r0 + i] = rr;
-                }
-            } else {
-                for (unsigned int i = t; i < nr; i += P1_TH) {
-                    const uint64_t rr = s_stage[i];
-                    const uint32_t b = s_bkt[i];
-                    const uint64_t first = reinterpret_cast<uint64_t>(out1 + ((uint64_t)b * P.nblk1 + grp) * P.cap1);
-                    const uint64_t pos = (uint64_t)(((int64_t)(s_base[b] - first) >> 3) + (int64_t)(r0 + i));   // position in the bucket's slice (s_base may lie below it)
-                    if (pos < P.cap1) reinterpret_cast<global_u64 *>(first)[pos] = rr;
-                    else defer_record(P.stats, hash_of((uint64_t)b, rr, P.recbits), deferred, deferred_n, deferred_cap);   // slice full
-                }
+                if (r0 == 0) slice_places();
+                if (total - r0 <= (unsigned int)P1_STAGE) break;                    // the last round leaves with the next tile's hashing
+                lds_barrier();
+                copy_out(r0, (unsigned int)P1_STAGE);
+                r0 += P1_STAGE;
+                lds_barrier();
             }
         }
-        if (total == 0 && prefetch) encode16(raw.w, c, iv);                          // (block-uniform) a tile without a k-mer
-        s_cnt[t] = 0;              // for the next tile (every staging round has read its offsets: a barrier lies behind each)
-        if (has_next && !prefetch) stage16(bases, base0 + (int64_t)PT_TILE + (int64_t)t * PT_GROUP, (int64_t)n, c, iv);      // (the piece's last tile)
-        // (the next tile's barriers order its writes to the stage, s_off and s_base against this copy-out)
+        pend_r0 = r0;
+        pend_nr = total - r0;
+        s_nxt[t] = 0;              // the next tile's counters (this copy was last looked at in the tile before this one)
+        if (has_next) {
+            if (prefetch) {
+                asm volatile("" : "+v"(raw.w[0]), "+v"(raw.w[1]), "+v"(raw.w[2]), "+v"(raw.w[3]));     // (not before this point)
+                encode16(raw.w, c, iv);
+            } else stage16(bases, base0 + (int64_t)PT_TILE + (int64_t)t * PT_GROUP, (int64_t)n, c, iv);      // (the piece's last tile)
+            int td = t;
+            asm volatile("" : "+v"(td));
+            s_code[td + PT_HALO] = c;
+            s_inv[td + PT_HALO] = iv;
+            if (td < PT_HALO) { s_code[td] = s_wsum[24 + td]; s_inv[td] = s_wsum[28 + td]; }
+        }
+        lds_barrier();
     }
+    if (pend_nr) copy_out(pend_r0, pend_nr);
     if (t == 0 && added) atomicAdd(&P.stats[ST_OCCURRENCES], added);
 }
 // the fill counts were the slices' cursors: one that ran past its slice's end becomes "full" (what did not fit was deferred)
 __global__ __launch_bounds__(256) void clamp_counts_kernel(unsigned int *__restrict__ cnt, uint32_t n, uint32_t cap) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n && cnt[i] > cap) cnt[i] = cap;
+}
+// (a table so small that one level of lists is enough: region_insert_kernel reads a region's slice counts side by side)
+__global__ __launch_bounds__(256) void transpose_counts_kernel(const unsigned int *__restrict__ in, unsigned int *__restrict__ out, uint32_t nb1, uint32_t nblk1) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < nb1 * nblk1) out[(i % nb1) * nblk1 + i / nb1] = in[i];
 }
 // one launch site for the three word counts: k <= 16, 17..32, 33..37
 static hipError_t launch_part1(hipStream_t stream, int k, const uint8_t *d_piece, uint64_t len, uint64_t ntiles, uint64_t emit_from, const TableDev &d, const PartGeom &G,
@@ -443,13 +533,17 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
         if constexpr (MIN) return ((uint64_t)(j / in_per_src) * (1ull << G.p1) + b1) * in_per_src + j % in_per_src;
         else return (uint64_t)b1 * G.nblk1 + j;
     };
+    auto in_cnt = [&](uint32_t b1, uint32_t j) -> uint64_t {                               // where its fill count is (part1's counts are slice-major)
+        if constexpr (MIN) return in_list(b1, j);
+        else return ((uint64_t)j << G.p1) + b1;
+    };
     for (uint32_t b1 = blockIdx.y; b1 < (1u << G.p1); b1 += gridDim.y) {
         for (int i = t; i < nb2; i += PT_THREADS) { s_cur[i] = 0; s_cnt[i] = 0; }
         if (t < 64) {                                  // exclusive prefix of my slices' lengths (wave 0)
             unsigned int carry = 0;
             for (uint32_t x0 = 0; x0 < nmine; x0 += 64) {
                 const uint32_t x = x0 + t;
-                const unsigned int v = x < nmine ? cnt1[in_list(b1, blockIdx.x + x * G.nblk2)] : 0u;
+                const unsigned int v = x < nmine ? cnt1[in_cnt(b1, blockIdx.x + x * G.nblk2)] : 0u;
                 unsigned int inc = v;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(inc, o); if (t >= o) inc += u; }
@@ -600,7 +694,7 @@ __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *_
         const uint32_t sl_step = 16u * P.nblk2;
         const uint32_t npieces = P.nblk1 * P.vper;
         auto piece_len = [&](uint32_t j) -> uint32_t {                                       // records of piece j (j < npieces)
-            const uint32_t c = cnt1[(uint64_t)b1 * P.nblk1 + j / P.vper], first = (j % P.vper) * (uint32_t)P2F_PIECE;
+            const uint32_t c = cnt1[((uint64_t)(j / P.vper) << P.p1) + b1], first = (j % P.vper) * (uint32_t)P2F_PIECE;
             return c > first ? (c - first < (uint32_t)P2F_PIECE ? c - first : (uint32_t)P2F_PIECE) : 0u;
         };
         uint32_t sl = blockIdx.x + wave * P.nblk2;                                           // (scalar) current input piece of my wave
@@ -617,7 +711,7 @@ __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *_
         auto open_piece = [&](uint32_t &len_out, const uint64_t *&src_out) {
             len_out = 0;
             if (sl < npieces) {
-                const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt1[(uint64_t)b1 * P.nblk1 + ph]), first = sub * (uint32_t)P2F_PIECE;
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt1[((uint64_t)ph << P.p1) + b1]), first = sub * (uint32_t)P2F_PIECE;
                 len_out = c > first ? (c - first < (uint32_t)P2F_PIECE ? c - first : (uint32_t)P2F_PIECE) : 0u;
             }
             src_out = out1 + ((uint64_t)b1 * P.nblk1 + ph) * P.cap1 + (uint64_t)sub * P2F_PIECE;
@@ -1034,9 +1128,10 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     uint64_t grid1 = piece_bases / ((uint64_t)(1u << p1) * 512);
     grid1 = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(grid1, ntiles), 256));
     static const int ngrp_exp = getenv("JASPER_EXPERIMENT_NGRP") ? atoi(getenv("JASPER_EXPERIMENT_NGRP")) : 0;     // tuning experiments only
-    // (measured, 47 Mb workload: 1, 2 or 4 slices per list 4.9-5.0 ms, 8 slices 5.1, a slice per block 5.6-5.7 without and 6.2 with
-    //  the atomics; few buckets: 8 slices, so that part2's blocks per bucket each find slices of their own)
-    const uint64_t nblk1 = std::min<uint64_t>(grid1, ngrp_exp > 0 ? (uint64_t)ngrp_exp : ((1u << p1) >= 256 ? 2 : 8));
+    // (measured, 47 Mb workload, round 4's kernel with the fill counts slice-major: 2 to 16 slices per list 4.0-4.1 ms, 32 slices 4.2,
+    //  ONE slice 5.3 -- 256 blocks adding to each count; with the counts bucket-major a wave's 64 atomics were 8 x nblk1 requests
+    //  to the memory side, which alone took 4.4 ms at 2 slices and more at 8.  8 slices: part2f's 16 waves find slices of their own)
+    const uint64_t nblk1 = std::min<uint64_t>(grid1, ngrp_exp > 0 ? (uint64_t)ngrp_exp : 8);
     G.grid1 = (uint32_t)grid1;
     G.nblk1 = (uint32_t)nblk1;
     // (a slice takes the tiles of ceil(grid1 / nblk1) blocks of ceil(ntiles / grid1) tiles each)
@@ -1058,7 +1153,7 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     const PartGeom G = *reinterpret_cast<const PartGeom *>(geom);
     const uint32_t nb1 = 1u << G.p1, nregions = 1u << (G.p1 + G.p2);
     const uint64_t deferred_cap = std::max<uint64_t>(1u << 16, len / 48);      // (24 bytes each; a piece that needs more abandons itself: part_decide_kernel)
-    const size_t n_cnt1 = (size_t)nb1 * G.nblk1, n_cnt2 = G.p2 ? (size_t)nregions * G.nblk2 : 0;
+    const size_t n_cnt1 = (size_t)nb1 * G.nblk1, n_cnt2 = G.p2 ? (size_t)nregions * G.nblk2 : n_cnt1;      // (one level: the counts once more, bucket-major)
     uint64_t *out1 = (uint64_t *)workspace(WS_COUNT + 0, n_cnt1 * G.cap1 * 8, err);
     uint64_t *out2 = G.p2 ? (uint64_t *)workspace(WS_COUNT + 1, n_cnt2 * G.cap2 * 8, err) : nullptr;
     unsigned int *cur = (unsigned int *)workspace(WS_COUNT + 2, (n_cnt1 + n_cnt2 + 4) * 4, err);
@@ -1100,6 +1195,10 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
             hipLaunchKernelGGL(part2_kernel<false>, grid, dim3(PT_THREADS), P2_LDS, stream, out1, cnt1, d, G, out2, cnt2, defer_e, defer_n, deferred_cap, 1u);
         HIPCHK(hipGetLastError());
         lists = out2; lcnt = cnt2; lcap = G.cap2; nsl = G.nblk2;
+    } else {
+        hipLaunchKernelGGL(transpose_counts_kernel, dim3((uint32_t)((n_cnt1 + 255) / 256)), dim3(256), 0, stream, cnt1, cnt2, nb1, G.nblk1);
+        HIPCHK(hipGetLastError());
+        lcnt = cnt2;
     }
     hipLaunchKernelGGL(part_decide_kernel, dim3(1), dim3(1), 0, stream, defer_n, deferred_cap, d.stats);
     HIPCHK(hipGetLastError());

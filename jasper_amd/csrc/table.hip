@@ -961,7 +961,12 @@ int Table::count_device(const uint8_t *d_bases, uint64_t n, std::string &err, ui
                 // One k-mer (or a few) so frequent that its region list overflowed beyond the deferred list: the piece stopped before
                 // it wrote to the table.  Counted again, like everything after it, by the direct kernel -- the k-mer's atomics
                 // queue up on one address there, but they all arrive.
-                if (dbg) fprintf(stderr, "[count] partitioned piece abandoned (lists overflowed the deferred list): direct kernel from here on\n");
+                if (dbg) {
+                    float m1 = 0, m2 = 0;
+                    (void)hipEventElapsedTime(&m1, ev_stage_t[0], ev_stage_t[1]);
+                    (void)hipEventElapsedTime(&m2, ev_stage_t[1], ev_stage_t[2]);
+                    fprintf(stderr, "[count] partitioned piece abandoned (lists overflowed the deferred list; its partition passes took %.2f + %.2f ms): direct kernel from here on\n", m1, m2);
+                }
                 err.clear();
                 part_off = true;
                 part_stage_pending = false;

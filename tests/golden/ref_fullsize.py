@@ -51,6 +51,14 @@ os.makedirs(bindir)
 for fn in ("jasper.sh", "jasper.py", "jellyfish.py"):
     shutil.copy(os.path.join(G.REF, fn), bindir)
     os.chmod(os.path.join(bindir, fn), 0o755)
+# The reference removes its {0,P}qValCalcHelper.csv files at the end (src/jasper.sh:258), and without `bc` in this container its
+# log says "Q value = Inf": an `rm` of our own, first on PATH, keeps a copy of those files (the per-batch "bad total" lines
+# src/jasper.py:107-111 appended) before it removes them, so that the QV INPUTS of the real run are pinned.
+keep = os.path.join(work, "kept")
+os.makedirs(keep)
+open(os.path.join(bindir, "rm"), "w").write(
+    "#!/bin/bash\nfor a in \"$@\"; do case \"$a\" in *qValCalcHelper.csv) [ -f \"$a\" ] && cp \"$a\" %s/ ;; esac; done\nexec /bin/rm \"$@\"\n" % keep)
+os.chmod(os.path.join(bindir, "rm"), 0o755)
 env = dict(os.environ, PATH=bindir + ":" + os.path.dirname(G.JF_BIN) + ":" + os.environ["PATH"], PYTHONPATH=pp,
            LD_LIBRARY_PATH=os.path.join(os.path.dirname(os.path.dirname(G.JF_BIN)), "lib"))
 t1 = time.time()
@@ -65,6 +73,10 @@ out = dict(genome_mb=gmb, coverage=coverage, contigs=contigs, populations=popula
            stdout=[G.re_sub_date(l) for l in p.stdout.splitlines()])
 if p.returncode == 0:
     out.update(synth.output_digests(run_dir, k=K))
+    for key, fn in (("qv_before", "0qValCalcHelper.csv"), ("qv_after", "%dqValCalcHelper.csv" % P)):
+        rows = [l.split() for l in open(os.path.join(keep, fn)).read().splitlines() if l.strip()]
+        out[key] = [sum(int(r[0]) for r in rows), sum(int(r[1]) for r in rows)]      # exact integer column sums (gawk's behaviour)
+        out[key + "_lines"] = len(rows)
 json.dump(out, open(os.path.join(HERE, name), "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v for k, v in out.items() if k != "stdout"}, indent=1))
 shutil.rmtree(work)

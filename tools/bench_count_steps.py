@@ -20,6 +20,9 @@ kmers = nreads * (150 - K + 1)
 jf_size = int(nreads * 150 * 2.1 / 10)
 t = KmerTable(K, min_slots=max(1 << 21, int(1.25 * jf_size)))
 for r in range(reps):
+    if os.environ.get("FRESH_TABLE") and r:      # (experiment builds whose pieces abandon themselves: a table takes the partition passes once)
+        t.close()
+        t = KmerTable(K, min_slots=max(1 << 21, int(1.25 * jf_size)))
     t.clear()
     t.sync()
     t0 = time.perf_counter()
