@@ -695,6 +695,8 @@ def _qv_block(passes, kmer):
         b1, t1 = colsum("%dqValCalcHelper.csv" % passes)
         log("Before Polishing: Q value = %s" % qv.q_value(b0, t0, kmer))
         log("After Polishing: Q value = %s" % qv.q_value(b1, t1, kmer))
+        if os.environ.get("JASPER_AMD_TIMING"):       # (the column sums themselves: the reference removes the files it takes them from, :258)
+            sys.stderr.write("[qv] before %d %d after %d %d\n" % (b0, t0, b1, t1))
         for p in glob.glob("*qValCalcHelper.csv"):
             os.remove(p)
 
@@ -886,22 +888,7 @@ def run(argv):
                 if os.path.exists(p):
                     os.remove(p)
 
-    # QV (:235-257)
-    def colsum(path):
-        a = b = 0
-        with open(path) as f:
-            for ln in f:
-                F = ln.split()
-                if len(F) >= 2:
-                    a += int(F[0]); b += int(F[1])
-        return a, b
-    if os.path.exists("0qValCalcHelper.csv") and os.path.exists("%dqValCalcHelper.csv" % passes):
-        b0, t0 = colsum("0qValCalcHelper.csv")
-        b1, t1 = colsum("%dqValCalcHelper.csv" % passes)
-        log("Before Polishing: Q value = %s" % qv.q_value(b0, t0, kmer))
-        log("After Polishing: Q value = %s" % qv.q_value(b1, t1, kmer))
-        for p in glob.glob("*qValCalcHelper.csv"):
-            os.remove(p)
+    _qv_block(passes, kmer)      # (:235-257)
     _timing("join + QV")
     if jf_writer is not None:
         try:

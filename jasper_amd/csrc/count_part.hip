@@ -647,7 +647,7 @@ __global__ __launch_bounds__(PT_THREADS) void part2_kernel(const uint64_t *__res
 constexpr size_t P2_LDS = (size_t)PT_TILE * 8 + (size_t)(3 * PT_MAXBUCKETS + 1 + 16 + P2_MAXSL + 1) * 4;
 
 // ---- level 2, single-GPU form: whole 128-byte lines only ---------------------------------------------------------------------
-// The same job as part2_kernel<false> for the plain case with at most P2F_MAXB lists per bucket.  Two things differ:
+// The same job as part2_kernel<false> for the plain case with at most MAXB lists per bucket.  Two things differ:
 //  * A list's slice is only ever written in whole, aligned 128-byte lines.  What a round leaves over of a list (< 16 records)
 //    waits in LDS (s_carry) and leaves in front of the next round's records; the last round's rest closes the slice.  Measured on
 //    part1's copy-out: runs that begin and end inside a line cost twice -- the line is written by two rounds, and
@@ -656,29 +656,37 @@ constexpr size_t P2_LDS = (size_t)PT_TILE * 8 + (size_t)(3 * PT_MAXBUCKETS + 1 +
 //    is one add), a row that does not exist counts as a record of one extra list that sorts behind all others (no per-record
 //    branch), the copy-out is one lane per staged record, and the loads of the next round are in flight during this one --
 //    waited for before this round's copy-out stores are issued (see part1_kernel).
-constexpr int P2F_MAXB = 128;
+// Two instances.  <128, 7>: at most 128 lists per bucket (tables up to 2^29 slots), rounds of 7 rows of 1024 records -- 56 KB of
+// stage + 16 KB of carry, TWO workgroups per CU (one's loads and stores run under the other's LDS work; 64 registers per lane:
+// no room for a prefetch).  <512, 8>: up to 512 lists (tables of 2^30 .. 2^32 slots, and every shard of the larger configurations):
+// the carry alone is 64 KB, so one workgroup per CU with a 64-KB stage; a round brings a list 16 records on average, i.e. about
+// one line leaves per list and round and nearly every record passes through the carry (LDS traffic, which this kernel has to spare).
 constexpr int P2F_LINE = 16;           // records per 128-byte line
-constexpr int P2F_ROWS = 7;            // rows of 1024 records per round: 56 KB of stage, TWO workgroups per CU (one's loads and stores
-constexpr int P2F_TILE = PT_THREADS * P2F_ROWS;      // run under the other's LDS work; 64 registers per lane: no room for a prefetch)
 // per list and round: stage record i leaves to gbase + 8 i if i < lim, else waits in carry slot i + cadd
 struct P2Meta { uint64_t gbase; uint32_t lim; int32_t cadd; };
-constexpr size_t P2F_LDS = (size_t)P2F_TILE * 8 + (size_t)(3 * (P2F_MAXB + 4) + 32) * 4 + (size_t)P2F_MAXB * sizeof(P2Meta) + (size_t)P2F_MAXB * P2F_LINE * 8;
-constexpr int P2F_PIECE = 64 * P2F_ROWS * 9;         // records per input piece: nine full wave rounds (4032 records, 252 lines)
+template <int MAXB, int ROWS> struct P2F {
+    static constexpr int TILE = PT_THREADS * ROWS;
+    static constexpr int PIECE = 64 * ROWS * 9;          // records per input piece: nine full wave rounds (<128, 7>: 4032 records, 252 lines)
+    static constexpr size_t LDS = (size_t)TILE * 8 + (size_t)(3 * (MAXB + 4) + 32) * 4 + (size_t)MAXB * sizeof(P2Meta) + (size_t)MAXB * P2F_LINE * 8;
+};
 struct P2Args {
     int p1, p2, recbits;
     uint32_t nblk1, vper, nblk2, cap1, cap2;     // vper = pieces per level-1 slice; cap2: a multiple of P2F_LINE
     unsigned long long *stats;
 };
-__global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *__restrict__ out1, const unsigned int *__restrict__ cnt1, P2Args P, uint64_t *__restrict__ out2,
+template <int MAXB, int ROWS>
+__global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel(const uint64_t *__restrict__ out1, const unsigned int *__restrict__ cnt1, P2Args P, uint64_t *__restrict__ out2,
                                                             unsigned int *__restrict__ cnt2, unsigned long long *__restrict__ deferred,
                                                             unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
+    constexpr int P2F_MAXB = MAXB, P2F_ROWS = ROWS, P2F_TILE = P2F<MAXB, ROWS>::TILE, P2F_PIECE = P2F<MAXB, ROWS>::PIECE;
+    constexpr int NSW = MAXB / 64;                       // waves that scan the list counts
     extern __shared__ __align__(16) unsigned char s_raw[];
     P2Meta *s_meta = reinterpret_cast<P2Meta *>(s_raw);                                      // P2F_MAXB
     uint64_t *s_carry = reinterpret_cast<uint64_t *>(s_meta + P2F_MAXB);                      // P2F_MAXB x P2F_LINE: what a list has waiting
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_carry + P2F_MAXB * P2F_LINE);    // P2F_MAXB+4  records of this round per list ([nb2] = the padding)
     unsigned int *s_off = s_cnt + P2F_MAXB + 4;                                              // P2F_MAXB+4  exclusive prefix of s_cnt
     unsigned int *s_have = s_off + P2F_MAXB + 4;                                             // P2F_MAXB+4  records waiting per list, bit 31: they leave this round
-    unsigned int *s_wsum = s_have + P2F_MAXB + 4;                                            // [0], [1] wave totals, [16] = "a slice overflows", [17] = rounds
+    unsigned int *s_wsum = s_have + P2F_MAXB + 4;                                            // [0 .. NSW) wave totals, [16] = "a slice overflows", [17] = rounds
     uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_wsum + 32);                           // P2F_TILE records, list order
     const int t = threadIdx.x;
     const int nb2 = 1 << P.p2;
@@ -690,6 +698,7 @@ __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *_
         // x + (wave + 16 m) * nblk2, m = 0, 1, ... is my wave's input; rounds = the most any wave needs
         if (t < P2F_MAXB + 4) s_cnt[t] = 0;
         if (t == 0) { s_wsum[16] = 0; s_wsum[17] = 0; }
+        static_assert(P2F_MAXB + 4 <= PT_THREADS && NSW >= 1 && NSW <= 16, "list counts are scanned by the first MAXB / 64 waves");
         lds_barrier();
         const uint32_t sl_step = 16u * P.nblk2;
         const uint32_t npieces = P.nblk1 * P.vper;
@@ -739,8 +748,20 @@ __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *_
             pos += 64u * P2F_ROWS;
         };
         uint32_t vmask = 0;
-        for (uint32_t round = 0; round < rounds; ++round) {
+        // PF (the one-workgroup-per-CU instance, which has the registers): the records of round r + 1 are asked for at the top of
+        // round r and waited for right BEFORE round r's copy-out stores are issued (a wave's vector-memory operations retire in
+        // order: waited for at the top of round r + 1 they would wait for those stores as well), see part1_kernel
+        constexpr bool PF = MAXB > 128;
+        uint64_t nxt[P2F_ROWS];
+        uint32_t vmask_n = 0;
+        if (PF && rounds) {
             fetch(rec, vmask);
+#pragma unroll
+            for (int j = 0; j < P2F_ROWS; ++j) asm volatile("" : "+v"(rec[j]));               // (arrived before the loop: no wait for "all loads" at its top)
+        }
+        for (uint32_t round = 0; round < rounds; ++round) {
+            if constexpr (PF) { if (round + 1 < rounds) fetch(nxt, vmask_n); else vmask_n = 0; }
+            else fetch(rec, vmask);
             // A. the list of each record, a rank in the round's list histogram (a row that does not exist: the padding list nb2)
             uint32_t br[P2F_ROWS];
 #pragma unroll
@@ -749,7 +770,7 @@ __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *_
                 br[j] = (b2 << 16) | (atomicAdd(&s_cnt[b2], 1u) & 0xFFFFu);                  // LDS returning atomic; a round holds 2^14 rows
             }
             lds_barrier();
-            // B. exclusive prefix of the list counts: thread t owns list t (nb2 <= 128: the first two waves)
+            // B. exclusive prefix of the list counts: thread t owns list t (the first MAXB / 64 waves)
             unsigned int v = 0, inc = 0;
             if (t < P2F_MAXB) {
                 v = t < nb2 ? s_cnt[t] : 0u;
@@ -759,10 +780,16 @@ __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *_
                 if (t == 0) s_cnt[nb2] = 0;
             }
             lds_barrier();
-            const unsigned int total = s_wsum[0] + s_wsum[1];
+            unsigned int total, wbase;
+            if constexpr (NSW == 2) { total = s_wsum[0] + s_wsum[1]; wbase = wave ? s_wsum[0] : 0u; }
+            else {                                                                           // the wave totals scanned once more by every wave
+                const unsigned int ws = wave_scan_incl(lane < (uint32_t)NSW ? s_wsum[lane] : 0u);
+                wbase = wave && wave < (uint32_t)NSW ? (unsigned int)__builtin_amdgcn_readlane((int)ws, (int)wave - 1) : 0u;
+                total = (unsigned int)__builtin_amdgcn_readlane((int)ws, NSW - 1);
+            }
             unsigned int F = 0;                                                              // records of my list that leave now (whole lines)
             if (t < nb2) {
-                const unsigned int ex = inc - v + (wave ? s_wsum[0] : 0u);
+                const unsigned int ex = inc - v + wbase;
                 const unsigned int T = have + v;
                 F = T & ~(unsigned int)(P2F_LINE - 1);
                 const unsigned int L = F ? F - have : 0u;                                     // of the new records
@@ -784,10 +811,13 @@ __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *_
             //     the records that stay this round go into the same slots)
             int td = t;                                           // (an opaque copy: what is derived from it is recomputed here, not kept live -- and spilled -- across the round)
             asm volatile("" : "+v"(td));
-            uint64_t cw[2] = {0ull, 0ull};
-            uint32_t cat[2] = {~0u, ~0u};                                                    // its position in the list's slice, ~0 = nothing
+            constexpr int NU = P2F_MAXB / 64;                                                // lists per 16-lane group
+            uint64_t cw[NU];
+            uint32_t cat[NU];                                                                // its position in the list's slice, ~0 = nothing
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NU; ++u) {
+                cw[u] = 0ull;
+                cat[u] = ~0u;
                 const uint32_t b2 = ((uint32_t)td >> 4) + (uint32_t)u * 64u, q = (uint32_t)td & 15u;
                 if (b2 < (uint32_t)nb2) {
                     const unsigned int hv = s_have[b2];
@@ -799,10 +829,14 @@ __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *_
                 }
             }
             const bool overflow = s_wsum[16] != 0;
+            if constexpr (PF) {
+#pragma unroll
+                for (int j = 0; j < P2F_ROWS; ++j) asm volatile("" : "+v"(nxt[j]));           // (the next round's records have arrived: not after this point)
+            }
             lds_barrier();
             if (!overflow) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < NU; ++u)
                     if (cat[u] != ~0u) reinterpret_cast<global_u64 *>(slice_of(((uint32_t)td >> 4) + (uint32_t)u * 64u))[cat[u]] = cw[u];
                 // D2. one lane per staged record: into the slice, or into the list's carry
 #pragma unroll 2
@@ -820,7 +854,7 @@ __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *_
                     else defer_record(P.stats, hash_of(b1, rr, P.recbits), deferred, deferred_n, deferred_cap);
                 };
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < NU; ++u)
                     if (cat[u] != ~0u) put(((uint32_t)td >> 4) + (uint32_t)u * 64u, cat[u], cw[u]);
                 for (unsigned int i = (unsigned int)td; i < total; i += PT_THREADS) {
                     const uint64_t rr = s_stage[i];
@@ -831,6 +865,11 @@ __global__ __launch_bounds__(PT_THREADS, 8) void part2f_kernel(const uint64_t *_
                 }
             }
             if (t < nb2) { cur += F; have = have + v - F; }
+            if constexpr (PF) {
+#pragma unroll
+                for (int j = 0; j < P2F_ROWS; ++j) rec[j] = nxt[j];
+                vmask = vmask_n;
+            }
             // (the next round's barriers order its writes to the stage, s_meta and s_carry against this copy-out)
         }
         lds_barrier();
@@ -1112,13 +1151,15 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     // regions of 2^12 slots (three region_insert workgroups per CU); 2^13 only where the two list levels cannot split finer
     int p1 = 0, p2 = 0;
     bool ok = false;
+    // (first choice: at most 512 lists per bucket, which part2f_kernel writes in whole lines)
+    for (int maxp2 = 9; maxp2 <= 11 && !ok; maxp2 += 2)
     for (int rg = RG_MAXBITS; rg <= RG_MAXBITS + 1 && !ok; ++rg) {
         p1 = std::max(need_p1, (s - rg + 1) / 2);
         if (p1 < 1) p1 = 1;
         if (p1 > 10 || p1 > s - 8) continue;              // (k >= 38, or a table too small to be worth it)
         p2 = s - rg - p1;
         if (p2 < 0) p2 = 0;
-        ok = p2 <= 11;
+        ok = p2 <= maxp2;
     }
     if (!ok) return false;
     G.p1 = p1; G.p2 = p2; G.rbits = s - p1 - p2; G.recbits = B - p1;
@@ -1181,16 +1222,24 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr2_set = true;
         }
-        if ((1 << G.p2) <= P2F_MAXB && G.cap2 % P2F_LINE == 0 && !getenv("JASPER_EXPERIMENT_OLDP2")) {
+        if ((1 << G.p2) <= 512 && G.cap2 % P2F_LINE == 0 && !getenv("JASPER_EXPERIMENT_OLDP2")) {
             static bool attr2f_set = false;
             if (!attr2f_set) {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel<128, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel<512, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr2f_set = true;
             }
             P2Args P;
             P.p1 = G.p1; P.p2 = G.p2; P.recbits = G.recbits; P.nblk1 = G.nblk1; P.nblk2 = G.nblk2; P.cap1 = G.cap1; P.cap2 = G.cap2; P.stats = d.stats;
-            P.vper = (G.cap1 + (uint32_t)P2F_PIECE - 1u) / (uint32_t)P2F_PIECE;
-            hipLaunchKernelGGL(part2f_kernel, grid, dim3(PT_THREADS), P2F_LDS, stream, out1, cnt1, P, out2, cnt2, defer_e, defer_n, deferred_cap);
+            if ((1 << G.p2) <= 128) {
+                P.vper = (G.cap1 + (uint32_t)P2F<128, 7>::PIECE - 1u) / (uint32_t)P2F<128, 7>::PIECE;
+                constexpr size_t lds2 = P2F<128, 7>::LDS;
+                hipLaunchKernelGGL((part2f_kernel<128, 7>), grid, dim3(PT_THREADS), lds2, stream, out1, cnt1, P, out2, cnt2, defer_e, defer_n, deferred_cap);
+            } else {
+                P.vper = (G.cap1 + (uint32_t)P2F<512, 8>::PIECE - 1u) / (uint32_t)P2F<512, 8>::PIECE;
+                constexpr size_t lds2 = P2F<512, 8>::LDS;
+                hipLaunchKernelGGL((part2f_kernel<512, 8>), grid, dim3(PT_THREADS), lds2, stream, out1, cnt1, P, out2, cnt2, defer_e, defer_n, deferred_cap);
+            }
         } else
             hipLaunchKernelGGL(part2_kernel<false>, grid, dim3(PT_THREADS), P2_LDS, stream, out1, cnt1, d, G, out2, cnt2, defer_e, defer_n, deferred_cap, 1u);
         HIPCHK(hipGetLastError());

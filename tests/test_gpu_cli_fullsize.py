@@ -59,7 +59,7 @@ def _run(ref, tmp_path_factory, ranks, count=None, extra_env=None, expect_stderr
     for fn in files + ["asm.fa"]:
         os.symlink(os.path.join(src, fn), os.path.join(d, fn))
     args = ["-r", " ".join(files), "-a", "asm.fa", "-k", str(ref["k"]), "-t", str(ref["threads"]), "-p", str(ref["passes"])]
-    env = dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_NO_JF="1")
+    env = dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_NO_JF="1", JASPER_AMD_TIMING="1")
     if ranks == 1:
         cmd = [sys.executable, "-m", "jasper_amd.cli"] + args
     else:
@@ -97,6 +97,17 @@ def _run(ref, tmp_path_factory, ranks, count=None, extra_env=None, expect_stderr
         assert got[key] == ref[key], (key, got[key], ref[key])
     # same log lines (dates and Q digits aside: bc is missing in the build container, so the reference printed "Inf")
     assert strip(mine) == strip(ref["stdout"])
+    # The QV INPUTS are pinned by the reference: the column sums of its own {0,P}qValCalcHelper.csv (src/jasper.py:107-111), which
+    # tests/golden/ref_fullsize.py copies before src/jasper.sh:258 removes them.  The Q strings the drop-in prints must be
+    # qv.py (the bc restatement) of exactly those sums.
+    m = re.search(r"^\[qv\] before (\d+) (\d+) after (\d+) (\d+)$", p.stderr, re.M)
+    assert m, p.stderr
+    assert [int(m.group(1)), int(m.group(2))] == ref["qv_before"], (m.groups(), ref["qv_before"])
+    assert [int(m.group(3)), int(m.group(4))] == ref["qv_after"], (m.groups(), ref["qv_after"])
+    from jasper_amd import qv
+    qlines = [re.sub(r"^\[[^\]]*\] ", "", ln) for ln in mine if "Q value" in ln]
+    assert qlines == ["Before Polishing: Q value = %s" % qv.q_value(ref["qv_before"][0], ref["qv_before"][1], ref["k"]),
+                      "After Polishing: Q value = %s" % qv.q_value(ref["qv_after"][0], ref["qv_after"][1], ref["k"])], qlines
     print("%d-rank drop-in wall %.1f s%s vs reference %.1f s on %s" % (ranks, wall, " (counts by exchange of region lists)" if count == "exchange" else "",
                                                                      ref["reference_wall_seconds"], ref["host"]))
     for fn in os.listdir(d):          # (GBs of intermediates per case)
