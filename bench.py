@@ -271,6 +271,49 @@ def e2e_cli():
         shutil.rmtree(d, ignore_errors=True)
 
 
+def e2e_cli_cfg3():
+    """Second UNTIMED leg, a larger driver-visible size: BASELINE configs[2] exactly as stated -- 140 Mb in 7 contigs, 40x reads
+    (37.3 M reads, 11.5 GB of FASTQ), k = 37, 2 passes, `-t 16` -- through `python -m jasper_amd.cli` as ONE process, against the
+    digests of the real reference's run on the same deterministic files (tests/golden/fullsize_cfg3.json).  Skipped, with the
+    reason, when the scratch directory has no room for the files."""
+    import shutil
+    import subprocess
+    import tempfile
+    from jasper_amd import synth
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_cfg3.json")))
+    base = os.environ.get("TMPDIR", "/tmp")
+    free = shutil.disk_usage(base).free
+    if free < 40 << 30:
+        return {"seconds": None, "skipped": "%s has %.0f GB free: 12 GB of read files + working files need room" % (base, free / 1e9)}
+    d = tempfile.mkdtemp(prefix="jasper_e2e3_", dir=base)
+    try:
+        t0 = time.perf_counter()
+        nreads, asm_len = synth.write_cli_inputs(d, ref["genome_mb"], ref["seed"], coverage=ref["coverage"], contigs=ref["contigs"])
+        t_gen = time.perf_counter() - t0
+        fastq = sum(os.path.getsize(os.path.join(d, fn)) for fn in synth.read_files(1))
+        args = [sys.executable, "-m", "jasper_amd.cli", "-r", " ".join(synth.read_files(1)), "-a", "asm.fa", "-k", str(ref["k"]), "-t", str(ref["threads"]), "-p", str(ref["passes"])]
+        time.sleep(3.0)
+        t0 = time.perf_counter()
+        p = subprocess.run(args, cwd=d, env=dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_TIMING="1", JASPER_AMD_NO_JF="1"), capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        if p.returncode:
+            raise RuntimeError("jasper_amd.cli exit %d: %s" % (p.returncode, p.stderr[-400:]))
+        marks = {m.group(1): float(m.group(2)) for m in re.finditer(r"\[timing\] (.*?)\s+([0-9.]+) s", p.stderr)}
+        got = synth.output_digests(d, k=ref["k"])
+        keys = ("threshold", "jfhisto_sha256", "polished_bases", "polished_fasta_sha256", "fixes_csv_lines", "fixes_csv_sha256")
+        qm = re.search(r"^\[qv\] before (\d+) (\d+) after (\d+) (\d+)$", p.stderr, re.M)
+        count_s = next((v for k, v in marks.items() if k.startswith("count reads")), None)
+        split_s = marks.get("split", 0.0)
+        return {"seconds": round(wall, 3), "outputs_equal_reference": all(got[k] == ref[k] for k in keys),
+                "qv_sums_equal_reference": bool(qm) and [int(qm.group(1)), int(qm.group(2))] == ref.get("qv_before") and [int(qm.group(3)), int(qm.group(4))] == ref.get("qv_after"),
+                "stage_seconds": marks, "ingest_text_GBps": round(fastq / 1e9 / (count_s + split_s), 2) if count_s else None,
+                "input": "%.2f GB FASTQ (%d reads) + %.1f Mb FASTA in %d contigs on %s (written %.0f s before), flags -k %d -t %d -p %d" % (
+                    fastq / 1e9, nreads, asm_len / 1e6, ref["contigs"], base, t_gen, ref["k"], ref["threads"], ref["passes"]),
+                "reference_seconds_build_container_8_vcpu": ref["reference_wall_seconds"]}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,6 +324,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-selftest", action="store_true", help="N > 1: skip the transport self-test in throw-away processes")
     ap.add_argument("--no-e2e", action="store_true", help="skip the untimed files-in / files-out run of the drop-in CLI (e2e_cli)")
+    ap.add_argument("--no-e2e-cfg3", action="store_true", help="skip the second untimed leg (configs[2]-sized files through the CLI)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: all ranks share GPU 0")
     ap.add_argument("--count", choices=("auto", "exchange", "local"), default="auto",
@@ -317,6 +361,12 @@ def main():
             e2e = e2e_cli()
         except Exception as e:      # a report, like the CPU baseline: never a reason to lose the measurement
             e2e = {"seconds": None, "failed": "%r" % (e,)}
+    e2e3 = None
+    if a.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.genome_mb == 47.0 and not a.no_e2e and not a.no_e2e_cfg3:
+        try:
+            e2e3 = e2e_cli_cfg3()
+        except Exception as e:
+            e2e3 = {"seconds": None, "failed": "%r" % (e,)}
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -565,6 +615,8 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Mbp/s", "cores": host_cpu()[0], "kind": "port", "sample": "failed: %r" % (e,)}
         if e2e is not None:
             out["e2e_cli"] = e2e
+        if e2e3 is not None:
+            out["e2e_cli_cfg3"] = e2e3
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()           # nobody unmaps or frees a shard that a peer may still be reading

@@ -610,9 +610,14 @@ class _EarlyTable:
 
         def work():
             try:
+                import time
+                t0 = time.perf_counter()
                 t = KmerTable(k, min_slots=min_slots, device=device)
+                t1 = time.perf_counter()
                 if reads:
                     t.count_files(reads)
+                if os.environ.get("JASPER_AMD_TIMING"):
+                    sys.stderr.write("[timing-thread] library + GPU runtime + table %.3f s, files -> table %.3f s\n" % (t1 - t0, time.perf_counter() - t1))
                 self.out = t
             except BaseException as e:          # noqa: BLE001 -- handed to the caller of get()
                 self.err = e
@@ -726,11 +731,29 @@ def _init_multi(o):
 
 
 def run(argv):
+    if os.environ.get("JASPER_AMD_TIMING"):
+        import time
+        sys.stderr.write("[timing-abs] run() entered at %.6f\n" % time.time())
     o = parse_args(argv)
     rank, world, dev = _init_multi(o)
     multi = world > 1
     if not (os.path.isfile(o.query) and os.path.getsize(o.query) > 0):
         error_exit("The query file does not exist. Please supply a valid fasta file to be polished with -a option.")
+    # The counting stage -- the start of the GPU runtime, the table's allocation and reads -> table: everything of src/jasper.sh:177
+    # but the database file -- is the work of a thread that starts NOW, before this one even sizes the batches: the two do not
+    # depend on each other, counting is the longest stage of a run, and the log lines keep the reference's order.  Only when
+    # counting WILL happen and the flags are the ones run() accepts below (no exit while the thread is in the driver).
+    early = None
+    def _flags_ok():
+        try:
+            return (re.match(r"^-?[0-9]+$", str(o.kmer)) and int(o.kmer) - 1 >= 0 and re.match(r"^-?[0-9]+$", str(o.passes)) and int(o.passes) - 1 >= 0
+                    and float(o.num_threads) > 0)
+        except ValueError:
+            return False
+    if (not multi and _flags_ok()
+            and o.jf_db is None and not (os.path.isfile("mer_counts%d.jf" % int(o.kmer)) and os.path.getsize("mer_counts%d.jf" % int(o.kmer)) > 0)
+            and not os.environ.get("JASPER_AMD_NO_EARLY_TABLE") and o.reads.split() and all(os.path.isfile(fn) and os.path.getsize(fn) > 0 for fn in o.reads.split())):
+        early = _EarlyTable(int(o.kmer), max(1 << 20, int(1.25 * o.jf_size)), o.device, reads=o.reads.split())
     batch_size = o.batch_size
     if not re.match(r"^[0-9]+$", str(batch_size)):
         log("BATCH SIZE supplied is not a positive integer. Calculating BATCH SIZE from QUERY SIZE")
@@ -758,14 +781,7 @@ def run(argv):
     if multi:
         return _run_multi(o, rank, world, dev, batch_size, passes, kmer)
 
-    # the counting stage -- the start of the GPU runtime, the table's allocation and reads -> table: everything of src/jasper.sh:177
-    # but the database file -- is the work of a thread while this one splits the assembly (the two do not depend on each other;
-    # the log lines keep the reference's order)
-    early = None
     jf_writer = None
-    if (o.jf_db is None and not (os.path.isfile("mer_counts%d.jf" % kmer) and os.path.getsize("mer_counts%d.jf" % kmer) > 0)
-            and not os.environ.get("JASPER_AMD_NO_EARLY_TABLE") and o.reads.split() and all(os.path.isfile(fn) and os.path.getsize(fn) > 0 for fn in o.reads.split())):   # (only when counting WILL happen: no exit while the thread is in the driver)
-        early = _EarlyTable(kmer, max(1 << 20, int(1.25 * o.jf_size)), o.device, reads=o.reads.split())
 
     if not os.path.exists("jasper.split.success"):                      # :152-159
         log("Splitting query into batches for parallel execution")
@@ -797,6 +813,11 @@ def run(argv):
             _timing("split")
             log("Creating jellyfish database mer_counts%d.jf" % kmer)
             if early is not None:
+                try:                                    # (what the later stages import, while this thread only waits)
+                    import numpy                        # noqa: F401 -- 0.1 s that histo_rows / the fix records would otherwise spend
+                    import csv, io                      # noqa: F401,E401
+                except ImportError:
+                    pass
                 table = early.get()                     # (counted while the assembly was split)
                 early = None
             else:
@@ -924,7 +945,18 @@ def main():
                 sk.close()
             sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
                                       "--master-addr", "127.0.0.1", "--master-port", port, "-m", "jasper_amd.cli"] + argv))
-    sys.exit(run(argv))
+    rc = run(argv)
+    if os.environ.get("JASPER_AMD_TIMING"):
+        import time
+        sys.stderr.write("[timing-abs] run() returned at %.6f\n" % time.time())
+    # Every output file is closed and under its final name.  A normal interpreter exit would now free tens of GB of device
+    # memory allocation by allocation (hipFree of the table, the list workspaces, the pinned buffers: 0.1 s of a 0.7-s run);
+    # the driver releases all of it when the process ends anyway.
+    if not rc and "WORLD_SIZE" not in os.environ and not os.environ.get("JASPER_AMD_SLOW_EXIT"):
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    sys.exit(rc)
 
 
 if __name__ == "__main__":
