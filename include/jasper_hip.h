@@ -54,6 +54,9 @@ typedef struct jasper_fixrec {
 
 const char *jasper_last_error(void);
 int jasper_device_count(int *n);
+/* free and total device memory in bytes (hipMemGetInfo): lets the driver that replaces src/jasper.sh decide whether two stages
+ * that the reference runs one after the other (`tee $JF_DB` at :177, then the jasper.py processes at :207-212) fit side by side */
+int jasper_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* k in [1,64]; min_slots is a size hint like `jellyfish count -s` (rounded up to a power of two; the table
  * doubles by itself when half full).  k > 26 needs at least 2^(2k-53) slots (k=37: 2^21 = 32 MiB). */

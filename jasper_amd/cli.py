@@ -646,6 +646,7 @@ class _JfWriter:
     def __init__(self, table, tmp, final, cmdline):
         import threading
         self.err = None
+        self.cmdline = cmdline
 
         def work():
             try:
@@ -663,6 +664,25 @@ class _JfWriter:
         self.th.join()
         if self.err is not None:
             raise self.err
+
+
+def _jf_write_fits_beside_polishing(table, device, qfn):
+    """does the device have room for table.write_jf (entries + keys for the sort + the sort's temporaries + the formatted
+    records: ~64 bytes per distinct k-mer, measured 48 + rocPRIM's temporaries) AND the polisher's workspaces for the largest group
+    of batch files (two text arenas, classes, segment buffers, records: ~8 bytes per base of a group of <= 1 Gbase) at once?"""
+    import ctypes as C
+    from . import _lib
+    free, total = C.c_uint64(0), C.c_uint64(0)
+    try:
+        _lib.check(_lib.lib().jasper_device_mem_info(int(device), C.byref(free), C.byref(total)))
+        distinct = table.info()["distinct"]
+        text = sum(os.path.getsize(p) for p in glob.glob("%s.batch.*.fa" % glob.escape(qfn)))
+    except Exception:                                  # noqa: BLE001 -- no answer: the safe order
+        return False
+    need = 64 * distinct + 8 * min(text, 1 << 30) + (2 << 30)
+    if os.environ.get("JASPER_AMD_TEST_JF_SERIAL"):      # (tests: take the serial order whatever the device has)
+        return False
+    return need < free.value
 
 
 def _join_and_merge(o, qfn, batch_size, last_it, contigs):
@@ -824,14 +844,27 @@ def run(argv):
                 table = KmerTable(kmer, min_slots=max(1 << 20, int(1.25 * o.jf_size)), device=o.device)
                 table.count_files(reads)
             _timing("count reads (files -> table)")
-            if os.environ.get("JASPER_AMD_NO_JF", "") not in ("1", "true", "yes"):
-                # :177 `... | tee $JF_DB | ...`: leave the database behind for reruns and for other Jellyfish tools
-                jf_writer = _JfWriter(table, jf_file + ".tmp", jf_file,
-                                      ["count", "-C", "-t", str(o.num_threads), "-s", str(o.jf_size), "-m", str(kmer), "-o", jf_file] + reads)
+            # (the histogram first, on this thread: whatever a lazily cleared table still owes its slots is settled before a
+            #  second thread looks at them)
             with open(histo_file + ".tmp", "w") as f:
                 for m, n in table.histo_rows():
                     f.write("%d %d\n" % (m, n))
             os.replace(histo_file + ".tmp", histo_file)
+            if os.environ.get("JASPER_AMD_NO_JF", "") not in ("1", "true", "yes"):
+                # :177 `... | tee $JF_DB | ...`: leave the database behind for reruns and for other Jellyfish tools.  Written by a
+                # thread beside the polishing when the device has room for both (the writer holds ~48 bytes per distinct k-mer plus
+                # its sort's workspace, the polisher several times its batch's text); otherwise first the file, then the polishing,
+                # as the reference orders them.
+                jf_cmdline = ["count", "-C", "-t", str(o.num_threads), "-s", str(o.jf_size), "-m", str(kmer), "-o", jf_file] + reads
+                if _jf_write_fits_beside_polishing(table, o.device, qfn):
+                    jf_writer = _JfWriter(table, jf_file + ".tmp", jf_file, jf_cmdline)
+                else:
+                    try:
+                        table.write_jf(jf_file + ".tmp", jf_cmdline)
+                        os.replace(jf_file + ".tmp", jf_file)
+                    except Exception as e:             # noqa: BLE001 -- what `set -o pipefail` makes of a failing tee (src/jasper.sh:177-181)
+                        error_exit("Creating jellyfish database mer_counts%d.jf failed (%s)" % (kmer, e))
+                    _timing("write mer_counts.jf (before the polishing: not enough device memory for both at once)")
             open("jasper.no_cat.success", "w").close()
             open("jasper.histo.success", "w").close()
             if os.path.exists("jasper.correct.success"):
@@ -913,7 +946,13 @@ def run(argv):
     _timing("join + QV")
     if jf_writer is not None:
         try:
-            jf_writer.finish()
+            try:
+                jf_writer.finish()
+            except Exception as e1:            # noqa: BLE001 -- e.g. a device allocation that failed beside the polisher's: once more, alone
+                if "alloc" not in str(e1).lower() and "memory" not in str(e1).lower():
+                    raise
+                table.write_jf("mer_counts%d.jf.tmp" % kmer, jf_writer.cmdline)
+                os.replace("mer_counts%d.jf.tmp" % kmer, "mer_counts%d.jf" % kmer)
         except Exception as e:                 # noqa: BLE001 -- what `set -o pipefail` makes of a failing tee (src/jasper.sh:177-181)
             error_exit("Creating jellyfish database mer_counts%d.jf failed (%s)" % (kmer, e))
         _timing("mer_counts.jf complete (written beside the stages above)")

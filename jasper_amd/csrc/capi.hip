@@ -73,6 +73,16 @@ int jasper_device_count(int *n) {
     return JASPER_OK;
 }
 
+int jasper_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    size_t f = 0, t = 0;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMemGetInfo(&f, &t);
+    if (e != hipSuccess) { g_err = std::string("hipMemGetInfo: ") + hipGetErrorString(e); return JASPER_ERR; }
+    if (free_bytes) *free_bytes = (uint64_t)f;
+    if (total_bytes) *total_bytes = (uint64_t)t;
+    return JASPER_OK;
+}
+
 int jasper_table_create(int k, uint64_t min_slots, int device, jasper_table **out) {
     if (!out) { g_err = "null out"; return JASPER_ERR; }
     jasper_table *h = new jasper_table();

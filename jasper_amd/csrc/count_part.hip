@@ -672,9 +672,12 @@ template <int MAXB, int ROWS> struct P2F {
 struct P2Args {
     int p1, p2, recbits;
     uint32_t nblk1, vper, nblk2, cap1, cap2;     // vper = pieces per level-1 slice; cap2: a multiple of P2F_LINE
+    uint32_t nown;                               // OWN: the number of key owners
     unsigned long long *stats;
 };
-template <int MAXB, int ROWS>
+// OWN (the multi-GPU exchange, as part2_kernel<true>): a bucket is split nown x 2^p2 ways, by (owner of the key, next p2 hash bits),
+// and the lists are laid out owner-major.
+template <int MAXB, int ROWS, bool OWN = false>
 __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel(const uint64_t *__restrict__ out1, const unsigned int *__restrict__ cnt1, P2Args P, uint64_t *__restrict__ out2,
                                                             unsigned int *__restrict__ cnt2, unsigned long long *__restrict__ deferred,
                                                             unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
@@ -689,37 +692,51 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
     unsigned int *s_wsum = s_have + P2F_MAXB + 4;                                            // [0 .. NSW) wave totals, [16] = "a slice overflows", [17] = rounds
     uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_wsum + 32);                           // P2F_TILE records, list order
     const int t = threadIdx.x;
-    const int nb2 = 1 << P.p2;
+    const int nb2 = OWN ? (int)(P.nown << P.p2) : 1 << P.p2;
     const int shift2 = P.recbits - P.p2;               // the p2 bits right below the level-1 bucket bits
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6), lane = (uint32_t)t & 63u;
     for (uint32_t b1 = blockIdx.y; b1 < (1u << P.p1); b1 += gridDim.y) {
-        auto slice_of = [&](uint32_t b2) { return reinterpret_cast<uint64_t>(out2 + ((((uint64_t)b1 << P.p2) + (uint64_t)b2) * P.nblk2 + blockIdx.x) * P.cap2); };
-        // The bucket's few long slices are read in PIECES of P2F_PIECE records (P.vper pieces per slice, by its capacity): piece
-        // x + (wave + 16 m) * nblk2, m = 0, 1, ... is my wave's input; rounds = the most any wave needs
+        auto list_of = [&](uint32_t b2) -> uint64_t {                                        // the list's index in out2 / cnt2
+            if constexpr (OWN) return ((((uint64_t)(b2 >> P.p2) << P.p1) + b1) << P.p2) + (uint64_t)(b2 & ((1u << P.p2) - 1u));
+            else return ((uint64_t)b1 << P.p2) + (uint64_t)b2;
+        };
+        auto b2_of = [&](uint64_t rr) -> uint32_t {                                          // the list of a record of this bucket
+            if constexpr (OWN) {
+                const uint32_t lo = P.p2 ? (uint32_t)(rr >> shift2) & ((1u << P.p2) - 1u) : 0u;
+                return lo | (owner_of(hash_of(b1, rr, P.recbits), P.nown) << P.p2);
+            } else return (uint32_t)(rr >> shift2) & (uint32_t)(nb2 - 1);
+        };
+        auto slice_of = [&](uint32_t b2) { return reinterpret_cast<uint64_t>(out2 + (list_of(b2) * P.nblk2 + blockIdx.x) * P.cap2); };
+        // The bucket's few long slices are read in PIECES of P2F_PIECE records (P.vper pieces per slice, by its capacity);
+        // rounds = the most any wave needs
         if (t < P2F_MAXB + 4) s_cnt[t] = 0;
         if (t == 0) { s_wsum[16] = 0; s_wsum[17] = 0; }
         static_assert(P2F_MAXB + 4 <= PT_THREADS && NSW >= 1 && NSW <= 16, "list counts are scanned by the first MAXB / 64 waves");
         lds_barrier();
-        const uint32_t sl_step = 16u * P.nblk2;
-        const uint32_t npieces = P.nblk1 * P.vper;
-        auto piece_len = [&](uint32_t j) -> uint32_t {                                       // records of piece j (j < npieces)
-            const uint32_t c = cnt1[((uint64_t)(j / P.vper) << P.p1) + b1], first = (j % P.vper) * (uint32_t)P2F_PIECE;
+        // block x reads the level-1 slices x, x + nblk2, ... WHOLE (whatever their fill: the blocks' shares are as even as the
+        // slices are), each in pieces; my wave takes the block's pieces wave, wave + 16, ... -- piece q of the block = piece
+        // q % vper of slice x + nblk2 * (q / vper)
+        auto piece_len = [&](uint32_t ph_, uint32_t sub_) -> uint32_t {                      // records of piece sub_ of slice ph_ (ph_ < nblk1)
+            const uint32_t c = cnt1[((uint64_t)ph_ << P.p1) + b1], first = sub_ * (uint32_t)P2F_PIECE;
             return c > first ? (c - first < (uint32_t)P2F_PIECE ? c - first : (uint32_t)P2F_PIECE) : 0u;
         };
-        uint32_t sl = blockIdx.x + wave * P.nblk2;                                           // (scalar) current input piece of my wave
         {
             uint32_t rounds = 0;
-            for (uint32_t j = sl + lane * sl_step; j < npieces; j += 64u * sl_step) rounds += (piece_len(j) + 64u * P2F_ROWS - 1u) / (64u * P2F_ROWS);
+            for (uint32_t q = wave + 16u * lane;; q += 16u * 64u) {
+                const uint32_t ph_ = blockIdx.x + P.nblk2 * (q / P.vper);
+                if (ph_ >= P.nblk1) break;
+                rounds += (piece_len(ph_, q % P.vper) + 64u * P2F_ROWS - 1u) / (64u * P2F_ROWS);
+            }
             for (int o = 32; o > 0; o >>= 1) rounds += __shfl_xor(rounds, o);
             if (lane == 0) atomicMax(&s_wsum[17], rounds);
         }
         lds_barrier();
         const uint32_t rounds = s_wsum[17];
-        uint32_t pos = 0;                                                                    // (scalar) position in that piece
-        uint32_t ph = sl / P.vper, sub = sl % P.vper;                                        // (scalar) piece sl = piece `sub` of slice `ph`
+        uint32_t pos = 0;                                                                    // (scalar) position in the current piece
+        uint32_t ph = blockIdx.x + P.nblk2 * (wave / P.vper), sub = wave % P.vper;           // (scalar) my wave's current piece: `sub` of slice `ph`
         auto open_piece = [&](uint32_t &len_out, const uint64_t *&src_out) {
             len_out = 0;
-            if (sl < npieces) {
+            if (ph < P.nblk1) {
                 const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt1[((uint64_t)ph << P.p1) + b1]), first = sub * (uint32_t)P2F_PIECE;
                 len_out = c > first ? (c - first < (uint32_t)P2F_PIECE ? c - first : (uint32_t)P2F_PIECE) : 0u;
             }
@@ -731,10 +748,9 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
         unsigned int cur = 0, have = 0;                    // thread t < nb2, list t: records written to its slice so far (whole lines) / waiting in s_carry
         uint64_t rec[P2F_ROWS];
         auto fetch = [&](uint64_t (&dst)[P2F_ROWS], uint32_t &valid) {                       // up to 64 x P2F_ROWS records of my wave's stream; valid = rows that exist (bit j: row j)
-            while (pos >= slen && sl < npieces) {                                            // (scalar) next piece
-                sl += sl_step;
-                sub += sl_step;
-                while (sub >= P.vper) { sub -= P.vper; ++ph; }
+            while (pos >= slen && ph < P.nblk1) {                                            // (scalar) next piece
+                sub += 16u;
+                while (sub >= P.vper) { sub -= P.vper; ph += P.nblk2; }
                 pos = 0;
                 open_piece(slen, src);
             }
@@ -766,7 +782,7 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
             uint32_t br[P2F_ROWS];
 #pragma unroll
             for (int j = 0; j < P2F_ROWS; ++j) {
-                const uint32_t b2 = (vmask >> j) & 1u ? (uint32_t)(rec[j] >> shift2) & (uint32_t)(nb2 - 1) : (uint32_t)nb2;
+                const uint32_t b2 = (vmask >> j) & 1u ? b2_of(rec[j]) : (uint32_t)nb2;
                 br[j] = (b2 << 16) | (atomicAdd(&s_cnt[b2], 1u) & 0xFFFFu);                  // LDS returning atomic; a round holds 2^14 rows
             }
             lds_barrier();
@@ -842,7 +858,7 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
 #pragma unroll 2
                 for (unsigned int i = (unsigned int)td; i < total; i += PT_THREADS) {
                     const uint64_t rr = s_stage[i];
-                    const uint32_t b2 = (uint32_t)(rr >> shift2) & (uint32_t)(nb2 - 1);
+                    const uint32_t b2 = b2_of(rr);
                     const P2Meta M = s_meta[b2];
                     if (i < M.lim) reinterpret_cast<global_u64 *>(M.gbase)[i] = rr;
                     else s_carry[b2 * P2F_LINE + (uint32_t)((int32_t)i + M.cadd)] = rr;
@@ -858,7 +874,7 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
                     if (cat[u] != ~0u) put(((uint32_t)td >> 4) + (uint32_t)u * 64u, cat[u], cw[u]);
                 for (unsigned int i = (unsigned int)td; i < total; i += PT_THREADS) {
                     const uint64_t rr = s_stage[i];
-                    const uint32_t b2 = (uint32_t)(rr >> shift2) & (uint32_t)(nb2 - 1);
+                    const uint32_t b2 = b2_of(rr);
                     const P2Meta M = s_meta[b2];
                     if (i < M.lim) put(b2, (uint64_t)((int64_t)(M.gbase - slice_of(b2)) / 8 + (int64_t)i), rr);
                     else s_carry[b2 * P2F_LINE + (uint32_t)((int32_t)i + M.cadd)] = rr;
@@ -881,7 +897,7 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
                 else defer_record(P.stats, hash_of(b1, rr, P.recbits), deferred, deferred_n, deferred_cap);
             }
             const unsigned int n = cur + have;
-            cnt2[(((uint64_t)b1 << P.p2) + (uint64_t)t) * P.nblk2 + blockIdx.x] = n < P.cap2 ? n : P.cap2;
+            cnt2[list_of((uint32_t)t) * P.nblk2 + blockIdx.x] = n < P.cap2 ? n : P.cap2;
         }
         lds_barrier();
     }
@@ -1230,7 +1246,7 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
                 attr2f_set = true;
             }
             P2Args P;
-            P.p1 = G.p1; P.p2 = G.p2; P.recbits = G.recbits; P.nblk1 = G.nblk1; P.nblk2 = G.nblk2; P.cap1 = G.cap1; P.cap2 = G.cap2; P.stats = d.stats;
+            P.p1 = G.p1; P.p2 = G.p2; P.recbits = G.recbits; P.nblk1 = G.nblk1; P.nblk2 = G.nblk2; P.cap1 = G.cap1; P.cap2 = G.cap2; P.stats = d.stats; P.nown = 1;
             if ((1 << G.p2) <= 128) {
                 P.vper = (G.cap1 + (uint32_t)P2F<128, 7>::PIECE - 1u) / (uint32_t)P2F<128, 7>::PIECE;
                 constexpr size_t lds2 = P2F<128, 7>::LDS;
@@ -1326,6 +1342,9 @@ static bool xchg_geometry(const Table &t, uint64_t piece_max, uint64_t records_m
     piece_max = std::max<uint64_t>(piece_max, 8u << 20);
     if (!t.partition_geometry(piece_max, raw)) return false;
     G = *reinterpret_cast<const PartGeom *>(raw);
+    // the senders split by (owner, second-level bits): more than 512 lists per bucket would leave the whole-line kernel, so the
+    // owners take regions of 8192 slots instead of 4096 where that is what it takes
+    if (((uint64_t)nown << G.p2) > 512 && ((uint64_t)nown << (G.p2 - 1)) <= 512 && G.p2 > 0 && G.rbits == RG_MAXBITS && !getenv("JASPER_EXPERIMENT_XCHG_RB12")) { --G.p2; ++G.rbits; }
     p2b = 0;
     while (((uint64_t)nown << (G.p2 - p2b)) > (uint64_t)xchg_max_lists() && p2b < G.p2) ++p2b;
     if (((uint64_t)nown << (G.p2 - p2b)) > (uint64_t)PT_MAXBUCKETS) return false;
@@ -1339,6 +1358,7 @@ static bool xchg_geometry(const Table &t, uint64_t piece_max, uint64_t records_m
         const double keys = std::max(1.0, std::min(rec, 0.35 * (double)t.nslots * (double)nown));
         G.cap2 = xchg_cap(rec / lists, rec / keys);
     } else G.cap2 = list_cap((double)piece_max / lists);
+    G.cap2 = (G.cap2 + 15u) & ~15u;                       // whole 128-byte lines (part2f_kernel<., ., OWN>)
     return true;
 }
 
@@ -1415,6 +1435,20 @@ int Table::xchg_partition(uint64_t piece_max, uint64_t records_max, uint32_t now
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    if (((uint64_t)nown << G.p2) <= 512 && G.cap2 % P2F_LINE == 0 && !getenv("JASPER_EXPERIMENT_OLDP2")) {
+        // the sender's split in whole lines, like the single-GPU pass
+        static bool attrf_set = false;
+        if (!attrf_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel<512, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attrf_set = true;
+        }
+        P2Args P;
+        P.p1 = G.p1; P.p2 = G.p2; P.recbits = G.recbits; P.nblk1 = G.nblk1; P.nblk2 = G.nblk2; P.cap1 = G.cap1; P.cap2 = G.cap2; P.stats = d.stats; P.nown = nown;
+        P.vper = (G.cap1 + (uint32_t)P2F<512, 8>::PIECE - 1u) / (uint32_t)P2F<512, 8>::PIECE;
+        constexpr size_t lds2 = P2F<512, 8>::LDS;
+        hipLaunchKernelGGL((part2f_kernel<512, 8, true>), dim3(G.nblk2, std::min<uint32_t>(nb1, 2048)), dim3(PT_THREADS), lds2, stream, out1, cnt1, P, (uint64_t *)d_send,
+                           (unsigned int *)d_send_cnt, defer_e, defer_n, defer_cap);
+    } else
     hipLaunchKernelGGL(part2_kernel<true>, dim3(G.nblk2, std::min<uint32_t>(nb1, 2048)), dim3(PT_THREADS), P2_LDS, stream, out1, cnt1, d, G, (uint64_t *)d_send,
                        (unsigned int *)d_send_cnt, defer_e, defer_n, defer_cap, nown);
     HIPCHK(hipGetLastError());

@@ -631,8 +631,6 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
     try:
         shard.reserve(slots)
         plan = shard.exchange_plan(1 << 26, world)      # (whether there is a geometry does not depend on the piece size)
-        if clear and plan is not None:
-            shard.clear()
     except RuntimeError as e:
         ok, why = 0, str(e)
     okt = torch.tensor([1 if plan is not None else 0, ok], dtype=torch.int64, device=device)
@@ -641,6 +639,18 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
         raise CollectiveCountError("count_sharded: preparing the shards failed on some rank" + (": " + why if why else ""))
     if not int(okt[0].item()):
         return None
+    # only now, when EVERY rank has a geometry and the call will go through, is a shard emptied: a caller that keeps its shard
+    # after a `None` (some peer has no plan) or a CollectiveCountError must find its counts as they were on every rank
+    if clear:
+        ok, why = 1, ""
+        try:
+            shard.clear()
+        except RuntimeError as e:
+            ok, why = 0, str(e)
+        okc = torch.tensor([ok], dtype=torch.int64, device=device)
+        dist.all_reduce(okc, op=dist.ReduceOp.MIN, group=group)
+        if not int(okc.item()):
+            raise CollectiveCountError("count_sharded: emptying the shards failed on some rank" + (": " + why if why else ""))
     # a round holds its send and receive lists (~10 bytes per base each) next to the shard: at most 2^31 bases, fewer when the
     # memory is short (one value for all ranks: the buffers are sized by the longest piece of the round).  The gloo rehearsal
     # gathers every rank's send buffer on every rank, and its ranks may share one GPU.

@@ -81,6 +81,35 @@ def test_cli_matches_jasper_sh(hip, tmp_path, fixture):
     assert fasta_records(tmp_path / "asm.fa.polished.fasta") == fasta_records(os.path.join(E2E, "asm.fa.polished.fasta"))
 
 
+def test_cli_database_written_before_polishing_when_memory_is_short(hip, tmp_path):
+    """src/jasper.sh:177 `tee $JF_DB`: the database file is written by a thread beside the polishing only when the device has room
+    for both; otherwise first the file, then the polishing (the reference's order).  Both orders leave the same file and results."""
+    E2E = os.path.join(HERE, "golden", "e2e")
+    meta = json.load(open(os.path.join(E2E, "meta.json")))
+    outs = {}
+    for mode in ("beside", "before"):
+        d = tmp_path / mode
+        d.mkdir()
+        for fn in ("r1.fq", "r2.fq"):
+            with open(d / fn, "wb") as f:
+                f.write(gzip.open(os.path.join(E2E, fn + ".gz")).read())
+        shutil.copy(os.path.join(E2E, "asm.fa"), d)
+        env = dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_TIMING="1")
+        if mode == "before":
+            env["JASPER_AMD_TEST_JF_SERIAL"] = "1"
+        p = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-r", "r1.fq r2.fq", "-a", "asm.fa", "-k", str(meta["k"]), "-t", str(meta["threads"]),
+                            "-p", str(meta["passes"])], cwd=d, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert ("write mer_counts.jf (before the polishing" in p.stderr) == (mode == "before"), p.stderr
+        assert ("mer_counts.jf complete (written beside" in p.stderr) == (mode == "beside"), p.stderr
+        raw = open(d / ("mer_counts%d.jf" % meta["k"]), "rb").read()
+        hlen = int(raw[:9])
+        outs[mode] = (raw[9 + hlen:], open(d / "asm.fa.fixes.csv", newline="").read(), fasta_records(d / "asm.fa.polished.fasta"))
+        assert not os.path.exists(d / ("mer_counts%d.jf.tmp" % meta["k"]))
+    assert outs["beside"] == outs["before"]
+    assert outs["before"][2] == fasta_records(os.path.join(E2E, "asm.fa.polished.fasta"))
+
+
 def test_cli_errors(hip, tmp_path):
     env = dict(os.environ, PYTHONPATH=ROOT)
     p = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-a", "missing.fa"], cwd=tmp_path, env=env, capture_output=True, text=True)

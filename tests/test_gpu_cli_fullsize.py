@@ -18,7 +18,8 @@ the same flags -- as one process, or as two ranks (the multi-GPU form of the dri
                          below 4 and the REFERENCE aborts ("Local min of kmer counts is smaller than 4", src/jasper.sh:200-202) --
                          the drop-in must abort the same way, with the same log lines
   fullsize_cfg3          configs[2] EXACTLY as stated: 140 Mb in 7 contigs, 40x = 37.3 M reads (11.5 GB of FASTQ), two ranks
-  on request (JASPER_TEST_BIG=1): the same as one process, and fullsize_cfg3like (140 Mb, one contig, 30x)"""
+  on request (JASPER_TEST_BIG=1): the same as one process, fullsize_cfg3like (140 Mb, one contig, 30x), and
+  fullsize_cfg4_share    one rank's share of configs[3] (CHM13 on 8 GPUs): 390 Mb in 3 contigs, 30x, -t 64 (reference: 884 s)"""
 import json
 import os
 import re
@@ -120,7 +121,9 @@ CASES = [("fullsize_cfg1", 1), ("fullsize_cfg2", 1), ("fullsize_cfg2_t16", 1), (
          ("fullsize_cfg5_scaled", 1), ("fullsize_cfg5_scaled", 2), ("fullsize_cfg5_lowcov", 1),
          ("fullsize_cfg3", 2)]          # configs[2] exactly as stated (11.5 GB of FASTQ: ~40 s to generate, ~25 s to run as two ranks on one GPU)
 if BIG:
-    CASES += [("fullsize_cfg3", 1), ("fullsize_cfg3like", 1)]
+    CASES += [("fullsize_cfg3", 1), ("fullsize_cfg3like", 1),
+              ("fullsize_cfg4_share", 1)]     # ONE rank's share of configs[3]: 390 Mb in 3 contigs + 30x (78 M reads, 24 GB of FASTQ), -t 64: a 2^32-slot table,
+                                              # multi-piece counting, 36 batch files (also tools/run_big_case.py, which prints while it works)
 
 
 @pytest.mark.parametrize("name,ranks", CASES)
