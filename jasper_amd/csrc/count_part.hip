@@ -457,6 +457,254 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
     if (pend_nr) copy_out(pend_r0, pend_nr);
     if (t == 0 && added) atomicAdd(&P.stats[ST_OCCURRENCES], added);
 }
+// ---- level 1 for keys that do not fit an 8-byte record (k >= 38) -------------------------------------------------------------------
+// The same kernel shape with 16-byte records {low 64 hash bits, the hash bits between them and the bucket bits}.  A thread's
+// 16 windows would be 64 + 16 registers of records, so a tile goes through the phases in two HALVES of 8 windows per thread
+// (rolling state, codes and validity carry over); a half's ~6.2 K records fit the stage, whose entries are 16 bytes.  The copy-out
+// of one half runs inside the hash loop of the next, two steps one iteration apart (7 staged records per thread, 8 iterations).
+typedef uint64_t Rec16 __attribute__((ext_vector_type(2)));      // .lo = the low 64 hash bits, .hi = the bits above them (a vector type: stored through global-address-space pointers with one 16-byte store)
+constexpr int P1W_STAGE = 6912;         // 16-byte records per staging round
+constexpr size_t P1W_LDS = (size_t)P1W_STAGE * 18 + (size_t)(2 * (P1_MAXB + 4) + 32 + 64) * 4 + (size_t)2 * (P1_TH + PT_HALO) * 4 + (size_t)P1_MAXB * 8;
+typedef __attribute__((address_space(1))) Rec16 global_rec16;
+__device__ __forceinline__ u128 hash_of16(uint64_t b1, Rec16 r, int recbits) { return bor(shl(mk(0, b1), recbits), mk(r.hi, r.lo)); }
+
+template <int NW>          // words of a k-mer: 3 (k <= 48: the bits above the low 64 fit one word), 4 (k <= 64)
+__global__ __launch_bounds__(P1_TH) void part1w_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t ntiles, uint64_t emit_from, P1Args P,
+                                                       Rec16 *__restrict__ out1, unsigned int *__restrict__ cnt1, unsigned long long *__restrict__ deferred,
+                                                       unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
+    static_assert(NW == 3 || NW == 4, "16-byte records are for keys of 65 .. 128 bits");
+    using hi_t = typename std::conditional<NW == 3, uint32_t, uint64_t>::type;
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    unsigned int *s_cnt2 = reinterpret_cast<unsigned int *>(s_raw);                          // 2 x (P1_MAXB+4): rank counters / offsets of alternate halves
+    unsigned int *s_wsum = s_cnt2 + 2 * (P1_MAXB + 4);                                       // 16 wave totals, [16] = "a slice overflows", [24..31] the tile's last 64 bases
+    unsigned int *s_dummy = s_wsum + 32;                                                     // 64: what the rank atomics of windows that are no k-mer add to
+    uint32_t *s_code = reinterpret_cast<uint32_t *>(s_dummy + 64);                           // P1_TH + PT_HALO
+    uint32_t *s_inv = s_code + (P1_TH + PT_HALO);
+    uint64_t *s_base = reinterpret_cast<uint64_t *>(s_inv + (P1_TH + PT_HALO));              // P1_MAXB: address of stage index 0 in my slice of each list
+    unsigned short *s_bkt = reinterpret_cast<unsigned short *>(s_base + P1_MAXB);            // bucket of each staged record
+    Rec16 *s_stage = reinterpret_cast<Rec16 *>(s_bkt + P1W_STAGE);                           // P1W_STAGE records, bucket order
+    static_assert(((2 * (P1_MAXB + 4) + 32 + 64) * 4 + 2 * (P1_TH + PT_HALO) * 4 + P1_MAXB * 8 + P1W_STAGE * 2) % 16 == 0, "the stage is read and written 16 bytes at a time");
+    const int t = threadIdx.x;
+    const int k = P.k, p1 = P.p1;
+    const int nb = 1 << p1;
+    const int topbits = 2 * k - 32 * (NW - 1);                                  // 2..32: bits of the k-mer in its top word
+    const uint32_t topmask = topbits >= 32 ? ~0u : ((1u << topbits) - 1u);
+    const int rsh = topbits - 2;
+    const int hb = 2 * k - 64;                                                  // hash bits above the low 64: 12 .. 64
+    const hi_t himask = hb >= (int)(8 * sizeof(hi_t)) ? (hi_t)~(hi_t)0 : (hi_t)(((hi_t)1 << hb) - 1);
+    const int bsh = hb - p1;                                                    // the bucket is the top p1 of those bits (p1 <= 10 <= hb)
+    const hi_t restmask = bsh >= (int)(8 * sizeof(hi_t)) ? (hi_t)~(hi_t)0 : (hi_t)(((hi_t)1 << bsh) - 1);
+    int wlog = 0;
+    while ((2 << wlog) <= k) ++wlog;
+    unsigned long long added = 0;
+    const uint32_t grp = blockIdx.x % P.nblk1;
+    s_cnt2[t] = 0;
+    s_cnt2[P1_MAXB + 4 + t] = 0;
+    for (int i = t; i < P1W_STAGE; i += P1_TH) s_bkt[i] = 0;
+    if (t == 0) s_wsum[16] = 0;
+    const uint32_t nt32 = (uint32_t)ntiles;
+    const uint32_t per_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)((nt32 + gridDim.x - 1) / gridDim.x));
+    const uint32_t tile_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * per_block));
+    const uint32_t tile_end = tile_first + per_block < nt32 ? tile_first + per_block : nt32;
+    uint32_t c = 0, iv = 0xFFFFu;
+    if (tile_first < tile_end) {
+        uint32_t hc = 0, hiv = 0xFFFFu;
+        const int64_t b0 = (int64_t)tile_first * PT_TILE;
+        stage16(bases, b0 + (int64_t)t * PT_GROUP, (int64_t)n, c, iv);
+        if (t < PT_HALO) stage16(bases, b0 - (int64_t)(PT_HALO - t) * PT_GROUP, (int64_t)n, hc, hiv);
+        s_code[t + PT_HALO] = c;
+        s_inv[t + PT_HALO] = iv;
+        if (t < PT_HALO) { s_code[t] = hc; s_inv[t] = hiv; }
+    }
+    lds_barrier();
+    unsigned int pend_nr = 0, pend_r0 = 0;
+    auto copy_out = [&](unsigned int r0, unsigned int nr) {
+        for (unsigned int i = t; i < nr; i += P1_TH) {
+            const Rec16 rr = s_stage[i];
+            const uint32_t b = s_bkt[i];
+            if (!s_wsum[16]) reinterpret_cast<global_rec16 *>(s_base[b])[r0 + i] = rr;
+            else {                                                              // a slice of mine is full: with the bound
+                const uint64_t first = reinterpret_cast<uint64_t>(out1 + ((uint64_t)b * P.nblk1 + grp) * P.cap1);
+                const uint64_t pos = (uint64_t)(((int64_t)(s_base[b] - first) >> 4) + (int64_t)(r0 + i));
+                if (pos < P.cap1) reinterpret_cast<global_rec16 *>(first)[pos] = rr;
+                else defer_record(P.stats, hash_of16((uint64_t)b, rr, P.recbits), deferred, deferred_n, deferred_cap);
+            }
+        }
+    };
+    constexpr int HALF = PT_GROUP / 2;
+    constexpr int NCO = (P1W_STAGE + P1_TH - 1) / P1_TH;                            // staged records per thread (7)
+    static_assert(NCO + 1 <= HALF, "the copy-out pipeline must fit the hash loop of a half");
+    uint32_t halfno = 0;                                                            // halves done by this block: which copy of the counters
+    for (uint32_t tile = tile_first; tile < tile_end; ++tile) {
+        const int64_t base0 = (int64_t)tile * PT_TILE;
+        const bool has_next = tile + 1 < tile_end;
+        const bool prefetch = has_next && (uint64_t)(base0 + 2 * (int64_t)PT_TILE) <= n;
+        int ta = t;
+        asm volatile("" : "+v"(ta));
+        uint32_t f[NW], r[NW];
+        uint32_t vmask;
+        {
+            const uint32_t w4 = s_code[ta], w3 = s_code[ta + 1], w2 = s_code[ta + 2], w1 = s_code[ta + 3];
+            const uint64_t ivprev = ((uint64_t)s_inv[ta] << 48) | ((uint64_t)s_inv[ta + 1] << 32) | ((uint64_t)s_inv[ta + 2] << 16) | (uint64_t)s_inv[ta + 3];
+            const u128 fwd0 = band(mk(((uint64_t)w4 << 32) | w3, ((uint64_t)w2 << 32) | w1), maskbits(2 * k));
+            const u128 rc0 = revcomp(fwd0, k);
+            const uint32_t fw[4] = {(uint32_t)fwd0.lo, (uint32_t)(fwd0.lo >> 32), (uint32_t)fwd0.hi, (uint32_t)(fwd0.hi >> 32)};
+            const uint32_t rw[4] = {(uint32_t)rc0.lo, (uint32_t)(rc0.lo >> 32), (uint32_t)rc0.hi, (uint32_t)(rc0.hi >> 32)};
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { f[w] = fw[w]; r[w] = rw[w]; }
+            // bit q of z: my base 15 - q (q < 16), or the base q - 15 positions before my first (k <= 64: bits up to 15 + 63 matter)
+            const unsigned __int128 z = (unsigned __int128)iv | ((unsigned __int128)ivprev << 16);
+            unsigned __int128 sm = z;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) if (b < wlog) sm |= sm >> (1 << b);
+            sm |= sm >> (k - (1 << wlog));
+            vmask = ~(uint32_t)sm & 0xFFFFu;
+        }
+        if ((uint64_t)base0 < emit_from) {
+            const int64_t mine = base0 + (int64_t)ta * PT_GROUP;
+            const int jfirst = (int64_t)emit_from > mine ? (int)((int64_t)emit_from - mine < PT_GROUP ? (int64_t)emit_from - mine : PT_GROUP) : 0;
+            vmask &= 0xFFFFu >> jfirst;
+        }
+        Raw16 raw;
+        for (int half = 0; half < 2; ++half, ++halfno) {
+            unsigned int *s_cnt = s_cnt2 + (halfno & 1u) * (P1_MAXB + 4);
+            unsigned int *s_off = s_cnt;
+            unsigned int *s_nxt = s_cnt2 + ((halfno & 1u) ^ 1u) * (P1_MAXB + 4);
+            if (pend_nr && s_wsum[16]) {                                            // (block-uniform)
+                copy_out(pend_r0, pend_nr);
+                pend_nr = 0;
+            }
+            uint64_t rlo[HALF];
+            hi_t rhi[HALF];
+            uint32_t br[HALF];
+            uint32_t bprev = 0xFFFFu, rprev = 0;
+            uint32_t co_b[NCO];
+#pragma unroll
+            for (int jj = 0; jj < HALF; ++jj) {
+                const int j = half * HALF + jj;                                     // (uniform; the two halves are the same code)
+                if (jj < NCO) {
+                    unsigned int i = (unsigned int)ta + (unsigned int)jj * P1_TH;
+                    if ((jj + 1) * P1_TH > P1W_STAGE) i = i < (unsigned int)P1W_STAGE ? i : (unsigned int)P1W_STAGE - 1u;
+                    co_b[jj] = s_bkt[i];
+                }
+                const uint32_t cj = (c >> (30 - 2 * j)) & 3u;
+#pragma unroll
+                for (int w = NW - 1; w > 0; --w) f[w] = __builtin_amdgcn_alignbit(f[w], f[w - 1], 30);
+                f[0] = (f[0] << 2) | cj;
+                f[NW - 1] &= topmask;
+#pragma unroll
+                for (int w = 0; w < NW - 1; ++w) r[w] = __builtin_amdgcn_alignbit(r[w + 1], r[w], 2);
+                r[NW - 1] = (r[NW - 1] >> 2) | ((cj ^ 3u) << rsh);
+                const bool valid = (vmask >> (15 - j)) & 1u;
+                // canonical = numeric min of the two strands, compared from the top word down
+                bool rc_less = false, decided = false;
+#pragma unroll
+                for (int w = NW - 1; w >= 0; --w) {
+                    if (!decided && r[w] != f[w]) { rc_less = r[w] < f[w]; decided = true; }
+                }
+                uint32_t m[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) m[w] = rc_less ? r[w] : f[w];
+                const uint64_t lo = mix64(((uint64_t)m[1] << 32) | m[0]);
+                hi_t hi;
+                if constexpr (NW == 3) hi = (m[2] ^ __builtin_amdgcn_alignbit((uint32_t)(lo >> 32), (uint32_t)lo, 30)) & himask;
+                else hi = ((((uint64_t)m[3] << 32) | m[2]) ^ rotr64(lo, 30)) & himask;
+                const uint32_t b = (uint32_t)(hi >> bsh);
+                rlo[jj] = lo;
+                rhi[jj] = hi & restmask;
+                if (jj > 0) br[jj - 1] = (bprev << 16) | rprev;
+                bprev = valid ? b : 0xFFFFu;
+                rprev = atomicAdd(valid ? &s_cnt[b] : &s_dummy[ta & 63], 1u);
+                if (jj >= 1 && jj - 1 < NCO) {
+                    unsigned int i = (unsigned int)ta + (unsigned int)(jj - 1) * P1_TH;
+                    const unsigned int ic = jj * P1_TH > P1W_STAGE ? (i < (unsigned int)P1W_STAGE ? i : (unsigned int)P1W_STAGE - 1u) : i;
+                    const Rec16 rr = s_stage[ic];
+                    const uint64_t bs = s_base[co_b[jj - 1]];
+                    if (i < pend_nr) reinterpret_cast<global_rec16 *>(bs)[pend_r0 + i] = rr;
+                }
+            }
+            br[HALF - 1] = (bprev << 16) | rprev;
+            pend_nr = 0;
+            if (half == 1) {
+                // the next tile's text: asked for behind the copy-out stores, looked at after the staging
+                int tb = t;
+                asm volatile("" : "+v"(tb));
+                struct __attribute__((packed, aligned(1))) V16 { uint32_t w[4]; };
+                const V16 v = *reinterpret_cast<const V16 *>(bases + (prefetch ? base0 + (int64_t)PT_TILE + (int64_t)tb * PT_GROUP : (int64_t)0));
+                raw.w[0] = v.w[0]; raw.w[1] = v.w[1]; raw.w[2] = v.w[2]; raw.w[3] = v.w[3];
+                if (has_next && tb < PT_HALO) { s_wsum[24 + tb] = s_code[P1_TH + tb]; s_wsum[28 + tb] = s_inv[P1_TH + tb]; }
+            }
+            lds_barrier();
+            // B. exclusive prefix of the bucket counts, the run's place in the slice
+            unsigned int total;
+            unsigned int apos = 0;
+            {
+                int tb = t;
+                asm volatile("" : "+v"(tb));
+                const unsigned int v = tb < nb ? s_cnt[tb] : 0u;
+                if (v) apos = __hip_atomic_fetch_add(&cnt1[((uint32_t)grp << p1) + (uint32_t)tb], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int inc = wave_scan_incl(v);
+                if ((tb & 63) == 63) s_wsum[tb >> 6] = inc;
+                lds_barrier();
+                const unsigned int ws = wave_scan_incl((tb & 63) < P1_TH / 64 ? s_wsum[tb & 63] : 0u);
+                const unsigned int wbase = (tb >> 6) ? (unsigned int)__builtin_amdgcn_readlane((int)ws, (tb >> 6) - 1) : 0u;
+                total = (unsigned int)__builtin_amdgcn_readlane((int)ws, P1_TH / 64 - 1);
+                s_off[tb] = wbase + inc - v;
+            }
+            if (t == 0) added += total;
+            lds_barrier();
+            // C. records into LDS in bucket order (several rounds when the half holds more than the stage: text without read boundaries)
+            unsigned int r0 = 0;
+            for (;;) {
+#pragma unroll
+                for (int jj = 0; jj < HALF; ++jj) {
+                    const uint32_t b = br[jj] >> 16;
+                    if (b != 0xFFFFu) {
+                        const unsigned int pos = s_off[b] + (br[jj] & 0xFFFFu) - r0;
+                        if (pos < (unsigned int)P1W_STAGE) {
+                            Rec16 rr;
+                            rr.lo = rlo[jj]; rr.hi = (uint64_t)rhi[jj];
+                            s_stage[pos] = rr;
+                            s_bkt[pos] = (unsigned short)b;
+                        }
+                    }
+                }
+                if (r0 == 0 && total) {
+                    int tc = t;
+                    asm volatile("" : "+v"(tc), "+v"(apos));
+                    const unsigned int ex = s_off[tc];
+                    const unsigned int v = (tc + 1 < P1_MAXB ? s_off[tc + 1] : total) - ex;
+                    const uint64_t slice0 = reinterpret_cast<uint64_t>(out1 + ((uint64_t)tc * P.nblk1 + grp) * P.cap1);
+                    s_base[tc] = slice0 + ((uint64_t)apos - (uint64_t)ex) * 16ull;
+                    if (v && apos + v > P.cap1) s_wsum[16] = 1;
+                }
+                if (total - r0 <= (unsigned int)P1W_STAGE || !total) break;
+                lds_barrier();
+                copy_out(r0, (unsigned int)P1W_STAGE);
+                r0 += P1W_STAGE;
+                lds_barrier();
+            }
+            pend_r0 = r0;
+            pend_nr = total - r0;
+            s_nxt[t] = 0;
+            if (half == 1 && has_next) {
+                if (prefetch) {
+                    asm volatile("" : "+v"(raw.w[0]), "+v"(raw.w[1]), "+v"(raw.w[2]), "+v"(raw.w[3]));
+                    encode16(raw.w, c, iv);
+                } else stage16(bases, base0 + (int64_t)PT_TILE + (int64_t)t * PT_GROUP, (int64_t)n, c, iv);
+                int td = t;
+                asm volatile("" : "+v"(td));
+                s_code[td + PT_HALO] = c;
+                s_inv[td + PT_HALO] = iv;
+                if (td < PT_HALO) { s_code[td] = s_wsum[24 + td]; s_inv[td] = s_wsum[28 + td]; }
+            }
+            lds_barrier();
+        }
+    }
+    if (pend_nr) copy_out(pend_r0, pend_nr);
+    if (t == 0 && added) atomicAdd(&P.stats[ST_OCCURRENCES], added);
+}
+
 // the fill counts were the slices' cursors: one that ran past its slice's end becomes "full" (what did not fit was deferred)
 __global__ __launch_bounds__(256) void clamp_counts_kernel(unsigned int *__restrict__ cnt, uint32_t n, uint32_t cap) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -488,9 +736,20 @@ static hipError_t launch_part1(hipStream_t stream, int k, const uint8_t *d_piece
     }
 #define JK_P1_LAUNCH(...) hipLaunchKernelGGL((part1_kernel<__VA_ARGS__>), dim3(G.grid1), dim3(P1_TH), P1_LDS, stream, d_piece, len, ntiles, emit_from, P, out1, cnt1, defer_e, defer_n, deferred_cap)
     if (k == 37 && G.p1 == 10 && G.recbits == 64 && !getenv("JASPER_EXPERIMENT_NO_KFIX")) JK_P1_LAUNCH(3, 37);
+    else if (G.recbits > 64) {                // 16-byte records (k >= 38)
+        static bool attrw_set = false;
+        if (!attrw_set) {
+            hipError_t e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(part1w_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(part1w_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+            attrw_set = true;
+        }
+        if (k <= 48) hipLaunchKernelGGL((part1w_kernel<3>), dim3(G.grid1), dim3(P1_TH), P1W_LDS, stream, d_piece, len, ntiles, emit_from, P, reinterpret_cast<Rec16 *>(out1), cnt1, defer_e, defer_n, deferred_cap);
+        else hipLaunchKernelGGL((part1w_kernel<4>), dim3(G.grid1), dim3(P1_TH), P1W_LDS, stream, d_piece, len, ntiles, emit_from, P, reinterpret_cast<Rec16 *>(out1), cnt1, defer_e, defer_n, deferred_cap);
+    }
     else if (k <= 16) JK_P1_LAUNCH(1);
     else if (k <= 32) JK_P1_LAUNCH(2);
-    else JK_P1_LAUNCH(3);                     // (k <= 37: partition_geometry gives 8-byte records only while 2k - 64 <= p1 <= 10)
+    else JK_P1_LAUNCH(3);                     // (k <= 37: 8-byte records while 2k - 64 <= p1 <= 10)
 #undef JK_P1_LAUNCH
     hipLaunchKernelGGL(clamp_counts_kernel, dim3((n_cnt1 + 255) / 256), dim3(256), 0, stream, cnt1, n_cnt1, G.cap1);
     return hipGetLastError();
@@ -664,10 +923,12 @@ constexpr size_t P2_LDS = (size_t)PT_TILE * 8 + (size_t)(3 * PT_MAXBUCKETS + 1 +
 constexpr int P2F_LINE = 16;           // records per 128-byte line
 // per list and round: stage record i leaves to gbase + 8 i if i < lim, else waits in carry slot i + cadd
 struct P2Meta { uint64_t gbase; uint32_t lim; int32_t cadd; };
-template <int MAXB, int ROWS> struct P2F {
+__device__ __forceinline__ u128 rec_hash(uint64_t b1, uint64_t r, int recbits) { return hash_of(b1, r, recbits); }
+__device__ __forceinline__ u128 rec_hash(uint64_t b1, Rec16 r, int recbits) { return hash_of16(b1, r, recbits); }
+template <int MAXB, int ROWS, int RB = 8> struct P2F {
     static constexpr int TILE = PT_THREADS * ROWS;
     static constexpr int PIECE = 64 * ROWS * 9;          // records per input piece: nine full wave rounds (<128, 7>: 4032 records, 252 lines)
-    static constexpr size_t LDS = (size_t)TILE * 8 + (size_t)(3 * (MAXB + 4) + 32) * 4 + (size_t)MAXB * sizeof(P2Meta) + (size_t)MAXB * P2F_LINE * 8;
+    static constexpr size_t LDS = (size_t)TILE * RB + (size_t)(3 * (MAXB + 4) + 32) * 4 + (size_t)MAXB * sizeof(P2Meta) + (size_t)MAXB * 128;
 };
 struct P2Args {
     int p1, p2, recbits;
@@ -677,20 +938,24 @@ struct P2Args {
 };
 // OWN (the multi-GPU exchange, as part2_kernel<true>): a bucket is split nown x 2^p2 ways, by (owner of the key, next p2 hash bits),
 // and the lists are laid out owner-major.
-template <int MAXB, int ROWS, bool OWN = false>
-__global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel(const uint64_t *__restrict__ out1, const unsigned int *__restrict__ cnt1, P2Args P, uint64_t *__restrict__ out2,
+// REC: uint64_t, or Rec16 for keys that do not fit 8-byte records (k >= 38; a line is then 8 records).
+template <int MAXB, int ROWS, bool OWN = false, typename REC = uint64_t>
+__global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel(const REC *__restrict__ out1, const unsigned int *__restrict__ cnt1, P2Args P, REC *__restrict__ out2,
                                                             unsigned int *__restrict__ cnt2, unsigned long long *__restrict__ deferred,
                                                             unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
     constexpr int P2F_MAXB = MAXB, P2F_ROWS = ROWS, P2F_TILE = P2F<MAXB, ROWS>::TILE, P2F_PIECE = P2F<MAXB, ROWS>::PIECE;
+    constexpr bool W16 = sizeof(REC) == 16;
+    constexpr int RB = (int)sizeof(REC), P2F_LINE = 128 / RB;                  // (shadows the 8-byte constant)
+    typedef __attribute__((address_space(1))) REC global_rec;
     constexpr int NSW = MAXB / 64;                       // waves that scan the list counts
     extern __shared__ __align__(16) unsigned char s_raw[];
     P2Meta *s_meta = reinterpret_cast<P2Meta *>(s_raw);                                      // P2F_MAXB
-    uint64_t *s_carry = reinterpret_cast<uint64_t *>(s_meta + P2F_MAXB);                      // P2F_MAXB x P2F_LINE: what a list has waiting
+    REC *s_carry = reinterpret_cast<REC *>(s_meta + P2F_MAXB);                      // P2F_MAXB x P2F_LINE: what a list has waiting
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_carry + P2F_MAXB * P2F_LINE);    // P2F_MAXB+4  records of this round per list ([nb2] = the padding)
     unsigned int *s_off = s_cnt + P2F_MAXB + 4;                                              // P2F_MAXB+4  exclusive prefix of s_cnt
     unsigned int *s_have = s_off + P2F_MAXB + 4;                                             // P2F_MAXB+4  records waiting per list, bit 31: they leave this round
     unsigned int *s_wsum = s_have + P2F_MAXB + 4;                                            // [0 .. NSW) wave totals, [16] = "a slice overflows", [17] = rounds
-    uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_wsum + 32);                           // P2F_TILE records, list order
+    REC *s_stage = reinterpret_cast<REC *>(s_wsum + 32);                           // P2F_TILE records, list order
     const int t = threadIdx.x;
     const int nb2 = OWN ? (int)(P.nown << P.p2) : 1 << P.p2;
     const int shift2 = P.recbits - P.p2;               // the p2 bits right below the level-1 bucket bits
@@ -700,8 +965,9 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
             if constexpr (OWN) return ((((uint64_t)(b2 >> P.p2) << P.p1) + b1) << P.p2) + (uint64_t)(b2 & ((1u << P.p2) - 1u));
             else return ((uint64_t)b1 << P.p2) + (uint64_t)b2;
         };
-        auto b2_of = [&](uint64_t rr) -> uint32_t {                                          // the list of a record of this bucket
-            if constexpr (OWN) {
+        auto b2_of = [&](REC rr) -> uint32_t {                                               // the list of a record of this bucket
+            if constexpr (W16) return (uint32_t)shr(mk(rr.hi, rr.lo), (unsigned)shift2).lo & (uint32_t)(nb2 - 1);
+            else if constexpr (OWN) {
                 const uint32_t lo = P.p2 ? (uint32_t)(rr >> shift2) & ((1u << P.p2) - 1u) : 0u;
                 return lo | (owner_of(hash_of(b1, rr, P.recbits), P.nown) << P.p2);
             } else return (uint32_t)(rr >> shift2) & (uint32_t)(nb2 - 1);
@@ -734,7 +1000,7 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
         const uint32_t rounds = s_wsum[17];
         uint32_t pos = 0;                                                                    // (scalar) position in the current piece
         uint32_t ph = blockIdx.x + P.nblk2 * (wave / P.vper), sub = wave % P.vper;           // (scalar) my wave's current piece: `sub` of slice `ph`
-        auto open_piece = [&](uint32_t &len_out, const uint64_t *&src_out) {
+        auto open_piece = [&](uint32_t &len_out, const REC *&src_out) {
             len_out = 0;
             if (ph < P.nblk1) {
                 const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt1[((uint64_t)ph << P.p1) + b1]), first = sub * (uint32_t)P2F_PIECE;
@@ -743,11 +1009,11 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
             src_out = out1 + ((uint64_t)b1 * P.nblk1 + ph) * P.cap1 + (uint64_t)sub * P2F_PIECE;
         };
         uint32_t slen;
-        const uint64_t *src;
+        const REC *src;
         open_piece(slen, src);
         unsigned int cur = 0, have = 0;                    // thread t < nb2, list t: records written to its slice so far (whole lines) / waiting in s_carry
-        uint64_t rec[P2F_ROWS];
-        auto fetch = [&](uint64_t (&dst)[P2F_ROWS], uint32_t &valid) {                       // up to 64 x P2F_ROWS records of my wave's stream; valid = rows that exist (bit j: row j)
+        REC rec[P2F_ROWS];
+        auto fetch = [&](REC (&dst)[P2F_ROWS], uint32_t &valid) {                       // up to 64 x P2F_ROWS records of my wave's stream; valid = rows that exist (bit j: row j)
             while (pos >= slen && ph < P.nblk1) {                                            // (scalar) next piece
                 sub += 16u;
                 while (sub >= P.vper) { sub -= P.vper; ph += P.nblk2; }
@@ -758,7 +1024,7 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
 #pragma unroll
             for (int j = 0; j < P2F_ROWS; ++j) {
                 const uint32_t i = pos + (uint32_t)j * 64u + lane;
-                dst[j] = ~0ull;
+                if constexpr (W16) { dst[j].lo = ~0ull; dst[j].hi = ~0ull; } else dst[j] = ~0ull;
                 if (i < slen) { dst[j] = src[i]; valid |= 1u << j; }
             }
             pos += 64u * P2F_ROWS;
@@ -768,12 +1034,12 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
         // round r and waited for right BEFORE round r's copy-out stores are issued (a wave's vector-memory operations retire in
         // order: waited for at the top of round r + 1 they would wait for those stores as well), see part1_kernel
         constexpr bool PF = MAXB > 128;
-        uint64_t nxt[P2F_ROWS];
+        REC nxt[P2F_ROWS];
         uint32_t vmask_n = 0;
         if (PF && rounds) {
             fetch(rec, vmask);
 #pragma unroll
-            for (int j = 0; j < P2F_ROWS; ++j) asm volatile("" : "+v"(rec[j]));               // (arrived before the loop: no wait for "all loads" at its top)
+            for (int j = 0; j < P2F_ROWS; ++j) { if constexpr (W16) asm volatile("" : "+v"(rec[j].lo), "+v"(rec[j].hi)); else asm volatile("" : "+v"(rec[j])); }   // (arrived before the loop: no wait for "all loads" at its top)
         }
         for (uint32_t round = 0; round < rounds; ++round) {
             if constexpr (PF) { if (round + 1 < rounds) fetch(nxt, vmask_n); else vmask_n = 0; }
@@ -811,7 +1077,7 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
                 const unsigned int L = F ? F - have : 0u;                                     // of the new records
                 s_off[t] = ex;
                 P2Meta M;
-                M.gbase = slice_of((uint32_t)t) + ((uint64_t)cur + (uint64_t)have - (uint64_t)ex) * 8ull;      // stage index i -> slice position cur + have + (i - ex)
+                M.gbase = slice_of((uint32_t)t) + ((uint64_t)cur + (uint64_t)have - (uint64_t)ex) * (uint64_t)RB;      // stage index i -> slice position cur + have + (i - ex)
                 M.lim = ex + L;
                 M.cadd = F ? -(int32_t)(ex + L) : (int32_t)have - (int32_t)ex;                // carry slot of a record that stays: i + cadd
                 s_meta[t] = M;
@@ -828,11 +1094,11 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
             int td = t;                                           // (an opaque copy: what is derived from it is recomputed here, not kept live -- and spilled -- across the round)
             asm volatile("" : "+v"(td));
             constexpr int NU = P2F_MAXB / 64;                                                // lists per 16-lane group
-            uint64_t cw[NU];
+            REC cw[NU];
             uint32_t cat[NU];                                                                // its position in the list's slice, ~0 = nothing
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-                cw[u] = 0ull;
+                if constexpr (W16) { cw[u].lo = 0ull; cw[u].hi = 0ull; } else cw[u] = 0ull;
                 cat[u] = ~0u;
                 const uint32_t b2 = ((uint32_t)td >> 4) + (uint32_t)u * 64u, q = (uint32_t)td & 15u;
                 if (b2 < (uint32_t)nb2) {
@@ -840,43 +1106,43 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
                     if ((hv >> 31) && q < (hv & 0xFFFFu)) {
                         cw[u] = s_carry[b2 * P2F_LINE + q];
                         const P2Meta M = s_meta[b2];
-                        cat[u] = (uint32_t)((int64_t)(M.gbase - slice_of(b2)) / 8 + (int64_t)s_off[b2]) - (hv & 0xFFFFu) + q;      // cur + q
+                        cat[u] = (uint32_t)((int64_t)(M.gbase - slice_of(b2)) / RB + (int64_t)s_off[b2]) - (hv & 0xFFFFu) + q;      // cur + q
                     }
                 }
             }
             const bool overflow = s_wsum[16] != 0;
             if constexpr (PF) {
 #pragma unroll
-                for (int j = 0; j < P2F_ROWS; ++j) asm volatile("" : "+v"(nxt[j]));           // (the next round's records have arrived: not after this point)
+                for (int j = 0; j < P2F_ROWS; ++j) { if constexpr (W16) asm volatile("" : "+v"(nxt[j].lo), "+v"(nxt[j].hi)); else asm volatile("" : "+v"(nxt[j])); }   // (the next round's records have arrived: not after this point)
             }
             lds_barrier();
             if (!overflow) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u)
-                    if (cat[u] != ~0u) reinterpret_cast<global_u64 *>(slice_of(((uint32_t)td >> 4) + (uint32_t)u * 64u))[cat[u]] = cw[u];
+                    if (cat[u] != ~0u) reinterpret_cast<global_rec *>(slice_of(((uint32_t)td >> 4) + (uint32_t)u * 64u))[cat[u]] = cw[u];
                 // D2. one lane per staged record: into the slice, or into the list's carry
 #pragma unroll 2
                 for (unsigned int i = (unsigned int)td; i < total; i += PT_THREADS) {
-                    const uint64_t rr = s_stage[i];
+                    const REC rr = s_stage[i];
                     const uint32_t b2 = b2_of(rr);
                     const P2Meta M = s_meta[b2];
-                    if (i < M.lim) reinterpret_cast<global_u64 *>(M.gbase)[i] = rr;
+                    if (i < M.lim) reinterpret_cast<global_rec *>(M.gbase)[i] = rr;
                     else s_carry[b2 * P2F_LINE + (uint32_t)((int32_t)i + M.cadd)] = rr;
                 }
             } else {
                 // a slice is full: record by record, with the bound (what does not fit takes the deferred list)
-                auto put = [&](uint32_t b2, uint64_t at, uint64_t rr) {
-                    if (at < P.cap2) reinterpret_cast<global_u64 *>(slice_of(b2))[at] = rr;
-                    else defer_record(P.stats, hash_of(b1, rr, P.recbits), deferred, deferred_n, deferred_cap);
+                auto put = [&](uint32_t b2, uint64_t at, REC rr) {
+                    if (at < P.cap2) reinterpret_cast<global_rec *>(slice_of(b2))[at] = rr;
+                    else defer_record(P.stats, rec_hash(b1, rr, P.recbits), deferred, deferred_n, deferred_cap);
                 };
 #pragma unroll
                 for (int u = 0; u < NU; ++u)
                     if (cat[u] != ~0u) put(((uint32_t)td >> 4) + (uint32_t)u * 64u, cat[u], cw[u]);
                 for (unsigned int i = (unsigned int)td; i < total; i += PT_THREADS) {
-                    const uint64_t rr = s_stage[i];
+                    const REC rr = s_stage[i];
                     const uint32_t b2 = b2_of(rr);
                     const P2Meta M = s_meta[b2];
-                    if (i < M.lim) put(b2, (uint64_t)((int64_t)(M.gbase - slice_of(b2)) / 8 + (int64_t)i), rr);
+                    if (i < M.lim) put(b2, (uint64_t)((int64_t)(M.gbase - slice_of(b2)) / RB + (int64_t)i), rr);
                     else s_carry[b2 * P2F_LINE + (uint32_t)((int32_t)i + M.cadd)] = rr;
                 }
             }
@@ -892,9 +1158,9 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
         // the rest of every list closes its slice (the one line of a slice that is not written whole)
         if (t < nb2) {
             for (unsigned int q = 0; q < have; ++q) {
-                const uint64_t rr = s_carry[(uint32_t)t * P2F_LINE + q];
-                if (cur + q < P.cap2) reinterpret_cast<global_u64 *>(slice_of((uint32_t)t))[cur + q] = rr;
-                else defer_record(P.stats, hash_of(b1, rr, P.recbits), deferred, deferred_n, deferred_cap);
+                const REC rr = s_carry[(uint32_t)t * P2F_LINE + q];
+                if (cur + q < P.cap2) reinterpret_cast<global_rec *>(slice_of((uint32_t)t))[cur + q] = rr;
+                else defer_record(P.stats, rec_hash(b1, rr, P.recbits), deferred, deferred_n, deferred_cap);
             }
             const unsigned int n = cur + have;
             cnt2[list_of((uint32_t)t) * P.nblk2 + blockIdx.x] = n < P.cap2 ? n : P.cap2;
@@ -923,13 +1189,18 @@ constexpr int RI_PF = 8;              // records per lane in flight
 // concatenated list (prefix of their lengths in LDS).  cbits > 0 (lists deduplicated by the sender, list_dedupe_kernel): the top
 // fbits of a record's p2 field -- the second-level bits the SENDER resolved, implied by the list it made -- hold
 // (occurrences - 1) in their low cbits.
-template <bool FRESH, bool XCHG = false>
-__global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__restrict__ lists, const unsigned int *__restrict__ cnt, uint32_t cap, uint32_t nsl,
+// REC: uint64_t, or Rec16 (keys of 65 .. 128 bits, not with XCHG); a table whose remainders fit the tag (B - s <= 53) only: wide
+// tables (a second word per slot) take region_insertw_kernel.
+template <bool FRESH, bool XCHG = false, typename REC = uint64_t>
+__global__ __launch_bounds__(RI_TH) void region_insert_kernel(const REC *__restrict__ lists, const unsigned int *__restrict__ cnt, uint32_t cap, uint32_t nsl,
                                                               TableDev T, PartGeom G, uint32_t nregions, unsigned long long *__restrict__ deferred,
                                                               unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap,
                                                               unsigned long long *__restrict__ histo, uint32_t nsrc = 1, int cbits = 0, int fbits = 0) {
     // (an owner adds up what several senders counted in pieces of up to 2^31 bases each: 64-bit counts there)
     using cnt_t = typename std::conditional<FRESH && !XCHG, unsigned int, unsigned long long>::type;
+    constexpr bool W16 = sizeof(REC) == 16;
+    static_assert(!(W16 && XCHG), "the exchange ships 8-byte records");
+    auto rec_zero = []() { REC z; if constexpr (W16) { z.lo = 0ull; z.hi = 0ull; } else z = 0ull; return z; };
     extern __shared__ __align__(16) unsigned long long s_tag[];                      // R tags, R counts, LDS_HBINS bins (, LI_MAXSL + 1 slice offsets)
     const uint32_t R = 1u << G.rbits;
     cnt_t *s_cnt = reinterpret_cast<cnt_t *>(s_tag + R);
@@ -952,7 +1223,7 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__
             if constexpr (XCHG) return ((uint64_t)(x / per_src) * nregions + region) * per_src + x % per_src;
             else return (uint64_t)region * nsl + x;
         };
-        const uint64_t *src = lists + (uint64_t)region * nsl * cap;
+        const REC *src = lists + (uint64_t)region * nsl * cap;
         uint32_t nrec = XCHG ? 0u : cnt[(uint64_t)region * nsl];
         uint32_t total = 0;                                                          // XCHG: records of all the region's slices
         if constexpr (XCHG) {
@@ -970,10 +1241,10 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__
             if (!any) continue;
         }
         // the first records of the region's first slice (normally its only one) are requested before the image is set up
-        uint64_t recs[RI_PF];
+        REC recs[RI_PF];
         if constexpr (!XCHG) {
 #pragma unroll
-            for (int u = 0; u < RI_PF; ++u) { const uint32_t i = (uint32_t)u * RI_TH + t; recs[u] = i < nrec ? src[i] : 0ull; }
+            for (int u = 0; u < RI_PF; ++u) { const uint32_t i = (uint32_t)u * RI_TH + t; recs[u] = i < nrec ? src[i] : rec_zero(); }
         }
         if (FRESH) {
             for (uint32_t i = t; i < R; i += RI_TH) { s_tag[i] = 0ull; s_cnt[i] = 0; }
@@ -986,7 +1257,7 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__
         }
         lds_barrier();
         // the probe loop of the lanes that did not find their key in its home slot (cur = what the home slot held)
-        auto probe_on = [&](uint64_t rec, uint32_t idx, unsigned long long want, unsigned long long cur, cnt_t inc) {
+        auto probe_on = [&](REC rec, uint32_t idx, unsigned long long want, unsigned long long cur, cnt_t inc) {
             for (;;) {
                 if (cur == 0ull) {
                     cur = atomicCAS(&s_tag[idx], 0ull, want);                        // LDS compare-and-swap
@@ -1002,7 +1273,7 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__
                         const unsigned long long di = atomicAdd(deferred_n, 1ull);
                         if (di < deferred_cap) { deferred[3 * di] = hh.hi; deferred[3 * di + 1] = hh.lo; deferred[3 * di + 2] = (unsigned long long)inc; }
                         else atomicExch(&T.stats[ST_FATAL], 1ull);
-                    } else defer_record(T, hash_of(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
+                    } else defer_record(T, rec_hash(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
                     return;
                 }
                 cur = s_tag[idx];
@@ -1025,8 +1296,13 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__
                 }
                 // the record holds the low recbits hash bits; the bits above the slot index of this region are implied by the
                 // list it is in, so slot and remainder come from the record alone
-                idx[u] = (uint32_t)(recs[u] >> rs) & (R - 1);
-                want[u] = OCC | ((recs[u] & rmask) << OFFBITS);
+                if constexpr (W16) {
+                    idx[u] = (uint32_t)shr(mk(recs[u].hi, recs[u].lo), (unsigned)rs).lo & (R - 1);
+                    want[u] = OCC | ((recs[u].lo & rmask) << OFFBITS);                 // (rs <= 53: the remainder lies in the low word)
+                } else {
+                    idx[u] = (uint32_t)(recs[u] >> rs) & (R - 1);
+                    want[u] = OCC | ((recs[u] & rmask) << OFFBITS);
+                }
                 cur[u] = s_tag[idx[u]];
             }
 #pragma unroll
@@ -1043,7 +1319,7 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__
 #pragma unroll
                 for (int u = 0; u < RI_PF; ++u) {
                     const uint32_t i = i0 + (uint32_t)u * RI_TH + t;
-                    recs[u] = 0ull;
+                    recs[u] = rec_zero();
                     if (i < total) {
                         while (s_pref[x + 1] <= i) ++x;                              // (a handful of slices)
                         recs[u] = lists[slice_of(x) * cap + (i - s_pref[x])];
@@ -1057,7 +1333,7 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const uint64_t *__
             for (uint32_t i0 = 0; i0 < nrec; i0 += RI_PF * RI_TH) {
                 if (x || i0) {
 #pragma unroll
-                    for (int u = 0; u < RI_PF; ++u) { const uint32_t i = i0 + (uint32_t)u * RI_TH + t; recs[u] = i < nrec ? src[i] : 0ull; }
+                    for (int u = 0; u < RI_PF; ++u) { const uint32_t i = i0 + (uint32_t)u * RI_TH + t; recs[u] = i < nrec ? src[i] : rec_zero(); }
                 }
                 insert_batch(i0, nrec);
             }
@@ -1163,7 +1439,11 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     if (d.ext) return false;                              // wide remainders: the LDS images hold tags only
     if (piece_bases < (8u << 20)) return false;          // small pieces: the direct kernel is already latency-hidden
     const int B = d.B, s = d.s;
-    const int need_p1 = B > 64 ? B - 64 : 0;              // records are 8 bytes
+    // 8-byte records hold the hash below the p1 <= 10 bucket bits: keys of up to 74 bits (k <= 37).  Longer keys travel as
+    // 16-byte records (part1w_kernel, part2f_kernel<., ., ., Rec16>, region_insert_kernel<., ., Rec16>): half the records per LDS round.
+    const bool rec16 = B > 74;
+    if (rec16 && getenv("JASPER_COUNT_NO_REC16")) return false;
+    const int need_p1 = rec16 ? std::min(10, s - 12 - 1) : (B > 64 ? B - 64 : 0);
     // regions of 2^12 slots (three region_insert workgroups per CU); 2^13 only where the two list levels cannot split finer
     int p1 = 0, p2 = 0;
     bool ok = false;
@@ -1172,7 +1452,7 @@ bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     for (int rg = RG_MAXBITS; rg <= RG_MAXBITS + 1 && !ok; ++rg) {
         p1 = std::max(need_p1, (s - rg + 1) / 2);
         if (p1 < 1) p1 = 1;
-        if (p1 > 10 || p1 > s - 8) continue;              // (k >= 38, or a table too small to be worth it)
+        if (p1 > 10 || p1 > s - 8 || p1 < 1) continue;    // (a table too small to be worth it)
         p2 = s - rg - p1;
         if (p2 < 0) p2 = 0;
         ok = p2 <= maxp2;
@@ -1211,8 +1491,10 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     const uint32_t nb1 = 1u << G.p1, nregions = 1u << (G.p1 + G.p2);
     const uint64_t deferred_cap = std::max<uint64_t>(1u << 16, len / 48);      // (24 bytes each; a piece that needs more abandons itself: part_decide_kernel)
     const size_t n_cnt1 = (size_t)nb1 * G.nblk1, n_cnt2 = G.p2 ? (size_t)nregions * G.nblk2 : n_cnt1;      // (one level: the counts once more, bucket-major)
-    uint64_t *out1 = (uint64_t *)workspace(WS_COUNT + 0, n_cnt1 * G.cap1 * 8, err);
-    uint64_t *out2 = G.p2 ? (uint64_t *)workspace(WS_COUNT + 1, n_cnt2 * G.cap2 * 8, err) : nullptr;
+    const bool rec16 = G.recbits > 64;
+    const size_t RB = rec16 ? 16 : 8;
+    uint64_t *out1 = (uint64_t *)workspace(WS_COUNT + 0, n_cnt1 * G.cap1 * RB, err);
+    uint64_t *out2 = G.p2 ? (uint64_t *)workspace(WS_COUNT + 1, n_cnt2 * G.cap2 * RB, err) : nullptr;
     unsigned int *cur = (unsigned int *)workspace(WS_COUNT + 2, (n_cnt1 + n_cnt2 + 4) * 4, err);
     unsigned long long *defer = (unsigned long long *)workspace(WS_COUNT + 3, deferred_cap * 24 + 64, err);
     if (!out1 || (G.p2 && !out2) || !cur || !defer) return -2;
@@ -1238,7 +1520,21 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr2_set = true;
         }
-        if ((1 << G.p2) <= 512 && G.cap2 % P2F_LINE == 0 && !getenv("JASPER_EXPERIMENT_OLDP2")) {
+        if (rec16) {
+            static bool attr2w_set = false;
+            if (!attr2w_set) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel<512, 4, false, Rec16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr2w_set = true;
+            }
+            if ((1 << G.p2) > 512 || G.cap2 % P2F_LINE) { err = "count: no list geometry for 16-byte records"; return -1; }
+            P2Args P;
+            P.p1 = G.p1; P.p2 = G.p2; P.recbits = G.recbits; P.nblk1 = G.nblk1; P.nblk2 = G.nblk2; P.cap1 = G.cap1; P.cap2 = G.cap2; P.stats = d.stats; P.nown = 1;
+            constexpr uint32_t piece = (uint32_t)P2F<512, 4, 16>::PIECE;
+            P.vper = (G.cap1 + piece - 1u) / piece;
+            constexpr size_t lds2 = P2F<512, 4, 16>::LDS;
+            hipLaunchKernelGGL((part2f_kernel<512, 4, false, Rec16>), grid, dim3(PT_THREADS), lds2, stream, reinterpret_cast<const Rec16 *>(out1), cnt1, P, reinterpret_cast<Rec16 *>(out2), cnt2, defer_e, defer_n,
+                               deferred_cap);
+        } else if ((1 << G.p2) <= 512 && G.cap2 % P2F_LINE == 0 && !getenv("JASPER_EXPERIMENT_OLDP2")) {
             static bool attr2f_set = false;
             if (!attr2f_set) {
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel<128, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1289,7 +1585,17 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     {
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(lds, 1)));
         const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>(nregions, 256 * per_cu * 4));
-        if (fresh32) hipLaunchKernelGGL(region_insert_kernel<true>, dim3(nblk), dim3(RI_TH), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap, histo);
+        if (rec16) {
+            static bool attrw_set = false;
+            if (!attrw_set) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(region_insert_kernel<true, false, Rec16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(region_insert_kernel<false, false, Rec16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attrw_set = true;
+            }
+            const Rec16 *lw = reinterpret_cast<const Rec16 *>(lists);
+            if (fresh32) hipLaunchKernelGGL((region_insert_kernel<true, false, Rec16>), dim3(nblk), dim3(RI_TH), lds, stream, lw, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap, histo, 1u, 0, 0);
+            else hipLaunchKernelGGL((region_insert_kernel<false, false, Rec16>), dim3(nblk), dim3(RI_TH), lds, stream, lw, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap, histo, 1u, 0, 0);
+        } else if (fresh32) hipLaunchKernelGGL(region_insert_kernel<true>, dim3(nblk), dim3(RI_TH), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap, histo);
         else hipLaunchKernelGGL(region_insert_kernel<false>, dim3(nblk), dim3(RI_TH), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap, histo);
         HIPCHK(hipGetLastError());
     }
@@ -1342,6 +1648,7 @@ static bool xchg_geometry(const Table &t, uint64_t piece_max, uint64_t records_m
     piece_max = std::max<uint64_t>(piece_max, 8u << 20);
     if (!t.partition_geometry(piece_max, raw)) return false;
     G = *reinterpret_cast<const PartGeom *>(raw);
+    if (G.recbits > 64) return false;                     // (keys of more than 74 bits: per-GPU tables and the entry exchange instead)
     // the senders split by (owner, second-level bits): more than 512 lists per bucket would leave the whole-line kernel, so the
     // owners take regions of 8192 slots instead of 4096 where that is what it takes
     if (((uint64_t)nown << G.p2) > 512 && ((uint64_t)nown << (G.p2 - 1)) <= 512 && G.p2 > 0 && G.rbits == RG_MAXBITS && !getenv("JASPER_EXPERIMENT_XCHG_RB12")) { --G.p2; ++G.rbits; }

@@ -651,14 +651,18 @@ def test_histogram_fused_into_counting_pass_equals_table_scan(KT):
     t.close()
 
 
-@pytest.mark.parametrize("k", [15, 21, 25, 27, 31, 32, 33, 35, 37, 41])
-def test_atomic_free_counting_equals_direct_counting(KT, k):
-    """the two ways a table is filled must build the same table for every k (one-, two- and three-word k-mers): one record per
-    occurrence through the partition passes and LDS images (count_part.hip: part1 -> part2 -> region_insert; k <= 37, where the
-    hash bits below the 2^10 first-level buckets fit an 8-byte record) and the direct insert kernel (global atomics), which
-    every other k takes"""
+WIDE_PARTITIONED = False      # tables whose slots carry a second word (B - s > 53) through the partition passes
+
+
+@pytest.mark.parametrize("k,log2_slots", [(15, 0), (21, 0), (25, 0), (27, 0), (31, 0), (32, 0), (33, 0), (35, 0), (37, 0), (38, 0), (39, 25), (41, 29), (41, 0),
+                                          (45, 0), (48, 0), (49, 0), (51, 0), (63, 0), (64, 0)])
+def test_atomic_free_counting_equals_direct_counting(KT, k, log2_slots):
+    """the two ways a table is filled must build the same table for every k (one- to four-word k-mers): one record per occurrence
+    through the partition passes and LDS images (count_part.hip: part1 -> part2 -> region_insert; 8-byte records for k <= 37,
+    where the hash bits below the 2^10 first-level buckets fit them, 16-byte records above) and the direct insert kernel
+    (global atomics).  log2_slots: a table large enough that a slot's remainder fits its tag word (B - s <= 53) for this k."""
     import torch
-    G = 1_500_000
+    G = 1_500_000 if log2_slots < 28 else 3_200_000      # (a piece takes the partition passes when it is large relative to the table)
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev).manual_seed(100 + k)
     genome = synth.torch_genome(gen, G, dev)
@@ -670,10 +674,10 @@ def test_atomic_free_counting_equals_direct_counting(KT, k):
     reads[9000:9300] = ord("N")
     reads[2_000_000:2_050_000] = ord("N")         # whole 16384-base tiles of the partition pass without a single k-mer
     torch.cuda.synchronize()
-    slots = int(1.25 * nreads * 150 * 2.1 / 10)
+    slots = max(int(1.25 * nreads * 150 * 2.1 / 10), 1 << log2_slots)
     tp = KT(k, min_slots=slots)
     tp.count_bases_device(reads.data_ptr(), reads.numel())
-    if k <= 37:
+    if k <= 37 or WIDE_PARTITIONED or 2 * k - (tp.info()["slots"].bit_length() - 1) <= 53:
         assert tp.count_stages()[1] >= 1 and tp.count_path() == 1, "partitioned path not taken"
     else:
         assert tp.count_stages()[1] == 0 and tp.count_path() == 0
