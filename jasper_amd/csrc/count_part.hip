@@ -1366,6 +1366,136 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const REC *__restr
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
 }
 
+// ---- the same for a WIDE table (kmer.hpp: wide_rem -- B - s > 53: a slot's remainder does not fit its tag word, the low 64 bits
+// live in T.ext) -----------------------------------------------------------------------------------------------------------------------
+// The LDS image keeps tag, ext word and count of every slot (20 bytes per slot on a table that starts empty: regions of 2048 slots,
+// three workgroups per CU as above).  A key is two words, and LDS has no 128-bit compare-and-swap: a lane claims an empty slot by
+// the tag, writes the ext word, and only then adds its count -- a slot's key is complete once its count is non-zero.  A lane that
+// meets a matching tag with a zero count cannot tell yet whether that is its key and must not wait in place (the claimant may be
+// a lane of its own wave): the loop below is left only when every lane of the wave is done, so a trip is complete for all
+// lanes before the next one starts, and the undecided lane looks at the same slot again on the next trip (table.hpp:
+// table_put_wide is the same protocol on the table itself).
+constexpr int RIW_PF = 4;              // records per lane in flight (16 bytes each)
+template <bool FRESH>
+__global__ __launch_bounds__(RI_TH) void region_insertw_kernel(const Rec16 *__restrict__ lists, const unsigned int *__restrict__ cnt, uint32_t cap, uint32_t nsl, TableDev T,
+                                                               PartGeom G, uint32_t nregions, unsigned long long *__restrict__ deferred,
+                                                               unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
+    using cnt_t = typename std::conditional<FRESH, unsigned int, unsigned long long>::type;
+    extern __shared__ __align__(16) unsigned long long s_tag[];                      // R tags, R ext words, R counts
+    const uint32_t R = 1u << G.rbits;
+    unsigned long long *s_ext = s_tag + R;
+    cnt_t *s_cnt = reinterpret_cast<cnt_t *>(s_ext + R);
+    const int t = threadIdx.x;
+    const int rs = T.B - T.s;                                                        // remainder bits: 54 .. 117
+    const bool whole = nregions == 1;
+    unsigned long long fresh = 0;
+    if (deferred_n[1]) return;                                                       // (uniform) the piece was abandoned: part_decide_kernel
+    for (uint32_t region = blockIdx.x; region < nregions; region += gridDim.x) {
+        const uint64_t first = (uint64_t)region << G.rbits;
+        const uint64_t b1 = region >> G.p2;
+        if (!FRESH) {                                                                // (block-uniform) nothing to add: the slots stay as they are
+            uint32_t any = 0;
+            for (uint32_t x = 0; x < nsl; ++x) any |= cnt[(uint64_t)region * nsl + x];
+            if (!any) continue;
+        }
+        if (FRESH) {
+            for (uint32_t i = t; i < R; i += RI_TH) { s_tag[i] = 0ull; s_ext[i] = 0ull; s_cnt[i] = 0; }
+        } else {
+            for (uint32_t i = t; i < R; i += RI_TH) {
+                const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T.slots + 2 * (first + i));
+                s_tag[i] = e.x;
+                s_cnt[i] = (cnt_t)e.y;
+                s_ext[i] = T.ext[first + i];
+            }
+        }
+        lds_barrier();
+        for (uint32_t x = 0; x < nsl; ++x) {
+            const uint32_t nrec = cnt[(uint64_t)region * nsl + x];
+            const Rec16 *src = lists + ((uint64_t)region * nsl + x) * cap;
+            for (uint32_t i0 = 0; i0 < nrec; i0 += RIW_PF * RI_TH) {
+                Rec16 recs[RIW_PF];
+#pragma unroll
+                for (int u = 0; u < RIW_PF; ++u) {
+                    const uint32_t i = i0 + (uint32_t)u * RI_TH + t;
+                    recs[u].lo = 0ull; recs[u].hi = 0ull;
+                    if (i < nrec) recs[u] = src[i];
+                }
+#pragma unroll
+                for (int u = 0; u < RIW_PF; ++u) {
+                    const u128 rr = mk(recs[u].hi, recs[u].lo);
+                    uint32_t idx = (uint32_t)shr(rr, (unsigned)rs).lo & (R - 1);
+                    const u128 rem = band(rr, maskbits((unsigned)rs));
+                    unsigned long long want = OCC | (rem.hi << OFFBITS);             // tag_of(tag_rem, 0): the offset is the tag's low bits
+                    const unsigned long long ext = rem.lo;
+                    bool done = !(i0 + (uint32_t)u * RI_TH + t < nrec);
+                    uint32_t waited = 0;
+                    for (;;) {
+                        if (!done) {
+                            unsigned long long cur = __hip_atomic_load(&s_tag[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (cur == 0ull) {
+                                cur = atomicCAS(&s_tag[idx], 0ull, want);
+                                if (cur == 0ull) {                                   // mine: ext word, then the count that makes the key complete
+                                    __hip_atomic_store(&s_ext[idx], ext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_fetch_add(&s_cnt[idx], (cnt_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    ++fresh;
+                                    done = true;
+                                }
+                            }
+                            if (!done) {
+                                bool next = true;
+                                if (cur == want) {
+                                    const cnt_t c = __hip_atomic_load(&s_cnt[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (c == 0) {                                    // claimed, key not complete yet: the same slot again on the next trip
+                                        next = false;
+                                        if (++waited > (1u << 16)) { defer_record(T, hash_of16(b1, recs[u], G.recbits), deferred, deferred_n, deferred_cap); done = true; }
+                                    } else if (__hip_atomic_load(&s_ext[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == ext) {
+                                        __hip_atomic_fetch_add(&s_cnt[idx], (cnt_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        done = true;
+                                    }
+                                }
+                                if (!done && next) {
+                                    ++idx;
+                                    ++want;
+                                    if (whole) idx &= R - 1;
+                                    if (idx >= R || (want & (unsigned long long)(MAXPROBE - 1)) == 0ull) {   // leaves the region (or the probe limit): direct path, later
+                                        defer_record(T, hash_of16(b1, recs[u], G.recbits), deferred, deferred_n, deferred_cap);
+                                        done = true;
+                                    }
+                                }
+                            }
+                        }
+                        if (__ballot(!done) == 0ull) break;
+                    }
+                }
+            }
+        }
+        lds_barrier();
+        for (uint32_t i = t; i < R; i += RI_TH) {
+            *reinterpret_cast<ulonglong2 *>(T.slots + 2 * (first + i)) = make_ulonglong2(s_tag[i], (unsigned long long)s_cnt[i]);
+            T.ext[first + i] = s_ext[i];
+        }
+        lds_barrier();
+    }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+}
+
+// the deferred records of a piece that went into a wide table: through the table's own insert (no fused histogram there)
+__global__ __launch_bounds__(256) void import3w_kernel(const unsigned long long *__restrict__ entries, const unsigned long long *__restrict__ n_ptr, uint64_t cap, TableDev T) {
+    if (n_ptr[1]) return;
+    const uint64_t n = *n_ptr < cap ? *n_ptr : cap;
+    unsigned long long fresh = 0;
+    for (uint64_t i0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) & ~63ull; i0 < n; i0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = i0 + (threadIdx.x & 63);
+        int r = 1;
+        if (i < n) r = table_add(T, mk(entries[3 * i], entries[3 * i + 1]), entries[3 * i + 2]);       // (whole waves: table_put_wide votes)
+        if (r == 2) ++fresh;
+        if (r == 0) table_spill(T, mk(entries[3 * i], entries[3 * i + 1]), entries[3 * i + 2]);
+    }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+}
+
 // Between the partition passes and the insert: lists that overflowed more than the deferred list holds (one k-mer that makes up
 // a tenth of the input: all its records go to ONE region list) cannot be inserted completely.  Nothing has touched the table yet,
 // so the piece is ABANDONED here -- word 1 of the deferred list's header tells region_insert_kernel and import3h_kernel to do
@@ -1436,20 +1566,23 @@ static uint32_t list_cap(double avg) { return (uint32_t)std::min<double>(4.0e9, 
 bool Table::partition_geometry(uint64_t piece_bases, void *geom_out) const {
     PartGeom &G = *reinterpret_cast<PartGeom *>(geom_out);
     if (getenv("JASPER_COUNT_DIRECT")) return false;
-    if (d.ext) return false;                              // wide remainders: the LDS images hold tags only
     if (piece_bases < (8u << 20)) return false;          // small pieces: the direct kernel is already latency-hidden
     const int B = d.B, s = d.s;
     // 8-byte records hold the hash below the p1 <= 10 bucket bits: keys of up to 74 bits (k <= 37).  Longer keys travel as
     // 16-byte records (part1w_kernel, part2f_kernel<., ., ., Rec16>, region_insert_kernel<., ., Rec16>): half the records per LDS round.
     const bool rec16 = B > 74;
     if (rec16 && getenv("JASPER_COUNT_NO_REC16")) return false;
-    const int need_p1 = rec16 ? std::min(10, s - 12 - 1) : (B > 64 ? B - 64 : 0);
+    if (d.ext && !rec16) return false;                    // (a tiny table for short keys: its images would need the second word for 8-byte records)
+    if (d.ext && getenv("JASPER_COUNT_NO_WIDE")) return false;
+    const int need_p1 = rec16 ? std::min(10, s - 12) : (B > 64 ? B - 64 : 0);
     // regions of 2^12 slots (three region_insert workgroups per CU); 2^13 only where the two list levels cannot split finer
     int p1 = 0, p2 = 0;
     bool ok = false;
     // (first choice: at most 512 lists per bucket, which part2f_kernel writes in whole lines)
-    for (int maxp2 = 9; maxp2 <= 11 && !ok; maxp2 += 2)
-    for (int rg = RG_MAXBITS; rg <= RG_MAXBITS + 1 && !ok; ++rg) {
+    // (a wide table's image is 20 bytes per slot: regions of 2^11)
+    const int rg0 = d.ext ? RG_MAXBITS - 1 : RG_MAXBITS;
+    for (int maxp2 = 9; maxp2 <= (rec16 ? 9 : 11) && !ok; maxp2 += 2)
+    for (int rg = rg0; rg <= rg0 + 1 && !ok; ++rg) {
         p1 = std::max(need_p1, (s - rg + 1) / 2);
         if (p1 < 1) p1 = 1;
         if (p1 > 10 || p1 > s - 8 || p1 < 1) continue;    // (a table too small to be worth it)
@@ -1567,6 +1700,7 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     part_slots_dirty_before = slots_dirty;
     HIPCHK(hipEventRecord(ev_stage_t[2], stream));
     // fused histogram: asked for by count_device when this piece is the whole input going into an empty table
+    if (d.ext) histo_request = false;                      // (a wide table's histogram is read from the table afterwards)
     unsigned long long *histo = histo_request ? d_histo : nullptr;
     if (histo) HIPCHK(hipMemsetAsync(histo, 0, HISTO_WORDS * sizeof(unsigned long long), stream));
     // A table that is logically empty is not read: the images start from zeros and every slot is written (a lazily cleared table
@@ -1585,7 +1719,20 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     {
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(lds, 1)));
         const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>(nregions, 256 * per_cu * 4));
-        if (rec16) {
+        if (d.ext) {
+            static bool attrww_set = false;
+            if (!attrww_set) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(region_insertw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(region_insertw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attrww_set = true;
+            }
+            const size_t ldsw = (size_t)R * (fresh32 ? 20 : 24);
+            const uint32_t per_cuw = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / ldsw));
+            const uint32_t nblkw = std::max<uint32_t>(1, std::min<uint32_t>(nregions, 256 * per_cuw * 4));
+            const Rec16 *lw = reinterpret_cast<const Rec16 *>(lists);
+            if (fresh32) hipLaunchKernelGGL(region_insertw_kernel<true>, dim3(nblkw), dim3(RI_TH), ldsw, stream, lw, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap);
+            else hipLaunchKernelGGL(region_insertw_kernel<false>, dim3(nblkw), dim3(RI_TH), ldsw, stream, lw, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap);
+        } else if (rec16) {
             static bool attrw_set = false;
             if (!attrw_set) {
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(region_insert_kernel<true, false, Rec16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1601,7 +1748,8 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     }
     HIPCHK(hipEventRecord(ev_stage_t[3], stream));
     slots_dirty = false;   // every region has been written by the launch above
-    hipLaunchKernelGGL(import3h_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, deferred_cap, d, histo);
+    if (d.ext) hipLaunchKernelGGL(import3w_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, deferred_cap, d);
+    else hipLaunchKernelGGL(import3h_kernel, dim3(256), dim3(256), 0, stream, defer_e, defer_n, deferred_cap, d, histo);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_k1, stream));
     HIPCHK(hipEventRecord(ev_stage_t[4], stream));

@@ -651,7 +651,7 @@ def test_histogram_fused_into_counting_pass_equals_table_scan(KT):
     t.close()
 
 
-WIDE_PARTITIONED = False      # tables whose slots carry a second word (B - s > 53) through the partition passes
+WIDE_PARTITIONED = True       # tables whose slots carry a second word (B - s > 53) through the partition passes
 
 
 @pytest.mark.parametrize("k,log2_slots", [(15, 0), (21, 0), (25, 0), (27, 0), (31, 0), (32, 0), (33, 0), (35, 0), (37, 0), (38, 0), (39, 25), (41, 29), (41, 0),
