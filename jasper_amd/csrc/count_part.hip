@@ -691,7 +691,11 @@ __global__ __launch_bounds__(P1_TH) void part1w_kernel(const uint8_t *__restrict
                 if (prefetch) {
                     asm volatile("" : "+v"(raw.w[0]), "+v"(raw.w[1]), "+v"(raw.w[2]), "+v"(raw.w[3]));
                     encode16(raw.w, c, iv);
-                } else stage16(bases, base0 + (int64_t)PT_TILE + (int64_t)t * PT_GROUP, (int64_t)n, c, iv);
+                } else {                                                              // (the piece's last tile; through an opaque copy of the
+                    int te = t;                                                       //  thread number: hoisted out of the tile loop the byte
+                    asm volatile("" : "+v"(te));                                      //  addresses of the slow path end up in scratch memory)
+                    stage16(bases, base0 + (int64_t)PT_TILE + (int64_t)te * PT_GROUP, (int64_t)n, c, iv);
+                }
                 int td = t;
                 asm volatile("" : "+v"(td));
                 s_code[td + PT_HALO] = c;
