@@ -517,7 +517,7 @@ def main():
     traffic, traffic_src = None, None
     pol_traffic, pol_traffic_src = None, None
     from jasper_amd._lib import kernel_source_digest
-    for rnd in (("round3",) if (world == 1 and a.genome_mb == 47.0) else ()):      # (the committed counters are those of the N=1 configs[1] run)
+    for rnd in (("round4",) if (world == 1 and a.genome_mb == 47.0) else ()):      # (the committed counters are those of the N=1 configs[1] run)
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", rnd, "bench_hbm_counters.json")))
             if pj.get("kernel_source_sha256") != kernel_source_digest():
