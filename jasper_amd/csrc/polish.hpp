@@ -112,6 +112,9 @@ struct ChunkSummary {
 
 constexpr long long ARRIVE_PENDING = (long long)0x8080808080808080ull;   // what hipMemset(0x80) leaves
 constexpr long long ARRIVE_FAIL = -2, ARRIVE_END = -1;
+// what a segment puts into its slot when it STARTS (round 4): CLEAN = chained and nothing can happen in its range, its arrival follows
+// from any earlier segment's (successors look past it without waiting for it); WALKING = it walks, its arrival comes at its end
+constexpr long long ARRIVE_CLEAN = -3, ARRIVE_WALKING = -4;
 
 struct PolishParams {
     int k;
