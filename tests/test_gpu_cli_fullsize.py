@@ -9,6 +9,7 @@ the same flags -- as one process, or as two ranks (the multi-GPU form of the dri
   fullsize_cfg1          configs[0]: 4.6 Mb, 30x, k=25, 1 pass, -t 8
   fullsize_cfg2          configs[1]: 47 Mb, 30x, k=37, 2 passes, -t 8      (also as two ranks)
   fullsize_cfg2_t16      configs[1] chunked as -t 16 (the chunking bench.py uses)
+  fullsize_cfg2_k41/_k51 the same files polished with -k 41 / -k 51 (counting through the 16-byte-record passes; a wide table at 51)
   fullsize_cfg3_quarter  configs[2] shape at 1/4 scale: 35 Mb in 7 contigs, 40x, two ranks (read shards + table merge)
   fullsize_cfg4_scaled   configs[3] shape at 1/64 scale: 48.4 Mb in 24 contigs of 0.7-3.4 Mb, 30x, -t 64 -> BATCH_SIZE below the
                          contig sizes: several chunk records per contig, ~70 batch files (src/jasper.sh:132-139,155-156)
@@ -119,6 +120,7 @@ def _run(ref, tmp_path_factory, ranks, count=None, extra_env=None, expect_stderr
 CASES = [("fullsize_cfg1", 1), ("fullsize_cfg2", 1), ("fullsize_cfg2_t16", 1), ("fullsize_cfg2", 2),
          ("fullsize_cfg3_quarter", 2), ("fullsize_cfg3_quarter", 1), ("fullsize_cfg4_scaled", 1), ("fullsize_cfg4_scaled", 2),
          ("fullsize_cfg5_scaled", 1), ("fullsize_cfg5_scaled", 2), ("fullsize_cfg5_lowcov", 1),
+         ("fullsize_cfg2_k41", 1), ("fullsize_cfg2_k51", 1),      # configs[1] files at k = 41 / 51: keys of 82 / 102 bits -> 16-byte records, a wide table at k = 51 (src/jasper.sh:89-90 takes any -k)
          ("fullsize_cfg3", 2)]          # configs[2] exactly as stated (11.5 GB of FASTQ: ~40 s to generate, ~25 s to run as two ranks on one GPU)
 if BIG:
     CASES += [("fullsize_cfg3", 1), ("fullsize_cfg3like", 1),
