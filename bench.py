@@ -355,18 +355,22 @@ def main():
         sys.exit(subprocess.call(cmd, env=env))
     # the files-in / files-out run of the drop-in (untimed, N = 1 only) comes FIRST: its child process then has the GPU to itself,
     # as a user's run has (beside this process's tables and streams the same child took 2.1 s instead of 0.8)
-    e2e = None
-    if a.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.genome_mb == 47.0 and not a.no_e2e:
-        try:
-            e2e = e2e_cli()
-        except Exception as e:      # a report, like the CPU baseline: never a reason to lose the measurement
-            e2e = {"seconds": None, "failed": "%r" % (e,)}
+    # (the larger leg first, on a GPU nobody has used yet: device memory that a process frees is cleared in the background, ~28 ms
+    #  per GB, and an allocation that gets such memory waits for it -- the configs[2] run allocates ~100 GB and took 3.1 s instead
+    #  of 1.3 s right behind the four configs[1] runs, all of it in its first allocations; docs/experiments.md)
     e2e3 = None
     if a.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.genome_mb == 47.0 and not a.no_e2e and not a.no_e2e_cfg3:
         try:
             e2e3 = e2e_cli_cfg3()
         except Exception as e:
             e2e3 = {"seconds": None, "failed": "%r" % (e,)}
+        time.sleep(6.0)
+    e2e = None
+    if a.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.genome_mb == 47.0 and not a.no_e2e:
+        try:
+            e2e = e2e_cli()
+        except Exception as e:      # a report, like the CPU baseline: never a reason to lose the measurement
+            e2e = {"seconds": None, "failed": "%r" % (e,)}
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
