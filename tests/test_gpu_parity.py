@@ -706,15 +706,14 @@ def test_atomic_free_counting_equals_direct_counting(KT, k, log2_slots):
     td.close()
 
 
-@pytest.mark.parametrize("frac", [0.02, 0.10, 0.5])
-def test_one_kmer_that_makes_up_much_of_the_input(KT, frac, capfd):
+@pytest.mark.parametrize("frac,k", [(0.02, 37), (0.10, 37), (0.5, 37), (0.02, 41), (0.10, 41), (0.02, 51), (0.5, 51)])
+def test_one_kmer_that_makes_up_much_of_the_input(KT, frac, k, capfd):
     """reads of one repeated base: all their k-mers are ONE key, all its records go to one region list.  A few per cent of the
     input overflow that list into the deferred list (and reach the table through the direct path, a wave's 64 equal entries as one
     add); more than the deferred list holds makes the piece abandon itself before it touches the table, and the call counts it --
     and what follows -- through the direct kernel.  Either way the table is the one direct counting builds."""
     import torch
-    k = 37
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", 0)                 # (k = 41: 16-byte records; k = 51: those into a table with a second word per slot)
     gen = torch.Generator(device=dev).manual_seed(5)
     genome = synth.torch_genome(gen, 1_500_000, dev)
     nreads = 1_500_000 * 30 // 150
