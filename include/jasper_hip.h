@@ -54,6 +54,10 @@ typedef struct jasper_fixrec {
 
 const char *jasper_last_error(void);
 int jasper_device_count(int *n);
+/* on != 0: the long-running calls of OTHER threads (jasper_count_reads_files, jasper_table_write_jf) return JASPER_ERR ("cancelled")
+ * at their next chunk / block instead of finishing -- for a driver that exits on an error elsewhere, as src/jasper.sh:23-28 kills its
+ * children (`trap abort`); on == 0 re-arms.  Process-wide. */
+int jasper_request_cancel(int on);
 /* free and total device memory in bytes (hipMemGetInfo): lets the driver that replaces src/jasper.sh decide whether two stages
  * that the reference runs one after the other (`tee $JF_DB` at :177, then the jasper.py processes at :207-212) fit side by side */
 int jasper_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);

@@ -29,6 +29,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "jasper_last_error": (C.c_char_p, []),
     "jasper_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "jasper_request_cancel": (C.c_int, [C.c_int]),
     "jasper_device_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "jasper_table_create": (C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(_P)]),
     "jasper_table_load_jf": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),

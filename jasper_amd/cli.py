@@ -600,6 +600,24 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
     return 0
 
 
+def _stop_thread(th, leftover=None):
+    """atexit: a thread of ours that is still inside the library -- an exit taken on an error elsewhere, e.g. "Splitting files
+    failed" while the reads are being counted -- is asked to stop at its next chunk / block (jasper_request_cancel; src/jasper.sh:23-28
+    kills its children on the way out) and waited for: tearing the interpreter down under a thread that uses the GPU can hang."""
+    if th.is_alive():
+        try:
+            from . import _lib
+            _lib.lib().jasper_request_cancel(1)
+        except Exception:          # noqa: BLE001 -- no library: nothing of ours can be running
+            pass
+        th.join()
+        if leftover and os.path.exists(leftover):
+            try:
+                os.remove(leftover)
+            except OSError:
+                pass
+
+
 class _EarlyTable:
     """KmerTable(k, min_slots) created -- and the read files counted into it -- by a thread (the library calls release the GIL)
     while the caller splits the assembly; get() hands the table over, or raises what the thread raised"""
@@ -628,7 +646,7 @@ class _EarlyTable:
         # sys.exit on an unreadable assembly or a full disk) must wait for it: tearing the interpreter down under a thread that
         # initialises HIP can hang or crash instead of giving the reference's clean "Splitting files failed" exit code
         import atexit
-        atexit.register(self.th.join)
+        atexit.register(_stop_thread, self.th)
 
     def get(self):
         self.th.join()
@@ -658,7 +676,7 @@ class _JfWriter:
         self.th = threading.Thread(target=work, daemon=True)
         self.th.start()
         import atexit
-        atexit.register(self.th.join)          # (an exit taken meanwhile waits for the GPU work of the thread, as for _EarlyTable)
+        atexit.register(_stop_thread, self.th, tmp)   # (an exit taken meanwhile waits for the thread, as for _EarlyTable; its unfinished file goes)
 
     def finish(self):
         self.th.join()

@@ -73,6 +73,8 @@ int jasper_device_count(int *n) {
     return JASPER_OK;
 }
 
+int jasper_request_cancel(int on) { jk::g_cancel.store(on ? 1 : 0); return JASPER_OK; }
+
 int jasper_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
     size_t f = 0, t = 0;
     hipError_t e = hipSetDevice(device);

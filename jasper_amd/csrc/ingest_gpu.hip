@@ -567,6 +567,7 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
     size_t carry = 0;             // bytes at the start of h_buf left over from the previous chunk (an incomplete record / line)
     struct JoinOnExit { std::thread &t; bool &active; ~JoinOnExit() { if (active && t.joinable()) t.join(); } } join_on_exit{pf, pf_active};
     for (;;) {
+        if (g_cancel.load(std::memory_order_relaxed)) { err = "cancelled"; return -1; }      // (jasper_request_cancel: the caller is on its way out)
         if (carry > CHUNK) return host_rest(mode, h_buf, carry);                  // a line / record longer than a chunk
         long got;
         if (pf_active) {                                                          // the chunk read while the last one was parsed

@@ -224,6 +224,7 @@ int Table::write_jf(const char *path, const char *const *cmdline, int n_cmd, std
         };
         if (nblk) HIPCHK(issue(0));
         for (uint64_t b = 0; b < nblk; ++b) {
+            if (g_cancel.load(std::memory_order_relaxed)) { err = "cancelled"; rc = -1; goto done; }
             if (b + 1 < nblk) HIPCHK(issue(b + 1));
             for (;;) {                                   // poll: hipEventSynchronize may sleep for milliseconds
                 const hipError_t q = hipEventQuery(ev_fmt[b & 1]);

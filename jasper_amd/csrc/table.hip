@@ -647,11 +647,19 @@ int Table::init(int k_, uint64_t min_slots, int device_, std::string &err) {
     return 0;
 }
 
+std::atomic<int> g_cancel{0};
+
+void Table::wait_streams() {
+    if (stream) (void)jk_stream_wait(stream);
+    for (hipStream_t ps : polish_stream) if (ps) (void)jk_stream_wait(ps);
+    if (jf_stream) (void)jk_stream_wait(jf_stream);
+}
+
 void *Table::workspace(int id, size_t bytes, std::string &err) {
     if (bytes == 0) bytes = 256;
     WsBuf &b = ws[id];
     if (b.bytes >= bytes) return b.p;
-    if (b.p) { (void)jk_stream_wait(stream); (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    if (b.p) { wait_streams(); (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }      // (a lane's kernels run on its own stream)
     const size_t want = bytes + std::min<size_t>(bytes / 8, (size_t)256 << 20);   // a little headroom so that slightly larger batches do not reallocate
     const bool dbg = getenv("JASPER_COUNT_DEBUG") != nullptr && want >= (256u << 20);
     const auto t0 = std::chrono::steady_clock::now();
@@ -672,7 +680,7 @@ void *Table::pinned(int id, size_t bytes, std::string &err) {
     if (bytes == 0) bytes = 256;
     WsBuf &b = pin[id];
     if (b.bytes >= bytes) return b.p;
-    if (b.p) { (void)jk_stream_wait(stream); (void)hipHostFree(b.p); b.p = nullptr; b.bytes = 0; }
+    if (b.p) { wait_streams(); (void)hipHostFree(b.p); b.p = nullptr; b.bytes = 0; }
     const size_t want = bytes + bytes / 4;
     if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { err = "pinned host buffer allocation failed"; b.p = nullptr; return nullptr; }
     b.bytes = want;

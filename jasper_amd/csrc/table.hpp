@@ -7,11 +7,17 @@
 //   JF::sub_commands/histo_main.cc:34-44                              (histogram)
 #pragma once
 #include "kmer.hpp"
+#include <atomic>
 #include <functional>
 #include <string>
 #include <vector>
 
 namespace jk {
+
+// set by jasper_request_cancel (a driver that is about to exit on an error elsewhere): the long-running host loops -- read files ->
+// table, the .jf writer -- stop between two chunks / blocks with an error instead of finishing their work first
+extern std::atomic<int> g_cancel;
+
 
 // what kernels receive (by value)
 constexpr uint32_t MAX_SHARDS = 8;   // the GPUs of one node
@@ -341,6 +347,7 @@ struct Table {
     hipEvent_t polish_ev = nullptr;
     hipStream_t jf_stream = nullptr;        // write_jf's own (jfwrite.hip)
     void *workspace(int id, size_t bytes, std::string &err);
+    void wait_streams();                    // every stream of this table (its own, the polishing lanes', the .jf writer's): before a buffer they may use is freed
     // grow-only PINNED host buffers kept with the table (the polisher's segment tables, candidate lists and records travel through
     // them: a copy to or from pageable memory is staged by the runtime and makes the caller wait)
     static constexpr int PIN_PER_LANE = 8, PIN_SLOTS = PIN_PER_LANE * POLISH_LANES_MAX;

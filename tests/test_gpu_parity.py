@@ -346,6 +346,45 @@ def test_several_gzip_files_inflated_ahead(KT, O, tmp_path, monkeypatch, ahead_m
     ref.close()
 
 
+def test_counting_thread_stops_when_asked(KT, tmp_path):
+    """jasper_request_cancel: a count_files call running in another thread returns "cancelled" at its next chunk (what the CLI's
+    atexit hook uses when it leaves on an error elsewhere while the reads are being counted)"""
+    import threading
+    from jasper_amd import _lib
+    rng = np.random.default_rng(5)
+    genome = synth.make_genome(rng, 300_000, repeat_frac=0)
+    reads = [r for r in synth.make_reads_stream(rng, genome, 60, 150, 0.003).tobytes().split(b"N") if r]
+    fn = tmp_path / "r.fq"
+    with open(fn, "wb") as f:
+        for j, r in enumerate(reads):
+            f.write(b"@r%d\n%s\n+\n%s\n" % (j, r, b"I" * len(r)))
+    os.environ["JASPER_INGEST_CHUNK"] = str(64 << 10)          # (hundreds of chunks: there is a next one to stop at)
+    t = KT(25, min_slots=1 << 22)
+    out = {}
+    try:
+        _lib.lib().jasper_request_cancel(1)
+        th = threading.Thread(target=lambda: out.setdefault("err", _try(lambda: t.count_files([str(fn)]))))
+        th.start()
+        th.join(60)
+        assert not th.is_alive() and "cancelled" in str(out["err"])
+        _lib.lib().jasper_request_cancel(0)                     # re-armed: the same call goes through
+        t2 = KT(25, min_slots=1 << 22)
+        t2.count_files([str(fn)])
+        assert t2.info()["occurrences"] == sum(max(0, len(r) - 24) for r in reads)
+        t2.close()
+    finally:
+        _lib.lib().jasper_request_cancel(0)
+        del os.environ["JASPER_INGEST_CHUNK"]
+    t.close()
+
+
+def _try(f):
+    try:
+        return f()
+    except Exception as e:          # noqa: BLE001
+        return e
+
+
 def test_reads_from_named_pipes(KT, tmp_path):
     """`-r <(zcat a.gz)`-style input: a pipe cannot be sized, seeked or looked at twice; plain and gzip content both work"""
     import threading
