@@ -153,18 +153,19 @@ __global__ __launch_bounds__(P1_TH) void part1_kernel(const uint8_t *__restrict_
                                                       uint64_t *__restrict__ out1, unsigned int *__restrict__ cnt1, unsigned long long *__restrict__ deferred,
                                                       unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
     extern __shared__ __align__(16) unsigned char s_raw[];
-    // (the small arrays come first: their addresses fit the 16-bit offset field of the LDS instructions)
+    // (the stage comes first: the copy-out reads stage entry t + 1024 j, and with the stage at offset 0 that is ONE address register
+    //  per 64 KB plus the 16-bit offset field of the LDS instruction -- no address arithmetic per record)
+    // where stage index 0 of the staged tile goes in my slice of each bucket's list (slice base + (cursor - offset) records), as an integer
+    uint64_t *s_base = reinterpret_cast<uint64_t *>(s_raw);                                  // P1_MAXB (at offset 0: its address is one shift of the bucket)
+    uint64_t *s_stage = s_base + P1_MAXB;                                                    // P1_STAGE records, bucket order
+    unsigned short *s_bkt = reinterpret_cast<unsigned short *>(s_stage + P1_STAGE);          // bucket of each staged record
     // s_cnt2: two copies, used by alternate tiles -- records of the tile per bucket while they are ranked (A), then, in place, the
     // exclusive prefix of those counts (B, C); the copy of the tile before is cleared meanwhile
-    unsigned int *s_cnt2 = reinterpret_cast<unsigned int *>(s_raw);                          // 2 x (P1_MAXB+4)
+    unsigned int *s_cnt2 = reinterpret_cast<unsigned int *>(s_bkt + P1_STAGE);               // 2 x (P1_MAXB+4)
     unsigned int *s_wsum = s_cnt2 + 2 * (P1_MAXB + 4);                                       // 16 wave totals, [16] = "a slice overflows", [24..31] the tile's last 64 bases
     unsigned int *s_dummy = s_wsum + 32;                                                     // 64: what the rank atomics of windows that are no k-mer add to (one word per lane)
     uint32_t *s_code = reinterpret_cast<uint32_t *>(s_dummy + 64);                           // P1_TH + PT_HALO
     uint32_t *s_inv = s_code + (P1_TH + PT_HALO);
-    // where stage index 0 of the staged tile goes in my slice of each bucket's list (slice base + (cursor - offset) records), as an integer
-    uint64_t *s_base = reinterpret_cast<uint64_t *>(s_inv + (P1_TH + PT_HALO));              // P1_MAXB
-    unsigned short *s_bkt = reinterpret_cast<unsigned short *>(s_base + P1_MAXB);            // bucket of each staged record
-    uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_bkt + P1_STAGE);                      // P1_STAGE records, bucket order
     const int t = threadIdx.x;
     const int k = KFIX ? KFIX : P.k;
     const int p1 = KFIX ? 2 * KFIX - 64 : P.p1;
