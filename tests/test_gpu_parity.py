@@ -745,6 +745,36 @@ def test_atomic_free_counting_equals_direct_counting(KT, k, log2_slots):
     td.close()
 
 
+@pytest.mark.parametrize("k", [25, 37, 41])
+def test_partition_passes_with_one_level_of_lists(KT, k):
+    """a table so small (2^22 slots) that the first-level lists ARE the region lists (no second pass: region_insert reads the
+    level-1 slices, whose fill counts part1 keeps slice-major and a small kernel transposes): deep coverage of a small genome"""
+    import torch
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(300 + k)
+    genome = synth.torch_genome(gen, 250_000, dev)
+    nreads = 250_000 * 80 // 150                # (deep enough that a piece of >= 8 M bases fits the table's free room)
+    reads = synth.torch_reads_stream(gen, genome, nreads, 150, 0.001)
+    torch.cuda.synchronize()
+    assert reads.numel() >= 16 << 20
+    os.environ["JASPER_COUNT_DEBUG"] = "2"
+    try:
+        tp = KT(k, min_slots=1 << 22)
+        tp.count_bases_device(reads.data_ptr(), reads.numel())
+    finally:
+        del os.environ["JASPER_COUNT_DEBUG"]
+    assert tp.info()["slots"] == 1 << 22 and tp.count_stages()[1] >= 1, "no piece took the partition passes"
+    os.environ["JASPER_COUNT_DIRECT"] = "1"
+    try:
+        td = KT(k, min_slots=1 << 22)
+        td.count_bases_device(reads.data_ptr(), reads.numel())
+    finally:
+        del os.environ["JASPER_COUNT_DIRECT"]
+    assert tp.info() == td.info() and tp.histogram() == td.histogram()
+    tp.close()
+    td.close()
+
+
 @pytest.mark.parametrize("frac,k", [(0.02, 37), (0.10, 37), (0.5, 37), (0.02, 41), (0.10, 41), (0.02, 51), (0.5, 51)])
 def test_one_kmer_that_makes_up_much_of_the_input(KT, frac, k, capfd):
     """reads of one repeated base: all their k-mers are ONE key, all its records go to one region list.  A few per cent of the
