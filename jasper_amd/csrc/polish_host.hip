@@ -88,7 +88,7 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
         seg_rec_bound += (size_t)(RM * (2 * tb / k + 16 * ms));
         seg_aux_bound += (size_t)(RM * (2 * tb + 1024 * ms));
     }
-    DevBuf b_textA, b_textB, b_pack, b_cls, b_clsB, b_flags, b_segedit, b_cells, b_arrive, b_cand, b_ccount, b_ptrA, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks, b_scan, b_ticket;
+    DevBuf b_textA, b_textB, b_pack, b_cls, b_clsB, b_flags, b_segedit, b_cells, b_arrive, b_ptrA, b_segs, b_segtext, b_segrec, b_segaux, b_pool, b_locks, b_scan, b_ticket;
     int ws_next = 0;
     auto dmalloc = [&](DevBuf &b, size_t bytes) -> bool {      // persistent: slot of the table's workspace
         if (ws_next >= Table::WS_POLISH_MAX) { err = "polish: workspace slots exhausted"; return false; }
@@ -98,8 +98,8 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
     };
     if (!dmalloc(b_textA, text_bytes) || !dmalloc(b_textB, text_bytes) || 
         !dmalloc(b_cls, pos_items) || !dmalloc(b_clsB, pos_items) || !dmalloc(b_flags, flag_items) ||
-        !dmalloc(b_segedit, seg_rec_bound * sizeof(EditRec)) || !dmalloc(b_cells, cell_items * 8) ||
-        !dmalloc(b_arrive, ((size_t)max_segs + 4) * 8) || !dmalloc(b_cand, cand_items * 8) || !dmalloc(b_ccount, 256) ||
+        !dmalloc(b_segedit, seg_rec_bound * sizeof(EditRec)) || !dmalloc(b_cells, (2 + cell_items + cand_items) * 8) ||      // [count | clean-zone cells | sync-point candidates]: one copy brings the first two and the candidates' head
+        !dmalloc(b_arrive, ((size_t)max_segs + 4) * 8) ||
         !dmalloc(b_ptrA, (size_t)6 * n_chunks * sizeof(void *)) ||
         !dmalloc(b_segs, (size_t)max_segs * sizeof(SegDev)) || !dmalloc(b_segtext, seg_text_bound) ||
         !dmalloc(b_segrec, seg_rec_bound * sizeof(FixRec)) || !dmalloc(b_segaux, seg_aux_bound))
@@ -125,7 +125,7 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
     SegDev *segs_p = reinterpret_cast<SegDev *>(T.pinned(pin_base + 0, (size_t)max_segs * sizeof(SegDev), err));
     int32_t *first_p = reinterpret_cast<int32_t *>(T.pinned(pin_base + 1, ((size_t)n_chunks + 1) * 4, err));
     ChunkSummary *sum_p = reinterpret_cast<ChunkSummary *>(T.pinned(pin_base + 2, (size_t)n_chunks * sizeof(ChunkSummary), err));
-    int64_t *cand_p = reinterpret_cast<int64_t *>(T.pinned(pin_base + 3, (std::min<size_t>(cand_items, 32768) + cell_items + 8) * 8, err));
+    int64_t *cand_p = reinterpret_cast<int64_t *>(T.pinned(pin_base + 3, (std::min<size_t>(cand_items, 32768) + cell_items + 8) * 8, err));   // [count (2 words) | cells | first candidates]
     FixRec *recs_p = reinterpret_cast<FixRec *>(T.pinned(pin_base + 4, PIN_RECS * sizeof(FixRec), err));
     uint8_t *aux_p = reinterpret_cast<uint8_t *>(T.pinned(pin_base + 5, PIN_AUX, err));
     ScanChunk *sc_p = reinterpret_cast<ScanChunk *>(T.pinned(pin_base + 6, sizeof(ScanChunk) * (size_t)n_chunks, err));
@@ -201,6 +201,7 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
 
     std::vector<SegDev> segs;
     std::vector<ScanChunk> sc(n_chunks);            // lives across passes: the async H2D copy reads it after the call returns
+    int64_t *const d_count = b_cells.as<int64_t>(), *const d_cells = d_count + 2, *const d_cands = d_cells + cell_items;
     std::vector<int64_t> all_cands(cand_items);     // every chunk's sync-point candidates, fetched with one copy per pass
     std::vector<int64_t> all_cells(cell_items);     // clean-zone boundary candidates, one per CLEAN_CELL positions
     std::vector<std::vector<int64_t>> chunk_cands(n_chunks);
@@ -213,7 +214,7 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
     for (int pass = 0; pass <= passes && rc == 0; ++pass) {                                   // src/jasper.py:25
         // ---- 1. position classes + sync-point candidates: a dense scan in pass 0; afterwards the stitch has carried the
         //         classes of untouched windows over and only the tiles next to changed text are recomputed
-        HIPCHK(hipMemsetAsync(b_ccount.p, 0, 4, st));
+        HIPCHK(hipMemsetAsync(d_count, 0, 4, st));
         {
             for (int c = 0; c < n_chunks; ++c) {
                 ScanChunk &S = sc[c];
@@ -221,11 +222,11 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
                 S.len = len[c];
                 S.cls = clsIn + off_pos[c];
                 S.flags = b_flags.as<uint8_t>() + off_flag[c];
-                S.cand = b_cand.as<int64_t>();
-                S.cand_count = b_ccount.as<unsigned int>();
+                S.cand = d_cands;
+                S.cand_count = reinterpret_cast<unsigned int *>(d_count);
                 S.cand_cap = (unsigned int)std::min<size_t>(cand_items, 0x7fffffffu);
                 S.want_sync = (len[c] - k + 1) > 2 * TMIN;
-                S.clean_cand = b_cells.as<int64_t>() + off_cell[c];
+                S.clean_cand = d_cells + off_cell[c];
                 S.n_cells = (uint32_t)std::min<int64_t>(n_cells[c], std::max<int64_t>(0, len[c] - k + 1) / CLEAN_CELL + 1);
             }
             memcpy(sc_p, sc.data(), sizeof(ScanChunk) * n_chunks);
@@ -238,17 +239,15 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
         const size_t CAND_PRE = std::min<size_t>(cand_items, 32768);
         unsigned int n_cand = 0;
         {   // (pinned: [0] the count, [1 ..] the first CAND_PRE candidates, then the clean-zone cells)
-            HIPCHK(hipMemcpyAsync(cand_p, b_ccount.p, 4, hipMemcpyDeviceToHost, st));
-            if (CAND_PRE) HIPCHK(hipMemcpyAsync(cand_p + 1, b_cand.p, CAND_PRE * 8, hipMemcpyDeviceToHost, st));
-            if (cell_items) HIPCHK(hipMemcpyAsync(cand_p + 1 + CAND_PRE, b_cells.p, cell_items * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(cand_p, d_count, (2 + cell_items + CAND_PRE) * 8, hipMemcpyDeviceToHost, st));       // ONE copy command
             HIPCHK(jk_stream_wait(st));
             n_cand = *reinterpret_cast<const unsigned int *>(cand_p);
-            if (CAND_PRE) memcpy(all_cands.data(), cand_p + 1, std::min<size_t>(n_cand, CAND_PRE) * 8);
-            if (cell_items) memcpy(all_cells.data(), cand_p + 1 + CAND_PRE, cell_items * 8);
+            if (cell_items) memcpy(all_cells.data(), cand_p + 2, cell_items * 8);
+            if (CAND_PRE) memcpy(all_cands.data(), cand_p + 2 + cell_items, std::min<size_t>(n_cand, CAND_PRE) * 8);
         }
         n_cand = (unsigned int)std::min<size_t>(n_cand, cand_items);
         if (n_cand > CAND_PRE) {
-            HIPCHK(hipMemcpyAsync(all_cands.data() + CAND_PRE, b_cand.as<int64_t>() + CAND_PRE, (n_cand - CAND_PRE) * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(all_cands.data() + CAND_PRE, d_cands + CAND_PRE, (n_cand - CAND_PRE) * 8, hipMemcpyDeviceToHost, st));
             HIPCHK(jk_stream_wait(st));
         }
         for (int c = 0; c < n_chunks; ++c) chunk_cands[c].clear();
