@@ -84,24 +84,26 @@ __device__ __forceinline__ void defer_record(const TableDev &T, u128 h, unsigned
 // copied out in bucket order: consecutive lanes write consecutive records of one slice.  (Writing each 8-B record straight from
 // the thread that produced it cost 3.9x the bytes in WRITE_SIZE.)
 // A tile's run in one bucket is ~13 records = 108 bytes: it begins and ends inside 128-byte lines.  With a slice per BLOCK every
-// line is written by two consecutive tiles of its block, 16 us apart, and the open lines of all blocks (256 x 1024 lists x 128 B)
-// are as large as the L2s together: the half-written lines are evicted and written twice (+1.9 ms of 5.7).  So the blocks SHARE
-// their slices: block b appends to slice b % nblk1 of every list (nblk1 = 2), a tile's run gets its place by ONE returning
-// agent-scope atomic add per bucket on the slice's fill count (thread t: bucket t; 16 wave instructions per tile), and a line
-// that one block leaves open is completed by the next tile of any of the other blocks, within a microsecond.  (Sharing among the
-// blocks of one XCD only -- 8 slices, b and b + 8 share an L2 -- is no better than sharing among all: 5.1 against 4.9 ms.)  The
-// atomic's result is not needed before the copy-out: it is in flight during the scan and the staging.
+// line is written by two consecutive tiles of its block, a tile apart, and the open lines of all blocks (256 x 1024 lists x 128 B)
+// are as large as the L2s together: the half-written lines are evicted and written twice (round 3: +1.9 ms of 5.7).  So the
+// blocks SHARE their slices: block b appends to slice b % nblk1 of every list -- nblk1 = 8, i.e. the blocks of one XCD (blocks are
+// dispatched round-robin over the XCDs: tools/probes/xcc_probe.hip), so the writers of a slice share an L2 -- and a tile's run
+// gets its place by ONE returning agent-scope atomic add per bucket on the slice's fill count (thread t: bucket t).  The fill
+// counts are laid out [slice][bucket]: atomics execute at the memory side, ~20 G requests/s chip-wide, and a wave's 64 atomics are
+// then 256 contiguous bytes = 4 requests (laid out [bucket][slice] they were 8 x nblk1 requests, and the 88 M atomics of a
+// 47-Mb call were what bounded the kernel: 4.4 ms).  The atomic's result is not needed before the copy-out: it is in flight
+// during the scan and the staging.  WRITE_SIZE: 9.15 GB for 8.57 GB of records (round 3: 10.9).
 //
-// The kernel is bound by instruction ISSUE, not by bytes (round 2: 196 wave instructions per record at 4 waves per SIMD), so it
-// is written for few instructions per base:
+// The kernel is bound by vector-ALU issue (without any store it takes 3.3 of its 4.0-4.3 ms), so it is written for few
+// instructions per base:
 //   * NW = number of 32-bit words of a k-mer is a template parameter: both strands roll by v_alignbit_b32 on words (2 x NW
 //     instructions per base; 64-bit shifts by run-time amounts cost several each), the canonical choice is one compare chain;
 //   * the hash is ONE 64-bit multiply (kmer.hpp: mix);
-//   * no branch in the per-base loop except around the rank atomic;
+//   * no branch in the per-base loop: a window that is no k-mer takes its "rank" from a word of its lane;
 //   * the copy-out is per RECORD, not per bucket: a second LDS array holds the bucket of every staged record, so a lane needs
 //     three LDS reads and one multiply-add for its destination (the per-bucket loop of round 2 spent ~35 instructions per
-//     record on 16-lane groups that were 3/4 full);
-//   * five barriers per tile.
+//     record on 16-lane groups that were 3/4 full) -- and it is issued inside the NEXT tile's hash loop (below);
+//   * four barriers per tile (the rank counters are double-buffered).
 // The stage holds P1_STAGE records; a tile with more (only input without read boundaries: a genome) is staged in two rounds.
 constexpr int P1_MAXB = 1024;          // part1 handles p1 <= 10; larger p1 falls back to the direct kernel
 constexpr int P1_TH = 1024;
