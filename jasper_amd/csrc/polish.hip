@@ -53,6 +53,15 @@ struct FrontEntry {       // live path of the extension search
 };
 static_assert(sizeof(FrontEntry) == 80, "FrontEntry layout");
 
+// The walk's phase timers (SegDev::tk: how a segment's time splits into skipping good k-mers / finding the run / choosing a fix /
+// splicing) read the clock around every step of the walk: a tuning aid that costs registers, scratch and an instruction stream
+// the product does not need.  They are compiled in by `make EXTRA=-DJK_POLISH_TICKS=1` (JASPER_POLISH_DEBUG then prints the
+// breakdown; without it the breakdown reads zero); a segment's total time (SegDev::ticks, two clock reads) is always there.
+#ifndef JK_POLISH_TICKS
+#define JK_POLISH_TICKS 0
+#endif
+__device__ __forceinline__ uint64_t phase_clock() { return JK_POLISH_TICKS ? wall_clock64() : 0ull; }
+
 struct Walker {
     TableDev T;
     int k, step, lane;
@@ -243,9 +252,9 @@ struct Walker {
     }
     // seq = seq[:a] + patch + seq[b:]   (0 <= a <= b <= len), patch readable by every lane
     __device__ void replace(int64_t a, int64_t b, const uint8_t *patch, int64_t plen) {
-        const uint64_t tr0 = wall_clock64();
+        const uint64_t tr0 = phase_clock();
         replace_(a, b, patch, plen);
-        tk[3] += wall_clock64() - tr0;
+        tk[3] += phase_clock() - tr0;
     }
     __device__ void replace_(int64_t a, int64_t b, const uint8_t *patch, int64_t plen) {
         move_gap(a);
@@ -709,9 +718,9 @@ struct Walker {
     // tbf in s_tbf (only when n <= k), L = len(to_be_fixed). Emits records, splices the chunk.
     template <typename F>
     __device__ __forceinline__ auto timed(int slot, F f) -> decltype(f()) {
-        const uint64_t t0 = wall_clock64();
+        const uint64_t t0 = phase_clock();
         auto r = f();
-        tk[slot] += wall_clock64() - t0;
+        tk[slot] += phase_clock() - t0;
         return r;
     }
     __device__ void fixing_sid(int64_t L64, uint32_t thr, int64_t n, int64_t gb, int64_t ga) {
@@ -797,7 +806,7 @@ struct Walker {
     // ---------------- src/jasper.py:150-223 handle_bad_kmers ----------------
     __device__ int64_t handle_bad_kmers(int64_t i, int64_t &wrong, bool fix, int64_t rolling_thre, bool &brk) {
         brk = false;
-        const uint64_t th0 = wall_clock64();
+        const uint64_t th0 = phase_clock();
         uint32_t thre = solid;
         if (rolling_thre > 0) thre = (uint32_t)rolling_thre;                   // :151-153
         // backward: j = i-1; while cnt(seq[j:j+k]) < thre and j >= 0: j -= 1      (:155-159), 64 candidates per round
@@ -872,9 +881,9 @@ struct Walker {
         pyslice(len, s0, ga + k - 1, tlo, thi);                                // :206
         int64_t n = ga - s0; if (n < 0) n = 0;                                 // :207
         wrong += n;
-        const uint64_t tf0 = wall_clock64();
+        const uint64_t tf0 = phase_clock();
         tk[1] += tf0 - th0;
-        struct FixTimer { uint64_t &acc; uint64_t t0; __device__ ~FixTimer() { acc += wall_clock64() - t0; } } fix_timer{tk[2], tf0};
+        struct FixTimer { uint64_t &acc; uint64_t t0; __device__ ~FixTimer() { acc += phase_clock() - t0; } } fix_timer{tk[2], tf0};
         if (fix) {
             if (gb < 0) return i;                                              // :211-212
             const int64_t L = thi - tlo;
@@ -933,9 +942,9 @@ struct Walker {
         arrive_out = ARRIVE_FAIL;
         while (i < len - k + 1 && status == PS_OK) {                           // :55
             if (__ballot(spec_fail != 0)) { spec_fail = 1; break; }
-            const uint64_t ts0 = wall_clock64();
+            const uint64_t ts0 = phase_clock();
             i = skip_good(i);
-            tk[0] += wall_clock64() - ts0;
+            tk[0] += phase_clock() - ts0;
             if (i >= len - k + 1) { if (!is_last) spec_fail = 1; break; }
             // arriving at the next sync point: the next segment takes over from here
             if (!is_last && (i - delta + seg_lo) >= stop_orig) {
@@ -1017,7 +1026,10 @@ __device__ __forceinline__ void publish_arrival(long long *slot, long long v) {
     if (threadIdx.x == 0) __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(64) void seg_walk_kernel(TableDev T, SegDev *segs, int n_segs, PolishParams P, int pass, ScratchPool pool,
+// (two waves per SIMD: the walk is one long state machine -- left alone the compiler spends 280 registers on it, ONE wave per SIMD,
+//  1024 segments on the chip at a time, and pass 0 of a 47-Mb batch has 3824; capped at 256 registers the polish call takes 3.73
+//  instead of 4.00 ms; at 168 or 128 registers what it spills costs what the third and fourth wave bring)
+__global__ __launch_bounds__(64, 2) void seg_walk_kernel(TableDev T, SegDev *segs, int n_segs, PolishParams P, int pass, ScratchPool pool,
                                                       unsigned int *ticket) {
     __shared__ uint8_t s_tbf[SMAX], s_t1[SMAX], s_t2[SMAX], s_gkb[64], s_gka[64];
     // segments are taken in the order the waves START (a ticket, not blockIdx): a chained segment spins on its
