@@ -922,11 +922,13 @@ constexpr size_t P2_LDS = (size_t)PT_TILE * 8 + (size_t)(3 * PT_MAXBUCKETS + 1 +
 //    is one add), a row that does not exist counts as a record of one extra list that sorts behind all others (no per-record
 //    branch), the copy-out is one lane per staged record, and the loads of the next round are in flight during this one --
 //    waited for before this round's copy-out stores are issued (see part1_kernel).
-// Two instances.  <128, 7>: at most 128 lists per bucket (tables up to 2^29 slots), rounds of 7 rows of 1024 records -- 56 KB of
-// stage + 16 KB of carry, TWO workgroups per CU (one's loads and stores run under the other's LDS work; 64 registers per lane:
-// no room for a prefetch).  <512, 8>: up to 512 lists (tables of 2^30 .. 2^32 slots, and every shard of the larger configurations):
-// the carry alone is 64 KB, so one workgroup per CU with a 64-KB stage; a round brings a list 16 records on average, i.e. about
-// one line leaves per list and round and nearly every record passes through the carry (LDS traffic, which this kernel has to spare).
+// Instances: ONE workgroup per CU, with the next round's records asked for a round ahead.  <128, 12>: at most 128 lists per
+// bucket (tables up to 2^29 slots), rounds of 12 rows of 1024 records -- 96 KB of stage + 16 KB of carry, 120 registers.  (Until
+// round 4 this was <128, 7> with TWO workgroups per CU, one's loads and stores under the other's LDS work, 64 registers per lane
+// and no room for a prefetch: 3.71 ms against 3.53 on the 47 Mb workload; 14 rows: 3.50 with 24 bytes per lane spilled.)
+// <512, 8>: up to 512 lists (tables of 2^30 .. 2^32 slots, and every shard of the larger configurations): the carry alone is
+// 64 KB, next to a 64-KB stage; a round brings a list 16 records on average, i.e. about one line leaves per list and round and
+// nearly every record passes through the carry (LDS traffic, which this kernel has to spare).
 constexpr int P2F_LINE = 16;           // records per 128-byte line
 // per list and round: stage record i leaves to gbase + 8 i if i < lim, else waits in carry slot i + cadd
 struct P2Meta { uint64_t gbase; uint32_t lim; int32_t cadd; };
@@ -934,7 +936,7 @@ __device__ __forceinline__ u128 rec_hash(uint64_t b1, uint64_t r, int recbits) {
 __device__ __forceinline__ u128 rec_hash(uint64_t b1, Rec16 r, int recbits) { return hash_of16(b1, r, recbits); }
 template <int MAXB, int ROWS, int RB = 8> struct P2F {
     static constexpr int TILE = PT_THREADS * ROWS;
-    static constexpr int PIECE = 64 * ROWS * 9;          // records per input piece: nine full wave rounds (<128, 7>: 4032 records, 252 lines)
+    static constexpr int PIECE = 64 * ROWS * 9;          // records per input piece: nine full wave rounds (<128, 12>: 6912 records, 432 lines)
     static constexpr size_t LDS = (size_t)TILE * RB + (size_t)(3 * (MAXB + 4) + 32) * 4 + (size_t)MAXB * sizeof(P2Meta) + (size_t)MAXB * 128;
 };
 struct P2Args {
@@ -947,7 +949,7 @@ struct P2Args {
 // and the lists are laid out owner-major.
 // REC: uint64_t, or Rec16 for keys that do not fit 8-byte records (k >= 38; a line is then 8 records).
 template <int MAXB, int ROWS, bool OWN = false, typename REC = uint64_t>
-__global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel(const REC *__restrict__ out1, const unsigned int *__restrict__ cnt1, P2Args P, REC *__restrict__ out2,
+__global__ __launch_bounds__(PT_THREADS, 4) void part2f_kernel(const REC *__restrict__ out1, const unsigned int *__restrict__ cnt1, P2Args P, REC *__restrict__ out2,
                                                             unsigned int *__restrict__ cnt2, unsigned long long *__restrict__ deferred,
                                                             unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
     constexpr int P2F_MAXB = MAXB, P2F_ROWS = ROWS, P2F_TILE = P2F<MAXB, ROWS>::TILE, P2F_PIECE = P2F<MAXB, ROWS>::PIECE;
@@ -1037,10 +1039,10 @@ __global__ __launch_bounds__(PT_THREADS, MAXB <= 128 ? 8 : 4) void part2f_kernel
             pos += 64u * P2F_ROWS;
         };
         uint32_t vmask = 0;
-        // PF (the one-workgroup-per-CU instance, which has the registers): the records of round r + 1 are asked for at the top of
-        // round r and waited for right BEFORE round r's copy-out stores are issued (a wave's vector-memory operations retire in
-        // order: waited for at the top of round r + 1 they would wait for those stores as well), see part1_kernel
-        constexpr bool PF = MAXB > 128;
+        // PF: the records of round r + 1 are asked for at the top of round r and waited for right BEFORE round r's copy-out stores
+        // are issued (a wave's vector-memory operations retire in order: waited for at the top of round r + 1 they would wait for
+        // those stores as well), see part1_kernel.  (A switch: the two-workgroups-per-CU instance of round 3 had no registers for it.)
+        constexpr bool PF = true;
         REC nxt[P2F_ROWS];
         uint32_t vmask_n = 0;
         if (PF && rounds) {
@@ -1188,8 +1190,22 @@ constexpr int LI_MAXSL = 64;           // slices per region an owner reads (regi
 // touches).  Round 2's form (lds_insert_kernel, gone: 16-byte LDS slots, a 128-slot halo, even and odd regions in two launches,
 // one 1024-thread workgroup per CU) spent 178 wave instructions per record, most of them scalar branch bookkeeping of the probe
 // loop; here the first probe of four records is straight-line code and only the lanes that miss it loop.
+// a block-uniform word through the scalar cache (the compiler reads `cnt` with a vector load once stores have been issued, and
+// then waits for every vector-memory operation of the wave)
+__device__ __forceinline__ uint32_t scalar_load_u32(const unsigned int *p) {
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
 constexpr int RI_TH = 512;
+#ifndef JK_RI_PF
+#define JK_RI_PF 6
+#endif
+#ifndef JK_RI_MINW
+#define JK_RI_MINW 1
+#endif
 constexpr int RI_PF = 8;              // records per lane in flight
+constexpr int RI_PF_AHEAD = JK_RI_PF;  // ... per batch of the instance that keeps two batches in registers
 // XCHG (the owner's side of the list exchange, several GPUs): the region's slices come from nsrc senders, each of which laid out
 // ITS lists of all my regions as one block -- slice x of region r = sender x / (nsl/nsrc), its slice x % (nsl/nsrc): list index
 // ((sender * nregions + r) * (nsl/nsrc) + that).  They are short (1/nsrc of a region's records each) and are read as ONE
@@ -1198,8 +1214,8 @@ constexpr int RI_PF = 8;              // records per lane in flight
 // (occurrences - 1) in their low cbits.
 // REC: uint64_t, or Rec16 (keys of 65 .. 128 bits, not with XCHG); a table whose remainders fit the tag (B - s <= 53) only: wide
 // tables (a second word per slot) take region_insertw_kernel.
-template <bool FRESH, bool XCHG = false, typename REC = uint64_t>
-__global__ __launch_bounds__(RI_TH) void region_insert_kernel(const REC *__restrict__ lists, const unsigned int *__restrict__ cnt, uint32_t cap, uint32_t nsl,
+template <bool FRESH, bool XCHG = false, typename REC = uint64_t, bool R12 = false>
+__global__ __launch_bounds__(RI_TH, JK_RI_MINW) void region_insert_kernel(const REC *__restrict__ lists, const unsigned int *__restrict__ cnt, uint32_t cap, uint32_t nsl,
                                                               TableDev T, PartGeom G, uint32_t nregions, unsigned long long *__restrict__ deferred,
                                                               unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap,
                                                               unsigned long long *__restrict__ histo, uint32_t nsrc = 1, int cbits = 0, int fbits = 0) {
@@ -1207,9 +1223,11 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const REC *__restr
     using cnt_t = typename std::conditional<FRESH && !XCHG, unsigned int, unsigned long long>::type;
     constexpr bool W16 = sizeof(REC) == 16;
     static_assert(!(W16 && XCHG), "the exchange ships 8-byte records");
+    constexpr bool AHEAD = FRESH && !XCHG && R12 && !W16;                            // (see below)
+    constexpr int PF = AHEAD ? RI_PF_AHEAD : RI_PF;                                  // records per lane and batch
     auto rec_zero = []() { REC z; if constexpr (W16) { z.lo = 0ull; z.hi = 0ull; } else z = 0ull; return z; };
     extern __shared__ __align__(16) unsigned long long s_tag[];                      // R tags, R counts, LDS_HBINS bins (, LI_MAXSL + 1 slice offsets)
-    const uint32_t R = 1u << G.rbits;
+    const uint32_t R = 1u << G.rbits;                                                // (R12: 4096, the launcher says -- not folded in: as a constant it costs 18 registers)
     cnt_t *s_cnt = reinterpret_cast<cnt_t *>(s_tag + R);
     unsigned int *s_bins = reinterpret_cast<unsigned int *>(s_cnt + R);
     unsigned int *s_pref = s_bins + LDS_HBINS;                                       // XCHG: exclusive prefix of the region's slice lengths
@@ -1222,37 +1240,122 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const REC *__restr
     if (histo) {
         for (int i = t; i < LDS_HBINS; i += RI_TH) s_bins[i] = 0;
     }
-    for (uint32_t region = blockIdx.x; region < nregions; region += gridDim.x) {
-        const uint64_t first = (uint64_t)region << G.rbits;                          // first slot of the region
-        const uint64_t b1 = region >> G.p2;
-        const uint32_t per_src = XCHG ? nsl / nsrc : nsl;
-        auto slice_of = [&](uint32_t x) -> uint64_t {
-            if constexpr (XCHG) return ((uint64_t)(x / per_src) * nregions + region) * per_src + x % per_src;
-            else return (uint64_t)region * nsl + x;
-        };
-        const REC *src = lists + (uint64_t)region * nsl * cap;
-        uint32_t nrec = XCHG ? 0u : cnt[(uint64_t)region * nsl];
-        uint32_t total = 0;                                                          // XCHG: records of all the region's slices
+    // AHEAD (a table of 8-byte records that starts empty, regions of 4096 slots, one GPU -- the headline workload's instance,
+    // which has the registers): the records are a batch ahead of the insert loop.  While one batch of PF records per lane is
+    // inserted the next one is on its way, and the first batch of the block's NEXT region is asked for BEFORE this region's image
+    // is written out: a wave's vector-memory operations retire in order, so a load issued behind the write-out's stores is not
+    // back before every one of them has been acknowledged (part1_kernel).  So that the compiler can tell how many operations
+    // lie behind a load it waits for, the loads are unconditional (an index past the slice's end reads record 0 and is ignored),
+    // the slice counts come through the scalar cache, the write-out is eight stores per lane, and the region loop is rotated:
+    // its body is "ask for the next region's first batch; write this region out; set up and fill the next".
+    // Measured (47 Mb workload, one run, A/B): 3.42 -> 3.30 ms.  (With a region's three batches as straight-line code every wait
+    // is exact -- and the kernel needs 96 registers, two workgroups per CU instead of three: 3.87 ms.  As a loop, the wait before
+    // a region's second request still covers most of the write-out's stores: the loop's exit is, as the compiler lays it
+    // out, also a way back to its top.)
+    uint32_t region = blockIdx.x;
+    uint64_t first = 0, b1 = 0;                                                      // first slot of the region; its level-1 bucket
+    uint32_t nrec = 0, total = 0;                                                    // records of the slice in hand; XCHG: of all the region's slices
+    const uint32_t per_src = XCHG ? nsl / nsrc : nsl;
+    auto slice_of = [&](uint32_t x) -> uint64_t {
+        if constexpr (XCHG) return ((uint64_t)(x / per_src) * nregions + region) * per_src + x % per_src;
+        else return (uint64_t)region * nsl + x;
+    };
+    auto count_of = [&](uint32_t region_, uint32_t x_) -> uint32_t {                 // (not XCHG) records in slice x_ of region_
+        if constexpr (AHEAD) return scalar_load_u32(cnt + ((uint64_t)region_ * nsl + x_));
+        else return cnt[(uint64_t)region_ * nsl + x_];
+    };
+    REC recs[PF], recs2[PF];
+    auto fetch = [&](REC (&dst)[PF], uint32_t region_, uint32_t x_, uint32_t i0_, uint32_t n_) {   // (not XCHG)
+        const REC *s = lists + ((uint64_t)region_ * nsl + x_) * cap;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const uint32_t i = i0_ + (uint32_t)u * RI_TH + t;
+            if constexpr (AHEAD) dst[u] = s[i < n_ ? i : 0u];                        // (what lies past the end is not looked at: insert_batch)
+            else dst[u] = i < n_ ? s[i] : rec_zero();
+        }
+    };
+    // the probe loop of the lanes that did not find their key in its home slot (cur = what the home slot held)
+    auto probe_on = [&](REC rec, uint32_t idx, unsigned long long want, unsigned long long cur, cnt_t inc) {
+        for (;;) {
+            if (cur == 0ull) {
+                cur = atomicCAS(&s_tag[idx], 0ull, want);                            // LDS compare-and-swap
+                if (cur == 0ull) { ++fresh; cur = want; }
+            }
+            if (cur == want) { atomicAdd(&s_cnt[idx], inc); return; }                // LDS add
+            ++idx;
+            ++want;                                                                  // tag_of(rem, off + 1): the offset is the tag's low bits
+            if (whole) idx &= R - 1;
+            if (idx >= R || (want & (unsigned long long)(MAXPROBE - 1)) == 0ull) {   // leaves the region (or the probe limit): direct path, later
+                if constexpr (XCHG) {
+                    const u128 hh = hash_of(b1, rec, G.recbits);
+                    const unsigned long long di = atomicAdd(deferred_n, 1ull);
+                    if (di < deferred_cap) { deferred[3 * di] = hh.hi; deferred[3 * di + 1] = hh.lo; deferred[3 * di + 2] = (unsigned long long)inc; }
+                    else atomicExch(&T.stats[ST_FATAL], 1ull);
+                } else defer_record(T, rec_hash(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
+                return;
+            }
+            cur = s_tag[idx];
+        }
+    };
+    auto insert_batch = [&](REC (&rr)[PF], uint32_t i0, uint32_t n) {             // rr[u] = record i0 + u * RI_TH + t of a slice of n
+        uint32_t idx[PF];
+        unsigned long long want[PF], cur[PF];
+        cnt_t inc[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            inc[u] = (cnt_t)1;
+            if constexpr (XCHG) {
+                if (cbits) {                                                         // (uniform) the count, and the record as it was before the sender put it there
+                    const int csh = G.recbits - fbits;
+                    const uint64_t fmask = ((1ull << fbits) - 1ull) << csh;
+                    inc[u] = (cnt_t)(((rr[u] >> csh) & ((1ull << cbits) - 1ull)) + 1ull);
+                    rr[u] = (rr[u] & ~fmask) | ((uint64_t)((region >> (G.p2 - fbits)) & ((1u << fbits) - 1u)) << csh);
+                }
+            }
+            // the record holds the low recbits hash bits; the bits above the slot index of this region are implied by the
+            // list it is in, so slot and remainder come from the record alone
+            if constexpr (W16) {
+                idx[u] = (uint32_t)shr(mk(rr[u].hi, rr[u].lo), (unsigned)rs).lo & (R - 1);
+                want[u] = OCC | ((rr[u].lo & rmask) << OFFBITS);                     // (rs <= 53: the remainder lies in the low word)
+            } else {
+                idx[u] = (uint32_t)(rr[u] >> rs) & (R - 1);
+                want[u] = OCC | ((rr[u] & rmask) << OFFBITS);
+            }
+            cur[u] = s_tag[idx[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (i0 + (uint32_t)u * RI_TH + t < n) {
+                if (cur[u] == want[u]) atomicAdd(&s_cnt[idx[u]], inc[u]);
+                else probe_on(rr[u], idx[u], want[u], cur[u], inc[u]);
+            }
+        }
+    };
+    // what a region brings: false = nothing, and nothing to do for its slots (block-uniform)
+    auto open_region = [&]() -> bool {
+        first = (uint64_t)region << G.rbits;
+        b1 = region >> G.p2;
         if constexpr (XCHG) {
+            total = 0;
             for (uint32_t x = 0; x < nsl; ++x) total += cnt[slice_of(x)];
-            if (!FRESH && !histo && !total) continue;                                // (block-uniform)
+            if (!FRESH && !histo && !total) return false;
             if (t == 0) {
                 unsigned int run = 0;
                 for (uint32_t x = 0; x < nsl; ++x) { s_pref[x] = run; run += cnt[slice_of(x)]; }
                 s_pref[nsl] = run;
             }
-            // (the barrier after the image set-up below orders this before the first use)
-        } else if (!FRESH && !histo) {                                               // (block-uniform) nothing to add: the slots stay as they are
-            uint32_t any = nrec;
-            for (uint32_t x = 1; x < nsl; ++x) any |= cnt[(uint64_t)region * nsl + x];
-            if (!any) continue;
+            // (the barrier after the image set-up orders this before the first use)
+        } else {
+            nrec = count_of(region, 0u);
+            if (!FRESH && !histo) {                                                  // nothing to add: the slots stay as they are
+                uint32_t any = nrec;
+                for (uint32_t x = 1; x < nsl; ++x) any |= count_of(region, x);
+                if (!any) return false;
+            }
         }
-        // the first records of the region's first slice (normally its only one) are requested before the image is set up
-        REC recs[RI_PF];
-        if constexpr (!XCHG) {
-#pragma unroll
-            for (int u = 0; u < RI_PF; ++u) { const uint32_t i = (uint32_t)u * RI_TH + t; recs[u] = i < nrec ? src[i] : rec_zero(); }
-        }
+        return true;
+    };
+    auto image_setup = [&]() {
         if (FRESH) {
             for (uint32_t i = t; i < R; i += RI_TH) { s_tag[i] = 0ull; s_cnt[i] = 0; }
         } else {
@@ -1262,69 +1365,14 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const REC *__restr
                 s_cnt[i] = (cnt_t)e.y;
             }
         }
-        lds_barrier();
-        // the probe loop of the lanes that did not find their key in its home slot (cur = what the home slot held)
-        auto probe_on = [&](REC rec, uint32_t idx, unsigned long long want, unsigned long long cur, cnt_t inc) {
-            for (;;) {
-                if (cur == 0ull) {
-                    cur = atomicCAS(&s_tag[idx], 0ull, want);                        // LDS compare-and-swap
-                    if (cur == 0ull) { ++fresh; cur = want; }
-                }
-                if (cur == want) { atomicAdd(&s_cnt[idx], inc); return; }            // LDS add
-                ++idx;
-                ++want;                                                              // tag_of(rem, off + 1): the offset is the tag's low bits
-                if (whole) idx &= R - 1;
-                if (idx >= R || (want & (unsigned long long)(MAXPROBE - 1)) == 0ull) {   // leaves the region (or the probe limit): direct path, later
-                    if constexpr (XCHG) {
-                        const u128 hh = hash_of(b1, rec, G.recbits);
-                        const unsigned long long di = atomicAdd(deferred_n, 1ull);
-                        if (di < deferred_cap) { deferred[3 * di] = hh.hi; deferred[3 * di + 1] = hh.lo; deferred[3 * di + 2] = (unsigned long long)inc; }
-                        else atomicExch(&T.stats[ST_FATAL], 1ull);
-                    } else defer_record(T, rec_hash(b1, rec, G.recbits), deferred, deferred_n, deferred_cap);
-                    return;
-                }
-                cur = s_tag[idx];
-            }
-        };
-        auto insert_batch = [&](uint32_t i0, uint32_t n) {                           // recs[u] = record i0 + u * RI_TH + t of a slice of n
-            uint32_t idx[RI_PF];
-            unsigned long long want[RI_PF], cur[RI_PF];
-            cnt_t inc[RI_PF];
-#pragma unroll
-            for (int u = 0; u < RI_PF; ++u) {
-                inc[u] = (cnt_t)1;
-                if constexpr (XCHG) {
-                    if (cbits) {                                                     // (uniform) the count, and the record as it was before the sender put it there
-                        const int csh = G.recbits - fbits;
-                        const uint64_t fmask = ((1ull << fbits) - 1ull) << csh;
-                        inc[u] = (cnt_t)(((recs[u] >> csh) & ((1ull << cbits) - 1ull)) + 1ull);
-                        recs[u] = (recs[u] & ~fmask) | ((uint64_t)((region >> (G.p2 - fbits)) & ((1u << fbits) - 1u)) << csh);
-                    }
-                }
-                // the record holds the low recbits hash bits; the bits above the slot index of this region are implied by the
-                // list it is in, so slot and remainder come from the record alone
-                if constexpr (W16) {
-                    idx[u] = (uint32_t)shr(mk(recs[u].hi, recs[u].lo), (unsigned)rs).lo & (R - 1);
-                    want[u] = OCC | ((recs[u].lo & rmask) << OFFBITS);                 // (rs <= 53: the remainder lies in the low word)
-                } else {
-                    idx[u] = (uint32_t)(recs[u] >> rs) & (R - 1);
-                    want[u] = OCC | ((recs[u] & rmask) << OFFBITS);
-                }
-                cur[u] = s_tag[idx[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < RI_PF; ++u) {
-                if (i0 + (uint32_t)u * RI_TH + t < n) {
-                    if (cur[u] == want[u]) atomicAdd(&s_cnt[idx[u]], inc[u]);
-                    else probe_on(recs[u], idx[u], want[u], cur[u], inc[u]);
-                }
-            }
-        };
+    };
+    // all records of the region into the image; recs: the first batch of its first slice (not XCHG)
+    auto insert_region = [&]() {
         if constexpr (XCHG) {
             uint32_t x = 0;                                                          // slice of my current record: my indices only grow
-            for (uint32_t i0 = 0; i0 < total; i0 += RI_PF * RI_TH) {
+            for (uint32_t i0 = 0; i0 < total; i0 += PF * RI_TH) {
 #pragma unroll
-                for (int u = 0; u < RI_PF; ++u) {
+                for (int u = 0; u < PF; ++u) {
                     const uint32_t i = i0 + (uint32_t)u * RI_TH + t;
                     recs[u] = rec_zero();
                     if (i < total) {
@@ -1332,38 +1380,100 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const REC *__restr
                         recs[u] = lists[slice_of(x) * cap + (i - s_pref[x])];
                     }
                 }
-                insert_batch(i0, total);
+                insert_batch(recs, i0, total);
             }
-        } else
-        for (uint32_t x = 0; x < nsl; ++x) {
-            if (x) { nrec = cnt[(uint64_t)region * nsl + x]; src += cap; }
-            for (uint32_t i0 = 0; i0 < nrec; i0 += RI_PF * RI_TH) {
-                if (x || i0) {
+        } else {
+            uint32_t x = 0, i0 = 0;                                                  // the batch in hand: records i0 .. of slice x, which holds nrec
+            auto advance = [&]() -> bool {                                           // (block-uniform) to the region's next batch, if there is one
+                i0 += PF * RI_TH;
+                while (x < nsl && i0 >= nrec) { ++x; i0 = 0; nrec = x < nsl ? count_of(region, x) : 0u; }
+                return x < nsl;
+            };
+            if constexpr (AHEAD) {
+                for (;;) {                                                           // (the two register batches take turns)
+                    const uint32_t ia = i0, na = nrec;
+                    const bool more_b = advance();
+                    fetch(recs2, region, more_b ? x : 0u, more_b ? i0 : 0u, nrec);   // (no more: nrec == 0, a request for nothing)
+                    insert_batch(recs, ia, na);
+                    if (!more_b) break;
+                    const uint32_t ib = i0, nb_ = nrec;
+                    const bool more_a = advance();
+                    fetch(recs, region, more_a ? x : 0u, more_a ? i0 : 0u, nrec);
+                    insert_batch(recs2, ib, nb_);
+                    if (!more_a) break;
+                }
+                // (the last request has long arrived -- said here, or the wait for it is put where its registers are written
+                //  next: behind the write-out's stores, and for all of them)
 #pragma unroll
-                    for (int u = 0; u < RI_PF; ++u) { const uint32_t i = i0 + (uint32_t)u * RI_TH + t; recs[u] = i < nrec ? src[i] : rec_zero(); }
-                }
-                insert_batch(i0, nrec);
-            }
-        }
-        lds_barrier();
-        for (uint32_t i = t; i < R; i += RI_TH) {
-            const unsigned long long tag = s_tag[i];
-            const unsigned long long c64 = (unsigned long long)s_cnt[i];
-            *reinterpret_cast<ulonglong2 *>(T.slots + 2 * (first + i)) = make_ulonglong2(tag, c64);
-            if (histo) {
-                const bool occ = tag != 0ull && c64 != 0ull;
-                const uint32_t c = clamp32(c64);
-                const uint32_t b = c > 10001u ? 10001u : c;
-                // most occupied slots of a read set hold 1 (read errors): those are counted per wave, not by 64 same-address atomics
-                const unsigned long long ones = __ballot(occ && b == 1u);
-                if (ones && (t & 63) == (int)__builtin_ctzll(ones)) atomicAdd(&s_bins[1], (unsigned int)__popcll(ones));
-                if (occ && b != 1u) {
-                    if (b < (uint32_t)LDS_HBINS) atomicAdd(&s_bins[b], 1u);
-                    else atomicAdd(&histo[b], 1ull);
+                for (int u = 0; u < PF; ++u) asm volatile("" :: "v"(recs[u]), "v"(recs2[u]));
+            } else {
+                for (;;) {
+                    insert_batch(recs, i0, nrec);
+                    if (!advance()) break;
+                    fetch(recs, region, x, i0, nrec);
                 }
             }
         }
-        lds_barrier();
+    };
+    auto write_slot = [&](uint32_t i) {
+        const unsigned long long tag = s_tag[i];
+        const unsigned long long c64 = (unsigned long long)s_cnt[i];
+        *reinterpret_cast<ulonglong2 *>(T.slots + 2 * (first + i)) = make_ulonglong2(tag, c64);
+        if (histo) {
+            const bool occ = tag != 0ull && c64 != 0ull;
+            const uint32_t c = clamp32(c64);
+            const uint32_t b = c > 10001u ? 10001u : c;
+            // most occupied slots of a read set hold 1 (read errors): those are counted per wave, not by 64 same-address atomics
+            const unsigned long long ones = __ballot(occ && b == 1u);
+            if (ones && (t & 63) == (int)__builtin_ctzll(ones)) atomicAdd(&s_bins[1], (unsigned int)__popcll(ones));
+            if (occ && b != 1u) {
+                if (b < (uint32_t)LDS_HBINS) atomicAdd(&s_bins[b], 1u);
+                else atomicAdd(&histo[b], 1ull);
+            }
+        }
+    };
+    auto write_region = [&]() {
+        if constexpr (R12) {
+            static_assert(!R12 || (1 << 12) == 8 * RI_TH, "eight slots per lane");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) write_slot((uint32_t)t + (uint32_t)j * RI_TH);
+        } else
+            for (uint32_t i = t; i < R; i += RI_TH) write_slot(i);
+    };
+    if constexpr (AHEAD) {
+        if (region < nregions) {
+            open_region();
+            fetch(recs, region, 0u, 0u, nrec);
+            image_setup();
+            lds_barrier();
+            insert_region();
+            for (;;) {
+                const uint32_t next = region + gridDim.x;
+                const bool has_next = next < nregions;
+                const uint32_t n_next = has_next ? count_of(next, 0u) : 0u;
+                fetch(recs, has_next ? next : region, 0u, 0u, n_next);
+                lds_barrier();
+                write_region();
+                lds_barrier();
+                if (!has_next) break;
+                region = next;
+                open_region();
+                image_setup();
+                lds_barrier();
+                insert_region();
+            }
+        }
+    } else {
+        for (; region < nregions; region += gridDim.x) {
+            if (!open_region()) continue;
+            if constexpr (!XCHG) fetch(recs, region, 0u, 0u, nrec);                  // (requested before the image is set up)
+            image_setup();
+            lds_barrier();
+            insert_region();
+            lds_barrier();
+            write_region();
+            lds_barrier();
+        }
     }
     if (histo) {
         for (int i = t; i < LDS_HBINS; i += RI_TH)
@@ -1677,16 +1787,16 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
         } else if ((1 << G.p2) <= 512 && G.cap2 % P2F_LINE == 0 && !getenv("JASPER_EXPERIMENT_OLDP2")) {
             static bool attr2f_set = false;
             if (!attr2f_set) {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel<128, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel<512, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel<128, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr2f_set = true;
             }
             P2Args P;
             P.p1 = G.p1; P.p2 = G.p2; P.recbits = G.recbits; P.nblk1 = G.nblk1; P.nblk2 = G.nblk2; P.cap1 = G.cap1; P.cap2 = G.cap2; P.stats = d.stats; P.nown = 1;
             if ((1 << G.p2) <= 128) {
-                P.vper = (G.cap1 + (uint32_t)P2F<128, 7>::PIECE - 1u) / (uint32_t)P2F<128, 7>::PIECE;
-                constexpr size_t lds2 = P2F<128, 7>::LDS;
-                hipLaunchKernelGGL((part2f_kernel<128, 7>), grid, dim3(PT_THREADS), lds2, stream, out1, cnt1, P, out2, cnt2, defer_e, defer_n, deferred_cap);
+                P.vper = (G.cap1 + (uint32_t)P2F<128, 12>::PIECE - 1u) / (uint32_t)P2F<128, 12>::PIECE;
+                constexpr size_t lds2 = P2F<128, 12>::LDS;
+                hipLaunchKernelGGL((part2f_kernel<128, 12>), grid, dim3(PT_THREADS), lds2, stream, out1, cnt1, P, out2, cnt2, defer_e, defer_n, deferred_cap);
             } else {
                 P.vper = (G.cap1 + (uint32_t)P2F<512, 8>::PIECE - 1u) / (uint32_t)P2F<512, 8>::PIECE;
                 constexpr size_t lds2 = P2F<512, 8>::LDS;
@@ -1721,6 +1831,7 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(region_insert_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(region_insert_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(region_insert_kernel<true, false, uint64_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     {
@@ -1749,7 +1860,9 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
             const Rec16 *lw = reinterpret_cast<const Rec16 *>(lists);
             if (fresh32) hipLaunchKernelGGL((region_insert_kernel<true, false, Rec16>), dim3(nblk), dim3(RI_TH), lds, stream, lw, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap, histo, 1u, 0, 0);
             else hipLaunchKernelGGL((region_insert_kernel<false, false, Rec16>), dim3(nblk), dim3(RI_TH), lds, stream, lw, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap, histo, 1u, 0, 0);
-        } else if (fresh32) hipLaunchKernelGGL(region_insert_kernel<true>, dim3(nblk), dim3(RI_TH), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap, histo);
+        } else if (fresh32 && G.rbits == 12 && !getenv("JASPER_EXPERIMENT_NO_AHEAD"))      // (the instance that runs a batch of records ahead)
+            hipLaunchKernelGGL((region_insert_kernel<true, false, uint64_t, true>), dim3(nblk), dim3(RI_TH), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap, histo, 1u, 0, 0);
+        else if (fresh32) hipLaunchKernelGGL(region_insert_kernel<true>, dim3(nblk), dim3(RI_TH), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap, histo);
         else hipLaunchKernelGGL(region_insert_kernel<false>, dim3(nblk), dim3(RI_TH), lds, stream, lists, lcnt, lcap, nsl, d, G, nregions, defer_e, defer_n, deferred_cap, histo);
         HIPCHK(hipGetLastError());
     }
