@@ -346,15 +346,26 @@ def merge_fix_csvs(csv_files):
         m = re.match(r"[ \t]*-?\d+", x)
         return int(m.group(0)) if m else 0
 
-    def key(s):                                        # sort -k1,1 -k2,2n -k3,3n, last resort: whole line
-        F = awk_fields(s)
-        return (F[0].encode() if F else b"", num(F[1]) if len(F) > 1 else 0, num(F[2]) if len(F) > 2 else 0, s.encode())
+    # (a row of plain ASCII without the other characters str.split() takes for blanks -- every row this program writes -- splits the
+    #  same way with the built-in, whose fields are reused for the output line: the regular expressions cost 7 us a row)
+    odd = re.compile(r"[^\x20-\x7e\t]")
 
-    rows.sort(key=key)
+    def fields(s):
+        return awk_fields(s) if odd.search(s) else s.split()
+
+    def key_of(s, F):                                  # sort -k1,1 -k2,2n -k3,3n, last resort: whole line
+        f1 = F[1] if len(F) > 1 else ""
+        f2 = F[2] if len(F) > 2 else ""
+        return (F[0].encode() if F else b"", int(f1) if f1.isascii() and f1.isdigit() else num(f1), int(f2) if f2.isascii() and f2.isdigit() else num(f2), s.encode())
+
+    keyed = []
+    for s in rows:
+        F = fields(s)
+        keyed.append((key_of(s, F), F))
+    keyed.sort(key=lambda kf: kf[0])
     out = []
-    for s in rows:                                     # awk '{print $1":"$2" "$3" "$4" "$5}'
-        F = awk_fields(s)
-        F += [""] * (5 - len(F))
+    for _, F in keyed:                                 # awk '{print $1":"$2" "$3" "$4" "$5}'
+        F = F + [""] * (5 - len(F))
         out.append("%s:%s %s %s %s\n" % (F[0], F[1], F[2], F[3], F[4]))
     return "".join(out)
 
@@ -980,6 +991,62 @@ def run(argv):
     return 0
 
 
+def _front_process():
+    """The end of a process that holds tens of GB of device memory takes ~0.1 s in the kernel (tools/probes/exit_probe.py: 0.04 s with
+    nothing allocated, 0.10 s with 48 GB) -- a sixth of a configs[1] run, spent after every output file is complete.  So the
+    command the user waits for is a FRONT process that never touches the GPU: it forks the worker before anything is loaded,
+    waits for the worker's word that the outputs are complete (one byte on a pipe) and ends at once; the worker then ends on its
+    own time.  A worker that fails, is killed or exits with a status ends without the byte: the front waits for it and passes
+    its status on; SIGINT / SIGTERM / SIGHUP reaching the front are handed to the worker.
+    Returns the pipe's write end in the worker, None when there is no front (no fork(), a launcher's rank, a GPU runtime
+    already mapped into this process -- e.g. under a profiler's preload --, or JASPER_AMD_NO_FRONT=1)."""
+    if (not hasattr(os, "fork") or "WORLD_SIZE" in os.environ or os.environ.get("JASPER_AMD_NO_FRONT")
+            or os.environ.get("JASPER_AMD_SLOW_EXIT")):
+        return None
+    try:
+        with open("/proc/self/maps") as f:
+            maps = f.read()
+        if "libamdhip64" in maps or "libhsa-runtime" in maps:
+            return None
+    except OSError:
+        return None
+    import signal
+    sys.stdout.flush()
+    sys.stderr.flush()
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        os.close(r)
+        return w
+    os.close(w)
+    for sig in (signal.SIGINT, signal.SIGTERM, signal.SIGHUP):
+        try:
+            signal.signal(sig, lambda s, _f: os.kill(pid, s))
+        except (OSError, ValueError):
+            pass
+    while True:
+        try:
+            word = os.read(r, 1)
+            break
+        except InterruptedError:
+            continue
+    if word:
+        os._exit(0)
+    while True:
+        try:
+            _, st = os.waitpid(pid, 0)
+            break
+        except InterruptedError:
+            continue
+        except ChildProcessError:
+            os._exit(1)
+    if os.WIFSIGNALED(st):
+        signal.signal(os.WTERMSIG(st), signal.SIG_DFL)
+        os.kill(os.getpid(), os.WTERMSIG(st))
+        os._exit(128 + os.WTERMSIG(st))
+    os._exit(os.WEXITSTATUS(st))
+
+
 def main():
     argv = sys.argv[1:]
     if "--gpus" in argv and "WORLD_SIZE" not in os.environ:
@@ -1002,10 +1069,23 @@ def main():
                 sk.close()
             sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
                                       "--master-addr", "127.0.0.1", "--master-port", port, "-m", "jasper_amd.cli"] + argv))
+    done_fd = _front_process()
     rc = run(argv)
     if os.environ.get("JASPER_AMD_TIMING"):
         import time
         sys.stderr.write("[timing-abs] run() returned at %.6f\n" % time.time())
+    if done_fd is not None and not rc:
+        # (the worker of a front process, see _front_process: the outputs are complete -- tell the front, let go of the terminal's
+        #  files, and leave the release of the device memory to this process's own end)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        try:
+            os.write(done_fd, b"\0")
+            for fd in (0, 1, 2, done_fd):
+                os.close(fd)
+        except OSError:
+            pass
+        os._exit(0)
     # Every output file is closed and under its final name.  A normal interpreter exit would now free tens of GB of device
     # memory allocation by allocation (hipFree of the table, the list workspaces, the pinned buffers: 0.1 s of a 0.7-s run);
     # the driver releases all of it when the process ends anyway.

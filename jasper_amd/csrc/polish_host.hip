@@ -624,14 +624,17 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
 // chunks, each with its own stream, host thread and workspace, fill each other's gaps: one's walk tail and host work run under
 // another's kernels.  Measured (47 Mb in 18 chunk records): 4.7 ms in one lane, 4.55-4.7 in two, 4.35-4.65 in three, worse in
 // four -- the HBM-bound scans only share the bandwidth and every lane still has its own chain of walks -- while the first
-// call pays the workspace allocations once per lane (the drop-in end to end: 0.80 -> 0.97 s).  So ONE lane is the default and
-// JASPER_POLISH_LANES=n asks for more.  Results are per chunk, the same in any number of lanes -- only the records have to
-// be merged back into batch order (tests/test_gpu_parity.py).
+// call pays the workspace allocations once per lane (the drop-in end to end: 0.80 -> 0.97 s).  So a table's FIRST polishing call
+// runs in one lane -- the drop-in polishes a genome of up to ~1 Gbase in one call -- and a table that is polished again (the
+// further groups of a large genome, a resident service, the bench's steady state) takes three lanes from the second call on
+// when the batch has a dozen chunks or more: 3.70 -> 3.59 ms per call with round 4's kernels.  JASPER_POLISH_LANES=n overrides.
+// Results are per chunk, the same in any number of lanes -- only the records have to be merged back into batch order
+// (tests/test_gpu_parity.py, tests/test_gpu_determinism.py).
 int run_polish(Table &T, int n_chunks, const char *const *seqs, const int64_t *lens, int solid_thre, int passes, int fix,
                PolishOut &R, std::string &err, bool device_in, bool keep_on_device, int roomy) {
     HIPCHK(hipSetDevice(T.device));
     if (T.materialize(err)) return -1;
-    int lanes = 1;                                                                        // (measured: too little gained to be the default)
+    int lanes = T.polish_calls++ >= 1 && n_chunks >= 12 ? 3 : 1;
     if (const char *e = getenv("JASPER_POLISH_LANES")) lanes = atoi(e);                   // (tests, tuning)
     if (getenv("JASPER_POLISH_DEBUG")) lanes = 1;                                         // (its statistics are one lane's)
     lanes = std::max(1, std::min(std::min(lanes, (int)Table::POLISH_LANES_MAX), n_chunks / 2));

@@ -345,6 +345,7 @@ struct Table {
     WsBuf ws[WS_SLOTS];   // 0..WS_POLISH_MAX-1: polisher (polish_host.hip, in allocation order); WS_COUNT..+3: partitioned counting
     hipStream_t polish_stream[POLISH_LANES_MAX] = {nullptr, nullptr, nullptr, nullptr};      // [0] unused (= stream); created on first use
     hipEvent_t polish_ev = nullptr;
+    uint64_t polish_calls = 0;           // polishing calls this table has served (run_polish: a table that is polished again and again gets lanes)
     hipStream_t jf_stream = nullptr;        // write_jf's own (jfwrite.hip)
     void *workspace(int id, size_t bytes, std::string &err);
     void wait_streams();                    // every stream of this table (its own, the polishing lanes', the .jf writer's): before a buffer they may use is freed

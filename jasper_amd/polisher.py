@@ -254,7 +254,8 @@ def main_many(query_paths, k, test, fix, db, thre, num_iter):
             names.extend(d.keys())
             seqs.extend(d.values())
         do_fix = bool(fix)
-        fixed, _, _, res = polish_batch(db, names, seqs, thre, num_iter, fix=do_fix)
+        res = db.polish_batch(seqs, thre, num_iter, fix=do_fix)         # (polish_batch() above would build every CSV row a second time)
+        fixed = res.seqs
         rows_by_chunk = {}
         if do_fix:
             for r in res.records:

@@ -240,3 +240,85 @@ def test_fast_text_paths_equal_the_line_by_line_rules(tmp_path):
     ev = cli._fasta_events(str(p))
     assert ev == [("h", ">chr1"), ("s", "ACGT" * 15000), ("h", ">chr2"), ("s", "ACGT")] == cli._fasta_events(str(p), False)
     assert cli.sequence_bytes(str(p)) == 60000 + 4
+
+
+def test_front_process_passes_the_workers_status_and_output_on(tmp_path):
+    """cli._front_process: the command a user waits for is a front that forks the worker and ends on the worker's word; a worker
+    that exits with a status (here: the reference's own error exits, src/jasper.sh:35-39,125-128) ends without that word and its
+    status and messages are the command's -- the same with and without the front."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env_extra in ({}, {"JASPER_AMD_NO_FRONT": "1"}):
+        env = dict(os.environ, PYTHONPATH=root, **env_extra)
+        p = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-a", "nosuch.fa", "-r", "x.fq"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 1
+        outs.append(p.stderr.split("] ", 1)[-1])
+        h = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-h"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120)
+        assert h.returncode == 0 and "Usage: jasper.sh [options]" in h.stdout
+    assert outs[0] == outs[1] and "The query file does not exist" in outs[0]
+
+
+def test_front_process_hands_signals_to_the_worker(tmp_path):
+    import subprocess, sys, os, signal, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import os, sys, time\n"
+            "from jasper_amd import cli\n"
+            "fd = cli._front_process()\n"
+            "assert fd is not None\n"                      # (this is the worker)
+            "open('worker.pid', 'w').write(str(os.getpid()))\n"
+            "time.sleep(60)\n")
+    p = subprocess.Popen([sys.executable, "-c", prog], cwd=tmp_path, env=dict(os.environ, PYTHONPATH=root))
+    for _ in range(200):
+        if os.path.exists(tmp_path / "worker.pid") and open(tmp_path / "worker.pid").read():
+            break
+        time.sleep(0.05)
+    worker = int(open(tmp_path / "worker.pid").read())
+    assert worker != p.pid
+    p.send_signal(signal.SIGTERM)                         # to the front: it passes the signal on and ends the way the worker ended
+    rc = p.wait(timeout=30)
+    assert rc in (-signal.SIGTERM, 128 + signal.SIGTERM)
+    for _ in range(100):
+        try:
+            os.kill(worker, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.05)
+    else:
+        os.kill(worker, signal.SIGKILL)
+        raise AssertionError("the worker outlived the signal")
+
+
+def test_merge_fix_csvs_fast_path_equals_the_awk_rules(tmp_path):
+    """cli.merge_fix_csvs (src/jasper.sh:222-226): rows of plain ASCII are split with the built-in; every other row takes awk's
+    field rule ('\\r', '\\v', '\\f' and non-ASCII blanks are NOT separators) -- both orders and outputs must agree with the rule
+    applied to every row."""
+    import random, re
+    from jasper_amd import cli
+    random.seed(11)
+
+    def by_the_rule(files):
+        lines = []
+        for n, path in enumerate(files):
+            content = open(path, "r", newline="").read().split("\n")
+            if content and content[-1] == "":
+                content.pop()
+            lines += [ln for fnr, ln in enumerate(content, start=1) if (n == 0 and fnr == 1) or fnr > 1]
+        rows = [(ln.split(":") + [""])[0] + " " + (ln.split(":") + [""])[1] for ln in lines]
+        awk = lambda rec: re.split(r"[ \t\n]+", rec.strip(" \t\n")) if rec.strip(" \t\n") else []
+        num = lambda x: int(re.match(r"[ \t]*-?\d+", x).group(0)) if re.match(r"[ \t]*-?\d+", x) else 0
+        rows.sort(key=lambda s: ((awk(s) + [""])[0].encode(), num(awk(s)[1]) if len(awk(s)) > 1 else 0, num(awk(s)[2]) if len(awk(s)) > 2 else 0, s.encode()))
+        return "".join("%s:%s %s %s %s\n" % tuple((awk(s) + [""] * 5)[:5]) for s in rows)
+
+    field = lambda: random.choice(["12", "007", "-3", "x9", "", " 5", "\t7", "9\r", "a\x0bb", "é1", "33 44", "²"])
+    for trial in range(120):
+        files = []
+        for n in range(random.randint(1, 3)):
+            path = str(tmp_path / ("f%d_%d.csv" % (trial, n)))
+            with open(path, "w", newline="") as f:
+                f.write("Contig Base_coord Original Mutated\r\n")
+                for _ in range(random.randint(0, 10)):
+                    f.write("%s:%s %s %s %s%s" % (random.choice(["ctg1", "ctg2", "c t", "x\ty", "a"]), field(), field(), random.choice("ACGT-"),
+                                                  random.choice(["sA", "i-", "d-"]), random.choice(["\r\n", "\n"])))
+            files.append(path)
+        assert cli.merge_fix_csvs(files) == by_the_rule(files), trial
