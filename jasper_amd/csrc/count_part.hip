@@ -926,8 +926,8 @@ constexpr size_t P2_LDS = (size_t)PT_TILE * 8 + (size_t)(3 * PT_MAXBUCKETS + 1 +
 // bucket (tables up to 2^29 slots), rounds of 12 rows of 1024 records -- 96 KB of stage + 16 KB of carry, 120 registers.  (Until
 // round 4 this was <128, 7> with TWO workgroups per CU, one's loads and stores under the other's LDS work, 64 registers per lane
 // and no room for a prefetch: 3.71 ms against 3.53 on the 47 Mb workload; 14 rows: 3.50 with 24 bytes per lane spilled.)
-// <512, 8>: up to 512 lists (tables of 2^30 .. 2^32 slots, and every shard of the larger configurations): the carry alone is
-// 64 KB, next to a 64-KB stage; a round brings a list 16 records on average, i.e. about one line leaves per list and round and
+// <512, 10>: up to 512 lists (tables of 2^30 .. 2^32 slots, and every shard of the larger configurations): the carry alone is
+// 64 KB, next to an 80-KB stage (10 rows; 8 rows: 12.1-12.4 ms against 11.7 on the 140 Mb workload); a round brings a list 16 records on average, i.e. about one line leaves per list and round and
 // nearly every record passes through the carry (LDS traffic, which this kernel has to spare).
 constexpr int P2F_LINE = 16;           // records per 128-byte line
 // per list and round: stage record i leaves to gbase + 8 i if i < lim, else waits in carry slot i + cadd
@@ -1787,7 +1787,7 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
         } else if ((1 << G.p2) <= 512 && G.cap2 % P2F_LINE == 0 && !getenv("JASPER_EXPERIMENT_OLDP2")) {
             static bool attr2f_set = false;
             if (!attr2f_set) {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel<512, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel<512, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel<128, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr2f_set = true;
             }
@@ -1798,9 +1798,9 @@ int Table::launch_count_partitioned(const uint8_t *d_piece, uint64_t len, uint64
                 constexpr size_t lds2 = P2F<128, 12>::LDS;
                 hipLaunchKernelGGL((part2f_kernel<128, 12>), grid, dim3(PT_THREADS), lds2, stream, out1, cnt1, P, out2, cnt2, defer_e, defer_n, deferred_cap);
             } else {
-                P.vper = (G.cap1 + (uint32_t)P2F<512, 8>::PIECE - 1u) / (uint32_t)P2F<512, 8>::PIECE;
-                constexpr size_t lds2 = P2F<512, 8>::LDS;
-                hipLaunchKernelGGL((part2f_kernel<512, 8>), grid, dim3(PT_THREADS), lds2, stream, out1, cnt1, P, out2, cnt2, defer_e, defer_n, deferred_cap);
+                P.vper = (G.cap1 + (uint32_t)P2F<512, 10>::PIECE - 1u) / (uint32_t)P2F<512, 10>::PIECE;
+                constexpr size_t lds2 = P2F<512, 10>::LDS;
+                hipLaunchKernelGGL((part2f_kernel<512, 10>), grid, dim3(PT_THREADS), lds2, stream, out1, cnt1, P, out2, cnt2, defer_e, defer_n, deferred_cap);
             }
         } else
             hipLaunchKernelGGL(part2_kernel<false>, grid, dim3(PT_THREADS), P2_LDS, stream, out1, cnt1, d, G, out2, cnt2, defer_e, defer_n, deferred_cap, 1u);
@@ -2014,14 +2014,14 @@ int Table::xchg_partition(uint64_t piece_max, uint64_t records_max, uint32_t now
         // the sender's split in whole lines, like the single-GPU pass
         static bool attrf_set = false;
         if (!attrf_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel<512, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(part2f_kernel<512, 10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attrf_set = true;
         }
         P2Args P;
         P.p1 = G.p1; P.p2 = G.p2; P.recbits = G.recbits; P.nblk1 = G.nblk1; P.nblk2 = G.nblk2; P.cap1 = G.cap1; P.cap2 = G.cap2; P.stats = d.stats; P.nown = nown;
-        P.vper = (G.cap1 + (uint32_t)P2F<512, 8>::PIECE - 1u) / (uint32_t)P2F<512, 8>::PIECE;
-        constexpr size_t lds2 = P2F<512, 8>::LDS;
-        hipLaunchKernelGGL((part2f_kernel<512, 8, true>), dim3(G.nblk2, std::min<uint32_t>(nb1, 2048)), dim3(PT_THREADS), lds2, stream, out1, cnt1, P, (uint64_t *)d_send,
+        P.vper = (G.cap1 + (uint32_t)P2F<512, 10>::PIECE - 1u) / (uint32_t)P2F<512, 10>::PIECE;
+        constexpr size_t lds2 = P2F<512, 10>::LDS;
+        hipLaunchKernelGGL((part2f_kernel<512, 10, true>), dim3(G.nblk2, std::min<uint32_t>(nb1, 2048)), dim3(PT_THREADS), lds2, stream, out1, cnt1, P, (uint64_t *)d_send,
                            (unsigned int *)d_send_cnt, defer_e, defer_n, defer_cap);
     } else
     hipLaunchKernelGGL(part2_kernel<true>, dim3(G.nblk2, std::min<uint32_t>(nb1, 2048)), dim3(PT_THREADS), P2_LDS, stream, out1, cnt1, d, G, (uint64_t *)d_send,
