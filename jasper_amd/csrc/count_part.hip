@@ -952,7 +952,7 @@ template <int MAXB, int ROWS, bool OWN = false, typename REC = uint64_t>
 __global__ __launch_bounds__(PT_THREADS, 4) void part2f_kernel(const REC *__restrict__ out1, const unsigned int *__restrict__ cnt1, P2Args P, REC *__restrict__ out2,
                                                             unsigned int *__restrict__ cnt2, unsigned long long *__restrict__ deferred,
                                                             unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap) {
-    constexpr int P2F_MAXB = MAXB, P2F_ROWS = ROWS, P2F_TILE = P2F<MAXB, ROWS>::TILE, P2F_PIECE = P2F<MAXB, ROWS>::PIECE;
+    constexpr int P2F_MAXB = MAXB, P2F_ROWS = ROWS, P2F_PIECE = P2F<MAXB, ROWS>::PIECE;        // (P2F_TILE = 1024 x ROWS records per round)
     constexpr bool W16 = sizeof(REC) == 16;
     constexpr int RB = (int)sizeof(REC), P2F_LINE = 128 / RB;                  // (shadows the 8-byte constant)
     typedef __attribute__((address_space(1))) REC global_rec;
@@ -1201,9 +1201,6 @@ constexpr int RI_TH = 512;
 #ifndef JK_RI_PF
 #define JK_RI_PF 6
 #endif
-#ifndef JK_RI_MINW
-#define JK_RI_MINW 1
-#endif
 constexpr int RI_PF = 8;              // records per lane in flight
 constexpr int RI_PF_AHEAD = JK_RI_PF;  // ... per batch of the instance that keeps two batches in registers
 // XCHG (the owner's side of the list exchange, several GPUs): the region's slices come from nsrc senders, each of which laid out
@@ -1215,7 +1212,7 @@ constexpr int RI_PF_AHEAD = JK_RI_PF;  // ... per batch of the instance that kee
 // REC: uint64_t, or Rec16 (keys of 65 .. 128 bits, not with XCHG); a table whose remainders fit the tag (B - s <= 53) only: wide
 // tables (a second word per slot) take region_insertw_kernel.
 template <bool FRESH, bool XCHG = false, typename REC = uint64_t, bool R12 = false>
-__global__ __launch_bounds__(RI_TH, JK_RI_MINW) void region_insert_kernel(const REC *__restrict__ lists, const unsigned int *__restrict__ cnt, uint32_t cap, uint32_t nsl,
+__global__ __launch_bounds__(RI_TH) void region_insert_kernel(const REC *__restrict__ lists, const unsigned int *__restrict__ cnt, uint32_t cap, uint32_t nsl,
                                                               TableDev T, PartGeom G, uint32_t nregions, unsigned long long *__restrict__ deferred,
                                                               unsigned long long *__restrict__ deferred_n, uint64_t deferred_cap,
                                                               unsigned long long *__restrict__ histo, uint32_t nsrc = 1, int cbits = 0, int fbits = 0) {
