@@ -661,10 +661,11 @@ void *Table::workspace(int id, size_t bytes, std::string &err) {
     if (b.bytes >= bytes) return b.p;
     if (b.p) { wait_streams(); (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }      // (a lane's kernels run on its own stream)
     const size_t want = bytes + std::min<size_t>(bytes / 8, (size_t)256 << 20);   // a little headroom so that slightly larger batches do not reallocate
-    const bool dbg = getenv("JASPER_COUNT_DEBUG") != nullptr && want >= (256u << 20);
+    const char *dbg_e = getenv("JASPER_COUNT_DEBUG");
+    const bool dbg = dbg_e != nullptr && (want >= (256u << 20) || atoi(dbg_e) >= 2);      // (2: every allocation)
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&b.p, want);
-    if (dbg) fprintf(stderr, "[workspace] slot %d: hipMalloc of %.2f GB took %.1f ms\n", id, (double)want / 1e9,
+    if (dbg) fprintf(stderr, "[workspace] slot %d: hipMalloc of %.3f GB took %.1f ms\n", id, (double)want / 1e9,
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e != hipSuccess) {
         e = hipMalloc(&b.p, bytes);
@@ -682,7 +683,11 @@ void *Table::pinned(int id, size_t bytes, std::string &err) {
     if (b.bytes >= bytes) return b.p;
     if (b.p) { wait_streams(); (void)hipHostFree(b.p); b.p = nullptr; b.bytes = 0; }
     const size_t want = bytes + bytes / 4;
+    const char *dbg_e = getenv("JASPER_COUNT_DEBUG");
+    const auto t0 = std::chrono::steady_clock::now();
     if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { err = "pinned host buffer allocation failed"; b.p = nullptr; return nullptr; }
+    if (dbg_e && atoi(dbg_e) >= 2) fprintf(stderr, "[pinned] slot %d: hipHostMalloc of %.1f MB took %.1f ms\n", id, (double)want / 1e6,
+                                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     b.bytes = want;
     return b.p;
 }

@@ -10,7 +10,7 @@
 import csv, glob, json, os, sys
 
 src, dst = sys.argv[1], sys.argv[2]
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3      # --steps 2 --warmup 1
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6      # --steps 2 --warmup 4
 csv.field_size_limit(1 << 30)
 
 
