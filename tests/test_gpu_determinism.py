@@ -95,7 +95,7 @@ def _polish_digest(t, d_chunks, thr, n):
     return h.hexdigest(), r.qv, r.n_records, r.lookups
 
 
-@pytest.mark.parametrize("lanes,nslots,busy", [(1, 8, False), (1, 8, True), (3, 8, True), (1, 0, True)])
+@pytest.mark.parametrize("lanes,nslots,busy", [(1, 8, False), (1, 8, True), (3, 8, True), (1, 0, True), (0, 0, True)])
 def test_polishing_the_same_batch_twenty_times(work, lanes, nslots, busy):
     from jasper_amd import polisher
     t, noise = work["table"], work["noise"]
@@ -106,8 +106,11 @@ def test_polishing_the_same_batch_twenty_times(work, lanes, nslots, busy):
     thr = int(txt)
     for v in ("JASPER_POLISH_LANES", "JASPER_POLISH_TEST_NSLOTS"):
         os.environ.pop(v, None)
-    want = _polish_digest(t, work["d_chunks"], thr, work["n"])        # default configuration: 256 slots, one lane, idle memory
-    os.environ["JASPER_POLISH_LANES"] = str(lanes)
+    os.environ["JASPER_POLISH_LANES"] = "1"
+    want = _polish_digest(t, work["d_chunks"], thr, work["n"])        # 256 slots, one lane, idle memory
+    os.environ.pop("JASPER_POLISH_LANES")
+    if lanes:                                                         # (0: the product's own choice -- one lane on a table's first polishing call, three from the second on)
+        os.environ["JASPER_POLISH_LANES"] = str(lanes)
     if nslots:
         os.environ["JASPER_POLISH_TEST_NSLOTS"] = str(nslots)
     try:
