@@ -1476,8 +1476,15 @@ __global__ __launch_bounds__(RI_TH) void region_insert_kernel(const REC *__restr
         for (int i = t; i < LDS_HBINS; i += RI_TH)
             if (s_bins[i]) atomicAdd(&histo[i], (unsigned long long)s_bins[i]);
     }
+    // (one add per workgroup: the waves of the last workgroups all end within microseconds of each other, and thousands of adds
+    //  to ONE word are served one after the other, ~12 ns each -- tools/probes/mall_probe.hip's first version found out)
     for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
-    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
+    lds_barrier();
+    if (t == 0) s_tag[0] = 0ull;
+    lds_barrier();
+    if ((t & 63) == 0 && fresh) atomicAdd(&s_tag[0], fresh);
+    lds_barrier();
+    if (t == 0 && s_tag[0]) atomicAdd(&T.stats[ST_DISTINCT], s_tag[0]);
 }
 
 // ---- the same for a WIDE table (kmer.hpp: wide_rem -- B - s > 53: a slot's remainder does not fit its tag word, the low 64 bits
@@ -1626,6 +1633,12 @@ __global__ __launch_bounds__(256) void import3h_kernel(const unsigned long long 
     if (n_ptr[1]) return;                                                            // the piece was abandoned (part_decide_kernel)
     const uint64_t n = *n_ptr < cap ? *n_ptr : cap;
     unsigned long long fresh = 0;
+    // the bins' changes are summed per workgroup first (nearly all of them are "leaves bin 1 / 2, enters bin 2 / 3": hundreds of
+    // thousands of global atomics on a handful of words were most of this kernel's time)
+    constexpr int NB = 64;
+    __shared__ int s_delta[NB];
+    if (threadIdx.x < NB) s_delta[threadIdx.x] = 0;
+    __syncthreads();
     for (uint64_t i0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) & ~63ull; i0 < n; i0 += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = i0 + (threadIdx.x & 63);
         const bool have = i < n;
@@ -1659,8 +1672,8 @@ __global__ __launch_bounds__(256) void import3h_kernel(const unsigned long long 
                 const unsigned long long old = __hip_atomic_fetch_add(p + 1, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t b0 = histo_bin(old), b1 = histo_bin(old + inc);
                 if (histo && (old == 0ull || b0 != b1)) {
-                    if (old) atomicAdd(&histo[b0], ~0ull);                            // (minus one)
-                    atomicAdd(&histo[b1], 1ull);
+                    if (old) { if (b0 < (uint32_t)NB) atomicAdd(&s_delta[b0], -1); else atomicAdd(&histo[b0], ~0ull); }      // (minus one)
+                    if (b1 < (uint32_t)NB) atomicAdd(&s_delta[b1], 1); else atomicAdd(&histo[b1], 1ull);
                 }
                 done = true;
             }
@@ -1670,6 +1683,8 @@ __global__ __launch_bounds__(256) void import3h_kernel(const unsigned long long 
             if (histo) histo[10002] = 1ull;                                           // "not complete": the re-insertion after growth does not know the bins
         }
     }
+    __syncthreads();
+    if (histo && threadIdx.x < NB && s_delta[threadIdx.x]) atomicAdd(&histo[threadIdx.x], (unsigned long long)(long long)s_delta[threadIdx.x]);
     for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(&T.stats[ST_DISTINCT], fresh);
 }
