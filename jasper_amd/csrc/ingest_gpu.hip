@@ -453,7 +453,12 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
             if (f0) { const int c0 = fgetc(f0); fclose(f0); if (c0 == '@') est_bases = est / 2 + (16u << 20); }
         }
     }
-    const size_t BASES_CAP = (size_t)std::min<uint64_t>(3ull << 30, std::max<uint64_t>(est_bases, 16u << 20));
+    // Bases go to the counter in pieces of up to 1.5 G (round 3: 3 G).  The counting passes keep 20 bytes of list buffers per base
+    // of a piece, and on a GPU whose memory has not been handed out before the first hipMalloc costs ~28 ms per GB (the driver
+    // clears what it gives): 64 GB of buffers for a 3-G piece were 1.8 s of a 140-Mb run that takes 1.1 s otherwise, while a
+    // further piece costs one more read-modify-write of the table by region_insert_kernel (2 x 16 bytes per slot at ~5 TB/s:
+    // 14 ms for 2^31 slots).  The configs[1] input (1.42 G bases) is still one piece.
+    const size_t BASES_CAP = (size_t)std::min<uint64_t>(3ull << 29, std::max<uint64_t>(est_bases, 16u << 20));
     uint64_t n_gpu = 0, n_host = 0;
     Reader rd;
     rd.paths = paths;
