@@ -992,15 +992,18 @@ def run(argv):
 
 
 def _front_process():
-    """The end of a process that holds tens of GB of device memory takes ~0.1 s in the kernel (tools/probes/exit_probe.py: 0.04 s with
-    nothing allocated, 0.10 s with 48 GB) -- a sixth of a configs[1] run, spent after every output file is complete.  So the
-    command the user waits for is a FRONT process that never touches the GPU: it forks the worker before anything is loaded,
-    waits for the worker's word that the outputs are complete (one byte on a pipe) and ends at once; the worker then ends on its
-    own time.  A worker that fails, is killed or exits with a status ends without the byte: the front waits for it and passes
-    its status on; SIGINT / SIGTERM / SIGHUP reaching the front are handed to the worker.
-    Returns the pipe's write end in the worker, None when there is no front (no fork(), a launcher's rank, a GPU runtime
-    already mapped into this process -- e.g. under a profiler's preload --, or JASPER_AMD_NO_FRONT=1)."""
-    if (not hasattr(os, "fork") or "WORLD_SIZE" in os.environ or os.environ.get("JASPER_AMD_NO_FRONT")
+    """OPT-IN (JASPER_AMD_FRONT=1; the default is what jasper.sh does: the command returns when everything, device memory
+    included, has been released).  The end of a process that holds tens of GB of device memory takes ~0.1 s in the kernel
+    (tools/probes/exit_probe.py: 0.04 s with nothing allocated, 0.10 s with 48 GB), spent after every output file is complete.  With
+    the front, the command the user waits for never touches the GPU: it forks the worker before anything is loaded, waits for the
+    worker's word that the outputs are complete (one byte on a pipe) and ends at once; the worker then ends on its own time -- a
+    GPU job started right afterwards may find that memory not yet free, which is why a caller has to ask for this.  A worker that
+    fails, is killed or exits with a status ends without the byte: the front waits for it and passes its status on.  SIGTERM /
+    SIGHUP reaching the front are handed to the worker (which leaves through SystemExit, so its atexit clean-up runs); SIGINT is
+    not forwarded -- a terminal's Ctrl-C reaches the whole foreground process group, worker included -- unless the worker is in
+    another process group.
+    Returns the pipe's write end in the worker, None when there is no front."""
+    if (not hasattr(os, "fork") or "WORLD_SIZE" in os.environ or os.environ.get("JASPER_AMD_FRONT", "") not in ("1", "true", "yes")
             or os.environ.get("JASPER_AMD_SLOW_EXIT")):
         return None
     try:
@@ -1017,11 +1020,26 @@ def _front_process():
     pid = os.fork()
     if pid == 0:
         os.close(r)
+
+        def _leave(signum, _frame):         # (SIGTERM / SIGHUP: out through SystemExit -- atexit asks the GPU threads to stop and removes unfinished files)
+            sys.exit(128 + signum)
+        for sig in (signal.SIGTERM, signal.SIGHUP):
+            try:
+                signal.signal(sig, _leave)
+            except (OSError, ValueError):
+                pass
         return w
     os.close(w)
+
+    def _hand_on(signum, _frame):
+        try:
+            if signum != signal.SIGINT or os.getpgid(pid) != os.getpgid(0):
+                os.kill(pid, signum)
+        except OSError:
+            pass
     for sig in (signal.SIGINT, signal.SIGTERM, signal.SIGHUP):
         try:
-            signal.signal(sig, lambda s, _f: os.kill(pid, s))
+            signal.signal(sig, _hand_on)
         except (OSError, ValueError):
             pass
     while True:

@@ -288,7 +288,7 @@ struct Reader {           // the concatenation of all input files as one byte st
     // (measured on the GPU box, 2.9 GB of FASTQ in the page cache: 4 threads 0.25 s, 8 threads 0.16 s for files -> table)
     const int READ_THREADS = []() {
         if (const char *e = getenv("JASPER_INGEST_READ_THREADS")) return std::max(1, std::min(atoi(e), MAX_READ_THREADS));
-        return (int)std::max(4u, std::min(16u, std::thread::hardware_concurrency() / 8u));
+        return (int)std::max(8u, std::min(16u, std::thread::hardware_concurrency() / 8u));      // (8 is the floor: hardware_concurrency() may be 0)
     }();
     // fills buf with up to want bytes; returns bytes read, 0 at the end of the last file, -1 on error
     long read(char *buf, size_t want) {

@@ -610,7 +610,7 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
     round, and the reader parses the next batch while the last one is exchanged.
 
     Collective.  `shard` should be sized for the keys it will own (min_slots / reserve) -- it grows if it must.  Counts are
-    ADDED to what the shard holds; clear=True empties it first (at a point where no peer can still be reading it).  Returns
+    ADDED to what the shard holds; clear=True (rank-uniform: checked) empties it first (at a point where no peer can still be reading it).  Returns
     None (collectively, nothing consumed) when the table / k has no exchange geometry -- count into a local table and call
     shard_tables() then -- else a dict with the rounds and bytes moved.  Afterwards lookups through `shard` read the owner's HBM
     (own or peer's), as after shard_tables()."""
@@ -621,9 +621,13 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     was_empty = clear or shard.info()["distinct"] == 0
-    agree = torch.tensor([shard.info()["slots"], 0 if was_empty else 1], dtype=torch.int64, device=device)
+    agree = torch.tensor([shard.info()["slots"], 0 if was_empty else 1, 1 if clear else 0, 0 if clear else 1], dtype=torch.int64, device=device)
     dist.all_reduce(agree, op=dist.ReduceOp.MAX, group=group)
-    slots, any_filled = (int(v) for v in agree.tolist())
+    slots, any_filled, some_clear, some_keep = (int(v) for v in agree.tolist())
+    if some_clear and some_keep:
+        # `clear` adds a reduction below that only the clearing ranks would enter: ranks that disagree on it would hang there.  Every
+        # rank sees the same two maxima, so every rank leaves here together.
+        raise ValueError("count_sharded: clear must be the same on every rank")
     # (every rank is here: none of them still reads the shards of the last step through its peer mappings)
     # Every step below that can fail on ONE rank (a device allocation of reserve(), a library call) reports into the next
     # reduction instead of raising: a rank that left through an exception while its peers wait in a collective hangs the job.

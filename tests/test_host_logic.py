@@ -243,13 +243,13 @@ def test_fast_text_paths_equal_the_line_by_line_rules(tmp_path):
 
 
 def test_front_process_passes_the_workers_status_and_output_on(tmp_path):
-    """cli._front_process: the command a user waits for is a front that forks the worker and ends on the worker's word; a worker
+    """cli._front_process (opt-in, JASPER_AMD_FRONT=1): the command a user waits for is a front that forks the worker and ends on the worker's word; a worker
     that exits with a status (here: the reference's own error exits, src/jasper.sh:35-39,125-128) ends without that word and its
     status and messages are the command's -- the same with and without the front."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env_extra in ({}, {"JASPER_AMD_NO_FRONT": "1"}):
+    for env_extra in ({"JASPER_AMD_FRONT": "1"}, {}):
         env = dict(os.environ, PYTHONPATH=root, **env_extra)
         p = subprocess.run([sys.executable, "-m", "jasper_amd.cli", "-a", "nosuch.fa", "-r", "x.fq"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120)
         assert p.returncode == 1
@@ -268,7 +268,7 @@ def test_front_process_hands_signals_to_the_worker(tmp_path):
             "assert fd is not None\n"                      # (this is the worker)
             "open('worker.pid', 'w').write(str(os.getpid()))\n"
             "time.sleep(60)\n")
-    p = subprocess.Popen([sys.executable, "-c", prog], cwd=tmp_path, env=dict(os.environ, PYTHONPATH=root))
+    p = subprocess.Popen([sys.executable, "-c", prog], cwd=tmp_path, env=dict(os.environ, PYTHONPATH=root, JASPER_AMD_FRONT="1"))
     for _ in range(200):
         if os.path.exists(tmp_path / "worker.pid") and open(tmp_path / "worker.pid").read():
             break
