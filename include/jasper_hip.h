@@ -19,6 +19,7 @@
  *   jasper_lookup                      qf[jf.MerDNA(s).get_canonical()]                     JF::swig/mer_file.i:41, JF::swig/mer_dna.i:12-19 (src/jasper.py:70-71 ...)
  *   jasper_table_export/_import[_device]  `jellyfish merge` (sum by key)                    JF::jellyfish/merge_files.cc:44-176 -> multi-GPU table merge
  *   jasper_polish_batch + jasper_result_*   one `jasper.py --db DB --query BATCH ...` process   src/jasper.py:12-137 (invoked at src/jasper.sh:207-212)
+ *   jasper_asm_*                       the perl one-liners around it: batch size, split, join        src/jasper.sh:132,155-156,220; src/jasper.py:120-128
  */
 #ifndef JASPER_HIP_H
 #define JASPER_HIP_H
@@ -240,6 +241,51 @@ int jasper_result_segments(const jasper_result *r, uint64_t *n_segments, uint64_
 /* 1 if the batch had to be repeated with larger internal buffers (results are the same either way) */
 int jasper_result_retried(const jasper_result *r);
 void jasper_result_free(jasper_result *r);
+
+/* The assembly side of src/jasper.sh, natively and by several host threads (no GPU call except jasper_asm_polish):
+ *   jasper_asm_open          the assembly FASTA read once into ONE host arena (line ends taken out, contigs back to back).  Returns 1
+ *                            (not an error, *out = NULL) for anything but the ordinary file -- '\r', a first byte that is not '>',
+ *                            blanks / tabs / non-printable / non-ASCII bytes in sequence lines, odd bytes in header lines, a contig
+ *                            name that occurs twice -- for which the caller applies the line-by-line rules of the perl one-liners itself.
+ *   jasper_asm_info          *sequence_bytes = `grep -v '^>' $QUERY | tr -d '\n' | wc` third column      src/jasper.sh:132
+ *   jasper_asm_contig        name = first whitespace token of the header line WITH its '>' (perl -ane $F[0])  src/jasper.sh:155
+ *   jasper_asm_split         perl #1: chunk records ">name:offset" of <= batch_size bases at offsets 0, bs, 2bs ..; perl #2: batch files
+ *                            `$prefix.batch.N.fa`, a new one at a record once MORE than batch_size bases are in the current one
+ *                            (src/jasper.sh:155-156).  write_files != 0: the files (all, or only_files[0..n_only)) are written by a
+ *                            thread of the job while the caller goes on; jasper_asm_split_wait joins it and reports its failure
+ *                            ("Splitting files failed", src/jasper.sh:159).
+ *   jasper_asm_chunks        per record: contig index, offset, length, batch file (caller's arrays of n_chunks; any may be NULL)
+ *   jasper_asm_file_bytes    size of every batch file (what `ls -l` would show; dist.assign_chunks balances by it)
+ *   jasper_asm_chunk_text    a record's text: the input (polished = 0) or what jasper_asm_take kept (polished = 1)
+ *   jasper_asm_polish        jasper_polish_batch on the records of the listed batch files, read straight from the arena: one
+ *                            `jasper.py --query $prefix.batch.N.fa` process per listed file (src/jasper.sh:207-212); result chunk i =
+ *                            the i-th record of the files in list order
+ *   jasper_asm_take          moves the polished text out of the result into the job (for the two writers below)
+ *   jasper_asm_put           the polished text of one record given by the caller instead (read back from an `_iter*.fixed.fa` of
+ *                            an interrupted run; tests)
+ *   jasper_asm_write_fixed   `_iter{P-1}_<batch>.fixed.fa`: ">name:offset" + lines of 60            src/jasper.py:120-128,142-147
+ *   jasper_asm_polished_lens per record: length of the polished text held (0 if none), and whether it is held
+ *   jasper_asm_join          `$QUERY_FN.polished.fasta`: per contig ">name", its records in offset order on ONE line   src/jasper.sh:220
+ *                            (contigs in input order; the reference's order is perl's hash order).  all_lens: the polished length of
+ *                            EVERY record (NULL: this job holds them all).  mode 1 creates the file at its final size, mode 2 writes
+ *                            the records this job holds at their places (several processes, one per GPU, into one file), 3 = both. */
+typedef struct jasper_asm jasper_asm;
+int jasper_asm_open(const char *path, int threads, jasper_asm **out);
+void jasper_asm_close(jasper_asm *a);
+int jasper_asm_info(const jasper_asm *a, uint64_t *sequence_bytes, uint64_t *n_contigs, uint64_t *n_bases);
+int jasper_asm_contig(const jasper_asm *a, uint64_t i, const char **name, uint64_t *name_len, uint64_t *n_bases);
+int jasper_asm_split(jasper_asm *a, uint64_t batch_size, const char *prefix, const uint32_t *only_files, uint32_t n_only, int write_files, int threads,
+                     uint64_t *n_chunks, uint64_t *n_files);
+int jasper_asm_split_wait(jasper_asm *a);
+int jasper_asm_chunks(const jasper_asm *a, uint32_t *contig, uint64_t *ci, uint64_t *len, uint32_t *file);
+int jasper_asm_file_bytes(const jasper_asm *a, uint64_t *bytes);
+int jasper_asm_chunk_text(const jasper_asm *a, uint64_t chunk, int polished, const char **text, uint64_t *len);
+int jasper_asm_polish(jasper_table *t, jasper_asm *a, const uint32_t *files, uint32_t n_files, int solid_thre, int passes, int fix, jasper_result **out);
+int jasper_asm_take(jasper_asm *a, jasper_result *r, const uint32_t *files, uint32_t n_files);
+int jasper_asm_put(jasper_asm *a, uint64_t chunk, const char *text, uint64_t len);
+int jasper_asm_write_fixed(jasper_asm *a, const uint32_t *files, const char *const *out_paths, uint32_t n_files, int threads);
+int jasper_asm_polished_lens(const jasper_asm *a, uint64_t *lens, uint8_t *have);
+int jasper_asm_join(jasper_asm *a, const char *out_path, const uint64_t *all_lens, int mode, int threads);
 
 /* kernel timing for bench.py: HIP-event time of the last counting call on this table, and its launch count */
 int jasper_last_count_timing(jasper_table *t, double *kernel_ms, uint64_t *launches);

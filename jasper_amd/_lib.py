@@ -95,6 +95,21 @@ SYMBOLS = {
     "jasper_result_segments": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "jasper_result_retried": (C.c_int, [_P]),
     "jasper_result_free": (None, [_P]),
+    "jasper_asm_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
+    "jasper_asm_close": (None, [_P]),
+    "jasper_asm_info": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "jasper_asm_contig": (C.c_int, [_P, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "jasper_asm_split": (C.c_int, [_P, C.c_uint64, C.c_char_p, _P, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "jasper_asm_split_wait": (C.c_int, [_P]),
+    "jasper_asm_chunks": (C.c_int, [_P, _P, _P, _P, _P]),
+    "jasper_asm_file_bytes": (C.c_int, [_P, _P]),
+    "jasper_asm_chunk_text": (C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "jasper_asm_polish": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "jasper_asm_take": (C.c_int, [_P, _P, _P, C.c_uint32]),
+    "jasper_asm_put": (C.c_int, [_P, C.c_uint64, C.c_char_p, C.c_uint64]),
+    "jasper_asm_write_fixed": (C.c_int, [_P, _P, C.POINTER(C.c_char_p), C.c_uint32, C.c_int]),
+    "jasper_asm_polished_lens": (C.c_int, [_P, _P, _P]),
+    "jasper_asm_join": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int]),
     "jasper_last_count_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "jasper_last_count_stages": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
 }

@@ -377,7 +377,7 @@ def _write_histo(path, rows):
     os.replace(path + ".tmp", path)
 
 
-def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
+def _run_multi(o, rank, world, dev, batch_size, passes, kmer, job=None):
     """the stages of run() below with the work of one node's GPUs divided as SURVEY.md 8e says: every rank counts its byte
     ranges of the read files (or its record range of an existing database) into a local table, dist.shard_tables sums the
     counts by key owner, and every rank polishes its share of the batch files with lookups served from the owners' HBM.
@@ -415,19 +415,50 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
             error_exit(msg)
         return out
 
+    keep_fixed = bool(os.environ.get("JASPER_AMD_KEEP_INTERMEDIATES"))
+    job_split = job_polished = False
+    file_owner = None
+
+    def split_done():
+        """the job's batch files are complete on every rank (or "Splitting files failed" on all): jasper.split.success"""
+        if job_split and decide(lambda: not os.path.exists("jasper.split.success")):
+            together(job.split_wait, "Splitting files failed, do you have enough disk space?")
+            bar()
+            if is0:
+                if os.path.exists("jasper.correct.success"):
+                    os.remove("jasper.correct.success")
+                open("jasper.split.success", "w").close()
+
     if decide(lambda: not os.path.exists("jasper.split.success")):      # :152-159
+        log("Splitting query into batches for parallel execution")
+        # every rank holds the assembly in a job of its own (the same records and batch files everywhere: the plan is a function of
+        # the file and the batch size); a rank writes the batch files it will polish, on a thread, while the reads are counted --
+        # nobody splits alone behind a barrier.  Any rank without a job (not an ordinary FASTA): rank 0 splits in Python, as before.
+        use_job = bool(jdist.all_reduce_ints([1 if (job is not None and batch_size > 0 and job.n_contigs) else 0], device=dev, op="min")[0])
         if is0:
-            log("Splitting query into batches for parallel execution")
             for p in glob.glob("%s.batch.*.fa" % glob.escape(qfn)):
                 os.remove(p)
-            try:
-                split_batches(read_assembly(o.query), batch_size, qfn)
-            except OSError:
-                error_exit("Splitting files failed, do you have enough disk space?")
-            if os.path.exists("jasper.correct.success"):
-                os.remove("jasper.correct.success")
-            open("jasper.split.success", "w").close()
         bar()
+        if use_job:
+            def plan_and_write():
+                nonlocal file_owner
+                job.split(batch_size, qfn, write_files=False)
+                order = sorted(range(job.n_files), key=job.batch_file_name)                    # `ls` order, as the polishing stage lists them
+                own = jdist.assign_chunks([job.file_bytes[f] for f in order], world)
+                file_owner = {f: ow for f, ow in zip(order, own)}
+                job.split(batch_size, qfn, write_files=True, only_files=[f for f in order if file_owner[f] == rank])
+            together(plan_and_write, "Splitting files failed, do you have enough disk space?")
+            job_split = True
+        else:
+            if is0:
+                try:
+                    split_batches(read_assembly(o.query), batch_size, qfn)
+                except OSError:
+                    error_exit("Splitting files failed, do you have enough disk space?")
+                if os.path.exists("jasper.correct.success"):
+                    os.remove("jasper.correct.success")
+                open("jasper.split.success", "w").close()
+            bar()
 
     histo_file = "jfhisto%d.csv" % kmer
     counted = False
@@ -541,6 +572,7 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
             os.remove("jasper.correct.success")
     bar()
 
+    split_done()
     if decide(lambda: not os.path.exists("jasper.histo.success") or not (os.path.isfile(histo_file) and os.path.getsize(histo_file) > 0)):   # :187-193
         log("Computing K-mer histogram")
         if is0:
@@ -563,39 +595,90 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer):
             error_exit("Local min of kmer counts is smaller than 4. The input read data is not suitable for polishing.")
         thresh = int(open("threshold.txt").read().split()[0])
         log("Lower threshold for unreliable kmers is %d" % thresh)
-        batch_files = sorted(glob.glob("%s.batch.*.fa" % glob.escape(qfn)))   # `ls` order
-        owner = jdist.assign_chunks([os.path.getsize(bf) for bf in batch_files], world)
         group, group_bytes = [], 0
-
-        def flush_group():
-            if group:
-                polisher.main_many(group, kmer, True, True, table, thresh, passes)
-                for bf in group:
-                    os.replace("_iter%d_%s.fixed.fa.tmp" % (last_it, bf), "_iter%d_%s.fixed.fa" % (last_it, bf))
-                del group[:]
-        def polish_my_batches():
-            nonlocal group_bytes
-            for bf, ow in zip(batch_files, owner):
-                if ow != rank:
-                    continue
-                group.append(bf)
-                group_bytes += os.path.getsize(bf)
-                if group_bytes > (1 << 30):
-                    flush_group()
-                    group_bytes = 0
-            flush_group()
-        together(polish_my_batches, "Polishing failed")                          # :215
-        bar()
-        if is0:
-            if os.path.exists("jasper.join.success"):
+        if job_split:
+            # (as in run(): record text from the job's arena, polished text back into the job, no `_iter*.fixed.fa` unless asked for,
+            #  and jasper.correct.success only once the join below has made the polished FASTA)
+            def flush_group():
+                if group:
+                    polisher.main_many_job(job, list(group), kmer, True, True, table, thresh, passes, keep_fixed=keep_fixed)
+                    if keep_fixed:
+                        for f in group:
+                            bf = job.batch_file_name(f)
+                            os.replace("_iter%d_%s.fixed.fa.tmp" % (last_it, bf), "_iter%d_%s.fixed.fa" % (last_it, bf))
+                    del group[:]
+            def polish_my_batches():
+                nonlocal group_bytes
+                for f in sorted(range(job.n_files), key=job.batch_file_name):
+                    if file_owner[f] != rank:
+                        continue
+                    group.append(f)
+                    group_bytes += job.file_bytes[f]
+                    if group_bytes > (1 << 30):
+                        flush_group()
+                        group_bytes = 0
+                flush_group()
+            together(polish_my_batches, "Polishing failed")                          # :215
+            job_polished = True
+            bar()
+            if is0 and os.path.exists("jasper.join.success"):
                 os.remove("jasper.join.success")
-            open("jasper.correct.success", "w").close()
-        bar()
+            bar()
+        else:
+            batch_files = sorted(glob.glob("%s.batch.*.fa" % glob.escape(qfn)))   # `ls` order
+            owner = jdist.assign_chunks([os.path.getsize(bf) for bf in batch_files], world)
+
+            def flush_group():
+                if group:
+                    polisher.main_many(group, kmer, True, True, table, thresh, passes)
+                    for bf in group:
+                        os.replace("_iter%d_%s.fixed.fa.tmp" % (last_it, bf), "_iter%d_%s.fixed.fa" % (last_it, bf))
+                    del group[:]
+            def polish_my_batches():
+                nonlocal group_bytes
+                for bf, ow in zip(batch_files, owner):
+                    if ow != rank:
+                        continue
+                    group.append(bf)
+                    group_bytes += os.path.getsize(bf)
+                    if group_bytes > (1 << 30):
+                        flush_group()
+                        group_bytes = 0
+                flush_group()
+            together(polish_my_batches, "Polishing failed")                          # :215
+            bar()
+            if is0:
+                if os.path.exists("jasper.join.success"):
+                    os.remove("jasper.join.success")
+                open("jasper.correct.success", "w").close()
+            bar()
 
     if decide(lambda: not os.path.exists("jasper.join.success")):       # :218-232
         _timing("polish batches")
         log("Joining")
-        if is0:
+        if job_polished:
+            # every rank writes the records it polished straight into their places of ONE file: a record's place follows from the
+            # polished lengths of the records before it (a sum over ranks of a short vector), so no text moves between ranks and
+            # nobody reads the assembly or the fixed files again (src/jasper.sh:220)
+            lens, have = job.polished_lens()
+            all_lens = jdist.all_reduce_ints([int(v) for v in lens], device=dev)
+            held = jdist.all_reduce_ints([int(v) for v in have], device=dev)
+            tmp = qfn + ".fixed.fasta.tmp"
+
+            def create():
+                if min(held, default=1) != 1 or max(held, default=1) != 1:
+                    raise RuntimeError("a chunk record was polished by no rank, or by two")
+                if is0:
+                    job.join(tmp, all_lens=all_lens, mode=1)
+            together(create, "Joining failed")
+            bar()
+            together(lambda: job.join(tmp, all_lens=all_lens, mode=2), "Joining failed")
+            bar()
+            if is0:
+                os.replace(tmp, qfn + ".polished.fasta")
+                open("jasper.correct.success", "w").close()
+                _join_and_merge(o, qfn, batch_size, last_it, None, fasta_done=True)
+        elif is0:
             _join_and_merge(o, qfn, batch_size, last_it, read_assembly(o.query))
         bar()
     if is0:
@@ -714,13 +797,14 @@ def _jf_write_fits_beside_polishing(table, device, qfn):
     return need < free.value
 
 
-def _join_and_merge(o, qfn, batch_size, last_it, contigs):
-    """src/jasper.sh:218-232"""
-    fixed_files = sorted(glob.glob("_iter%d_%s.batch.*.fa.fixed.fa" % (last_it, glob.escape(qfn))))
-    text = join_polished(fixed_files, batch_size, [c[0] for c in contigs])
-    with open(qfn + ".fixed.fasta.tmp", "w") as f:
-        f.write(text)
-    os.replace(qfn + ".fixed.fasta.tmp", qfn + ".polished.fasta")
+def _join_and_merge(o, qfn, batch_size, last_it, contigs, fasta_done=False):
+    """src/jasper.sh:218-232 (fasta_done: the polished FASTA is already in place, written from an AssemblyJob)"""
+    if not fasta_done:
+        fixed_files = sorted(glob.glob("_iter%d_%s.batch.*.fa.fixed.fa" % (last_it, glob.escape(qfn))))
+        text = join_polished(fixed_files, batch_size, [c[0] for c in contigs])
+        with open(qfn + ".fixed.fasta.tmp", "w") as f:
+            f.write(text)
+        os.replace(qfn + ".fixed.fasta.tmp", qfn + ".polished.fasta")
     for p in glob.glob("_iter*_%s.batch.*.fa.fixed.fa" % glob.escape(qfn)) + glob.glob("_iter*_%s.batch.*.fa.fixed.fa.tmp" % glob.escape(qfn)):
         os.remove(p)
     csvs = sorted(glob.glob("_iter*_%s.batch.*.fa.fix.csv" % glob.escape(qfn)))
@@ -808,9 +892,19 @@ def run(argv):
         log("BATCH SIZE supplied is not a positive integer. Calculating BATCH SIZE from QUERY SIZE")
         batch_size = "0"
     batch_size = int(batch_size)
+    # The assembly is read ONCE, natively and by several threads, into a host arena that the split, the polisher and the join all
+    # work from (assembly.AssemblyJob); a file that is not an ordinary FASTA -- '\r', blanks in sequence lines, non-ASCII bytes,
+    # text before the first '>', a name that occurs twice -- gives None and takes the line-by-line rules below, in Python.
+    job = None
+    if not os.environ.get("JASPER_AMD_NO_NATIVE_ASM"):
+        try:
+            from .assembly import AssemblyJob
+            job = AssemblyJob.open(o.query)
+        except Exception:           # noqa: BLE001 -- no library: the table's constructor reports it
+            job = None
     try:
         nthreads = float(o.num_threads)
-        bs = int(sequence_bytes(o.query) / nthreads * .9)               # :132
+        bs = int((job.sequence_bytes if job is not None else sequence_bytes(o.query)) / nthreads * .9)               # :132
     except (ValueError, ZeroDivisionError):
         error_exit("The number of threads supplied by -t must be a positive integer")
     if bs > batch_size:                                                 # :133-138
@@ -828,22 +922,45 @@ def run(argv):
     qfn = o.query_fn
     contigs = None
     if multi:
-        return _run_multi(o, rank, world, dev, batch_size, passes, kmer)
+        return _run_multi(o, rank, world, dev, batch_size, passes, kmer, job)
 
     jf_writer = None
+    keep_fixed = bool(os.environ.get("JASPER_AMD_KEEP_INTERMEDIATES"))
+    job_split = False          # the batch files are the job's (being written by its thread until _split_done())
+    job_polished = False       # the polished records are in the job's memory
+
+    def _split_done():
+        nonlocal job_split
+        if job_split and not os.path.exists("jasper.split.success"):
+            try:
+                job.split_wait()
+            except Exception:           # noqa: BLE001 -- a full disk, a directory that went away
+                error_exit("Splitting files failed, do you have enough disk space?")
+            if os.path.exists("jasper.correct.success"):
+                os.remove("jasper.correct.success")
+            open("jasper.split.success", "w").close()
 
     if not os.path.exists("jasper.split.success"):                      # :152-159
         log("Splitting query into batches for parallel execution")
         for p in glob.glob("%s.batch.*.fa" % glob.escape(qfn)):
             os.remove(p)
-        try:
-            contigs = read_assembly(o.query)
-            split_batches(contigs, batch_size, qfn)
-        except OSError:
-            error_exit("Splitting files failed, do you have enough disk space?")
-        if os.path.exists("jasper.correct.success"):
-            os.remove("jasper.correct.success")
-        open("jasper.split.success", "w").close()
+        if job is not None and batch_size > 0 and job.n_contigs:
+            # perl #1 + perl #2 on the arena; the files are written by a thread of the job while the reads are counted, and
+            # jasper.split.success appears when they are complete (_split_done, before "Polishing")
+            try:
+                job.split(batch_size, qfn, write_files=True)
+            except Exception:           # noqa: BLE001
+                error_exit("Splitting files failed, do you have enough disk space?")
+            job_split = True
+        else:
+            try:
+                contigs = read_assembly(o.query)
+                split_batches(contigs, batch_size, qfn)
+            except OSError:
+                error_exit("Splitting files failed, do you have enough disk space?")
+            if os.path.exists("jasper.correct.success"):
+                os.remove("jasper.correct.success")
+            open("jasper.split.success", "w").close()
 
     table = None
     histo_file = "jfhisto%d.csv" % kmer
@@ -906,6 +1023,7 @@ def run(argv):
             error_exit("Computing mer counts histogram from %s failed, please make sure that %s is a valid Jellyfish mer counts file (%s)"
                        % (o.jf_db, o.jf_db, e))
 
+    _split_done()
     if not os.path.exists("jasper.histo.success") or not (os.path.isfile(histo_file) and os.path.getsize(histo_file) > 0):   # :187-193
         log("Computing K-mer histogram")
         with open(histo_file + ".tmp", "w") as f:
@@ -928,37 +1046,70 @@ def run(argv):
             error_exit("Local min of kmer counts is smaller than 4. The input read data is not suitable for polishing.")
         thresh = int(open("threshold.txt").read().split()[0])
         log("Lower threshold for unreliable kmers is %d" % thresh)
-        batch_files = sorted(glob.glob("%s.batch.*.fa" % glob.escape(qfn)))   # `ls` order
         # the reference starts one jasper.py process per batch file (:207-212); chunk records are independent, so all
         # files go through the GPU in groups (<= ~1 Gbase of text per call) and leave the same per-file artefacts
         group, group_bytes = [], 0
-        def flush_group():
-            if group:
-                polisher.main_many(group, kmer, True, True, table, thresh, passes)
-                for bf in group:
-                    os.replace("_iter%d_%s.fixed.fa.tmp" % (last_it, bf), "_iter%d_%s.fixed.fa" % (last_it, bf))
-                del group[:]
-        for bf in batch_files:
-            group.append(bf)
-            group_bytes += os.path.getsize(bf)
-            if group_bytes > (1 << 30):
-                flush_group()
-                group_bytes = 0
-        flush_group()
-        if os.path.exists("jasper.join.success"):
-            os.remove("jasper.join.success")
-        open("jasper.correct.success", "w").close()
+        if job_split:
+            # the job's own batch files, in `ls` order; record text goes from the arena to the GPU and the polished text back into
+            # the job.  The `_iter*.fixed.fa` files have one reader, the join below, which then works from memory: they are not
+            # written (JASPER_AMD_KEEP_INTERMEDIATES=1 writes them), and so jasper.correct.success -- "the fixed files are
+            # complete" -- appears only once the join has made the polished FASTA from them (a run that dies in between starts the
+            # polishing over instead of joining files that are not there).
+            def flush_group():
+                if group:
+                    polisher.main_many_job(job, list(group), kmer, True, True, table, thresh, passes, keep_fixed=keep_fixed)
+                    if keep_fixed:
+                        for f in group:
+                            bf = job.batch_file_name(f)
+                            os.replace("_iter%d_%s.fixed.fa.tmp" % (last_it, bf), "_iter%d_%s.fixed.fa" % (last_it, bf))
+                    del group[:]
+            for f in sorted(range(job.n_files), key=job.batch_file_name):
+                group.append(f)
+                group_bytes += job.file_bytes[f]
+                if group_bytes > (1 << 30):
+                    flush_group()
+                    group_bytes = 0
+            flush_group()
+            job_polished = True
+            if os.path.exists("jasper.join.success"):
+                os.remove("jasper.join.success")
+        else:
+            batch_files = sorted(glob.glob("%s.batch.*.fa" % glob.escape(qfn)))   # `ls` order
+            def flush_group():
+                if group:
+                    polisher.main_many(group, kmer, True, True, table, thresh, passes)
+                    for bf in group:
+                        os.replace("_iter%d_%s.fixed.fa.tmp" % (last_it, bf), "_iter%d_%s.fixed.fa" % (last_it, bf))
+                    del group[:]
+            for bf in batch_files:
+                group.append(bf)
+                group_bytes += os.path.getsize(bf)
+                if group_bytes > (1 << 30):
+                    flush_group()
+                    group_bytes = 0
+            flush_group()
+            if os.path.exists("jasper.join.success"):
+                os.remove("jasper.join.success")
+            open("jasper.correct.success", "w").close()
 
     if not os.path.exists("jasper.join.success"):                       # :218-232
         _timing("polish batches")
         log("Joining")
-        if contigs is None:
-            contigs = read_assembly(o.query)
-        fixed_files = sorted(glob.glob("_iter%d_%s.batch.*.fa.fixed.fa" % (last_it, glob.escape(qfn))))
-        text = join_polished(fixed_files, batch_size, [c[0] for c in contigs])
-        with open(qfn + ".fixed.fasta.tmp", "w") as f:
-            f.write(text)
-        os.replace(qfn + ".fixed.fasta.tmp", qfn + ".polished.fasta")
+        if job_polished:
+            try:
+                job.join(qfn + ".fixed.fasta.tmp")
+            except Exception:           # noqa: BLE001
+                error_exit("Joining failed")
+            os.replace(qfn + ".fixed.fasta.tmp", qfn + ".polished.fasta")
+            open("jasper.correct.success", "w").close()
+        else:
+            if contigs is None:
+                contigs = read_assembly(o.query)
+            fixed_files = sorted(glob.glob("_iter%d_%s.batch.*.fa.fixed.fa" % (last_it, glob.escape(qfn))))
+            text = join_polished(fixed_files, batch_size, [c[0] for c in contigs])
+            with open(qfn + ".fixed.fasta.tmp", "w") as f:
+                f.write(text)
+            os.replace(qfn + ".fixed.fasta.tmp", qfn + ".polished.fasta")
         for p in glob.glob("_iter*_%s.batch.*.fa.fixed.fa" % glob.escape(qfn)) + glob.glob("_iter*_%s.batch.*.fa.fixed.fa.tmp" % glob.escape(qfn)):
             os.remove(p)
         csvs = sorted(glob.glob("_iter*_%s.batch.*.fa.fix.csv" % glob.escape(qfn)))

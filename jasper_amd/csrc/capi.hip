@@ -4,6 +4,7 @@
 #include "polish_host.hpp"
 #include "table.hpp"
 #include "pgunzip.hpp"
+#include "asmio.hpp"
 #include <zlib.h>
 #include <algorithm>
 #include <cmath>
@@ -14,6 +15,7 @@
 using namespace jk;
 
 static thread_local std::string g_err;
+std::string &jasper_err_ref() { return g_err; }
 
 struct jasper_result;
 struct jasper_table {
@@ -503,6 +505,43 @@ int jasper_polish_batch_device(jasper_table *t, int n_chunks, const void *d_text
         lens[c] = offsets[c + 1] - offsets[c];
     }
     return polish_common(t, n_chunks, ptrs.data(), lens.data(), solid_thre, passes, fix, true, out);
+}
+
+// the chunk records of the listed batch files of a split assembly (asmio.cpp), straight from the job's arena; result chunk i is
+// the i-th record of the files in list order
+static int asm_records(const jasper_asm *a, const uint32_t *files, uint32_t n_files, std::vector<size_t> &recs) {
+    if (!a || (n_files && !files)) { g_err = "bad arguments"; return JASPER_ERR; }
+    for (uint32_t i = 0; i < n_files; ++i) {
+        if ((size_t)files[i] + 1 >= a->file_first.size()) { g_err = "batch file out of range"; return JASPER_ERR; }
+        for (size_t c = a->file_first[files[i]]; c < a->file_first[files[i] + 1]; ++c) recs.push_back(c);
+    }
+    return JASPER_OK;
+}
+
+int jasper_asm_polish(jasper_table *t, jasper_asm *a, const uint32_t *files, uint32_t n_files, int solid_thre, int passes, int fix, jasper_result **out) {
+    std::vector<size_t> recs;
+    if (int rc = asm_records(a, files, n_files, recs)) return rc;
+    if (recs.size() > (size_t)INT32_MAX) { g_err = "too many chunk records for one call"; return JASPER_ERR; }
+    std::vector<const char *> ptrs(recs.size());
+    std::vector<int64_t> lens(recs.size());
+    for (size_t i = 0; i < recs.size(); ++i) {
+        const AsmChunk &ch = a->chunks[recs[i]];
+        ptrs[i] = (const char *)a->arena + a->contigs[ch.contig].seq_off + ch.ci;
+        lens[i] = (int64_t)ch.len;
+    }
+    return polish_common(t, (int)recs.size(), ptrs.data(), lens.data(), solid_thre, passes, fix, false, out);
+}
+
+int jasper_asm_take(jasper_asm *a, jasper_result *r, const uint32_t *files, uint32_t n_files) {
+    std::vector<size_t> recs;
+    if (int rc = asm_records(a, files, n_files, recs)) return rc;
+    if (!r || r->seqs.size() != recs.size()) { g_err = "the result is not the one of these batch files"; return JASPER_ERR; }
+    if (r->owner && result_fetch(r)) return JASPER_ERR;
+    for (size_t i = 0; i < recs.size(); ++i) {
+        a->polished[recs[i]].swap(r->seqs[i]);
+        a->have[recs[i]] = 1;
+    }
+    return JASPER_OK;
 }
 
 int jasper_result_num_chunks(const jasper_result *r) { return (int)r->seqs.size(); }

@@ -315,6 +315,64 @@ def main_many(query_paths, k, test, fix, db, thre, num_iter):
         sys.exit(1)
 
 
+def main_many_job(job, files, k, test, fix, db, thre, num_iter, keep_fixed=False):
+    """main_many() for batch files of an assembly.AssemblyJob (numbers in `files`): the record text goes from the job's arena to the
+    GPU and the polished text back into the job (job.take) without becoming Python objects; what is left per file is what
+    main_many leaves -- `_iter{i}_<file>.fix.csv`, one line per file in {0,P}qValCalcHelper.csv -- except that
+    `_iter{P-1}_<file>.fixed.fa.tmp` is written (natively, src/jasper.py:120-128) only when keep_fixed: its one reader is the join
+    (src/jasper.sh:220), which a job does from memory."""
+    try:
+        if not isinstance(db, KmerTable):
+            raise TypeError("db must be a jasper_amd.KmerTable resident in HBM")
+        do_fix = bool(fix)
+        res = job.polish(db, files, thre, num_iter, fix=do_fix)
+        recs = job.records_of(files)                  # result chunk i = record recs[i]
+        rows_by_chunk = {}
+        if do_fix:
+            for r in res.records:
+                rows_by_chunk.setdefault((r["pass_"], r["chunk"]), []).append((r["seqno"], rows_from_record(job.chunk_name(recs[r["chunk"]]), r)))
+        at = 0
+        outs = []
+        for f in files:
+            n = job.file_first[f + 1] - job.file_first[f]
+            qp = job.batch_file_name(f)
+            if test:                                                            # :107-111, one line per process
+                q = [0, 0, 0, 0]
+                for c in range(at, at + n):
+                    q = [a + b for a, b in zip(q, res.qv_chunk(c))]
+                with open("0qValCalcHelper.csv", 'a') as fh:
+                    fh.write("{} {}\n".format(q[0], q[1]))
+                if num_iter != 0:
+                    with open(str(num_iter) + "qValCalcHelper.csv", 'a') as fh:
+                        fh.write("{} {}\n".format(q[2], q[3]))
+            if do_fix:
+                fo = os.path.split(qp + ".fix.csv")
+                for ite in range(num_iter):
+                    flat = []
+                    for c in range(at, at + n):
+                        for _, rr in sorted(rows_by_chunk.get((ite, c), []), key=lambda x: x[0]):
+                            flat.extend(rr)
+                    with open(fo[0] + "_iter" + str(ite) + "_" + fo[1], 'w', newline='') as csvf:
+                        csvf.write(fix_csv_text(flat))
+                ff = os.path.split(qp + ".fixed.fa.tmp")
+                outs.append(ff[0] + "_iter" + str(num_iter - 1) + "_" + ff[1])
+            at += n
+        if do_fix:
+            job.take(res, files)
+            if keep_fixed:
+                job.write_fixed(files, outs)
+        return outs
+    except SystemExit:
+        raise
+    except BaseException:
+        # what the reference's bare `except` leaves on stdout -- the line number, then the exc_info triple -- and exit status 1
+        # (src/jasper.py:27-32; jasper.sh only looks at the status)
+        info = sys.exc_info()
+        print(info[2].tb_lineno)
+        print(info)
+        sys.exit(1)
+
+
 def threshold_from_histo_rows(rows):
     """The solid-k-mer threshold rule of src/jellyfish.py:8-22, on histogram rows (multiplicity, ..., n_distinct).
 
