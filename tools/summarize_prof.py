@@ -60,12 +60,27 @@ out["counting_pipeline"] = {"steps_profiled": steps, "hbm_bytes_per_step": tot_k
                             "fetch_bytes_per_step_as_reported": fetch_kb * 1024.0 / steps, "write_bytes_per_step": write_kb * 1024.0 / steps,
                             "note": "part1 + part2 + region_insert (+ deferred import): FETCH_SIZE + WRITE_SIZE as reported by rocprofv3, and the "
                                     "corrected figure 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B read requests at 64 B)"}
+# the polishing kernels, per polish CALL: a table polishes in several lanes from its second call on, so no kernel's dispatch count is
+# the number of calls; the profiled process says how many it made (bench.py: warm-up + timed steps + the untimed host-buffer calls)
+pk = ("scan_classify_batch", "find_sync_batch", "find_clean_batch", "seg_init", "seg_walk", "seg_summary", "seg_gather", "seg_stitch", "rescan_batch")
+calls = steps + 3
+try:
+    calls = int(json.loads(open(os.path.join(src, "trace_run.json")).read().strip().splitlines()[-1])["polish_calls_in_process"])
+except Exception:
+    pass
+pf = sum(v["sum_KB"] for k, v in out["FETCH_SIZE"].items() if k.startswith(tuple("jk::%s_kernel" % n for n in pk)))
+pw = sum(v["sum_KB"] for k, v in out["WRITE_SIZE"].items() if k.startswith(tuple("jk::%s_kernel" % n for n in pk)))
+out["polishing"] = {"polish_calls_profiled": calls, "fetch_bytes_per_call_as_reported": pf * 1024.0 / calls, "write_bytes_per_call": pw * 1024.0 / calls,
+                    "hbm_bytes_per_call": (pf + pw) * 1024.0 / calls,
+                    "note": "FETCH_SIZE + WRITE_SIZE of the polishing kernels as reported, divided by the polish CALLS of the profiled process (their reads "
+                            "are mostly 16-byte slot probes that each bring a 64-byte sector: not the wide streaming reads whose FETCH_SIZE gfx950 halves)"}
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jasper_amd._lib import kernel_source_digest
 out["kernel_source_sha256"] = kernel_source_digest()      # bench.py cites these counters only while the sources are the same
 json.dump(out, open(os.path.join(dst, "bench_hbm_counters.json"), "w"), indent=1)
 for r in rows[:14]:
     print("%-34s calls %4s avg %10.1f us" % (short(r["Name"])[:34], r["Calls"], float(r["AverageNs"]) / 1e3))
+print("polishing: %.2f GB per call over %d calls" % (out["polishing"]["hbm_bytes_per_call"] / 1e9, calls))
 print("counting pipeline: %.2f GB HBM traffic per step as reported, %.2f GB corrected" % (out["counting_pipeline"]["hbm_bytes_per_step"] / 1e9, out["counting_pipeline"]["hbm_bytes_per_step_corrected"] / 1e9))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in out[c].items():
