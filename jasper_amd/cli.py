@@ -749,6 +749,29 @@ class _EarlyTable:
         return self.out
 
 
+class _JobJoin:
+    """job.join(tmp) by a thread (src/jasper.sh:220 from the job's memory; the library call releases the GIL); finish() waits and
+    raises what the thread raised"""
+
+    def __init__(self, job, tmp):
+        import threading
+        self.err = None
+
+        def work():
+            try:
+                job.join(tmp)
+            except BaseException as e:          # noqa: BLE001 -- handed to the caller of finish()
+                self.err = e
+
+        self.th = threading.Thread(target=work, daemon=True)
+        self.th.start()
+
+    def finish(self):
+        self.th.join()
+        if self.err is not None:
+            raise self.err
+
+
 class _JfWriter:
     """table.write_jf(tmp) + rename to `final`, by a thread, while the caller goes on to the histogram and the polishing (the
     database file is `tee`'s by-product in the reference, src/jasper.sh:177: nothing in the same run reads it, and writing 14 bytes
@@ -778,7 +801,7 @@ class _JfWriter:
             raise self.err
 
 
-def _jf_write_fits_beside_polishing(table, device, qfn):
+def _jf_write_fits_beside_polishing(table, device, qfn, text_bytes=None):
     """does the device have room for table.write_jf (entries + keys for the sort + the sort's temporaries + the formatted
     records: ~64 bytes per distinct k-mer, measured 48 + rocPRIM's temporaries) AND the polisher's workspaces for the largest group
     of batch files (two text arenas, classes, segment buffers, records: ~8 bytes per base of a group of <= 1 Gbase) at once?"""
@@ -788,7 +811,7 @@ def _jf_write_fits_beside_polishing(table, device, qfn):
     try:
         _lib.check(_lib.lib().jasper_device_mem_info(int(device), C.byref(free), C.byref(total)))
         distinct = table.info()["distinct"]
-        text = sum(os.path.getsize(p) for p in glob.glob("%s.batch.*.fa" % glob.escape(qfn)))
+        text = text_bytes if text_bytes is not None else sum(os.path.getsize(p) for p in glob.glob("%s.batch.*.fa" % glob.escape(qfn)))
     except Exception:                                  # noqa: BLE001 -- no answer: the safe order
         return False
     need = 64 * distinct + 8 * min(text, 1 << 30) + (2 << 30)
@@ -928,6 +951,7 @@ def run(argv):
     keep_fixed = bool(os.environ.get("JASPER_AMD_KEEP_INTERMEDIATES"))
     job_split = False          # the batch files are the job's (being written by its thread until _split_done())
     job_polished = False       # the polished records are in the job's memory
+    join_writer = []           # [_JobJoin]: the polished FASTA being written from them
 
     def _split_done():
         nonlocal job_split
@@ -1002,7 +1026,7 @@ def run(argv):
                 # its sort's workspace, the polisher several times its batch's text); otherwise first the file, then the polishing,
                 # as the reference orders them.
                 jf_cmdline = ["count", "-C", "-t", str(o.num_threads), "-s", str(o.jf_size), "-m", str(kmer), "-o", jf_file] + reads
-                if _jf_write_fits_beside_polishing(table, o.device, qfn):
+                if _jf_write_fits_beside_polishing(table, o.device, qfn, sum(job.file_bytes) if job_split else None):      # (the job's files may still be being written)
                     jf_writer = _JfWriter(table, jf_file + ".tmp", jf_file, jf_cmdline)
                 else:
                     try:
@@ -1055,24 +1079,27 @@ def run(argv):
             # written (JASPER_AMD_KEEP_INTERMEDIATES=1 writes them), and so jasper.correct.success -- "the fixed files are
             # complete" -- appears only once the join has made the polished FASTA from them (a run that dies in between starts the
             # polishing over instead of joining files that are not there).
-            def flush_group():
-                if group:
-                    polisher.main_many_job(job, list(group), kmer, True, True, table, thresh, passes, keep_fixed=keep_fixed)
-                    if keep_fixed:
-                        for f in group:
-                            bf = job.batch_file_name(f)
-                            os.replace("_iter%d_%s.fixed.fa.tmp" % (last_it, bf), "_iter%d_%s.fixed.fa" % (last_it, bf))
-                    del group[:]
+            groups = [[]]
             for f in sorted(range(job.n_files), key=job.batch_file_name):
-                group.append(f)
+                groups[-1].append(f)
                 group_bytes += job.file_bytes[f]
                 if group_bytes > (1 << 30):
-                    flush_group()
+                    groups.append([])
                     group_bytes = 0
-            flush_group()
-            job_polished = True
+            groups = [g for g in groups if g]
             if os.path.exists("jasper.join.success"):
                 os.remove("jasper.join.success")
+            for gi, g in enumerate(groups):
+                # (the moment the last group's polished text is in the job, a thread starts writing the polished FASTA from it,
+                #  src/jasper.sh:220, while this one still turns fix records into CSV rows)
+                last = gi == len(groups) - 1
+                polisher.main_many_job(job, g, kmer, True, True, table, thresh, passes, keep_fixed=keep_fixed,
+                                       on_taken=(lambda: join_writer.append(_JobJoin(job, qfn + ".fixed.fasta.tmp"))) if last else None)
+                if keep_fixed:
+                    for f in g:
+                        bf = job.batch_file_name(f)
+                        os.replace("_iter%d_%s.fixed.fa.tmp" % (last_it, bf), "_iter%d_%s.fixed.fa" % (last_it, bf))
+            job_polished = True
         else:
             batch_files = sorted(glob.glob("%s.batch.*.fa" % glob.escape(qfn)))   # `ls` order
             def flush_group():
@@ -1097,11 +1124,15 @@ def run(argv):
         log("Joining")
         if job_polished:
             try:
-                job.join(qfn + ".fixed.fasta.tmp")
+                if join_writer:
+                    join_writer[0].finish()
+                else:
+                    job.join(qfn + ".fixed.fasta.tmp")
             except Exception:           # noqa: BLE001
                 error_exit("Joining failed")
             os.replace(qfn + ".fixed.fasta.tmp", qfn + ".polished.fasta")
             open("jasper.correct.success", "w").close()
+            _timing("  polished FASTA complete")
         else:
             if contigs is None:
                 contigs = read_assembly(o.query)

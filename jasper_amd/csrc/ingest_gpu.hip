@@ -429,6 +429,9 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
     const bool dbg_t = getenv("JASPER_COUNT_DEBUG") != nullptr;
     auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t_in = now_ms();
+    // tools/probes/ingest_stages.py: stop after a stage of the chunk loop so that the stages can be timed one on top of the other --
+    // 1: file -> pinned buffer only, 2: + the copy to the device, 3: + the parsing kernels (bases not counted); 0 / unset: everything
+    const int probe_stage = getenv("JASPER_INGEST_STAGE") ? atoi(getenv("JASPER_INGEST_STAGE")) : 0;
     HIPCHK(hipSetDevice(device));
     // sizes follow the input (pinning and device allocation cost ~0.1 ms per MB): text chunk <= 128 MiB (+ carry), device
     // base buffer <= 3 GiB (counted and emptied whenever it is that full)
@@ -500,7 +503,7 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
     auto flush_bases = [&]() -> int {
         if (!bases_len) return 0;
         if (dbg_t) fprintf(stderr, "[ingest] %.1f ms after the call: %llu bases to the counter\n", now_ms() - t_in, (unsigned long long)bases_len);
-        const int rc = bases_sink ? bases_sink(d_bases, bases_len) : count_device(d_bases, bases_len, err);
+        const int rc = probe_stage ? 0 : bases_sink ? bases_sink(d_bases, bases_len) : count_device(d_bases, bases_len, err);
         if (dbg_t) fprintf(stderr, "[ingest] %.1f ms after the call: counted\n", now_ms() - t_in);
         bases_len = 0;
         return rc;
@@ -605,7 +608,9 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
             pf_active = true;
             pf = std::thread([&rd, &pf_got, dst, CHUNK] { pf_got = rd.read(dst, CHUNK); });
         }
+        if (probe_stage == 1) { n_gpu += n; carry = 0; continue; }
         HIPCHK(hipMemcpyAsync(d_text, h_buf, n, hipMemcpyHostToDevice, stream));
+        if (probe_stage == 2) { HIPCHK(jk_stream_wait(stream)); n_gpu += n; carry = 0; continue; }
         HIPCHK(hipMemsetAsync(d_flags, 0, 8, stream));
         const uint32_t nblk = (uint32_t)((n + IG_BYTES - 1) / IG_BYTES);
         hipLaunchKernelGGL(ig_count_nl_kernel, dim3(nblk), dim3(IG_THREADS), 0, stream, d_text, (uint64_t)n, d_blk_nl, d_flags);

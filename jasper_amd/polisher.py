@@ -315,7 +315,7 @@ def main_many(query_paths, k, test, fix, db, thre, num_iter):
         sys.exit(1)
 
 
-def main_many_job(job, files, k, test, fix, db, thre, num_iter, keep_fixed=False):
+def main_many_job(job, files, k, test, fix, db, thre, num_iter, keep_fixed=False, on_taken=None):
     """main_many() for batch files of an assembly.AssemblyJob (numbers in `files`): the record text goes from the job's arena to the
     GPU and the polished text back into the job (job.take) without becoming Python objects; what is left per file is what
     main_many leaves -- `_iter{i}_<file>.fix.csv`, one line per file in {0,P}qValCalcHelper.csv -- except that
@@ -325,12 +325,26 @@ def main_many_job(job, files, k, test, fix, db, thre, num_iter, keep_fixed=False
         if not isinstance(db, KmerTable):
             raise TypeError("db must be a jasper_amd.KmerTable resident in HBM")
         do_fix = bool(fix)
+        import time
+        tm = [time.perf_counter()]
+
+        def mark(what):
+            if os.environ.get("JASPER_AMD_TIMING"):
+                now = time.perf_counter()
+                sys.stderr.write("[timing-polish] %-34s %.3f s\n" % (what, now - tm[0]))
+                tm[0] = now
         res = job.polish(db, files, thre, num_iter, fix=do_fix)
+        mark("GPU call (%d files, device %.3f s)" % (len(files), res.seconds))
+        if do_fix:
+            job.take(res, files)
+            if on_taken is not None:
+                on_taken()          # (the caller may start writing the polished text while the rows below are made)
         recs = job.records_of(files)                  # result chunk i = record recs[i]
         rows_by_chunk = {}
         if do_fix:
             for r in res.records:
                 rows_by_chunk.setdefault((r["pass_"], r["chunk"]), []).append((r["seqno"], rows_from_record(job.chunk_name(recs[r["chunk"]]), r)))
+        mark("fix records -> rows (%d)" % res.n_records)
         at = 0
         outs = []
         for f in files:
@@ -357,10 +371,10 @@ def main_many_job(job, files, k, test, fix, db, thre, num_iter, keep_fixed=False
                 ff = os.path.split(qp + ".fixed.fa.tmp")
                 outs.append(ff[0] + "_iter" + str(num_iter - 1) + "_" + ff[1])
             at += n
-        if do_fix:
-            job.take(res, files)
-            if keep_fixed:
-                job.write_fixed(files, outs)
+        mark("QV lines + fix CSVs")
+        if do_fix and keep_fixed:
+            job.write_fixed(files, outs)
+            mark("fixed files")
         return outs
     except SystemExit:
         raise
