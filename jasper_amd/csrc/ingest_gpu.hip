@@ -433,6 +433,12 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
     // 1: file -> pinned buffer only, 2: + the copy to the device, 3: + the parsing kernels (bases not counted); 0 / unset: everything
     const int probe_stage = getenv("JASPER_INGEST_STAGE") ? atoi(getenv("JASPER_INGEST_STAGE")) : 0;
     HIPCHK(hipSetDevice(device));
+    // the reader's copies and kernels have a stream of their own: a full buffer of bases is counted on the table's stream (by a thread
+    // of its own, below) while the next buffer is being read and parsed here
+    if (!ingest_stream) HIPCHK(hipStreamCreateWithFlags(&ingest_stream, hipStreamNonBlocking));
+    hipStream_t const table_stream = this->stream;
+    (void)table_stream;
+    hipStream_t const stream = ingest_stream;         // (every use of `stream` below is the reader's)
     // sizes follow the input (pinning and device allocation cost ~0.1 ms per MB): text chunk <= 128 MiB (+ carry), device
     // base buffer <= 3 GiB (counted and emptied whenever it is that full)
     uint64_t est = 0;
@@ -486,6 +492,30 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
     bool pf_active = false;
     uint8_t *d_text = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 0, 2 * CHUNK + 64, err));
     uint8_t *d_bases = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 1, BASES_CAP + 2 * CHUNK + 64, err));
+    // An input of more than one buffer of bases: TWO buffers, and the counting of a full one is a thread's business (count_device
+    // waits for its kernels, reads their statistics, grows the table) while this thread goes on reading, copying and parsing into
+    // the other -- files -> bases and bases -> table are two pipeline stages instead of taking turns (tools/probes/ingest_stages.py:
+    // 33 GB/s of text for the first alone, 28 with the counting of a 2^29-slot table in between, less with a larger table).
+    uint8_t *d_bases_two[2] = {d_bases, nullptr};
+    int bases_cur = 0;
+    const bool two_buffers = !bases_sink && !probe_stage && est_bases > BASES_CAP && !getenv("JASPER_INGEST_ONE_BUFFER");
+    if (two_buffers) {
+        d_bases_two[1] = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 6, BASES_CAP + 2 * CHUNK + 64, err));
+        if (!d_bases_two[1]) return -1;
+    }
+    std::thread counter;
+    bool counter_active = false;
+    int counter_rc = 0;
+    std::string counter_err;
+    auto drain = [&]() -> int {              // the buffer handed to the counter has been counted
+        if (counter_active) {
+            counter.join();
+            counter_active = false;
+            if (counter_rc) { err = counter_err; return counter_rc; }
+        }
+        return 0;
+    };
+    struct DrainOnExit { std::thread &t; bool &active; ~DrainOnExit() { if (active && t.joinable()) t.join(); } } drain_on_exit{counter, counter_active};
     const size_t max_blocks = (2 * CHUNK + IG_BYTES - 1) / IG_BYTES + 1;
     uint32_t *d_blk = reinterpret_cast<uint32_t *>(workspace(WS_INGEST + 2, (3 * max_blocks + 16) * 4, err));
     if (!d_text || !d_bases || !d_blk) return -1;
@@ -502,6 +532,21 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
                        (double)(BASES_CAP + 4 * CHUNK) / 1e9);
     auto flush_bases = [&]() -> int {
         if (!bases_len) return 0;
+        if (two_buffers) {
+            if (int rc = drain()) return rc;                 // (the other buffer is free again)
+            if (dbg_t) fprintf(stderr, "[ingest] %.1f ms after the call: %llu bases to the counter's thread\n", now_ms() - t_in, (unsigned long long)bases_len);
+            const uint8_t *full = d_bases;
+            const uint64_t full_n = bases_len;
+            counter_active = true;
+            counter = std::thread([this, full, full_n, &counter_rc, &counter_err, dbg_t, t_in, now_ms] {
+                counter_rc = count_device(full, full_n, counter_err);
+                if (dbg_t) fprintf(stderr, "[ingest] %.1f ms after the call: counted\n", now_ms() - t_in);
+            });
+            bases_cur ^= 1;
+            d_bases = d_bases_two[bases_cur];
+            bases_len = 0;
+            return 0;
+        }
         if (dbg_t) fprintf(stderr, "[ingest] %.1f ms after the call: %llu bases to the counter\n", now_ms() - t_in, (unsigned long long)bases_len);
         const int rc = probe_stage ? 0 : bases_sink ? bases_sink(d_bases, bases_len) : count_device(d_bases, bases_len, err);
         if (dbg_t) fprintf(stderr, "[ingest] %.1f ms after the call: counted\n", now_ms() - t_in);
@@ -548,6 +593,7 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
     FastxParser hp(host_bases);
     auto host_rest = [&](int mode, const char *first, size_t first_n) -> int {
         if (int rc = flush_bases()) return rc;
+        if (int rc = drain()) return rc;                     // (the host parser's bases are counted by this thread, on the table's stream)
         hp.resume(mode);
         int rc = hp.feed(first, first_n);
         n_host += first_n;
@@ -654,7 +700,8 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
         carry = n - (size_t)n_use;
         h_buf += n_use;                                                           // (moved in front of the next chunk at the top of the loop)
     }
-    return flush_bases();
+    if (int rc = flush_bases()) return rc;
+    return drain();
 }
 
 // ---- feed: the same reader and parsers, the bases handed to the caller instead of counted -----------------------------

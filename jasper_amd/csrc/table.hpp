@@ -340,13 +340,14 @@ struct Table {
     // workspace of its own: polish_host.hip): lane 0 uses the table's stream and the first WS_POLISH_MAX slots, lane l > 0
     // polish_stream[l] and the slots from WS_LANE0 + (l - 1) * WS_POLISH_MAX on.
     static constexpr int POLISH_LANES_MAX = 4;
-    static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_INGEST = 44, WS_XCHG = 50, WS_HOSTBASES = 54, WS_LANE0 = 55,
+    static constexpr int WS_POLISH_MAX = 40, WS_COUNT = 40, WS_INGEST = 44, WS_XCHG = 51, WS_HOSTBASES = 55, WS_LANE0 = 56,
                          WS_SLOTS = WS_LANE0 + (POLISH_LANES_MAX - 1) * WS_POLISH_MAX;
     WsBuf ws[WS_SLOTS];   // 0..WS_POLISH_MAX-1: polisher (polish_host.hip, in allocation order); WS_COUNT..+3: partitioned counting
     hipStream_t polish_stream[POLISH_LANES_MAX] = {nullptr, nullptr, nullptr, nullptr};      // [0] unused (= stream); created on first use
     hipEvent_t polish_ev = nullptr;
     uint64_t polish_calls = 0;           // polishing calls this table has served (run_polish: a table that is polished again and again gets lanes)
     hipStream_t jf_stream = nullptr;        // write_jf's own (jfwrite.hip)
+    hipStream_t ingest_stream = nullptr;    // the file reader's copies and parsing kernels (ingest_gpu.hip): they run while the table's stream counts the bases before
     void *workspace(int id, size_t bytes, std::string &err);
     void wait_streams();                    // every stream of this table (its own, the polishing lanes', the .jf writer's): before a buffer they may use is freed
     // grow-only PINNED host buffers kept with the table (the polisher's segment tables, candidate lists and records travel through

@@ -171,6 +171,89 @@ def _write_fastq(path, reads, read_len):
     return n
 
 
+def _write_reads_fastq(path, rng, genomes, coverage, read_len, err, workers=None):
+    """make_reads_stream() of every array of `genomes` in turn + _write_fastq() of their concatenation, byte for byte and
+    draw for draw (the full-size fixtures of tests/golden/ were made from these bytes) -- as a pipeline: ONE thread makes the random
+    draws of every block of 200 000 reads in the generator's order (they depend on nothing but the generator and each other),
+    a few threads turn a block's draws into FASTQ records (the gathers and substitutions: numpy releases the GIL in them), and the
+    caller's thread writes the blocks in order.  Returns the number of reads."""
+    import os, queue, threading
+    if workers is None:
+        workers = max(2, min(6, (os.cpu_count() or 4) // 2))
+    bs = 200000
+    ar = np.arange(read_len)
+    tasks, done = queue.Queue(maxsize=2 * workers), queue.Queue()
+    total = sum(int(len(g) * coverage / read_len) for g in genomes)
+    failed = []
+
+    def produce():
+        seq = 0
+        try:
+            for g in genomes:
+                n = len(g)
+                nreads = int(n * coverage / read_len)
+                for a in range(0, nreads, bs):
+                    m = min(bs, nreads - a)
+                    starts = rng.integers(0, n - read_len + 1, m)
+                    e = rng.random((m, read_len)) < err
+                    ei, ej = np.nonzero(e)
+                    subs = rng.integers(1, 4, len(ei)) if len(ei) else None
+                    flip = rng.random(m) < 0.5
+                    tasks.put((seq, g, starts, ei, ej, subs, flip))
+                    seq += 1
+        except BaseException as ex:          # noqa: BLE001 -- handed to the caller
+            failed.append(ex)
+        for _ in range(workers):
+            tasks.put(None)
+
+    def work():
+        try:
+            while True:
+                tk = tasks.get()
+                if tk is None:
+                    break
+                seq, g, starts, ei, ej, subs, flip = tk
+                m = len(starts)
+                r = g[starts[:, None] + ar[None, :]]
+                if subs is not None:
+                    code = np.searchsorted(ACGT, r[ei, ej]) % 4
+                    r[ei, ej] = ACGT[(code + subs) % 4]
+                r[flip] = _COMP[r[flip][:, ::-1]]
+                rec = np.empty((m, 2 * read_len + 7), dtype=np.uint8)
+                rec[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+                rec[:, 3:3 + read_len] = r
+                rec[:, 3 + read_len:6 + read_len] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+                rec[:, 6 + read_len:6 + 2 * read_len] = ord("I")
+                rec[:, 6 + 2 * read_len] = ord("\n")
+                done.put((seq, rec))
+        except BaseException as ex:          # noqa: BLE001
+            failed.append(ex)
+        done.put(None)
+
+    threads = [threading.Thread(target=produce, daemon=True)] + [threading.Thread(target=work, daemon=True) for _ in range(workers)]
+    for th in threads:
+        th.start()
+    held, nxt, ended, written = {}, 0, 0, 0
+    with open(path, "wb") as f:
+        while ended < workers:
+            item = done.get()
+            if item is None:
+                ended += 1
+                continue
+            held[item[0]] = item[1]
+            while nxt in held:
+                rec = held.pop(nxt)
+                rec.tofile(f)
+                written += rec.shape[0]
+                nxt += 1
+    for th in threads:
+        th.join()
+    if failed:
+        raise failed[0]
+    assert not held and written == total
+    return written
+
+
 def contig_lengths(total, contigs):
     """deterministic contig sizes: one contig = everything; otherwise weights falling linearly 5 : 1 from the first to
     the last contig (SURVEY 8d cfg 4: "24 contigs 50-250 Mb"; cfg 3's 7 contigs get the same shape)"""
@@ -197,8 +280,7 @@ def write_cli_inputs(d, genome_mb=47.0, seed=2, coverage=30, read_len=150, err=0
     rng = np.random.default_rng(seed)
     genome = make_genome(rng, int(genome_mb * 1e6))
     if contigs <= 1 and populations <= 1:      # (the round-1 inputs: same generator calls in the same order)
-        reads = make_reads_stream(rng, genome, coverage, read_len, err).reshape(-1, read_len + 1)[:, :read_len]
-        n = _write_fastq(os.path.join(d, "reads.fq"), reads, read_len)
+        n = _write_reads_fastq(os.path.join(d, "reads.fq"), rng, [genome], coverage, read_len, err)
         asm = make_assembly(rng, genome)
         a = asm.tobytes()
         with open(os.path.join(d, "asm.fa"), "wb") as f:
@@ -216,11 +298,8 @@ def write_cli_inputs(d, genome_mb=47.0, seed=2, coverage=30, read_len=150, err=0
             m = rng.random(len(g)) < snp
             code = np.searchsorted(ACGT, g[m]) % 4
             g[m] = ACGT[(code + rng.integers(1, 4, int(m.sum()))) % 4]
-        parts = [make_reads_stream(rng, g[starts[c]:starts[c + 1]], coverage, read_len, err).reshape(-1, read_len + 1)[:, :read_len]
-                 for c in range(contigs)]
-        reads = np.concatenate(parts) if len(parts) > 1 else parts[0]
-        n += _write_fastq(os.path.join(d, "reads.fq" if populations <= 1 else "reads_%d.fq" % p), reads, read_len)
-        del reads, parts
+        n += _write_reads_fastq(os.path.join(d, "reads.fq" if populations <= 1 else "reads_%d.fq" % p), rng, [g[starts[c]:starts[c + 1]] for c in range(contigs)],
+                                coverage, read_len, err)
     total = 0
     with open(os.path.join(d, "asm.fa"), "wb") as f:
         for c in range(contigs):
