@@ -260,7 +260,11 @@ void jasper_result_free(jasper_result *r);
  *   jasper_asm_polish        jasper_polish_batch on the records of the listed batch files, read straight from the arena: one
  *                            `jasper.py --query $prefix.batch.N.fa` process per listed file (src/jasper.sh:207-212); result chunk i =
  *                            the i-th record of the files in list order
- *   jasper_asm_take          moves the polished text out of the result into the job (for the two writers below)
+ *   jasper_asm_pin           optional, any thread (it waits for the GPU runtime to start): registers the arena with the runtime and
+ *                            allocates one pinned buffer for the polished text, so that record text crosses PCIe without staging
+ *                            copies in either direction
+ *   jasper_asm_take          moves the polished text out of the result into the job (for the two writers below); a result of
+ *                            jasper_asm_polish leaves its text in HBM until this call copies it
  *   jasper_asm_put           the polished text of one record given by the caller instead (read back from an `_iter*.fixed.fa` of
  *                            an interrupted run; tests)
  *   jasper_asm_write_fixed   `_iter{P-1}_<batch>.fixed.fa`: ">name:offset" + lines of 60            src/jasper.py:120-128,142-147
@@ -281,11 +285,16 @@ int jasper_asm_chunks(const jasper_asm *a, uint32_t *contig, uint64_t *ci, uint6
 int jasper_asm_file_bytes(const jasper_asm *a, uint64_t *bytes);
 int jasper_asm_chunk_text(const jasper_asm *a, uint64_t chunk, int polished, const char **text, uint64_t *len);
 int jasper_asm_polish(jasper_table *t, jasper_asm *a, const uint32_t *files, uint32_t n_files, int solid_thre, int passes, int fix, jasper_result **out);
+int jasper_asm_pin(jasper_asm *a, int device);
 int jasper_asm_take(jasper_asm *a, jasper_result *r, const uint32_t *files, uint32_t n_files);
 int jasper_asm_put(jasper_asm *a, uint64_t chunk, const char *text, uint64_t len);
 int jasper_asm_write_fixed(jasper_asm *a, const uint32_t *files, const char *const *out_paths, uint32_t n_files, int threads);
 int jasper_asm_polished_lens(const jasper_asm *a, uint64_t *lens, uint8_t *have);
 int jasper_asm_join(jasper_asm *a, const char *out_path, const uint64_t *all_lens, int mode, int threads);
+/* `$QUERY_FN.fixes.csv` from the per-batch fix CSVs (src/jasper.sh:222-226: awk | awk -F: | sort -k1,1 -k2,2n -k3,3n | awk), byte order
+ * for names and for sort's last-resort whole-line comparison.  Returns 1 (not an error, nothing written) when a line holds bytes
+ * other than printable ASCII / blank / tab / '\r' or a number of more than 18 digits: the caller applies the rules itself. */
+int jasper_merge_fix_csvs(const char *const *paths, uint32_t n_paths, const char *out_path);
 
 /* kernel timing for bench.py: HIP-event time of the last counting call on this table, and its launch count */
 int jasper_last_count_timing(jasper_table *t, double *kernel_ms, uint64_t *launches);

@@ -105,11 +105,13 @@ SYMBOLS = {
     "jasper_asm_file_bytes": (C.c_int, [_P, _P]),
     "jasper_asm_chunk_text": (C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "jasper_asm_polish": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "jasper_asm_pin": (C.c_int, [_P, C.c_int]),
     "jasper_asm_take": (C.c_int, [_P, _P, _P, C.c_uint32]),
     "jasper_asm_put": (C.c_int, [_P, C.c_uint64, C.c_char_p, C.c_uint64]),
     "jasper_asm_write_fixed": (C.c_int, [_P, _P, C.POINTER(C.c_char_p), C.c_uint32, C.c_int]),
     "jasper_asm_polished_lens": (C.c_int, [_P, _P, _P]),
     "jasper_asm_join": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int]),
+    "jasper_merge_fix_csvs": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p]),
     "jasper_last_count_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "jasper_last_count_stages": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
 }

@@ -111,6 +111,11 @@ class AssemblyJob:
         rc = self._L.jasper_asm_polish(table._h, self._h, fl.ctypes.data, len(fl), int(solid_thre), int(passes), 1 if fix else 0, C.byref(res))
         return table._wrap_result(rc, res, len(self.records_of(files)), False)
 
+    def pin(self, device=0):
+        """optional: the arena registered with the GPU runtime + one pinned buffer for the polished text (waits for the runtime to
+        start: meant for a thread beside the counting)"""
+        check(self._L.jasper_asm_pin(self._h, int(device)))
+
     def take(self, result, files):
         """keep the polished text of `result` (of polish(table, files, ...)) in the job: result.seqs is empty afterwards"""
         fl = self._files(files)

@@ -351,6 +351,16 @@ def merge_fix_csvs(csv_files):
     odd = re.compile(r"[^\x20-\x7e\t]")
 
     def fields(s):
+        # (the rows this program writes end with the CSV's '\r', which awk keeps on the last field -- or as a field of its own
+        #  behind a blank)
+        if s.endswith("\r") and not odd.search(s, 0, len(s) - 1):
+            body = s[:-1]
+            F = body.split()
+            if not F or body[-1] in " \t":
+                F.append("\r")
+            else:
+                F[-1] += "\r"
+            return F
         return awk_fields(s) if odd.search(s) else s.split()
 
     def key_of(s, F):                                  # sort -k1,1 -k2,2n -k3,3n, last resort: whole line
@@ -368,6 +378,22 @@ def merge_fix_csvs(csv_files):
         F = F + [""] * (5 - len(F))
         out.append("%s:%s %s %s %s\n" % (F[0], F[1], F[2], F[3], F[4]))
     return "".join(out)
+
+
+def write_merged_fix_csvs(csv_files, out_path):
+    """merge_fix_csvs(csv_files) into out_path: natively (libjasper_hip.so: jasper_merge_fix_csvs, the same rules on bytes) for rows
+    of printable ASCII, by the restatement above for anything else"""
+    try:
+        import ctypes as C
+        from . import _lib
+        arr = (C.c_char_p * max(len(csv_files), 1))(*[os.fsencode(p) for p in csv_files])
+        rc = _lib.lib().jasper_merge_fix_csvs(arr, len(csv_files), os.fsencode(out_path))
+        if rc == 0:
+            return
+    except Exception:           # noqa: BLE001 -- no library here: the rules in Python
+        pass
+    with open(out_path, "w", newline="") as f:
+        f.write(merge_fix_csvs(csv_files))
 
 
 def _write_histo(path, rows):
@@ -418,6 +444,7 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer, job=None):
     keep_fixed = bool(os.environ.get("JASPER_AMD_KEEP_INTERMEDIATES"))
     job_split = job_polished = False
     file_owner = None
+    pinner = None
 
     def split_done():
         """the job's batch files are complete on every rank (or "Splitting files failed" on all): jasper.split.success"""
@@ -449,6 +476,7 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer, job=None):
                 job.split(batch_size, qfn, write_files=True, only_files=[f for f in order if file_owner[f] == rank])
             together(plan_and_write, "Splitting files failed, do you have enough disk space?")
             job_split = True
+            pinner = _in_thread(lambda: job.pin(o.device))
         else:
             if is0:
                 try:
@@ -609,6 +637,8 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer, job=None):
                     del group[:]
             def polish_my_batches():
                 nonlocal group_bytes
+                if pinner is not None:
+                    pinner.join()
                 for f in sorted(range(job.n_files), key=job.batch_file_name):
                     if file_owner[f] != rank:
                         continue
@@ -749,6 +779,20 @@ class _EarlyTable:
         return self.out
 
 
+def _in_thread(fn):
+    """fn() on a daemon thread; what it raises is dropped (optional work: pinning buffers)"""
+    import threading
+
+    def work():
+        try:
+            fn()
+        except BaseException:           # noqa: BLE001
+            pass
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    return th
+
+
 class _JobJoin:
     """job.join(tmp) by a thread (src/jasper.sh:220 from the job's memory; the library call releases the GIL); finish() waits and
     raises what the thread raised"""
@@ -831,8 +875,7 @@ def _join_and_merge(o, qfn, batch_size, last_it, contigs, fasta_done=False):
     for p in glob.glob("_iter*_%s.batch.*.fa.fixed.fa" % glob.escape(qfn)) + glob.glob("_iter*_%s.batch.*.fa.fixed.fa.tmp" % glob.escape(qfn)):
         os.remove(p)
     csvs = sorted(glob.glob("_iter*_%s.batch.*.fa.fix.csv" % glob.escape(qfn)))
-    with open(qfn + ".fixes.csv.tmp", "w", newline="") as f:
-        f.write(merge_fix_csvs(csvs))
+    write_merged_fix_csvs(csvs, qfn + ".fixes.csv.tmp")
     os.replace(qfn + ".fixes.csv.tmp", qfn + ".fixes.csv")
     open("jasper.join.success", "w").close()
     if not o.debug:
@@ -952,6 +995,7 @@ def run(argv):
     job_split = False          # the batch files are the job's (being written by its thread until _split_done())
     job_polished = False       # the polished records are in the job's memory
     join_writer = []           # [_JobJoin]: the polished FASTA being written from them
+    pinner = None              # thread: job.pin()
 
     def _split_done():
         nonlocal job_split
@@ -976,6 +1020,7 @@ def run(argv):
             except Exception:           # noqa: BLE001
                 error_exit("Splitting files failed, do you have enough disk space?")
             job_split = True
+            pinner = _in_thread(lambda: job.pin(o.device))      # (waits for the GPU runtime, pins the arena: beside the counting)
         else:
             try:
                 contigs = read_assembly(o.query)
@@ -1079,6 +1124,8 @@ def run(argv):
             # written (JASPER_AMD_KEEP_INTERMEDIATES=1 writes them), and so jasper.correct.success -- "the fixed files are
             # complete" -- appears only once the join has made the polished FASTA from them (a run that dies in between starts the
             # polishing over instead of joining files that are not there).
+            if pinner is not None:
+                pinner.join()
             groups = [[]]
             for f in sorted(range(job.n_files), key=job.batch_file_name):
                 groups[-1].append(f)
@@ -1144,8 +1191,7 @@ def run(argv):
         for p in glob.glob("_iter*_%s.batch.*.fa.fixed.fa" % glob.escape(qfn)) + glob.glob("_iter*_%s.batch.*.fa.fixed.fa.tmp" % glob.escape(qfn)):
             os.remove(p)
         csvs = sorted(glob.glob("_iter*_%s.batch.*.fa.fix.csv" % glob.escape(qfn)))
-        with open(qfn + ".fixes.csv.tmp", "w", newline="") as f:
-            f.write(merge_fix_csvs(csvs))
+        write_merged_fix_csvs(csvs, qfn + ".fixes.csv.tmp")
         os.replace(qfn + ".fixes.csv.tmp", qfn + ".fixes.csv")
         open("jasper.join.success", "w").close()
         if not o.debug:

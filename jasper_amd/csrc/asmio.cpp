@@ -106,6 +106,7 @@ const size_t UNIT = 4u << 20;      // bytes of file per unit of parallel work
 
 jasper_asm::~jasper_asm() {
     if (writer_running) writer.join();
+    if (gpu_release) gpu_release(this);
     if (arena && arena_cap) munmap(arena, arena_cap);
 }
 
@@ -322,7 +323,8 @@ int jasper_asm_split(jasper_asm *a, uint64_t batch_size, const char *prefix, con
         ct.n_chunks = a->chunks.size() - ct.first_chunk;
     }
     a->file_first.push_back(a->chunks.size());
-    a->polished.assign(a->chunks.size(), std::string());
+    a->polished.assign(a->chunks.size(), jasper_asm::Polished());
+    a->out_used = 0;
     a->have.assign(a->chunks.size(), 0);
     if (n_chunks) *n_chunks = a->chunks.size();
     if (n_files) *n_files = a->file_bytes.size();
@@ -395,7 +397,8 @@ int jasper_asm_chunk_text(const jasper_asm *a, uint64_t chunk, int polished, con
 
 int jasper_asm_put(jasper_asm *a, uint64_t chunk, const char *text, uint64_t len) {
     if (!a || chunk >= a->chunks.size() || (len && !text)) { jasper_err_ref() = "chunk out of range"; return JASPER_ERR; }
-    a->polished[chunk].assign(text ? text : "", (size_t)len);
+    a->polished[chunk].p = nullptr;
+    a->polished[chunk].own.assign(text ? text : "", (size_t)len);
     a->have[chunk] = 1;
     return JASPER_OK;
 }
@@ -419,7 +422,7 @@ int jasper_asm_write_fixed(jasper_asm *a, const uint32_t *files, const char *con
         bool ok = true;
         for (size_t c = a->file_first[files[i]]; c < a->file_first[files[i] + 1] && ok; ++c) {
             const AsmChunk &ch = a->chunks[c];
-            const std::string &s = a->polished[c];
+            const jasper_asm::Polished &s = a->polished[c];
             buf.clear();
             buf.reserve(s.size() + s.size() / 60 + 64 + a->contigs[ch.contig].name.size());
             buf += a->contigs[ch.contig].name;
@@ -427,7 +430,7 @@ int jasper_asm_write_fixed(jasper_asm *a, const uint32_t *files, const char *con
             buf += std::to_string(ch.ci);
             buf += '\n';
             for (size_t at = 0; at < s.size(); at += 60) {
-                buf.append(s, at, 60);
+                buf.append(s.data() + at, std::min<size_t>(60, s.size() - at));
                 buf += '\n';
             }
             struct iovec v = {(void *)buf.data(), buf.size()};
@@ -502,7 +505,7 @@ int jasper_asm_join(jasper_asm *a, const char *out_path, const uint64_t *all_len
             if (a->have[ct.first_chunk + ct.n_chunks - 1]) pieces.push_back({&nl, 1, end_at[i]});
             for (size_t c = ct.first_chunk; c < ct.first_chunk + ct.n_chunks; ++c) {
                 if (!a->have[c]) continue;
-                const std::string &s = a->polished[c];
+                const jasper_asm::Polished &s = a->polished[c];
                 if (s.size() != all_lens[c]) { err = "a chunk record's polished length is not the one the file was laid out for"; close(fd); return JASPER_ERR; }
                 for (size_t q = 0; q < s.size(); q += UNIT) pieces.push_back({s.data() + q, std::min(UNIT, s.size() - q), at[c] + q});
             }
@@ -516,6 +519,113 @@ int jasper_asm_join(jasper_asm *a, const char *out_path, const uint64_t *all_len
     }
     if (close(fd) != 0 && ok) { err = std::string("closing ") + out_path + ": " + strerror(errno); ok = false; }
     return ok ? JASPER_OK : JASPER_ERR;
+}
+
+// src/jasper.sh:222-226:  awk 'NR==1 || FNR>1' FILES | awk -F ':' '{print $1" "$2}' | sort -k1,1 -k2,2n -k3,3n | awk '{print $1":"$2" "$3" "$4" "$5}'
+// on the per-batch fix CSVs (space-delimited, CRLF: the '\r' is no separator for awk and stays on the last field).  Byte order
+// for the name key and for sort's last-resort comparison of whole lines.  Returns 1 (nothing written) when a line holds a byte
+// that is not printable ASCII, blank, tab or '\r', or a number of more than 18 digits: the caller's own restatement of the rules
+// (jasper_amd/cli.py: merge_fix_csvs) decides then.
+int jasper_merge_fix_csvs(const char *const *paths, uint32_t n_paths, const char *out_path) {
+    std::string &err = jasper_err_ref();
+    if ((n_paths && !paths) || !out_path) { err = "bad arguments"; return JASPER_ERR; }
+    struct Row { std::string line; uint32_t f[5][2]; uint32_t nf; int64_t k1, k2; };
+    std::vector<Row> rows;
+    std::string content;
+    for (uint32_t i = 0; i < n_paths; ++i) {
+        FILE *fp = fopen(paths[i], "rb");
+        if (!fp) { err = std::string("cannot open ") + paths[i] + ": " + strerror(errno); return JASPER_ERR; }
+        content.clear();
+        char buf[1 << 16];
+        size_t k;
+        while ((k = fread(buf, 1, sizeof buf, fp)) > 0) content.append(buf, k);
+        const bool bad = ferror(fp) != 0;
+        fclose(fp);
+        if (bad) { err = std::string("read error in ") + paths[i]; return JASPER_ERR; }
+        size_t pos = 0, fnr = 0;
+        while (pos < content.size()) {                           // (a last line without '\n' counts; nothing after a final '\n' does)
+            size_t e = content.find('\n', pos);
+            if (e == std::string::npos) e = content.size();
+            ++fnr;
+            if ((i == 0 && fnr == 1) || fnr > 1) {
+                // awk -F ':' '{print $1" "$2}'
+                const char *l = content.data() + pos;
+                const size_t ln = e - pos;
+                for (size_t q = 0; q < ln; ++q) {
+                    const unsigned char c = (unsigned char)l[q];
+                    if (!((c >= 0x20 && c <= 0x7e) || c == '\t' || c == '\r')) return 1;
+                }
+                const char *c1 = (const char *)memchr(l, ':', ln);
+                Row r;
+                if (!c1) { r.line.assign(l, ln); r.line += ' '; }
+                else {
+                    const char *c2 = (const char *)memchr(c1 + 1, ':', (size_t)(l + ln - c1 - 1));
+                    r.line.assign(l, (size_t)(c1 - l));
+                    r.line += ' ';
+                    r.line.append(c1 + 1, (size_t)((c2 ? c2 : l + ln) - c1 - 1));
+                }
+                // awk's default fields: runs of blanks / tabs separate
+                r.nf = 0;
+                const std::string &s = r.line;
+                size_t q = 0;
+                uint32_t n_all = 0;
+                while (q < s.size()) {
+                    while (q < s.size() && (s[q] == ' ' || s[q] == '\t')) ++q;
+                    if (q >= s.size()) break;
+                    size_t b = q;
+                    while (q < s.size() && s[q] != ' ' && s[q] != '\t') ++q;
+                    if (n_all < 5) { r.f[n_all][0] = (uint32_t)b; r.f[n_all][1] = (uint32_t)(q - b); r.nf = n_all + 1; }
+                    ++n_all;
+                }
+                auto num = [&](uint32_t fi, int64_t &out) -> bool {      // sort -n: a leading integer, 0 if none
+                    out = 0;
+                    if (fi >= r.nf) return true;
+                    const char *p = s.data() + r.f[fi][0];
+                    uint32_t m = r.f[fi][1], at = 0;
+                    bool neg = false;
+                    if (at < m && p[at] == '-') { neg = true; ++at; }
+                    uint32_t digits = 0;
+                    int64_t v = 0;
+                    while (at < m && p[at] >= '0' && p[at] <= '9') { if (++digits > 18) return false; v = v * 10 + (p[at] - '0'); ++at; }
+                    out = digits ? (neg ? -v : v) : 0;
+                    return true;
+                };
+                if (!num(1, r.k1) || !num(2, r.k2)) return 1;
+                rows.push_back(std::move(r));
+            }
+            pos = e + 1;
+        }
+    }
+    auto cmp_bytes = [](const char *a, size_t na, const char *b, size_t nb) {
+        const int c = memcmp(a, b, std::min(na, nb));
+        return c ? c : (na < nb ? -1 : na > nb ? 1 : 0);
+    };
+    std::vector<uint32_t> order(rows.size());
+    for (size_t i = 0; i < rows.size(); ++i) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const Row &a = rows[x], &b = rows[y];
+        const int c = cmp_bytes(a.nf ? a.line.data() + a.f[0][0] : "", a.nf ? a.f[0][1] : 0, b.nf ? b.line.data() + b.f[0][0] : "", b.nf ? b.f[0][1] : 0);
+        if (c) return c < 0;
+        if (a.k1 != b.k1) return a.k1 < b.k1;
+        if (a.k2 != b.k2) return a.k2 < b.k2;
+        const int w = cmp_bytes(a.line.data(), a.line.size(), b.line.data(), b.line.size());
+        return w ? w < 0 : x < y;
+    });
+    std::string out;
+    out.reserve(rows.size() * 40);
+    for (uint32_t idx : order) {                                  // awk '{print $1":"$2" "$3" "$4" "$5}'
+        const Row &r = rows[idx];
+        for (uint32_t fi = 0; fi < 5; ++fi) {
+            if (fi < r.nf) out.append(r.line.data() + r.f[fi][0], r.f[fi][1]);
+            if (fi < 4) out += fi == 0 ? ':' : ' ';
+        }
+        out += '\n';
+    }
+    const int fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) { err = std::string("cannot create ") + out_path + ": " + strerror(errno); return JASPER_ERR; }
+    const bool ok = write_all(fd, out.data(), out.size(), 0);
+    if (close(fd) != 0 || !ok) { err = std::string("writing ") + out_path + ": " + strerror(errno); return JASPER_ERR; }
+    return JASPER_OK;
 }
 
 }  // extern "C"

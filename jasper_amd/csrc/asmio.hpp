@@ -46,9 +46,23 @@ struct jasper_asm {
     bool writer_running = false;
     std::atomic<int> writer_failed{0};
     std::string writer_err;
-    // polished text per chunk (moved out of the polisher's results)
-    std::vector<std::string> polished;
+    // polished text per chunk: a view into out_pinned (jasper_asm_take of a result whose text was still on the device), or `own`
+    // (moved out of a host result; jasper_asm_put)
+    struct Polished {
+        const char *p = nullptr;
+        size_t n = 0;
+        std::string own;
+        const char *data() const { return p ? p : own.data(); }
+        size_t size() const { return p ? n : own.size(); }
+    };
+    std::vector<Polished> polished;
     std::vector<uint8_t> have;
+    // jasper_asm_pin (capi.hip): the arena registered with the GPU runtime (chunk text is then copied to the device without a
+    // staging copy), and ONE pinned buffer that receives the polished text
+    bool arena_registered = false;
+    char *out_pinned = nullptr;
+    size_t out_cap = 0, out_used = 0;
+    void (*gpu_release)(jasper_asm *) = nullptr;      // set by whoever pinned something: called by the destructor
     ~jasper_asm();
 };
 

@@ -452,7 +452,8 @@ int jasper_table_import(jasper_table *t, const uint64_t *host_entries, uint64_t 
 // polishing (host orchestration in polish_host.hip)
 // ---------------------------------------------------------------------------------------------------
 static int polish_common(jasper_table *t, int n_chunks, const char *const *seqs, const int64_t *lens, int solid_thre, int passes, int fix,
-                         bool device_io, jasper_result **out) {
+                         bool device_io, jasper_result **out, int keep = -1) {
+    const bool device_in = device_io, keep_on_device = keep < 0 ? device_io : keep != 0;
     Table &T = t->t;
     if (T.k < 6) { g_err = "polishing needs k >= 6"; return JASPER_ERR; }
     if (passes < 0 || passes > 200) { g_err = "bad number of passes"; return JASPER_ERR; }
@@ -462,11 +463,11 @@ static int polish_common(jasper_table *t, int n_chunks, const char *const *seqs,
     jasper_result *R = new jasper_result();
     *out = R;
     PolishOut po;
-    int rc = run_polish(T, n_chunks, seqs, lens, solid_thre, passes, fix, po, g_err, device_io, device_io, getenv("JASPER_POLISH_ROOMY") ? 1 : 0);      // (tests: the roomy sizes at once)
+    int rc = run_polish(T, n_chunks, seqs, lens, solid_thre, passes, fix, po, g_err, device_in, keep_on_device, getenv("JASPER_POLISH_ROOMY") ? 1 : 0);      // (tests: the roomy sizes at once)
     if (rc == -2) {                      // a slack / record / scratch bound was too small for this input: once more with 8x the room
         R->retried = 1;
         po = PolishOut();
-        rc = run_polish(T, n_chunks, seqs, lens, solid_thre, passes, fix, po, g_err, device_io, device_io, 1);
+        rc = run_polish(T, n_chunks, seqs, lens, solid_thre, passes, fix, po, g_err, device_in, keep_on_device, 1);
     }
     R->seqs.swap(po.seqs);
     R->aux.swap(po.aux);
@@ -478,7 +479,7 @@ static int polish_common(jasper_table *t, int n_chunks, const char *const *seqs,
     R->seconds = po.seconds;
     R->n_segments = po.n_segments;
     R->n_respeculated = po.n_respeculated;
-    if (rc == 0 && device_io) {
+    if (rc == 0 && keep_on_device) {
         R->d_seqs.swap(po.d_seqs);
         R->d_lens.swap(po.d_lens);
         R->owner = t;
@@ -529,16 +530,65 @@ int jasper_asm_polish(jasper_table *t, jasper_asm *a, const uint32_t *files, uin
         ptrs[i] = (const char *)a->arena + a->contigs[ch.contig].seq_off + ch.ci;
         lens[i] = (int64_t)ch.len;
     }
-    return polish_common(t, (int)recs.size(), ptrs.data(), lens.data(), solid_thre, passes, fix, false, out);
+    // host text in; the polished text stays in HBM until jasper_asm_take copies it -- into the job's pinned buffer when there is one
+    return polish_common(t, (int)recs.size(), ptrs.data(), lens.data(), solid_thre, passes, fix, false, out, 1);
+}
+
+static void asm_gpu_release(jasper_asm *a) {
+    if (a->arena_registered) { (void)hipHostUnregister(a->arena); a->arena_registered = false; }
+    if (a->out_pinned) { (void)hipHostFree(a->out_pinned); a->out_pinned = nullptr; a->out_cap = 0; }
+}
+
+// (any thread, once: blocks while the GPU runtime starts -- the caller runs it beside the counting)
+int jasper_asm_pin(jasper_asm *a, int device) {
+    if (!a) { g_err = "bad arguments"; return JASPER_ERR; }
+    CHK(hipSetDevice(device));
+    a->gpu_release = asm_gpu_release;
+    if (!a->arena_registered && a->arena && a->arena_cap)
+        a->arena_registered = hipHostRegister(a->arena, a->arena_cap, hipHostRegisterDefault) == hipSuccess;      // (refused: the copies are staged, as before)
+    (void)hipGetLastError();
+    if (!a->out_pinned) {
+        const size_t want = a->arena_len + a->arena_len / 64 + (1u << 20);
+        if (hipHostMalloc((void **)&a->out_pinned, want, hipHostMallocDefault) == hipSuccess) a->out_cap = want;
+        else { a->out_pinned = nullptr; (void)hipGetLastError(); }
+    }
+    return JASPER_OK;
 }
 
 int jasper_asm_take(jasper_asm *a, jasper_result *r, const uint32_t *files, uint32_t n_files) {
     std::vector<size_t> recs;
     if (int rc = asm_records(a, files, n_files, recs)) return rc;
     if (!r || r->seqs.size() != recs.size()) { g_err = "the result is not the one of these batch files"; return JASPER_ERR; }
-    if (r->owner && result_fetch(r)) return JASPER_ERR;
+    if (r->owner) {
+        // still on the device: one copy per record into the job's pinned buffer (after what earlier calls put there); a buffer
+        // that is missing or too small -> through the result's own host strings
+        size_t total = 0;
+        for (size_t i = 0; i < recs.size(); ++i) total += (size_t)r->d_lens[i];
+        if (a->out_pinned && a->out_used + total <= a->out_cap) {
+            Table &T = r->owner->t;
+            CHK(hipSetDevice(T.device));
+            size_t at = a->out_used;
+            for (size_t i = 0; i < recs.size(); ++i) {
+                const size_t n = (size_t)r->d_lens[i];
+                if (n) CHK(hipMemcpyAsync(a->out_pinned + at, r->d_seqs[i], n, hipMemcpyDeviceToHost, T.stream));
+                jasper_asm::Polished &P = a->polished[recs[i]];
+                P.p = a->out_pinned + at;
+                P.n = n;
+                P.own.clear();
+                at += n;
+            }
+            CHK(jk_stream_wait(T.stream));
+            a->out_used = at;
+            for (size_t i = 0; i < recs.size(); ++i) a->have[recs[i]] = 1;
+            if (r->owner->pending == r) r->owner->pending = nullptr;
+            r->owner = nullptr;              // (the text has left the device with the job: the result keeps records, counters, aux)
+            return JASPER_OK;
+        }
+        if (result_fetch(r)) return JASPER_ERR;
+    }
     for (size_t i = 0; i < recs.size(); ++i) {
-        a->polished[recs[i]].swap(r->seqs[i]);
+        a->polished[recs[i]].p = nullptr;
+        a->polished[recs[i]].own.swap(r->seqs[i]);
         a->have[recs[i]] = 1;
     }
     return JASPER_OK;

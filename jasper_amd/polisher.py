@@ -315,6 +315,50 @@ def main_many(query_paths, k, test, fix, db, thre, num_iter):
         sys.exit(1)
 
 
+def _rows_by_pass_and_chunk(res, name_of):
+    """{(pass, chunk): CSV rows in emission order} of a PolishResult, as rows_from_record makes them -- the plain kinds ('s', 'i',
+    'd': all but a handful) straight from the record array's columns, without a dict per record"""
+    import numpy as np
+    raw = res._raw
+    out = {}
+    if not len(raw):
+        return out
+    order = np.lexsort((raw["seqno"], raw["pass_"], raw["chunk"]))          # by chunk, pass, emission
+    chunk = raw["chunk"][order].tolist()
+    pas = raw["pass_"][order].tolist()
+    kind = raw["kind"][order].tolist()
+    index = raw["index"][order].tolist()
+    newc = raw["newc"][order].tolist()
+    oldc = raw["oldc"][order].tolist()
+    rep = raw["rep"][order].tolist()
+    which = order.tolist()
+    S, I, D = ord("s"), ord("i"), ord("d")
+    names = {}
+    decoded = None
+    for j in range(len(chunk)):
+        c = chunk[j]
+        nm = names.get(c)
+        if nm is None:
+            nm = names[c] = name_of(c)
+        kd = kind[j]
+        if kd == S:
+            rows = [[nm, index[j], chr(newc[j]), "s" + chr(oldc[j])]]
+        elif kd == I:
+            rows = [[nm, index[j], "-", "i" + chr(oldc[j]) * rep[j]]]
+        elif kd == D:
+            rows = [[nm, index[j], chr(newc[j]) * rep[j], "d-"]]
+        else:
+            if decoded is None:
+                decoded = res.records               # (the 'x' records carry aux bytes: the general decoder)
+            rows = rows_from_record(nm, decoded[which[j]])
+        key = (pas[j], c)
+        lst = out.get(key)
+        if lst is None:
+            out[key] = lst = []
+        lst.extend(rows)
+    return out
+
+
 def main_many_job(job, files, k, test, fix, db, thre, num_iter, keep_fixed=False, on_taken=None):
     """main_many() for batch files of an assembly.AssemblyJob (numbers in `files`): the record text goes from the job's arena to the
     GPU and the polished text back into the job (job.take) without becoming Python objects; what is left per file is what
@@ -342,8 +386,7 @@ def main_many_job(job, files, k, test, fix, db, thre, num_iter, keep_fixed=False
         recs = job.records_of(files)                  # result chunk i = record recs[i]
         rows_by_chunk = {}
         if do_fix:
-            for r in res.records:
-                rows_by_chunk.setdefault((r["pass_"], r["chunk"]), []).append((r["seqno"], rows_from_record(job.chunk_name(recs[r["chunk"]]), r)))
+            rows_by_chunk = _rows_by_pass_and_chunk(res, lambda c: job.chunk_name(recs[c]))
         mark("fix records -> rows (%d)" % res.n_records)
         at = 0
         outs = []
@@ -364,8 +407,7 @@ def main_many_job(job, files, k, test, fix, db, thre, num_iter, keep_fixed=False
                 for ite in range(num_iter):
                     flat = []
                     for c in range(at, at + n):
-                        for _, rr in sorted(rows_by_chunk.get((ite, c), []), key=lambda x: x[0]):
-                            flat.extend(rr)
+                        flat.extend(rows_by_chunk.get((ite, c), ()))
                     with open(fo[0] + "_iter" + str(ite) + "_" + fo[1], 'w', newline='') as csvf:
                         csvf.write(fix_csv_text(flat))
                 ff = os.path.split(qp + ".fixed.fa.tmp")

@@ -310,7 +310,8 @@ def test_merge_fix_csvs_fast_path_equals_the_awk_rules(tmp_path):
         rows.sort(key=lambda s: ((awk(s) + [""])[0].encode(), num(awk(s)[1]) if len(awk(s)) > 1 else 0, num(awk(s)[2]) if len(awk(s)) > 2 else 0, s.encode()))
         return "".join("%s:%s %s %s %s\n" % tuple((awk(s) + [""] * 5)[:5]) for s in rows)
 
-    field = lambda: random.choice(["12", "007", "-3", "x9", "", " 5", "\t7", "9\r", "a\x0bb", "é1", "33 44", "²"])
+    field = lambda: random.choice(["12", "007", "-3", "x9", "", " 5", "\t7", "9\r", "33 44"] + ([] if trial % 2 else ["a\x0bb", "é1", "²"]))
+    native_taken = 0
     for trial in range(120):
         files = []
         for n in range(random.randint(1, 3)):
@@ -322,3 +323,47 @@ def test_merge_fix_csvs_fast_path_equals_the_awk_rules(tmp_path):
                                                   random.choice(["sA", "i-", "d-"]), random.choice(["\r\n", "\n"])))
             files.append(path)
         assert cli.merge_fix_csvs(files) == by_the_rule(files), trial
+        # the native merge (jasper_merge_fix_csvs): the same bytes whenever it takes the input (printable ASCII, blanks, tabs, '\r')
+        import ctypes as C
+        from jasper_amd import _lib
+        arr = (C.c_char_p * len(files))(*[p.encode() for p in files])
+        out = str(tmp_path / ("merged%d.csv" % trial))
+        rc = _lib.lib().jasper_merge_fix_csvs(arr, len(files), out.encode())
+        raw = b"".join(open(p, "rb").read() for p in files)
+        plain = all((0x20 <= c <= 0x7e) or c in (9, 10, 13) for c in raw)
+        assert rc == (0 if plain else 1), (trial, rc)
+        if rc == 0:
+            native_taken += 1
+            assert open(out, "r", newline="").read() == by_the_rule(files), trial
+    assert native_taken >= 10
+
+
+def test_rows_straight_from_the_record_array_equal_rows_from_record():
+    """polisher._rows_by_pass_and_chunk (the plain kinds from the array's columns) against rows_from_record on decoded records"""
+    import numpy as np
+    from jasper_amd import polisher
+    from jasper_amd.table import FIXREC_DTYPE, PolishResult
+    rng = np.random.default_rng(3)
+    n = 500
+    raw = np.zeros(n, dtype=FIXREC_DTYPE)
+    raw["chunk"] = np.sort(rng.integers(0, 7, n))
+    raw["pass_"] = rng.integers(0, 3, n)
+    raw["seqno"] = rng.permutation(n)
+    raw["index"] = rng.integers(0, 10**7, n)
+    raw["kind"] = np.frombuffer(b"sidx", dtype=np.uint8)[rng.choice(4, n, p=[.6, .2, .15, .05])]
+    raw["newc"] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)]
+    raw["oldc"] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)]
+    raw["rep"] = rng.integers(1, 4, n)
+    aux = [b""] * 7
+    for i in np.flatnonzero(raw["kind"] == ord("x")):
+        c = int(raw["chunk"][i])
+        orig = "".join(rng.choice(list("ACGT"), 30))
+        patch = orig[:10] + "T" + orig[10:17] + orig[19:]            # two differences at least
+        raw["aux_off"][i], raw["aux_len"][i], raw["rep"][i] = len(aux[c]), len(patch), len(orig)
+        aux[c] += (patch + orig).encode()
+    res = PolishResult(None, None, 7, False, raw, aux, (0, 0, 0, 0), 0, 0.0)
+    got = polisher._rows_by_pass_and_chunk(res, lambda c: "ctg%d:0" % c)
+    want = {}
+    for r in sorted(res.records, key=lambda r: (r["chunk"], r["pass_"], r["seqno"])):
+        want.setdefault((r["pass_"], r["chunk"]), []).extend(polisher.rows_from_record("ctg%d:0" % r["chunk"], r))
+    assert got == want and sum(len(v) for v in got.values()) >= n
