@@ -239,6 +239,7 @@ def e2e_cli():
             #  ~28 ms per GB -- a run started right behind another one's 40 GB measures the other's clean-up; docs/experiments.md)
             time.sleep(3.0)
             t0 = time.perf_counter()
+            t0_epoch = time.time()
             p = subprocess.run(args, cwd=d, env=dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_TIMING="1", **extra), capture_output=True, text=True, timeout=600)
             wall = time.perf_counter() - t0
             if p.returncode:
@@ -250,7 +251,8 @@ def e2e_cli():
                     marks[m.group(1)] = float(m.group(2))
             got = synth.output_digests(d, k=ref["k"])
             keys = ("threshold", "jfhisto_sha256", "polished_bases", "polished_fasta_sha256", "fixes_csv_lines", "fixes_csv_sha256")
-            this = {"seconds": round(wall, 3), "stage_seconds": marks, "outputs_equal_reference": all(got[k] == ref[k] for k in keys)}
+            this = {"seconds": round(wall, 3), "seconds_until_outputs_complete": _outputs_complete_s(p.stderr, t0_epoch), "stage_seconds": marks,
+                    "outputs_equal_reference": all(got[k] == ref[k] for k in keys)}
             prev = runs.get(label)
             if prev is not None:
                 this["outputs_equal_reference"] = this["outputs_equal_reference"] and prev["outputs_equal_reference"]
@@ -259,32 +261,42 @@ def e2e_cli():
             runs[label] = this
         best = runs["no_database_file"]
         count_s = next((v for k, v in best["stage_seconds"].items() if k.startswith("count reads")), None)
-        return {"seconds": best["seconds"], "seconds_with_database_file": runs["with_database_file"]["seconds"],
+        return {"seconds": best["seconds"], "seconds_until_outputs_complete": best["seconds_until_outputs_complete"],
+                "seconds_with_database_file": runs["with_database_file"]["seconds"],
                 "outputs_equal_reference": all(r["outputs_equal_reference"] for r in runs.values()),
                 "ingest_text_GBps": round(fastq / 1e9 / count_s, 2) if count_s else None, "stage_seconds": best["stage_seconds"],
                 "stage_seconds_with_database_file": runs["with_database_file"]["stage_seconds"],
                 "input": "%.2f GB FASTQ (%d reads) + %.1f Mb FASTA on %s (page cache warm: written %.0f s before), flags -k %d -t %d -p %d" % (
                     fastq / 1e9, nreads, asm_len / 1e6, d.rsplit("/", 1)[0], t_gen, ref["k"], ref["threads"], ref["passes"]),
                 "reference_seconds_build_container_8_vcpu": ref["reference_wall_seconds"],
-                "note": "untimed leg; wall time of the child process (the faster of two runs each): interpreter start, split, count (files -> table), histogram, threshold, polish of the batch files, join, QV; the database file is written beside the stages after the counting"}
+                "note": "untimed leg; `seconds` = wall time of the child process to its END (the faster of two runs each; like jasper.sh the command returns when its device memory has been released), seconds_until_outputs_complete = to the moment every output file was in place: interpreter start, split, count (files -> table), histogram, threshold, polish of the batch files, join, QV; the database file is written beside the stages after the counting"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
 
-def e2e_cli_cfg3():
-    """Second UNTIMED leg, a larger driver-visible size: BASELINE configs[2] exactly as stated -- 140 Mb in 7 contigs, 40x reads
-    (37.3 M reads, 11.5 GB of FASTQ), k = 37, 2 passes, `-t 16` -- through `python -m jasper_amd.cli` as ONE process, against the
-    digests of the real reference's run on the same deterministic files (tests/golden/fullsize_cfg3.json).  Skipped, with the
-    reason, when the scratch directory has no room for the files."""
+def _outputs_complete_s(stderr, t_start_epoch):
+    """seconds from the start of the child to the moment its run() returned (every output file complete and under its final name);
+    what follows in the child is the release of tens of GB of device memory at process end -- part of `seconds`, as for jasper.sh"""
+    m = re.search(r"\[timing-abs\] run\(\) returned at ([0-9.]+)", stderr)
+    return round(float(m.group(1)) - t_start_epoch, 3) if m else None
+
+
+def e2e_cli_big(fixture="fullsize_cfg3", need_gb=40):
+    """Further UNTIMED legs at larger driver-visible sizes, through `python -m jasper_amd.cli` as ONE process, against the digests
+    (and QV column sums) of the real reference's run on the same deterministic files (tests/golden/<fixture>.json):
+      fullsize_cfg3        BASELINE configs[2] exactly as stated -- 140 Mb in 7 contigs, 40x reads (37.3 M reads, 11.5 GB of FASTQ), -t 16
+      fullsize_cfg4_share  one rank's share of configs[3] (CHM13 on 8 GPUs): 390 Mb in 3 contigs, 30x (78 M reads, 24 GB of FASTQ), -t 64:
+                           a 2^32-slot table filled in 8 pieces, 36 batch files
+    Skipped, with the reason, when the scratch directory has no room for the files."""
     import shutil
     import subprocess
     import tempfile
     from jasper_amd import synth
-    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_cfg3.json")))
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", fixture + ".json")))
     base = os.environ.get("TMPDIR", "/tmp")
     free = shutil.disk_usage(base).free
-    if free < 40 << 30:
-        return {"seconds": None, "skipped": "%s has %.0f GB free: 12 GB of read files + working files need room" % (base, free / 1e9)}
+    if free < need_gb << 30:
+        return {"seconds": None, "skipped": "%s has %.0f GB free: the read files + working files need %d GB" % (base, free / 1e9, need_gb)}
     d = tempfile.mkdtemp(prefix="jasper_e2e3_", dir=base)
     try:
         t0 = time.perf_counter()
@@ -294,6 +306,7 @@ def e2e_cli_cfg3():
         args = [sys.executable, "-m", "jasper_amd.cli", "-r", " ".join(synth.read_files(1)), "-a", "asm.fa", "-k", str(ref["k"]), "-t", str(ref["threads"]), "-p", str(ref["passes"])]
         time.sleep(3.0)
         t0 = time.perf_counter()
+        t0_epoch = time.time()
         p = subprocess.run(args, cwd=d, env=dict(os.environ, PYTHONPATH=ROOT, JASPER_AMD_TIMING="1", JASPER_AMD_NO_JF="1"), capture_output=True, text=True, timeout=900)
         wall = time.perf_counter() - t0
         if p.returncode:
@@ -304,7 +317,8 @@ def e2e_cli_cfg3():
         qm = re.search(r"^\[qv\] before (\d+) (\d+) after (\d+) (\d+)$", p.stderr, re.M)
         count_s = next((v for k, v in marks.items() if k.startswith("count reads")), None)
         split_s = marks.get("split", 0.0)
-        return {"seconds": round(wall, 3), "outputs_equal_reference": all(got[k] == ref[k] for k in keys),
+        return {"seconds": round(wall, 3), "seconds_until_outputs_complete": _outputs_complete_s(p.stderr, t0_epoch),
+                "outputs_equal_reference": all(got[k] == ref[k] for k in keys),
                 "qv_sums_equal_reference": bool(qm) and [int(qm.group(1)), int(qm.group(2))] == ref.get("qv_before") and [int(qm.group(3)), int(qm.group(4))] == ref.get("qv_after"),
                 "stage_seconds": marks, "ingest_text_GBps": round(fastq / 1e9 / (count_s + split_s), 2) if count_s else None,
                 "input": "%.2f GB FASTQ (%d reads) + %.1f Mb FASTA in %d contigs on %s (written %.0f s before), flags -k %d -t %d -p %d" % (
@@ -358,10 +372,15 @@ def main():
     # (the larger leg first, on a GPU nobody has used yet: device memory that a process frees is cleared in the background, ~28 ms
     #  per GB, and an allocation that gets such memory waits for it -- the configs[2] run allocates ~100 GB and took 3.1 s instead
     #  of 1.3 s right behind the four configs[1] runs, all of it in its first allocations; docs/experiments.md)
-    e2e3 = None
+    e2e3 = e2e4 = None
     if a.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.genome_mb == 47.0 and not a.no_e2e and not a.no_e2e_cfg3:
+        try:        # one rank's share of configs[3] (24 GB of FASTQ, a 2^32-slot table): the largest case, on the untouched GPU
+            e2e4 = e2e_cli_big("fullsize_cfg4_share", need_gb=70)
+        except Exception as e:
+            e2e4 = {"seconds": None, "failed": "%r" % (e,)}
+        time.sleep(8.0)
         try:
-            e2e3 = e2e_cli_cfg3()
+            e2e3 = e2e_cli_big("fullsize_cfg3", need_gb=40)
         except Exception as e:
             e2e3 = {"seconds": None, "failed": "%r" % (e,)}
         time.sleep(6.0)
@@ -429,7 +448,7 @@ def main():
         occ = nreads * (READ_LEN - K + 1)
         lam = COVERAGE * (READ_LEN - K + 1) / READ_LEN
         plan = shard.exchange_plan(reads.numel(), world)
-        dedup = plan is not None and plan["p2"] >= 1 and os.environ.get("JASPER_AMD_EXCHANGE_DEDUPE", "1") not in ("0", "no", "false")
+        dedup = plan is not None and plan["p2"] >= 1 and jdist.dedupe_pays(world)
         exchange = plan is not None and jdist.prefer_exchange(world, occ, world * a.genome_mb * 1e6 * (1.0 - math.exp(-lam / world)) + 0.103 * occ, deduplicated=dedup)
         if not exchange:
             shard.close()
@@ -622,6 +641,8 @@ def main():
             out["e2e_cli"] = e2e
         if e2e3 is not None:
             out["e2e_cli_cfg3"] = e2e3
+        if e2e4 is not None:
+            out["e2e_cli_cfg4_share"] = e2e4
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()           # nobody unmaps or frees a shard that a peer may still be reading

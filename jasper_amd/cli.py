@@ -519,7 +519,7 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer, job=None):
                 take = plan is not None
                 if take and how == "auto":   # bytes per link decide (dist.prefer_exchange): FASTQ is ~2.1 bytes per base; -s is the expected number of distinct k-mers
                     occ = sum((e if e >= 0 else os.path.getsize(p)) - b for p, b, e in my_ranges) / 2.1
-                    dedup = plan["p2"] >= 1 and os.environ.get("JASPER_AMD_EXCHANGE_DEDUPE", "1") not in ("0", "no", "false")
+                    dedup = plan["p2"] >= 1 and jdist.dedupe_pays(world)
                     take = jdist.prefer_exchange(world, occ, o.jf_size, deduplicated=dedup)
                 if not jdist.all_reduce_ints([1 if take else 0], device=dev, op="min")[0]:
                     sharded.close()
@@ -561,7 +561,24 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer, job=None):
     # key-wise sum over the GPUs; the result stays sharded by key owner unless the peers' HBM cannot be mapped
     write_db = counted and os.environ.get("JASPER_AMD_NO_JF", "") not in ("1", "true", "yes")
     db_cmdline = ["count", "-C", "-t", str(o.num_threads), "-s", str(o.jf_size), "-m", str(kmer), "-o", "mer_counts%d.jf" % kmer] + (o.reads.split() if counted else [])
+    # sharded by owner, or a copy of the whole table on every GPU?  dist.prefer_replicated: it must fit and the gather must cost less than
+    # the remote lookups it saves -- with one polish call per counted table it does not (JASPER_AMD_TABLE=replicated|sharded overrides)
+    how_table = os.environ.get("JASPER_AMD_TABLE", "auto")
+    replicate = how_table == "replicated"
+    if how_table == "auto":
+        try:
+            import ctypes as C
+            from . import _lib
+            free_b, total_b = C.c_uint64(0), C.c_uint64(0)
+            _lib.check(_lib.lib().jasper_device_mem_info(int(o.device), C.byref(free_b), C.byref(total_b)))
+            asm_bases = job.n_bases if job is not None else os.path.getsize(o.query)
+            replicate = jdist.prefer_replicated(world, max(o.jf_size, 1), asm_bases / world, passes + 1, free_b.value)
+        except Exception:           # noqa: BLE001 -- no answer: the default
+            replicate = False
+    replicate = bool(jdist.all_reduce_ints([1 if replicate else 0], device=dev, op="min")[0])
     try:
+        if replicate:
+            raise jdist.ShardAttachError("a copy of the whole table on every GPU was asked for (or is expected to pay)")
         if local is None:       # counted straight into the owners' shards
             table = sharded
             local = table       # (what the fallback below merges: the shards are disjoint, their key-wise sum is the whole table)
@@ -578,6 +595,9 @@ def _run_multi(o, rank, world, dev, batch_size, passes, kmer, job=None):
     except jdist.ShardAttachError as e:
         if is0:
             sys.stderr.write("jasper_amd: %s -- replicating the merged table on every GPU instead\n" % e)
+        if replicate:
+            table = local if local is not None else sharded
+            local = table
         table.detach()          # (whatever was mapped is unmapped on every rank before anybody frees its slot array)
         bar()
         if table is not local:

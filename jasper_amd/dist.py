@@ -555,6 +555,61 @@ def prefer_exchange(world, occurrences_per_rank, distinct_per_rank, link_gb_s=70
     return t_exchange < t_local
 
 
+XGMI_LINK_GB_S = 153.0       # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links per GPU, point to point)
+
+
+def dedupe_pays(world, occurrences_per_rank=None, link_gb_s=XGMI_LINK_GB_S, setting=None):
+    """Should the sender deduplicate its region lists (list_dedupe_kernel) before the all_to_all?  The pass costs kernel time on
+    every sender and saves bytes on the wire; with a link per peer the saving shrinks as the ranks grow.  From the role-play of
+    round 4's kernels on the bench workload (profiles/round4/exchange_kernel_stats.csv; 1.07 G records per rank):
+
+        ranks   dedupe pass   records left   raw wire / rank       wire saved          net
+          2       5.3 ms        1 / 3.7       4.3 GB on 1 link     (4.3-1.4)/153 = 19 ms   +14 ms   -> dedupe
+          4       5.4 ms        1 / 3.6       6.4 GB on 3 links    (6.4-2.1)/459 =  9 ms   + 4 ms   -> dedupe
+          8       6.0 ms        1 / 2.4       7.5 GB on 7 links    (7.5-3.7)/1071 = 3.5 ms  - 2.5 ms -> ship the lists as they are
+
+    (a rank's piece repeats fewer of its k-mers the more ranks share the reads, and more links carry what is left).  So: dedupe for
+    2..4 ranks, not beyond -- until the pass runs hidden under the all_to_all of the round before, which is when the bytes alone
+    would decide.  JASPER_AMD_EXCHANGE_DEDUPE=0 / 1 (`setting`) overrides.  Nothing here has run over xGMI."""
+    if setting is None:
+        setting = os.environ.get("JASPER_AMD_EXCHANGE_DEDUPE", "auto")
+    if str(setting).lower() in ("0", "no", "false"):
+        return False
+    if str(setting).lower() in ("1", "yes", "true"):
+        return True
+    return world <= 4
+
+
+def prefer_replicated(world, distinct_total, bases_per_rank, scans, free_bytes, polish_calls=1, link_gb_s=XGMI_LINK_GB_S):
+    """After the counts have reached their key owners: keep the table sharded by owner (every lookup of the polishing kernels
+    reads the owner's HBM, 7/8 of them over xGMI at N = 8), or give every GPU a copy of the whole table (merge: all-gather of the
+    owners' entries + one import sweep; lookups local)?  The stated rule:
+
+      it must FIT:   2 x 16 B x 2^ceil(log2(2 x distinct)) (the table at load <= 1/2, and the entries in flight) <= 80 % of the free HBM
+      it must PAY:   t_gather + t_import < polish_calls x t_remote_penalty, with
+          t_gather         = 16 B x distinct x (N-1)/N / ((N-1) links x link rate)        every rank receives the other owners' entries
+          t_import         = distinct / 40e9                                              one region-ordered sweep (the rate of region_insert)
+          t_remote_penalty = bases_per_rank x (N-1)/N x 1.2 x 64 B / ((N-1) links x link rate)      the dense scan of pass 0 probes every
+                             window once (the later passes and the walks add ~0.07 lookups per base and scan: the 1.2), a 64-byte sector each
+                           + scans x 2900 x (N-1)/N x 1.2 us        a pass is as long as its slowest segment's chain of dependent lookups
+                             (2 900 in pass 0 of the bench workload, 0.24 us each locally; ~1.2 us more per remote round trip assumed)
+
+    With BASELINE's shapes (distinct ~ 3..10 x assembly bases, one polish call of P + 1 scans per counted table) the gather costs more
+    than all the remote lookups of the run -- the table stays sharded; a table that is polished many times over (a resident
+    service, `polish_calls`) flips the rule.  configs[3] / [4] at 8 GPUs do not fit replicated at all.  Unmeasured on hardware."""
+    n = max(int(world), 2)
+    slots = 1
+    while slots < 2 * max(int(distinct_total), 1):
+        slots *= 2
+    if 2 * 16 * slots > 0.8 * float(free_bytes):
+        return False
+    links = (n - 1) * link_gb_s * 1e9
+    t_gather = 16.0 * distinct_total * (n - 1) / n / links
+    t_import = distinct_total / 40e9
+    t_penalty = bases_per_rank * (n - 1) / n * 1.2 * 64.0 / links + scans * 2900 * (n - 1) / n * 1.2e-6
+    return t_gather + t_import < polish_calls * t_penalty
+
+
 class _ResidentBases:
     """one buffer of bases in HBM, cut into pieces of at most `piece` bases"""
 
@@ -659,7 +714,7 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
     # memory is short (one value for all ranks: the buffers are sized by the longest piece of the round).  The gloo rehearsal
     # gathers every rank's send buffer on every rank, and its ranks may share one GPU.
     if dedupe is None:
-        dedupe = os.environ.get("JASPER_AMD_EXCHANGE_DEDUPE", "1") not in ("0", "no", "false")
+        dedupe = dedupe_pays(world)
     piece = int(piece_limit or os.environ.get("JASPER_AMD_EXCHANGE_PIECE", 1 << 31))
     if device.type == "cuda" and not piece_limit:
         torch.cuda.empty_cache()

@@ -19,8 +19,12 @@ the same flags -- as one process, or as two ranks (the multi-GPU form of the dri
                          below 4 and the REFERENCE aborts ("Local min of kmer counts is smaller than 4", src/jasper.sh:200-202) --
                          the drop-in must abort the same way, with the same log lines
   fullsize_cfg3          configs[2] EXACTLY as stated: 140 Mb in 7 contigs, 40x = 37.3 M reads (11.5 GB of FASTQ), two ranks
-  on request (JASPER_TEST_BIG=1): the same as one process, fullsize_cfg3like (140 Mb, one contig, 30x), and
-  fullsize_cfg4_share    one rank's share of configs[3] (CHM13 on 8 GPUs): 390 Mb in 3 contigs, 30x, -t 64 (reference: 884 s)"""
+  fullsize_cfg4_share    one rank's share of configs[3] (CHM13 on 8 GPUs): 390 Mb in 3 contigs, 30x = 78 M reads (24 GB of FASTQ),
+                         -t 64: a 2^32-slot table filled in 8 pieces, 36 batch files (reference: 884 s)
+  fullsize_cfg5_chr21    configs[4]'s shape at chr21 size: 47 Mb, 10 read sets (individuals with 0.1 % private SNPs) x 30x = 94 M reads
+                         (29 GB of FASTQ, 10.7 G k-mer occurrences, counts in the hundreds), 4 passes, -t 16 (reference: 850 s):
+                         the rolling threshold (src/jasper.py:80-93) at 300x
+  on request (JASPER_TEST_BIG=1): fullsize_cfg3 as one process, fullsize_cfg3like (140 Mb, one contig, 30x)"""
 import json
 import os
 import re
@@ -53,7 +57,30 @@ def _input_dir(ref, tmp_path_factory):
     return _inputs[key]
 
 
+def _input_key(ref):
+    return (ref["genome_mb"], ref["seed"], ref.get("coverage", 30), ref.get("contigs", 1), ref.get("populations", 1))
+
+
+_uses_left = {}          # input key -> runs that still need it (the large inputs -- tens of GB -- go as soon as their last run is over)
+
+
+def _done_with(ref):
+    import shutil
+    key = _input_key(ref)
+    if key in _uses_left:
+        _uses_left[key] -= 1
+        if _uses_left[key] <= 0 and key in _inputs:
+            shutil.rmtree(_inputs.pop(key), ignore_errors=True)
+
+
 def _run(ref, tmp_path_factory, ranks, count=None, extra_env=None, expect_stderr=None):
+    try:
+        _run_case(ref, tmp_path_factory, ranks, count, extra_env, expect_stderr)
+    finally:
+        _done_with(ref)
+
+
+def _run_case(ref, tmp_path_factory, ranks, count=None, extra_env=None, expect_stderr=None):
     from jasper_amd import synth
     src = _input_dir(ref, tmp_path_factory)
     d = str(tmp_path_factory.mktemp("run"))
@@ -121,11 +148,16 @@ CASES = [("fullsize_cfg1", 1), ("fullsize_cfg2", 1), ("fullsize_cfg2_t16", 1), (
          ("fullsize_cfg3_quarter", 2), ("fullsize_cfg3_quarter", 1), ("fullsize_cfg4_scaled", 1), ("fullsize_cfg4_scaled", 2),
          ("fullsize_cfg5_scaled", 1), ("fullsize_cfg5_scaled", 2), ("fullsize_cfg5_lowcov", 1),
          ("fullsize_cfg2_k41", 1), ("fullsize_cfg2_k51", 1),      # configs[1] files at k = 41 / 51: keys of 82 / 102 bits -> 16-byte records, a wide table at k = 51 (src/jasper.sh:89-90 takes any -k)
-         ("fullsize_cfg3", 2)]          # configs[2] exactly as stated (11.5 GB of FASTQ: ~40 s to generate, ~25 s to run as two ranks on one GPU)
+         ("fullsize_cfg3", 2),          # configs[2] exactly as stated (11.5 GB of FASTQ, as two ranks on one GPU)
+         ("fullsize_cfg4_share", 1),    # ONE rank's share of configs[3]: 390 Mb in 3 contigs + 30x (78 M reads, 24 GB of FASTQ), -t 64: a 2^32-slot table,
+                                        # multi-piece counting, 36 batch files (also tools/run_big_case.py, which prints while it works)
+         ("fullsize_cfg5_chr21", 1)]    # configs[4]'s shape at chr21 size: 10 x 30x on 47 Mb (94 M reads, 29 GB of FASTQ), 4 passes
 if BIG:
-    CASES += [("fullsize_cfg3", 1), ("fullsize_cfg3like", 1),
-              ("fullsize_cfg4_share", 1)]     # ONE rank's share of configs[3]: 390 Mb in 3 contigs + 30x (78 M reads, 24 GB of FASTQ), -t 64: a 2^32-slot table,
-                                              # multi-piece counting, 36 batch files (also tools/run_big_case.py, which prints while it works)
+    CASES += [("fullsize_cfg3", 1), ("fullsize_cfg3like", 1)]
+EXCHANGE_CASES = [("fullsize_cfg2", 2), ("fullsize_cfg3_quarter", 2), ("fullsize_cfg5_scaled", 2), ("fullsize_cfg3", 2)]
+for _name, _ranks in CASES + EXCHANGE_CASES + [("fullsize_cfg1", 2)]:          # (the last: test_cli_exchange_falls_back_...)
+    _k = _input_key(_ref(_name))
+    _uses_left[_k] = _uses_left.get(_k, 0) + 1
 
 
 @pytest.mark.parametrize("name,ranks", CASES)
@@ -134,7 +166,7 @@ def test_cli_fullsize_matches_real_reference(hip, tmp_path_factory, name, ranks)
     _run(_ref(name), tmp_path_factory, ranks, count=("local" if ranks > 1 else None))
 
 
-@pytest.mark.parametrize("name,ranks", [("fullsize_cfg2", 2), ("fullsize_cfg3_quarter", 2), ("fullsize_cfg5_scaled", 2), ("fullsize_cfg3", 2)])
+@pytest.mark.parametrize("name,ranks", EXCHANGE_CASES)
 def test_cli_fullsize_counts_by_exchange_of_region_lists(hip, tmp_path_factory, name, ranks):
     """the same digests with no table per GPU: file reader -> batches of bases -> region lists grouped by key owner -> one
     all_to_all per batch -> owners' shards (dist.count_sharded; what `auto` picks whenever the table has a geometry for it)"""

@@ -92,3 +92,19 @@ def test_pipes_are_not_touched(tmp_path):
     plain.write_bytes(b"@a\nACGT\n+\nIIII\n")
     # (opening the FIFO would block forever here: the plan must come back without looking at it)
     assert jd.plan_read_shards([str(plain), str(fifo)], 2) == [[(str(plain), 0, -1), (str(fifo), 0, -1)], []]
+
+
+def test_stated_rules_for_dedupe_and_replication(monkeypatch):
+    """dist.dedupe_pays / dist.prefer_replicated: the bytes-per-link rules of DESIGN.md section 7 (models: nothing has run over xGMI)"""
+    from jasper_amd import dist as jdist
+    monkeypatch.delenv("JASPER_AMD_EXCHANGE_DEDUPE", raising=False)
+    assert [jdist.dedupe_pays(w) for w in (2, 3, 4, 6, 8)] == [True, True, True, False, False]
+    assert jdist.dedupe_pays(8, setting="1") and not jdist.dedupe_pays(2, setting="0")
+    hbm = 288e9
+    # BASELINE shapes, one polish call of P + 1 scans per counted table: the gather costs more than every remote lookup of the run
+    assert not jdist.prefer_replicated(2, 0.5e9, 70e6, 3, 0.9 * hbm)              # configs[2]
+    assert not jdist.prefer_replicated(8, 8 * 157e6, 47e6, 3, 0.9 * hbm)          # the bench's weak scaling at N = 8
+    assert not jdist.prefer_replicated(8, 8e9, 390e6, 3, 0.9 * hbm)               # configs[3]: 2^34 slots x 16 B x 2 do not even fit
+    # a resident table that is polished over and over is worth a copy per GPU -- if it fits
+    assert jdist.prefer_replicated(8, 8 * 157e6, 47e6, 3, 0.9 * hbm, polish_calls=200)
+    assert not jdist.prefer_replicated(8, 8 * 157e6, 47e6, 3, 30e9, polish_calls=200)
