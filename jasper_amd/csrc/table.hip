@@ -619,6 +619,14 @@ int Table::init(int k_, uint64_t min_slots, int device_, std::string &err) {
     k = k_;
     device = device_;
     HIPCHK(hipSetDevice(device));
+    if (const char *e = getenv("JASPER_EXPERIMENT_CU_MASK")) {
+        // experiments only (docs/experiments.md, round 5): the table's stream restricted to a part of the chip -- "alt2" every second
+        // CU bit (128 of 256), "alt4x3" three of every four (192), "lo128" / "lo192" the first 128 / 192 bits
+        uint32_t m[8];
+        for (int w = 0; w < 8; ++w)
+            m[w] = !strcmp(e, "alt2") ? 0x55555555u : !strcmp(e, "alt4x3") ? 0x77777777u : !strcmp(e, "lo128") ? (w < 4 ? ~0u : 0u) : !strcmp(e, "lo192") ? (w < 6 ? ~0u : 0u) : ~0u;
+        HIPCHK(hipExtStreamCreateWithCUMask(&stream, 8, m));
+    } else
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     int s = min_log2_slots(k);
     size_hint = min_slots;

@@ -185,6 +185,45 @@ def _all_to_all_rows(send, group=None):
     return torch.stack([parts[src][rank] for src in range(world)])
 
 
+def _all_to_all_rows_async(send, group=None):
+    """_all_to_all_rows without waiting: returns (get, wait) -- wait() blocks the host until the rows have arrived, get() then gives
+    recv with recv[src] = what rank src sent to this rank.  RCCL: all_to_all_single(async_op=True) on the communicator's own stream;
+    gloo (rehearsal): an asynchronous all_gather, the column picked afterwards."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if dist.get_backend(group) == "nccl":
+        recv = torch.empty_like(send)
+        work = dist.all_to_all_single(recv.view(-1), send.view(-1), group=group, async_op=True)
+
+        def wait():
+            work.wait()                                  # (the current torch stream waits for the collective ...)
+            torch.cuda.current_stream(send.device).synchronize()      # (... and the host for that stream: the library works on a stream of its own)
+        return (lambda: recv), wait
+    parts = [torch.empty_like(send) for _ in range(world)]
+    work = dist.all_gather(parts, send, group=group, async_op=True)
+    return (lambda: torch.stack([parts[src][rank] for src in range(world)])), (lambda: work.wait())
+
+
+_CONTROL_GROUPS = {}
+
+
+def _control_group(group=None):
+    """a gloo group over the ranks of `group` for the small agreements of a pipelined exchange (host tensors): a reduction of four
+    integers must not queue behind gigabytes of lists on the data communicator.  Made once per data group; every rank makes it at
+    the same point of the program (its first pipelined count_sharded)."""
+    import torch.distributed as dist
+    key = id(group) if group is not None else None
+    if key not in _CONTROL_GROUPS:
+        if dist.get_backend(group) == "gloo":
+            _CONTROL_GROUPS[key] = group                 # (the rehearsal's transport already is one)
+        else:
+            ranks = dist.get_process_group_ranks(group) if group is not None else None
+            _CONTROL_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo")
+    return _CONTROL_GROUPS[key]
+
+
 def merge_tables(table, device, group=None):
     """key-wise sum of the per-GPU tables; afterwards every rank's table holds the counts of ALL reads.
 
@@ -715,18 +754,53 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
     # gathers every rank's send buffer on every rank, and its ranks may share one GPU.
     if dedupe is None:
         dedupe = dedupe_pays(world)
+    # THE ROUNDS ARE A PIPELINE OF THREE STAGES (round 5).  A round's work is: SENDER -- this rank's piece through part1 and the split by
+    # owner (+ dedupe), kernels on the library's stream; WIRE -- the all_to_all of the lists; OWNER -- region_insert of what arrived.
+    # Run one after the other a rank's GPU idles during the wire and its links idle during the kernels (~24 ms per rank at
+    # N = 8 where the kernels are ~15).  So the all_to_all of round r is started without waiting for it (async_op), the sender stage of
+    # round r + 1 runs while it is under way, and only then is it waited for and inserted -- behind the START of round r + 1's own
+    # all_to_all, which is then under way during that insert and during the sender stage of round r + 2.  A rank's kernels stay on one
+    # stream (they would only share the chip), what overlaps is the fabric with the kernels.
+    # The small agreements between the stages (sizes, record counts, "did every rank get through") must not queue behind a list
+    # exchange on the same communicator: they go through a CONTROL group of their own on host tensors (gloo).
+    pipeline = os.environ.get("JASPER_AMD_EXCHANGE_PIPELINE", "1") not in ("0", "no", "false")
+    ctrl = _control_group(group) if pipeline else group
+    cdev = torch.device("cpu") if (pipeline and ctrl is not group) or dist.get_backend(group) != "nccl" else device
+
+    def agree(values, op):
+        t = torch.tensor(list(values), dtype=torch.int64, device=cdev)
+        dist.all_reduce(t, op=op, group=ctrl)
+        return [int(v) for v in t.tolist()]
+
+    def gather_rows(values):
+        t = torch.tensor(list(values), dtype=torch.int64, device=cdev)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=ctrl)
+        return [q.tolist() for q in parts]
+
     piece = int(piece_limit or os.environ.get("JASPER_AMD_EXCHANGE_PIECE", 1 << 31))
     if device.type == "cuda" and not piece_limit:
         torch.cuda.empty_cache()
-        per_base = 48 if dist.get_backend(group) == "nccl" else 48 + 48 * world
+        # a round holds its send and receive lists (~10 bytes per base each) next to the library's level-1 lists; with the pipeline the
+        # lists of up to three rounds exist at once (being made / on the wire / being inserted)
+        per_base = (72 if pipeline else 48) if dist.get_backend(group) == "nccl" else (72 if pipeline else 48) + 48 * world
         piece = max(8 << 20, min(piece, torch.cuda.mem_get_info(device)[0] // per_base))
-    pt = torch.tensor([piece], dtype=torch.int64, device=device)
-    dist.all_reduce(pt, op=dist.ReduceOp.MIN, group=group)
-    piece = int(pt.item())
+    longest = int(n_bases) if feeder is None else 0
+    piece, longest = agree([piece, -longest], dist.ReduceOp.MIN)
+    longest = -longest
+    if pipeline and feeder is None and not piece_limit and longest <= piece and longest >= (1 << 30):
+        # bases resident in HBM that would be ONE round: three rounds, so that two thirds of the lists travel under kernels
+        # (a round costs ~1 ms of launches and agreements of its own: not worth it for small inputs)
+        piece = (longest + 2) // 3 + 64
     source = _FeedBases(feeder, piece) if feeder is not None else _ResidentBases(d_bases, n_bases, piece)
     wire = n_deferred = rounds = 0
     records_max = 0
-    while True:
+    plan = None
+    last = {}
+
+    def sender_stage(index):
+        """this rank's next piece -> send lists; None (on every rank together) when no rank has a piece left"""
+        nonlocal records_max, plan
         ok, why = 1, ""
         mine = None
         try:
@@ -735,24 +809,21 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
             ok, why = 0, str(e)
         length = (mine[3] - mine[2]) if mine else 0
         more = 1 if (mine and mine[4]) else 0
-        st = torch.tensor([length, shard.info()["slots"], more, 1 - ok], dtype=torch.int64, device=device)
-        dist.all_reduce(st, op=dist.ReduceOp.MAX, group=group)
-        piece_max, slots, any_more, bad = (int(v) for v in st.tolist())
+        piece_max, slots, any_more, bad = agree([length, shard.info()["slots"], more, 1 - ok], dist.ReduceOp.MAX)
         if bad:
             raise CollectiveCountError("count_sharded: reading the reads failed on some rank" + (": " + why if why else ""))
         if piece_max == 0:
-            break
+            return None
         plan = None
         try:
             shard.reserve(slots)                        # a shard that grew in the last round changes the geometry for all
             plan = shard.exchange_plan(piece_max, world)
         except RuntimeError as e:
             ok, why = 0, str(e)
-        okt = torch.tensor([1 if plan is not None else 0, ok], dtype=torch.int64, device=device)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
-        if not int(okt[1].item()):
+        has_plan, all_ok = agree([1 if plan is not None else 0, ok], dist.ReduceOp.MIN)
+        if not all_ok:
             raise CollectiveCountError("count_sharded: growing the shards failed on some rank" + (": " + why if why else ""))
-        if not int(okt[0].item()):
+        if not has_plan:
             raise CollectiveCountError("count_sharded: the shards outgrew the exchange geometry between rounds")
         dcap = plan["deferred_cap"]
         found = 0
@@ -768,11 +839,10 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
                 found = shard.exchange_scan(0, 0, 0, 0, piece_max, world, deferred.data_ptr(), dcap)
         except RuntimeError as e:
             ok, why = 0, str(e)
-        st = torch.tensor([found, 1 - ok], dtype=torch.int64, device=device)
-        dist.all_reduce(st, op=dist.ReduceOp.MAX, group=group)
-        if int(st[1].item()):
+        found_max, failed = agree([found, 1 - ok], dist.ReduceOp.MAX)
+        if failed:
             raise CollectiveCountError("count_sharded: the first partition pass failed on some rank" + (": " + why if why else ""))
-        records_max = max(int(st[0].item()), 1)         # the send lists are sized from the records that are really there
+        records_max = max(found_max, 1)                 # the send lists are sized from the records that are really there
         send = send_cnt = None
         nrec = ncnt = 0
         try:                                            # second pass: level-1 lists -> region lists grouped by owner
@@ -799,42 +869,75 @@ def count_sharded(shard, d_bases, n_bases, device, group=None, piece_limit=None,
                     fill, cbits = dd
             except RuntimeError as e:
                 ok, why = 0, str(e)
-        nd = torch.tensor([ndef, 1 - ok, fill], dtype=torch.int64, device=device)
-        parts = [torch.zeros_like(nd) for _ in range(world)]
-        dist.all_gather(parts, nd, group=group)
-        parts = [p.tolist() for p in parts]
-        if any(p[1] for p in parts):
+        parts = gather_rows([ndef, 1 - ok, fill])
+        if any(q[1] for q in parts):
             raise CollectiveCountError("count_sharded: partitioning failed on some rank" + (": " + why if why else ""))
         slice_cap = 0
         if cbits:
-            slice_cap = max(max(p[2] for p in parts), 1)
+            slice_cap = max(max(q[2] for q in parts), 1)
             send = send.view(world * ncnt, plan["slice_cap"])[:, :slice_cap].contiguous().view(world, ncnt * slice_cap)
             nrec = ncnt * slice_cap
-        recv = _all_to_all_rows(send, group)
-        recv_cnt = _all_to_all_rows(send_cnt, group)
-        wire += (world - 1) * (nrec * 8 + ncnt * 4)
-        d_all, n_all = None, 0
-        mx = max(p[0] for p in parts)
+        _sync(device)                                   # (the lists are complete and packed: they may travel)
+        return dict(send=send, send_cnt=send_cnt, deferred=deferred, parts=parts, piece_max=piece_max, records_max=records_max, slice_cap=slice_cap, cbits=cbits,
+                    nrec=nrec, ncnt=ncnt, slots=shard.info()["slots"], whole=(index == 0 and not any_more and not any_filled), plan=plan)
+
+    def start_wire(R):
+        """the lists, their fill counts and (rare) the deferred entries of all ranks on their way; nothing is waited for"""
+        nonlocal wire, n_deferred
+        R["recv"], w1 = _all_to_all_rows_async(R["send"], group)
+        R["recv_cnt"], w2 = _all_to_all_rows_async(R["send_cnt"], group)
+        R["works"] = [w1, w2]
+        wire += (world - 1) * (R["nrec"] * 8 + R["ncnt"] * 4)
+        R["d_all"], R["n_all"] = None, 0
+        mx = max(q[0] for q in R["parts"])
         if mx:                                          # rare: the deferred entries of all ranks go to everybody, owners pick theirs
-            pad = deferred[8:8 + 3 * mx].contiguous()
+            pad = R["deferred"][8:8 + 3 * mx].contiguous()
             allp = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(allp, pad, group=group)
-            d_all = torch.cat([allp[src][:3 * parts[src][0]] for src in range(world)]).contiguous()
-            n_all = sum(p[0] for p in parts)
-            n_deferred += n_all
+            R["works"].append((lambda w: (lambda: w.wait()))(dist.all_gather(allp, pad, group=group, async_op=True)))
+            R["allp"], R["n_all"] = allp, sum(q[0] for q in R["parts"])
+            n_deferred += R["n_all"]
+
+    def owner_stage(R):
+        """what arrived for this owner into its shard"""
+        ok, why = 1, ""
+        for w in R["works"]:
+            w()
         _sync(device)
-        del send, send_cnt
+        recv, recv_cnt = R["recv"](), R["recv_cnt"]()
+        d_all = None
+        if R["n_all"]:
+            d_all = torch.cat([R["allp"][src][:3 * R["parts"][src][0]] for src in range(world)]).contiguous()
+        _sync(device)
+        R["send"] = R["send_cnt"] = None
         try:
-            shard.exchange_insert(recv.data_ptr(), recv_cnt.data_ptr(), piece_max, records_max, world, rank, d_all.data_ptr() if n_all else 0, n_all,
-                                  whole_input=(rounds == 0 and not any_more and not any_filled), slice_cap=slice_cap, count_bits=cbits)
+            if shard.info()["slots"] != R["slots"]:     # (a shard that grew while these lists were on their way: they are lists of the old geometry)
+                raise RuntimeError("a shard grew between the split of a round and its insert")
+            shard.exchange_insert(recv.data_ptr(), recv_cnt.data_ptr(), R["piece_max"], R["records_max"], world, rank, d_all.data_ptr() if R["n_all"] else 0, R["n_all"],
+                                  whole_input=R["whole"], slice_cap=R["slice_cap"], count_bits=R["cbits"])
+            shard.sync()
         except RuntimeError as e:
             ok, why = 0, str(e)
-        okt = torch.tensor([ok], dtype=torch.int64, device=device)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=group)
-        if not int(okt.item()):
+        if not agree([ok], dist.ReduceOp.MIN)[0]:
             raise CollectiveCountError("count_sharded: inserting the received lists failed on some rank" + (": " + why if why else ""))
-        del recv, recv_cnt, deferred, d_all
-        rounds += 1
+        last.update(plan=R["plan"], slice_cap=R["slice_cap"], cbits=R["cbits"])
+
+    in_flight = None
+    while True:
+        cur = sender_stage(rounds + (1 if in_flight is not None else 0))
+        if cur is not None:
+            start_wire(cur)
+        if not pipeline and cur is not None:
+            owner_stage(cur)
+            rounds += 1
+            continue
+        if in_flight is not None:
+            owner_stage(in_flight)
+            rounds += 1
+        in_flight = cur
+        if cur is None:
+            break
+    plan = last.get("plan", plan)
+    slice_cap, cbits = last.get("slice_cap", 0), last.get("cbits", 0)
     if device.type == "cuda" and rounds > 1:
         torch.cuda.empty_cache()                        # (rounds of different sizes leave cached blocks behind: back to the driver)
     _attach_shards(shard, device, group)

@@ -334,7 +334,6 @@ def _rows_by_pass_and_chunk(res, name_of):
     which = order.tolist()
     S, I, D = ord("s"), ord("i"), ord("d")
     names = {}
-    decoded = None
     for j in range(len(chunk)):
         c = chunk[j]
         nm = names.get(c)
@@ -348,9 +347,7 @@ def _rows_by_pass_and_chunk(res, name_of):
         elif kd == D:
             rows = [[nm, index[j], chr(newc[j]) * rep[j], "d-"]]
         else:
-            if decoded is None:
-                decoded = res.records               # (the 'x' records carry aux bytes: the general decoder)
-            rows = rows_from_record(nm, decoded[which[j]])
+            rows = rows_from_record(nm, res.record(which[j]))      # (the 'x' records carry aux bytes: the general decoder, for these alone)
         key = (pas[j], c)
         lst = out.get(key)
         if lst is None:

@@ -81,23 +81,23 @@ class PolishResult:
     def n_records(self):
         return len(self._raw)
 
+    def record(self, i):
+        """record i as a dict (chunk, pass_, seqno, kind, index, newc, oldc, rep[, patch, orig])"""
+        e = self._raw[i]
+        d = dict(chunk=int(e["chunk"]), pass_=int(e["pass_"]), seqno=int(e["seqno"]), kind=chr(int(e["kind"])), index=int(e["index"]),
+                 newc=chr(int(e["newc"])), oldc=chr(int(e["oldc"])), rep=int(e["rep"]))
+        if d["kind"] == "x":
+            a = self.aux[d["chunk"]]
+            o, n = int(e["aux_off"]), int(e["aux_len"])
+            d["patch"] = a[o:o + n].decode("latin-1")
+            d["orig"] = a[o + n:o + n + d["rep"]].decode("latin-1")
+        return d
+
     @property
     def records(self):
-        """list of dicts (chunk, pass_, seqno, kind, index, newc, oldc, rep[, patch, orig]); decoded on first use"""
+        """list of dicts (see record()); decoded on first use"""
         if self._records is None:
-            out = []
-            r = self._raw
-            for i in range(len(r)):
-                e = r[i]
-                d = dict(chunk=int(e["chunk"]), pass_=int(e["pass_"]), seqno=int(e["seqno"]), kind=chr(int(e["kind"])), index=int(e["index"]),
-                         newc=chr(int(e["newc"])), oldc=chr(int(e["oldc"])), rep=int(e["rep"]))
-                if d["kind"] == "x":
-                    a = self.aux[d["chunk"]]
-                    o, n = int(e["aux_off"]), int(e["aux_len"])
-                    d["patch"] = a[o:o + n].decode("latin-1")
-                    d["orig"] = a[o + n:o + n + d["rep"]].decode("latin-1")
-                out.append(d)
-            self._records = out
+            self._records = [self.record(i) for i in range(len(self._raw))]
         return self._records
 
 
