@@ -415,6 +415,12 @@ def main():
             if rank == 0:
                 sys.stderr.write("bench.py: RCCL self-test failed (%s) -- collectives over gloo instead\n" % selftest.get("error"))
             a.backend = "gloo"
+        elif not selftest.get("pipeline_ok", False):
+            # RCCL works, the pattern of the pipelined exchange (an asynchronous all_to_all with agreements on a control group beside it)
+            # did not: the rounds of the exchange one stage after the other, as before round 5
+            if rank == 0:
+                sys.stderr.write("bench.py: the pipelined exchange failed its self-test (%s) -- stages one after the other\n" % selftest.get("pipeline_error"))
+            os.environ["JASPER_AMD_EXCHANGE_PIPELINE"] = "0"
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible; the product has no CPU path\n")
         sys.exit(2)

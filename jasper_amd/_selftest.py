@@ -6,7 +6,8 @@ tree).  A collective that never returns would hang the job; here it costs a kill
         -m jasper_amd._selftest --out FILE [--backend nccl|gloo] [--one-gpu] [--mb 64]
 
 Every rank: process group, ONE all_to_all_single of --mb megabytes of int64 (the call that moves the region lists, checked word
-by word), one all_reduce, one all_gather, a barrier.  Rank 0 writes {"ok", "world", "backend", "ms": {...}, "error"} to FILE.
+by word), one all_reduce, one all_gather, a barrier; then the pattern of the pipelined exchange (an asynchronous all_to_all with
+agreements on the control group beside it: "pipeline_ok").  Rank 0 writes {"ok", "world", "backend", "ms": {...}, "error"} to FILE.
 """
 import argparse
 import datetime
@@ -71,6 +72,29 @@ def main():
         res["ms"]["all_reduce_all_gather_barrier"] = round((time.perf_counter() - t0) * 1e3, 2)
         res["bytes_all_to_all"] = int(send.numel() * 8)
         res["ok"] = True
+        # the pattern of the pipelined exchange (dist.count_sharded): a list all_to_all under way, not waited for, while small
+        # agreements go through the control group on host tensors -- its own verdict (a failure here costs the pipeline, not RCCL)
+        res["pipeline_ok"] = False
+        try:
+            from jasper_amd import dist as jdist
+            t0 = time.perf_counter()
+            ctrl = jdist._control_group(None)
+            res["ms"]["control_group"] = round((time.perf_counter() - t0) * 1e3, 1)
+            t0 = time.perf_counter()
+            get, wait = jdist._all_to_all_rows_async(send.view(world, per), None)
+            cdev = torch.device("cpu") if dist.get_backend(ctrl) == "gloo" else dev
+            for i in range(3):
+                c = torch.tensor([rank + 1 + i], dtype=torch.int64, device=cdev)
+                dist.all_reduce(c, group=ctrl)
+                if int(c.item()) != world * (world + 1) // 2 + world * i:
+                    raise RuntimeError("control all_reduce gave a wrong sum")
+            wait()
+            if not bool((get().reshape(-1) == want).all().item()):
+                raise RuntimeError("the asynchronous all_to_all delivered wrong words")
+            res["ms"]["async_all_to_all_with_agreements"] = round((time.perf_counter() - t0) * 1e3, 2)
+            res["pipeline_ok"] = True
+        except Exception as e:      # noqa: BLE001
+            res["pipeline_error"] = "rank %d: %r" % (rank, e)
     except Exception as e:      # noqa: BLE001 -- the verdict is the file
         res["error"] = "rank %d: %r" % (rank, e)
     # every rank's verdict counts: a rank that failed writes its own file next to rank 0's

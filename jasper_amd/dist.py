@@ -426,6 +426,7 @@ def transport_selftest(world, backend="nccl", one_gpu=False, seconds=240, mb=64)
             if parts[0]:
                 res.update(parts[0])
             res["ok"] = p.returncode == 0 and all(q and q.get("ok") for q in parts)
+            res["pipeline_ok"] = bool(res["ok"] and all(q and q.get("pipeline_ok") for q in parts))
             if not res["ok"] and not res.get("error"):
                 bad = [q["error"] for q in parts if q and q.get("error")]
                 res["error"] = bad[0] if bad else "self-test exit code %s: %s" % (p.returncode, (errtxt or "")[-300:])

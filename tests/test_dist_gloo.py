@@ -214,6 +214,7 @@ class FakeExchangeTable(FakeTable):
         self.scanned = None
         self.whole = []
         self.plans = []
+        self.stage_calls = []    # "s" a sender stage's partition, "i" an owner's insert, in the order they were made
 
     @staticmethod
     def _arr(ptr, n, ctype):
@@ -254,6 +255,7 @@ class FakeExchangeTable(FakeTable):
         cnt = self._arr(d_send_cnt, nown, ctypes.c_int32)
         dfr = self._arr(d_deferred, 8 + 3 * dcap, ctypes.c_int64)
         cnt[:] = 0
+        self.stage_calls.append("s")
         for key in self.scanned:
             o = key % nown
             if cnt[o] < cap:
@@ -282,6 +284,7 @@ class FakeExchangeTable(FakeTable):
                 if int(key) % nown == me:
                     self.d[int(key)] = self.d.get(int(key), 0) + int(inc)
         self.whole.append(bool(whole_input))
+        self.stage_calls.append("i")
 
 
 def _reads_of(rank, step):
@@ -296,9 +299,9 @@ def _reads_of(rank, step):
     return a
 
 
-def _count_worker(rank, world, port, q, mode):
+def _count_worker(rank, world, port, q, mode, pipeline="1"):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), JASPER_AMD_EXCHANGE_PIPELINE=pipeline)
     import torch
     import torch.distributed as dist
     from jasper_amd import dist as jd
@@ -319,19 +322,20 @@ def _count_worker(rank, world, port, q, mode):
             if info is None:
                 out.append(None)
                 continue
-            out.append((dict(shard.d), info["rounds"], info["deferred"], list(shard.whole), shard.slots, list(shard.attached)))
+            out.append((dict(shard.d), info["rounds"], info["deferred"], list(shard.whole), shard.slots, list(shard.attached), "".join(shard.stage_calls)))
             shard.whole.clear()
+            del shard.stage_calls[:]
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
 
 
-def _run_count(mode, world=2):
+def _run_count(mode, world=2, pipeline="1"):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_count_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    ps = [ctx.Process(target=_count_worker, args=(r, world, port, q, mode, pipeline)) for r in range(world)]
     for p in ps:
         p.start()
     res = dict(q.get(timeout=180) for _ in ps)
@@ -351,7 +355,7 @@ def test_count_sharded_protocol_world2():
                 exp[int(key)] = exp.get(int(key), 0) + 1
         carried = exp
         for r in range(2):
-            d, rounds, deferred, whole, slots, attached = res[r][step]
+            d, rounds, deferred, whole, slots, attached, calls = res[r][step]
             assert d == {k: c for k, c in exp.items() if k % 2 == r}          # owner r holds exactly its keys, summed over ranks and rounds
         assert res[0][step][1] == res[1][step][1] and res[0][step][2] == res[1][step][2]
         assert res[0][step][4] == res[1][step][4] and res[0][step][5] == res[1][step][5]      # one geometry, same handle list
@@ -360,6 +364,20 @@ def test_count_sharded_protocol_world2():
     assert res[0][1][1] == 1 and res[0][1][3] == [True]          # step 1: one round although rank 1 has nothing
     assert res[0][2][2] > 0                      # step 2: the heavy key overflowed its list and arrived as deferred entries
     assert res[0][3][3] == [False]               # step 3: one round, but the shard was not empty
+    # the rounds are a pipeline: a round's lists are inserted only after the NEXT round's sender stage (its all_to_all is under way
+    # meanwhile); the last round's insert closes the call
+    assert res[0][0][6] == res[1][0][6] == "ssisisii"
+    assert res[0][1][6] == "si"
+
+
+def test_count_sharded_stages_one_after_the_other_give_the_same_shards():
+    """JASPER_AMD_EXCHANGE_PIPELINE=0 (what bench.py falls back to when the pipeline's pattern fails the transport self-test): every
+    round sender -> all_to_all -> insert before the next one starts; same shards, rounds and deferred records as the pipeline"""
+    a, b = _run_count("ok"), _run_count("ok", pipeline="0")
+    for r in range(2):
+        for step in range(4):
+            assert a[r][step][:6] == b[r][step][:6]
+    assert b[0][0][6] == "sisisisi"
 
 
 def test_count_sharded_protocol_world8():

@@ -107,6 +107,8 @@ def test_transport_selftest_in_throwaway_processes(hip):
     res = jd.transport_selftest(2, backend="gloo", one_gpu=True, seconds=240, mb=16)
     assert res["ok"], res
     assert res["world"] == 2 and res["ms"]["all_to_all_single"] > 0 and res["bytes_all_to_all"] >= (15 << 20)
+    # ... and the pattern of the pipelined exchange: an all_to_all that is not waited for, agreements on the control group beside it
+    assert res["pipeline_ok"] and res["ms"]["async_all_to_all_with_agreements"] > 0, res
     res = jd.transport_selftest(2, backend="gloo", one_gpu=True, seconds=1, mb=16)      # (two interpreters do not even start in 1 s)
     assert not res["ok"] and "killed" in res["error"] and "did not go away" not in res["error"], res
     # nothing of the killed job is left behind (the launcher starts every rank in a session of its own)

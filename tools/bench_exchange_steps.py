@@ -33,7 +33,8 @@ cnt = torch.empty((W, ncnt), dtype=torch.int32, device=dev)
 dfr = torch.empty(8 + 3 * dcap, dtype=torch.int64, device=dev)
 recv = torch.empty((W, nrec), dtype=torch.int64, device=dev)
 rcnt = torch.empty((W, ncnt), dtype=torch.int32, device=dev)
-DEDUPE = os.environ.get("DEDUPE", "1") != "0"
+from jasper_amd import dist as jdist
+DEDUPE = (os.environ["DEDUPE"] != "0") if "DEDUPE" in os.environ else jdist.dedupe_pays(W)      # (the rule of dist.count_sharded: dedupe for 2..4 ranks)
 slice_cap, cbits = 0, 0
 prev = [0.0] * 8
 for rep in range(reps):
@@ -81,6 +82,7 @@ for rep in range(reps):
     st = [a - b for a, b in zip(acc, prev)]
     prev = acc
     info = shard.info()
+    owner_ms = st[2] + st[3] + st[4]
     used = int(rcnt.to(torch.int64).sum().item())
     print("rep %d (last sender deferred %d): owner 0 received %d records (%.3f of one rank's k-mers) in %d x %d slices of cap %d (mean fill %.0f, fullest %d): "
           "region_insert %.2f (+%.2f) deferred %.2f ms (wall %.2f); shard distinct %d in 2^%d slots"
@@ -110,3 +112,15 @@ st = best
 wire = (W - 1) * ((ncnt * slice_cap if slice_cap else nrec) * 8 + ncnt * 4)
 print("sender: part1 %.2f ms, part2 by owner (+ dedupe) %.2f ms; wire per rank %.2f GB as shipped (%.2f GB of raw records); sum sender + owner kernels %.2f ms -> %.1f Gk-mers/s per GPU"
       % (st[0], st[1], wire / 1e9, 8.0 * kmers * (W - 1) / W / 1e9, st[0] + st[1] + 0, kmers / ((st[0] + st[1]) * 1e-3) / 1e9), flush=True)
+
+# what a rank's counting step costs with these kernels, by the bytes-per-link model of DESIGN.md 7 (one xGMI link per peer, all of them busy
+# in an all_to_all; NOTHING here has run over xGMI): the stages one after the other, and as the three-stage pipeline of dist.count_sharded
+# (the lists of round r travel while the sender kernels of round r + 1 and the owner's insert of round r - 1 run; R = 3 rounds for an input
+# of >= 1 G bases that is resident in HBM; ~1 ms of launches and agreements per additional round)
+link = jdist.XGMI_LINK_GB_S * 1e9
+t_wire = wire / ((W - 1) * link) * 1e3
+kern = st[0] + st[1] + owner_ms
+R = 3
+print("model, W = %d, dedupe %s: kernels %.1f ms (sender %.1f + owner %.1f), wire %.2f GB over %d links = %.1f ms -> one stage after the other %.1f ms, "
+      "pipelined (%d rounds) %.1f ms per rank (one GPU alone: part1 + part2f + region_insert ~11.1 ms)"
+      % (W, "on" if DEDUPE else "off", kern, st[0] + st[1], owner_ms, wire / 1e9, W - 1, t_wire, kern + t_wire, R, kern + t_wire / R + (R - 1) * 1.0), flush=True)
