@@ -67,6 +67,14 @@ def verify(outdir):
         assert open(os.path.join(work, "%dqValCalcHelper.csv" % P)).read() == meta["qvP"]
         shutil.rmtree(work)
         print(name, "ok: unmodified src/jasper.py run on our .jf reproduces the golden fixed FASTA, fix CSVs and QV counters")
+        # `jellyfish merge` (JF::jellyfish/merge_files.cc:96-150) takes files of one size and one hash matrix: two files written by this
+        # library (identity matrix in the header, same size) merge, and the merged counts are the sums
+        merged = os.path.join(outdir, name + ".merged.jf")
+        subprocess.run([JF, "merge", "-o", merged, p, p], env=env, check=True)
+        dump2 = subprocess.run([JF, "dump", "-c", merged], env=env, capture_output=True, text=True, check=True).stdout
+        assert dict((a, int(b)) for a, b in (l.split() for l in dump2.splitlines())) == {k: 2 * v for k, v in want.items()}, name
+        os.remove(merged)
+        print(name, "ok: jellyfish merge of two of our files gives twice the counts")
 
 
 if __name__ == "__main__":
