@@ -975,7 +975,22 @@ struct Walker {
             if (mn) { i += (int64_t)__builtin_ctzll(mn) + 1; continue; }
             const uint64_t mo = __ballot(code(ch) < 0) & inwin;                // :65-68
             if (mo) { i += 1; continue; }
-            const uint32_t occ = cnt_seq(i, i + k);                            // :70-71
+            // Everything this position can look up depends on the TEXT alone -- the window itself (:70-71), the window k back (:80) and
+            // the samples of the rolling mean (:82-89) -- so one lane each asks for its count at once (round 5: they used to be three
+            // dependent round trips, 0.24 us each, at every position the scan could not class; a pass's walk is as long as its
+            // slowest segment's chain of them).  What the reference would not have looked at is simply not used.
+            const int64_t ind0 = i - k > 0 ? i - k : 0;
+            const int64_t num = i > 0 ? (i - ind0 + step - 1) / step : 0;      // iterations of `while ind < i` (:84)
+            const bool fused = num <= 62;
+            unsigned long long mine = 0;
+            {
+                int64_t la = i, lb = i + k;
+                bool act = lane == 0 || !fused;                                // (not fused: every lane the window itself, as before)
+                if (fused && lane == 1 && i > 0) { la = ind0; lb = i > k ? i : k; act = true; }
+                if (fused && lane >= 2 && (int64_t)(lane - 2) < num) { la = ind0 + (int64_t)(lane - 1) * step; lb = la + k; act = true; }
+                if (act) mine = cnt_seq(la, lb);                               // (ONE call site: one memory round trip for all lanes)
+            }
+            const uint32_t occ = (uint32_t)__shfl(mine, 0);
             nlook += 1;
             bool brk = false;
             if (occ < solid) {                                                 // :73
@@ -987,14 +1002,17 @@ struct Walker {
             if (i > 0) {                                                       // :80
                 const int64_t a = i - k > 0 ? i - k : 0;
                 const int64_t b = i > k ? i : k;
-                cond2 = 50ull * occ < (uint64_t)cnt_seq(a, b);
+                cond2 = 50ull * occ < (fused ? (uint64_t)__shfl(mine, 1) : (uint64_t)cnt_seq(a, b));
                 nlook += 1;
             }
             if (!cond2) { i += k - 1; continue; }                              // :100
             // rolling mean of the counts sampled every `step` over the previous k positions (:82-89)
-            int64_t ind0 = i - k > 0 ? i - k : 0;
-            int64_t num = (i - ind0 + step - 1) / step;                        // iterations of `while ind < i`
             double sum = 0.0;
+            if (fused) {
+                unsigned long long c = (lane >= 2 && (int64_t)(lane - 2) < num) ? mine : 0ull;
+                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);       // exact integer sum across lanes
+                sum = (double)c;
+            } else
             for (int64_t base = 0; base < num; base += 64) {
                 const int64_t t = base + lane;
                 unsigned long long c = 0;
