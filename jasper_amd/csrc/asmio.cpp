@@ -328,6 +328,13 @@ int jasper_asm_split(jasper_asm *a, uint64_t batch_size, const char *prefix, con
     a->have.assign(a->chunks.size(), 0);
     if (n_chunks) *n_chunks = a->chunks.size();
     if (n_files) *n_files = a->file_bytes.size();
+    a->own_bases = a->arena_len;
+    if (only_files) {
+        a->own_bases = 0;
+        for (uint32_t i = 0; i < n_only; ++i)
+            if (only_files[i] < a->file_bytes.size())
+                for (size_t c = a->file_first[only_files[i]]; c < a->file_first[only_files[i] + 1]; ++c) a->own_bases += a->chunks[c].len;
+    }
     if (write_files) {
         std::vector<uint32_t> todo;
         if (only_files) {

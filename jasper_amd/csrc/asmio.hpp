@@ -42,6 +42,7 @@ struct jasper_asm {
     std::vector<AsmChunk> chunks;
     std::vector<size_t> file_first;         // file f = chunks [file_first[f], file_first[f + 1])
     std::vector<uint64_t> file_bytes;       // size of batch file f
+    uint64_t own_bases = 0;                 // bases of the records of the batch files this job writes (all, or only_files): what it will polish
     std::thread writer;                     // the batch files are written beside whatever the caller does next
     bool writer_running = false;
     std::atomic<int> writer_failed{0};

@@ -548,7 +548,8 @@ int jasper_asm_pin(jasper_asm *a, int device) {
         a->arena_registered = hipHostRegister(a->arena, a->arena_cap, hipHostRegisterDefault) == hipSuccess;      // (refused: the copies are staged, as before)
     (void)hipGetLastError();
     if (!a->out_pinned) {
-        const size_t want = a->arena_len + a->arena_len / 64 + (1u << 20);
+        const size_t own = a->own_bases ? (size_t)a->own_bases : a->arena_len;      // (one GPU of several: its own batch files' records only)
+        const size_t want = own + own / 64 + (1u << 20);
         if (hipHostMalloc((void **)&a->out_pinned, want, hipHostMallocDefault) == hipSuccess) a->out_cap = want;
         else { a->out_pinned = nullptr; (void)hipGetLastError(); }
     }

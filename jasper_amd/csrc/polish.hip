@@ -52,15 +52,6 @@ struct FrontEntry {       // live path of the extension search
     uint8_t tail[72];     // last min(len, k+3) bytes of start_km1 + path
 };
 static_assert(sizeof(FrontEntry) == 80, "FrontEntry layout");
-// The search's state starts in LDS: almost every search has a handful of live paths and a few hundred trie nodes, and with the state in
-// global scratch every level of it paid several round trips to the L2 (the compaction's loads, the stores of the updated paths and the
-// waits of the fences between them) on top of the one table lookup it is about: 0.59 of the 0.75 ms of pass 0's slowest segment.  A
-// search that outgrows either array moves it to its scratch slot and goes on there, as before.
-#ifndef JK_BFS_LDS_FRONT
-#define JK_BFS_LDS_FRONT 40
-#define JK_BFS_LDS_NODES 1536
-#endif
-constexpr int BFS_LDS_FRONT = JK_BFS_LDS_FRONT, BFS_LDS_NODES = JK_BFS_LDS_NODES;      // (a test build with 2 / 8 moves every search into its slot on the way)
 
 // The walk's phase timers (SegDev::tk: how a segment's time splits into skipping good k-mers / finding the run / choosing a fix /
 // splicing) read the clock around every step of the walk: a tuning aid that costs registers, scratch and an instruction stream
@@ -84,8 +75,7 @@ struct Walker {
     int status;
     uint64_t nlook;
     uint64_t tk[12];
-    uint8_t *s_tbf, *s_t1, *s_t2, *s_gkb, *s_gka, *s_front;
-    uint32_t *s_nodes;
+    uint8_t *s_tbf, *s_t1, *s_t2, *s_gkb, *s_gka;
     // segment context
     int64_t delta;        // len - len0: how far text right of the last edit has shifted
     int64_t dirty_end;    // local positions >= dirty_end hold pass-start text (shifted by delta)
@@ -540,21 +530,7 @@ struct Walker {
     // release_scratch()) or -1 for None.
     __device__ int64_t base_extension(int64_t Ltbf, int nb, int na, uint32_t thr) {
         if (nb < k || na < k || thr > solid) return -1;
-        // The search works in LDS (live paths, trie, patch) and takes a slot of the global scratch pool only when it outgrows one of
-        // them (take_scratch): taking and giving back a slot are agent-scope acquire / release fences -- an invalidate and a write-back
-        // of the XCD's L2, ~0.1-0.5 ms under load -- which was nine tenths of a 40-level search (round 5).
-        bfs_slot = -1;
-        bfs_nodes = nullptr;
-        bfs_front = nullptr;
-        bfs_patch = s_t2;               // (free in this branch: SMAX bytes)
-        if (pool.no_lds) take_scratch();
-        const int64_t r = base_extension_impl(Ltbf, thr);
-        if (r < 0) release_scratch();
-        return r;
-    }
-    // a slot of the scratch pool (searches that outgrow the LDS arrays are rare; a wave holds a slot only while it searches and splices)
-    __device__ void take_scratch() {
-        if (bfs_slot >= 0) return;
+        // take a scratch slot (searches are rare; a wave holds a slot only while it searches and splices)
         uint32_t slot = (uint32_t)((blockIdx.x * 2654435761u) % pool.nslots);
         for (;;) {
             unsigned int old = 1;
@@ -570,6 +546,10 @@ struct Walker {
         uint8_t *sb = pool.base + (size_t)slot * pool.stride;
         bfs_nodes = reinterpret_cast<uint32_t *>(sb);
         bfs_front = sb + pool.off_front;
+        bfs_patch = sb + pool.off_patch;
+        const int64_t r = base_extension_impl(Ltbf, thr);
+        if (r < 0) release_scratch();
+        return r;
     }
     __device__ void release_scratch() {
         if (bfs_slot < 0) return;
@@ -585,36 +565,11 @@ struct Walker {
         const int64_t min_overlap = 5, slack = 10;
         const int64_t max_ext = pyround((double)(Ltbf - 2 * k) * 1.2) + min_overlap + slack;
         const int64_t min_patch_len = pyround((double)(Ltbf - 2 * k) / 1.2) - slack;
-        FrontEntry *F = reinterpret_cast<FrontEntry *>(s_front);
-        uint32_t fcap = BFS_LDS_FRONT;
-        uint32_t *nodes = s_nodes;
-        uint32_t ncap = BFS_LDS_NODES;
-        if (bfs_slot >= 0) {            // (pool.no_lds: in the slot from the start)
-            F = reinterpret_cast<FrontEntry *>(bfs_front); fcap = pool.front_cap;
-            nodes = bfs_nodes; ncap = pool.node_cap;
-            bfs_patch = pool.base + (size_t)bfs_slot * pool.stride + pool.off_patch;
-        }
+        FrontEntry *F = reinterpret_cast<FrontEntry *>(bfs_front);
+        const uint32_t fcap = pool.front_cap;
+        uint32_t *nodes = bfs_nodes;
         uint32_t nn = 1;            // node 0 = the initial one-base path (last base of the good k-mer before)
         uint32_t np = 1;
-        // the live paths / the trie move from LDS to the scratch slot (whole, same indices) when they outgrow it
-        auto front_to_scratch = [&]() {
-            take_scratch();
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(s_front);
-            uint32_t *dst = reinterpret_cast<uint32_t *>(bfs_front);
-            for (uint32_t q = lane; q < np * (uint32_t)(sizeof(FrontEntry) / 4); q += 64) dst[q] = src[q];
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            F = reinterpret_cast<FrontEntry *>(bfs_front);
-            fcap = pool.front_cap;
-        };
-        auto nodes_to_scratch = [&]() {
-            take_scratch();
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            for (uint32_t q = lane; q < nn; q += 64) bfs_nodes[q] = s_nodes[q];
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            nodes = bfs_nodes;
-            ncap = pool.node_cap;
-        };
         const int TCAP = k + 3;
         if (lane == 0) {
             nodes[0] = 0;
@@ -701,10 +656,6 @@ struct Walker {
                                     if (i == min_overlap) return -1;                          // :568-571 "patch empty"
                                     // return_path = (path_before + base)[1:-5]  = path_before[1 : i-4]   (:561/:564)
                                     const int64_t plen = i - 5;
-                                    if (plen > (int64_t)SMAX) {                               // (longer than the LDS buffer: into the slot)
-                                        take_scratch();
-                                        bfs_patch = pool.base + (size_t)bfs_slot * pool.stride + pool.off_patch;
-                                    }
                                     if (plen > (int64_t)pool.patch_cap) { status = PS_BFS_ARENA; return -1; }
                                     if (lane == 0) {
                                         uint32_t nd = pnode;
@@ -722,9 +673,7 @@ struct Walker {
                         if (ext < 0) {
                             ext = j;                                                          // :576-578 (applied below)
                         } else {                                                              // :579-580 sibling
-                            if (np >= fcap && F == reinterpret_cast<FrontEntry *>(s_front)) front_to_scratch();
-                            if (nn >= ncap && nodes == s_nodes) nodes_to_scratch();
-                            if (np >= fcap || nn >= ncap) { status = PS_BFS_ARENA; return -1; }
+                            if (np >= fcap || nn >= pool.node_cap) { status = PS_BFS_ARENA; return -1; }
                             if (lane == 0) nodes[nn] = (pnode << 2) | (uint32_t)j;
                             // sibling tail = tail_before + base
                             const int keep = tl < TCAP ? tl : TCAP - 1;
@@ -739,8 +688,7 @@ struct Walker {
                     // apply the first extension to the path itself, or kill it                (:576-578,:581-582)
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     if (ext >= 0) {
-                        if (nn >= ncap && nodes == s_nodes) nodes_to_scratch();
-                        if (nn >= ncap) { status = PS_BFS_ARENA; return -1; }
+                        if (nn >= pool.node_cap) { status = PS_BFS_ARENA; return -1; }
                         const uint8_t bj = (uint8_t)("ACGT"[ext]);
                         if (lane == 0) nodes[nn] = (pnode << 2) | (uint32_t)ext;
                         if (tl < TCAP) {
@@ -1136,8 +1084,6 @@ __device__ __forceinline__ void publish_arrival(long long *slot, long long v) {
 __global__ __launch_bounds__(64, 2) void seg_walk_kernel(TableDev T, SegDev *segs, int n_segs, PolishParams P, int pass, ScratchPool pool,
                                                       unsigned int *ticket) {
     __shared__ uint8_t s_tbf[SMAX], s_t1[SMAX], s_t2[SMAX], s_gkb[64], s_gka[64];
-    __shared__ __align__(16) uint8_t s_front[BFS_LDS_FRONT * sizeof(FrontEntry)];      // the path search's live paths and trie while they are few (base_extension_impl)
-    __shared__ uint32_t s_nodes[BFS_LDS_NODES];
     // segments are taken in the order the waves START (a ticket, not blockIdx): a chained segment spins on its
     // predecessor's arrival, and a ticket guarantees that predecessor is already running or done
     unsigned int tk = 0;
@@ -1232,7 +1178,7 @@ __global__ __launch_bounds__(64, 2) void seg_walk_kernel(TableDev T, SegDev *seg
     w.buf = C->buf; w.len = C->len; w.gs = C->gs; w.glen = C->glen; w.cap = C->cap;
     w.C = C; w.chunk_id = C->chunk; w.nrec = 0; w.naux = 0; w.seqno = 0; w.nedit = 0; w.pass = pass;
     w.status = PS_OK; w.nlook = 0; for (int q = 0; q < 12; ++q) w.tk[q] = 0;
-    w.s_tbf = s_tbf; w.s_t1 = s_t1; w.s_t2 = s_t2; w.s_gkb = s_gkb; w.s_gka = s_gka; w.s_front = s_front; w.s_nodes = s_nodes;
+    w.s_tbf = s_tbf; w.s_t1 = s_t1; w.s_t2 = s_t2; w.s_gkb = s_gkb; w.s_gka = s_gka;
     w.delta = 0; w.dirty_end = INT64_MIN / 2; w.glo = P.k;
     w.is_first = C->first != 0; w.is_last = C->last != 0; w.spec_fail = 0;
     w.cls = C->cls; w.cls_n = C->cls_n; w.seg_lo = C->seg_lo; w.stop_orig = C->stop_orig;

@@ -47,7 +47,6 @@ struct ScratchPool {
     uint32_t front_cap;    // frontier entries (80 B)
     uint32_t patch_cap;    // bytes
     size_t off_front, off_patch;
-    uint32_t no_lds;       // tests: every search works in a slot from its first step (the state of round 4), so that the hand-off of slots between waves stays exercised
 };
 
 // One SEGMENT of a chunk record for one pass.  A chunk is cut at "sync points": starts of runs of >= k-1 bad k-mers

@@ -110,8 +110,7 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
     pool.front_cap = 20480;            // (the search gives up beyond 5000 live paths, src/jasper.py:543-546; each adds <= 3 siblings per level)
     pool.patch_cap = (uint32_t)(RM << 16);
     if (roomy) pool.nslots = 64;
-    pool.no_lds = 0;
-    if (const char *e = getenv("JASPER_POLISH_TEST_NSLOTS")) { pool.nslots = (uint32_t)std::max(1, std::min(atoi(e), 256)); pool.no_lds = 1; }     // (tests: slots handed from wave to wave all the time)
+    if (const char *e = getenv("JASPER_POLISH_TEST_NSLOTS")) pool.nslots = (uint32_t)std::max(1, std::min(atoi(e), 256));     // (tests: slots handed from wave to wave all the time)
     pool.off_front = al256((size_t)pool.node_cap * 4);
     pool.off_patch = pool.off_front + al256((size_t)pool.front_cap * 80);
     pool.stride = pool.off_patch + al256(pool.patch_cap);

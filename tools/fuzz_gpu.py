@@ -21,7 +21,17 @@ for i, seed in enumerate(range(seed0, seed0 + n)):
         T._one(seed, KmerTable, polisher, O, G, F, tmp)
     except AssertionError as e:
         bad += 1
-        log.write("seed %d FAILED: %s\n" % (seed, str(e)[:300]))
+        import traceback
+        tb = traceback.extract_tb(e.__traceback__)[-1]
+        log.write("seed %d FAILED at test_gpu_fuzz.py:%d (%s): %s\n" % (seed, tb.lineno, tb.line, str(e)[:300]))
+        for again in range(3):          # the same case again in this very process: does it fail every time?
+            try:
+                T._one(seed, KmerTable, polisher, O, G, F, tmp)
+                log.write("   again %d: passes\n" % again)
+            except AssertionError as e2:
+                tb2 = traceback.extract_tb(e2.__traceback__)[-1]
+                log.write("   again %d: FAILS at line %d (%s)\n" % (again, tb2.lineno, tb2.line))
+        log.flush()
     for f in tmp.iterdir():
         f.unlink()
     if (i + 1) % 250 == 0:
