@@ -152,7 +152,7 @@ struct Walker {
     }
 
     // qf[jf.MerDNA(seq[a:b]).get_canonical()] -- python slice semantics, per lane
-    __device__ __attribute__((noinline)) uint32_t cnt_seq(int64_t a, int64_t b) {
+    __device__ __forceinline__ uint32_t cnt_seq(int64_t a, int64_t b) {
         int64_t lo, hi;
         guard(a, b);
         pyslice(len, a, b, lo, hi);
@@ -165,7 +165,7 @@ struct Walker {
     }
     // same for a string in LDS / global scratch: all byte loads are issued before the first is used (the loop that stops at
     // the first non-ACGT byte made every load wait for the previous one)
-    __device__ __attribute__((noinline)) uint32_t cnt_str(const uint8_t *p, int n) const {
+    __device__ __forceinline__ uint32_t cnt_str(const uint8_t *p, int n) const {
         const int lim = n < k ? n : k;
         uint32_t w[16];
 #pragma unroll
@@ -903,40 +903,6 @@ struct Walker {
     __device__ int64_t skip_good(int64_t i) {
         const int64_t end = len - k + 1;
         for (;;) {
-            // Four rounds' worth of stride positions at once where their classes are all known (round 5): the class bytes of 256
-            // positions are four independent loads per lane instead of four dependent round trips -- a chunk's chain of segments
-            // through its clean zones (passes 1 and 2) is mostly this loop.
-            {
-                bool all_known = true;
-                uint8_t cl4[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int64_t p = i + (int64_t)(lane + 64 * u) * (k - 1);
-                    cl4[u] = PC_OTHER;
-                    bool known = false;
-                    if (p >= end) { known = true; }                               // (beyond the text: "not a plain step" -- ends the search below)
-                    else if (cls != nullptr && p >= dirty_end + k) {
-                        const int64_t o = p - delta + seg_lo;
-                        if (!is_last && o >= stop_orig) known = true;             // the next segment's: hand over here
-                        else if (o >= 0 && o < cls_n) { known = true; cl4[u] = cls[o]; }
-                    }
-                    all_known = all_known && known;
-                }
-                if (!__ballot(!all_known)) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint64_t mask = __ballot(cl4[u] != PC_CLEAN);
-                        nlook += 128;
-                        if (mask) {
-                            const int64_t r = i + (int64_t)(64 * u + __builtin_ctzll(mask)) * (k - 1);
-                            // (a position beyond the text is reported as the old loop did: the first stride position >= end of its round)
-                            return r;
-                        }
-                    }
-                    i += 256ll * (k - 1);
-                    continue;
-                }
-            }
             const int64_t p = i + (int64_t)lane * (k - 1);
             bool ev = true;
             bool known = false;
@@ -1009,22 +975,7 @@ struct Walker {
             if (mn) { i += (int64_t)__builtin_ctzll(mn) + 1; continue; }
             const uint64_t mo = __ballot(code(ch) < 0) & inwin;                // :65-68
             if (mo) { i += 1; continue; }
-            // Everything this position can look up depends on the TEXT alone -- the window itself (:70-71), the window k back (:80) and
-            // the samples of the rolling mean (:82-89) -- so one lane each asks for its count at once (round 5: they used to be three
-            // dependent round trips, 0.24 us each, at every position the scan could not class; a pass's walk is as long as its
-            // slowest segment's chain of them).  What the reference would not have looked at is simply not used.
-            const int64_t ind0 = i - k > 0 ? i - k : 0;
-            const int64_t num = i > 0 ? (i - ind0 + step - 1) / step : 0;      // iterations of `while ind < i` (:84)
-            const bool fused = num <= 62;
-            unsigned long long mine = 0;
-            {
-                int64_t la = i, lb = i + k;
-                bool act = lane == 0 || !fused;                                // (not fused: every lane the window itself, as before)
-                if (fused && lane == 1 && i > 0) { la = ind0; lb = i > k ? i : k; act = true; }
-                if (fused && lane >= 2 && (int64_t)(lane - 2) < num) { la = ind0 + (int64_t)(lane - 1) * step; lb = la + k; act = true; }
-                if (act) mine = cnt_seq(la, lb);                               // (ONE call site: one memory round trip for all lanes)
-            }
-            const uint32_t occ = (uint32_t)__shfl(mine, 0);
+            const uint32_t occ = cnt_seq(i, i + k);                            // :70-71
             nlook += 1;
             bool brk = false;
             if (occ < solid) {                                                 // :73
@@ -1036,17 +987,14 @@ struct Walker {
             if (i > 0) {                                                       // :80
                 const int64_t a = i - k > 0 ? i - k : 0;
                 const int64_t b = i > k ? i : k;
-                cond2 = 50ull * occ < (fused ? (uint64_t)__shfl(mine, 1) : (uint64_t)cnt_seq(a, b));
+                cond2 = 50ull * occ < (uint64_t)cnt_seq(a, b);
                 nlook += 1;
             }
             if (!cond2) { i += k - 1; continue; }                              // :100
             // rolling mean of the counts sampled every `step` over the previous k positions (:82-89)
+            int64_t ind0 = i - k > 0 ? i - k : 0;
+            int64_t num = (i - ind0 + step - 1) / step;                        // iterations of `while ind < i`
             double sum = 0.0;
-            if (fused) {
-                unsigned long long c = (lane >= 2 && (int64_t)(lane - 2) < num) ? mine : 0ull;
-                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);       // exact integer sum across lanes
-                sum = (double)c;
-            } else
             for (int64_t base = 0; base < num; base += 64) {
                 const int64_t t = base + lane;
                 unsigned long long c = 0;

@@ -371,7 +371,7 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
         // ---- 3. + 4. the bookkeeping per chunk came back as summaries.  Anything out of the ordinary -- a segment that ran out of
         //         room, the reference's own IndexError, a speculation that failed -- takes the host's own bookkeeping (below),
         //         on the whole segment table; so does the debug output, which wants every segment's counters.
-        bool ordinary = !getenv("JASPER_POLISH_DEBUG");
+        bool ordinary = !getenv("JASPER_POLISH_DEBUG") && !getenv("JASPER_POLISH_HOST_BOOKKEEPING");      // (the second: tests take the rare path every time)
         for (int c = 0; c < n_chunks && ordinary; ++c) ordinary = sum_p[c].bad_seg < 0 && !sum_p[c].spec_fail;
         std::vector<int64_t> idx_base;
         std::vector<uint32_t> seq_base, rec_off, aux_off;
@@ -546,6 +546,11 @@ static int run_polish_lane(Table &T, const int lane, hipStream_t st, int n_chunk
                           carry ? (uint8_t *const *)ptrFlags : nullptr, st);
         HIPCHK(hipGetLastError());
         for (int c = 0; c < n_chunks; ++c) len[c] = newlen[c];
+        // The host's own bookkeeping went up from vectors of THIS iteration (segs, idx_base, seq_base, rec_off, aux_off: ordinary host
+        // memory): an asynchronous copy may read its source when the stream gets to it, not when it is issued -- the vectors must
+        // outlive that.  (Round 5: without this wait a chunk whose speculation had failed now and then came back with the records
+        // or the text of freed memory: 1 run in ~1 000 of one fuzz case, on some boxes.)  The rare path can afford the wait.
+        if (!ordinary) HIPCHK(jk_stream_wait(st));
         // the text just written is read next; the next pass writes into the arena that is free (never into the caller's buffer)
         std::swap(hIn, hOut);
         std::swap(dIn, dOut);

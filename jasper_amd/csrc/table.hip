@@ -683,6 +683,12 @@ void *Table::workspace(int id, size_t bytes, std::string &err) {
         return b.p;
     }
     b.bytes = want;
+    // debugging aid (round 5: a result that depended on what a fresh workspace happened to hold): every new workspace buffer filled with
+    // one byte value, so that a read of memory nobody wrote gives the same wrong answer every time -- and another one for another value
+    if (const char *pz = getenv("JASPER_DEBUG_POISON")) {
+        const char *only = getenv("JASPER_DEBUG_POISON_SLOT");
+        if (!only || atoi(only) == id) { (void)hipMemset(b.p, atoi(pz) & 0xFF, want); (void)hipDeviceSynchronize(); }
+    }
     return b.p;
 }
 
