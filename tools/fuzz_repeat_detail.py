@@ -53,6 +53,8 @@ for r in range(reps):
                     j = next((q for q in range(min(len(a), len(b))) if a[q] != b[q]), min(len(a), len(b)))
                     print("   chunk %d: lens %d / %d, first difference at %d: ...%s | ...%s" % (i, len(a), len(b), j, a[max(0, j - 20):j + 40], b[max(0, j - 20):j + 40]))
             print("   records:", [(x["chunk"], x["pass_"], x["seqno"], x["kind"], x["index"], x["newc"], x["oldc"], x["rep"]) for x in res.records][:50], flush=True)
+        if r == 0:
+            print("seed %d run 0: segments %d, chunks redone unsegmented %d, retried %s, records %d" % (seed, res.segments, res.respeculated, res.retried, res.n_records), flush=True)
         del res
         t.close()
 print("done: %d runs, %d differing" % (reps * len(cases), bad))
