@@ -51,6 +51,12 @@ def _input_dir(ref, tmp_path_factory):
     key = (ref["genome_mb"], ref["seed"], ref.get("coverage", 30), ref.get("contigs", 1), ref.get("populations", 1))
     if key not in _inputs:
         d = str(tmp_path_factory.mktemp("inputs"))
+        # (the read files of the large cases are 11-29 GB: a scratch disk without room for them is a reason to skip, not to fail)
+        import shutil
+        need = int(ref["reads"] * 307 * 1.25) + (4 << 30)
+        free = shutil.disk_usage(d).free
+        if free < need:
+            pytest.skip("%s has %.0f GB free, the inputs of this case need %.0f GB" % (d, free / 1e9, need / 1e9))
         nreads, asm_len = synth.write_cli_inputs(d, ref["genome_mb"], ref["seed"], coverage=key[2], contigs=key[3], populations=key[4])
         assert nreads == ref["reads"] and asm_len == ref["assembly_bases"]
         _inputs[key] = d
