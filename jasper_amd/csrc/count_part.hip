@@ -1930,8 +1930,13 @@ static bool xchg_geometry(const Table &t, uint64_t piece_max, uint64_t records_m
     G = *reinterpret_cast<const PartGeom *>(raw);
     if (G.recbits > 64) return false;                     // (keys of more than 74 bits: per-GPU tables and the entry exchange instead)
     // the senders split by (owner, second-level bits): more than 512 lists per bucket would leave the whole-line kernel, so the
-    // owners take regions of 8192 slots instead of 4096 where that is what it takes
-    if (((uint64_t)nown << G.p2) > 512 && ((uint64_t)nown << (G.p2 - 1)) <= 512 && G.p2 > 0 && G.rbits == RG_MAXBITS && !getenv("JASPER_EXPERIMENT_XCHG_RB12")) { --G.p2; ++G.rbits; }
+    // owners take regions of 8192 slots instead of 4096 where that is what it takes -- for up to four owners, whose lists travel
+    // deduplicated (dist.dedupe_pays).  Beyond that the lists travel as they are, and an owner inserting 10^9 raw records into
+    // 8192-slot regions (one workgroup per CU) takes 8.6 ms against 5.7 into 4096-slot ones, which the general split kernel's
+    // 5.7 ms against 4.6 does not eat up (role-play at 8 ranks, profiles/round5/exchange_roleplay_model.txt: 15.7 against 17.3 ms
+    // of kernels per rank).  JASPER_EXPERIMENT_XCHG_RB12 / _RB13 force one or the other.
+    const bool rb13 = getenv("JASPER_EXPERIMENT_XCHG_RB13") ? true : getenv("JASPER_EXPERIMENT_XCHG_RB12") ? false : nown <= 4;
+    if (((uint64_t)nown << G.p2) > 512 && ((uint64_t)nown << (G.p2 - 1)) <= 512 && G.p2 > 0 && G.rbits == RG_MAXBITS && rb13) { --G.p2; ++G.rbits; }
     p2b = 0;
     while (((uint64_t)nown << (G.p2 - p2b)) > (uint64_t)xchg_max_lists() && p2b < G.p2) ++p2b;
     if (((uint64_t)nown << (G.p2 - p2b)) > (uint64_t)PT_MAXBUCKETS) return false;
