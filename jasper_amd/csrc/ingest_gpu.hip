@@ -45,8 +45,11 @@ struct Raw { uint32_t w[4]; };
 __device__ __forceinline__ Raw load_text16(const uint8_t *__restrict__ text, uint64_t pos, uint64_t n) {
     Raw r;
     if (pos + 16 <= n) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(text + pos);     // chunk buffers are 16-byte aligned, pos % 16 == 0
-        r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+        // (one 16-byte load; pos % 16 == 0, but a chunk's text begins wherever the record carried over from the chunk before puts it:
+        //  the type says so, the hardware reads global memory at any address)
+        struct __attribute__((packed, aligned(1))) V16 { uint32_t w[4]; };
+        const V16 v = *reinterpret_cast<const V16 *>(text + pos);
+        r.w[0] = v.w[0]; r.w[1] = v.w[1]; r.w[2] = v.w[2]; r.w[3] = v.w[3];
     } else {
         r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
         for (int j = 0; j < 16; ++j)
@@ -503,20 +506,38 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
     if (!h_ingest || ingest_chunk < CHUNK) {              // kept with the table between calls
         if (h_ingest) (void)hipHostFree(h_ingest);
         h_ingest = nullptr;
-        HIPCHK(hipHostMalloc((void **)&h_ingest, 2 * (2 * CHUNK + 64), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&h_ingest, 3 * (2 * CHUNK + 64), hipHostMallocDefault));
         ingest_chunk = CHUNK;
     }
     // Two text buffers: while the GPU parses one, a thread reads the next CHUNK of the stream into the other (file -> pinned memory
     // is a copy out of the page cache at ~10 GB/s: as long as the whole GPU side of a chunk, and until round 3 the two took turns).
     // A chunk's bytes go to offset CHUNK of its buffer; what the chunk before left over (an incomplete record, <= CHUNK) is put
     // right in front of them.
-    char *h_two[2] = {h_ingest, h_ingest + ingest_chunk * 2 + 64};
+    // OVERLAP (late round 5): the GPU side of a chunk was its copy to the device (1.3 ms per 64 MiB at ~50 GB/s) and then the parsing
+    // kernels with their four host waits (0.55 ms), taking turns on ONE device buffer.  Now the text of chunk i + 1 -- read by a
+    // thread while chunk i - 1 was parsed -- goes to a SECOND device buffer on a copy stream of its own while chunk i is parsed, and
+    // the thread reads chunk i + 2 meanwhile (three pinned buffers).  What chunk i leaves over (an incomplete record) is known only
+    // after its parsing: those few bytes follow, in front of the text that is already there.  JASPER_INGEST_OVERLAP=0: as before.
+    char *h_two[3] = {h_ingest, h_ingest + ingest_chunk * 2 + 64, h_ingest + 2 * (ingest_chunk * 2 + 64)};
     int cur_buf = 0;
     char *h_buf = h_two[0] + CHUNK;
     std::thread pf;                       // the read ahead
     long pf_got = 0;
     bool pf_active = false;
-    uint8_t *d_text = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 0, 2 * CHUNK + 64, err));
+    int pf_buf = 1;                       // ... into this buffer
+    const bool overlap = probe_stage != 1 && probe_stage != 2 && !(getenv("JASPER_INGEST_OVERLAP") && atoi(getenv("JASPER_INGEST_OVERLAP")) == 0);
+    bool have_nxt = false;                // overlap: the chunk after this one has been read (nxt_got bytes in h_two[nxt_buf]) and, if it
+    long nxt_got = 0;                     //          holds anything, is on its way to the other device buffer (ev_pre)
+    int nxt_buf = 0;
+    int dev = 0;                          // the device text buffer of the chunk in hand
+    if (overlap && !ingest_copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&ingest_copy_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ingest_copy_ev, hipEventDisableTiming));
+    }
+    if (ingest_copy_stream) HIPCHK(jk_stream_wait(ingest_copy_stream));      // (a call that ended early may have left a copy behind)
+    uint8_t *d_text0 = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 0, 2 * (2 * CHUNK + 64), err));
+    uint8_t *d_text_two[2] = {d_text0, d_text0 ? d_text0 + 2 * CHUNK + 64 : nullptr};
+    uint8_t *d_text = d_text0;
     uint8_t *d_bases = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 1, BASES_CAP + 2 * CHUNK + 64, err));
     // An input of more than one buffer of bases: TWO buffers, and the counting of a full one is a thread's business (count_device
     // waits for its kernels, reads their statistics, grows the table) while this thread goes on reading, copying and parsing into
@@ -618,16 +639,22 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
     // the host state machine takes over from here (and keeps the rest of the stream)
     FastxParser hp(host_bases);
     auto host_rest = [&](int mode, const char *first, size_t first_n) -> int {
+        if (ingest_copy_stream) HIPCHK(jk_stream_wait(ingest_copy_stream));      // (a copy under way reads a pinned buffer)
         if (int rc = flush_bases()) return rc;
         if (int rc = drain()) return rc;                     // (the host parser's bases are counted by this thread, on the table's stream)
         hp.resume(mode);
         int rc = hp.feed(first, first_n);
         n_host += first_n;
-        if (pf_active) {                                       // the chunk a thread has been reading ahead comes next in the stream
+        if (have_nxt) {                                        // the chunk that has been read already comes next in the stream
+            have_nxt = false;
+            if (nxt_got < 0) { err = rd.err; return -1; }
+            if (!rc && nxt_got > 0) { rc = hp.feed(h_two[nxt_buf] + CHUNK, (size_t)nxt_got); n_host += (uint64_t)nxt_got; }
+        }
+        if (pf_active) {                                       // then the chunk a thread has been reading ahead
             pf.join();
             pf_active = false;
             if (pf_got < 0) { err = rd.err; return -1; }
-            if (!rc && pf_got > 0) { rc = hp.feed(h_two[1 - cur_buf] + CHUNK, (size_t)pf_got); n_host += (uint64_t)pf_got; }
+            if (!rc && pf_got > 0) { rc = hp.feed(h_two[pf_buf] + CHUNK, (size_t)pf_got); n_host += (uint64_t)pf_got; }
         }
         char *rb = h_two[cur_buf];                             // (`first` and the read-ahead have been consumed: the buffer is free)
         while (!rc) {
@@ -650,14 +677,24 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
         if (g_cancel.load(std::memory_order_relaxed)) { err = "cancelled"; return -1; }      // (jasper_request_cancel: the caller is on its way out)
         if (carry > CHUNK) return host_rest(mode, h_buf, carry);                  // a line / record longer than a chunk
         long got;
-        if (pf_active) {                                                          // the chunk read while the last one was parsed
+        bool pre = false;                                                         // this chunk's text (not the carry) is on its way to d_text_two[dev] already
+        if (have_nxt) {                                                           // the chunk read two chunks ago
+            have_nxt = false;
+            got = nxt_got;
+            pre = got > 0;
+            char *nb = h_two[nxt_buf] + CHUNK - carry;
+            if (carry) memcpy(nb, h_buf, carry);
+            h_buf = nb;
+            cur_buf = nxt_buf;
+            if (pre) dev ^= 1;
+        } else if (pf_active) {                                                   // the chunk read while the last one was parsed
             pf.join();
             pf_active = false;
             got = pf_got;
-            char *nb = h_two[1 - cur_buf] + CHUNK - carry;
+            char *nb = h_two[pf_buf] + CHUNK - carry;
             if (carry) memcpy(nb, h_buf, carry);                                  // (h_buf: where the loop below left the incomplete record)
             h_buf = nb;
-            cur_buf = 1 - cur_buf;
+            cur_buf = pf_buf;
         } else {
             char *nb = h_two[cur_buf] + CHUNK - carry;
             if (carry && nb != h_buf) memmove(nb, h_buf, carry);
@@ -675,13 +712,38 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
             else return host_rest(0, h_buf, n);                                   // (the host parser words the error)
         }
         if (eof) return host_rest(mode, h_buf, n);                                // the tail: at most one incomplete record / line
-        {   // read ahead: the next CHUNK of the stream into the other buffer while this one is parsed
-            char *dst = h_two[1 - cur_buf] + CHUNK;
+        // a thread reads the next chunk of the stream into a free buffer
+        auto read_ahead = [&]() {
+            int b = (cur_buf + 1) % 3;
+            if (have_nxt && b == nxt_buf) b = (b + 1) % 3;
+            pf_buf = b;
+            char *dst = h_two[b] + CHUNK;
             pf_active = true;
             pf = std::thread([&rd, &pf_got, dst, CHUNK] { pf_got = rd.read(dst, CHUNK); });
-        }
+        };
+        // overlap: the chunk the thread has read becomes "the next one" -- its text goes to the other device buffer on the copy stream
+        // (nobody reads that buffer: the parsing of the chunk before this one was waited for) -- and the thread reads the one after it
+        auto look_ahead = [&]() -> int {
+            if (have_nxt || !pf_active) return 0;
+            pf.join();
+            pf_active = false;
+            have_nxt = true;
+            nxt_got = pf_got;
+            nxt_buf = pf_buf;
+            if (nxt_got > 0) {
+                HIPCHK(hipMemcpyAsync(d_text_two[dev ^ 1] + CHUNK, h_two[nxt_buf] + CHUNK, (size_t)nxt_got, hipMemcpyHostToDevice, ingest_copy_stream));
+                HIPCHK(hipEventRecord(ingest_copy_ev, ingest_copy_stream));
+                read_ahead();
+            }
+            return 0;
+        };
+        if (!overlap) read_ahead();
         if (probe_stage == 1) { n_gpu += n; carry = 0; continue; }
-        HIPCHK(hipMemcpyAsync(d_text, h_buf, n, hipMemcpyHostToDevice, stream));
+        d_text = d_text_two[dev] + CHUNK - carry;
+        if (pre) {                                                                // the text is there (or on its way): the carried bytes go in front of it
+            HIPCHK(hipStreamWaitEvent(stream, ingest_copy_ev, 0));
+            if (carry) HIPCHK(hipMemcpyAsync(d_text, h_buf, carry, hipMemcpyHostToDevice, stream));
+        } else HIPCHK(hipMemcpyAsync(d_text, h_buf, n, hipMemcpyHostToDevice, stream));
         if (probe_stage == 2) { HIPCHK(jk_stream_wait(stream)); n_gpu += n; carry = 0; continue; }
         HIPCHK(hipMemsetAsync(d_flags, 0, 8, stream));
         const uint32_t nblk = (uint32_t)((n + IG_BYTES - 1) / IG_BYTES);
@@ -691,6 +753,10 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
         unsigned int flags = 0;
         HIPCHK(hipMemcpyAsync(&n_lines, d_blk_nl + nblk, 4, hipMemcpyDeviceToHost, stream));      // (entry nblk of the exclusive scan = total)
         HIPCHK(hipMemcpyAsync(&flags, d_flags, 4, hipMemcpyDeviceToHost, stream));
+        if (overlap) {                                                            // (while the first parsing kernels run)
+            if (pf_active) { if (int rc = look_ahead()) return rc; }
+            else if (!have_nxt) read_ahead();                                     // (the stream's first chunk: nothing has been read ahead yet)
+        }
         HIPCHK(jk_stream_wait(stream));
         if (flags & IGF_CR) return host_rest(mode, h_buf, n);
         const uint64_t use_lines = mode == 2 ? (uint64_t)(n_lines / 4) * 4 : n_lines;
@@ -725,6 +791,7 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
         if (bases_len >= BASES_CAP) { if (int rc = flush_bases()) return rc; }
         carry = n - (size_t)n_use;
         h_buf += n_use;                                                           // (moved in front of the next chunk at the top of the loop)
+        if (overlap) { if (int rc = look_ahead()) return rc; }                    // (the stream's second chunk: read while this one was parsed)
     }
     if (int rc = flush_bases()) return rc;
     return drain();

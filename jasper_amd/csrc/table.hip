@@ -662,6 +662,7 @@ void Table::wait_streams() {
     for (hipStream_t ps : polish_stream) if (ps) (void)jk_stream_wait(ps);
     if (jf_stream) (void)jk_stream_wait(jf_stream);
     if (ingest_stream) (void)jk_stream_wait(ingest_stream);
+    if (ingest_copy_stream) (void)jk_stream_wait(ingest_copy_stream);
 }
 
 void *Table::workspace(int id, size_t bytes, std::string &err) {
@@ -716,6 +717,8 @@ void Table::destroy() {
     if (polish_ev) { (void)hipEventDestroy(polish_ev); polish_ev = nullptr; }
     if (jf_stream) { (void)jk_stream_wait(jf_stream); (void)hipStreamDestroy(jf_stream); jf_stream = nullptr; }
     if (ingest_stream) { (void)jk_stream_wait(ingest_stream); (void)hipStreamDestroy(ingest_stream); ingest_stream = nullptr; }
+    if (ingest_copy_stream) { (void)jk_stream_wait(ingest_copy_stream); (void)hipStreamDestroy(ingest_copy_stream); ingest_copy_stream = nullptr; }
+    if (ingest_copy_ev) { (void)hipEventDestroy(ingest_copy_ev); ingest_copy_ev = nullptr; }
     for (WsBuf &b : ws) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
     for (WsBuf &b : pin) { if (b.p) (void)hipHostFree(b.p); b.p = nullptr; b.bytes = 0; }
     for (int i = 0; i < 2; ++i) {

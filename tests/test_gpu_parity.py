@@ -883,14 +883,20 @@ def test_gpu_text_ingest_equals_host_parser_and_oracle(KT, O, tmp_path, name):
     finally:
         del os.environ["JASPER_INGEST_HOST"]
     assert t2.histogram() == t.histogram()
-    # the same stream in many small chunks: records and lines straddle chunk ends and are carried over
-    for chunk in (4096, 50_000):
+    # the same stream in many small chunks: records and lines straddle chunk ends and are carried over -- with the next chunk's text
+    # copied to the second device buffer while this one is parsed (the default), with the chunks taking turns on one buffer, and with
+    # the files read by pread instead of out of a mapping
+    for chunk, switches in ((4096, {}), (50_000, {}), (4096, {"JASPER_INGEST_OVERLAP": "0"}), (50_000, {"JASPER_INGEST_MMAP": "0"}),
+                            (4096, {"JASPER_INGEST_OVERLAP": "0", "JASPER_INGEST_MMAP": "0"})):
         os.environ["JASPER_INGEST_CHUNK"] = str(chunk)
+        os.environ.update(switches)
         try:
             t3 = KT(k, min_slots=1 << 16)
             t3.count_files(paths)
         finally:
             del os.environ["JASPER_INGEST_CHUNK"]
+            for name_ in switches:
+                del os.environ[name_]
         g3, h3 = t3.last_ingest()
         assert g3 + h3 == len(whole) and t3.histogram() == t.histogram(), (chunk, g3, h3)
         if expect == "gpu":
