@@ -532,7 +532,8 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
     int dev = 0;                          // the device text buffer of the chunk in hand
     if (overlap && !ingest_copy_stream) {
         HIPCHK(hipStreamCreateWithFlags(&ingest_copy_stream, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&ingest_copy_ev, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ingest_copy_ev[0], hipEventDisableTiming));      // (one per device buffer: a wait that is still
+        HIPCHK(hipEventCreateWithFlags(&ingest_copy_ev[1], hipEventDisableTiming));      //  queued never meets a later recording)
     }
     if (ingest_copy_stream) HIPCHK(jk_stream_wait(ingest_copy_stream));      // (a call that ended early may have left a copy behind)
     uint8_t *d_text0 = reinterpret_cast<uint8_t *>(workspace(WS_INGEST + 0, 2 * (2 * CHUNK + 64), err));
@@ -732,7 +733,7 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
             nxt_buf = pf_buf;
             if (nxt_got > 0) {
                 HIPCHK(hipMemcpyAsync(d_text_two[dev ^ 1] + CHUNK, h_two[nxt_buf] + CHUNK, (size_t)nxt_got, hipMemcpyHostToDevice, ingest_copy_stream));
-                HIPCHK(hipEventRecord(ingest_copy_ev, ingest_copy_stream));
+                HIPCHK(hipEventRecord(ingest_copy_ev[dev ^ 1], ingest_copy_stream));
                 read_ahead();
             }
             return 0;
@@ -741,7 +742,7 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
         if (probe_stage == 1) { n_gpu += n; carry = 0; continue; }
         d_text = d_text_two[dev] + CHUNK - carry;
         if (pre) {                                                                // the text is there (or on its way): the carried bytes go in front of it
-            HIPCHK(hipStreamWaitEvent(stream, ingest_copy_ev, 0));
+            HIPCHK(hipStreamWaitEvent(stream, ingest_copy_ev[dev], 0));
             if (carry) HIPCHK(hipMemcpyAsync(d_text, h_buf, carry, hipMemcpyHostToDevice, stream));
         } else HIPCHK(hipMemcpyAsync(d_text, h_buf, n, hipMemcpyHostToDevice, stream));
         if (probe_stage == 2) { HIPCHK(jk_stream_wait(stream)); n_gpu += n; carry = 0; continue; }

@@ -718,7 +718,7 @@ void Table::destroy() {
     if (jf_stream) { (void)jk_stream_wait(jf_stream); (void)hipStreamDestroy(jf_stream); jf_stream = nullptr; }
     if (ingest_stream) { (void)jk_stream_wait(ingest_stream); (void)hipStreamDestroy(ingest_stream); ingest_stream = nullptr; }
     if (ingest_copy_stream) { (void)jk_stream_wait(ingest_copy_stream); (void)hipStreamDestroy(ingest_copy_stream); ingest_copy_stream = nullptr; }
-    if (ingest_copy_ev) { (void)hipEventDestroy(ingest_copy_ev); ingest_copy_ev = nullptr; }
+    for (hipEvent_t &e : ingest_copy_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     for (WsBuf &b : ws) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
     for (WsBuf &b : pin) { if (b.p) (void)hipHostFree(b.p); b.p = nullptr; b.bytes = 0; }
     for (int i = 0; i < 2; ++i) {

@@ -349,7 +349,7 @@ struct Table {
     hipStream_t jf_stream = nullptr;        // write_jf's own (jfwrite.hip)
     hipStream_t ingest_stream = nullptr;    // the file reader's copies and parsing kernels (ingest_gpu.hip): they run while the table's stream counts the bases before
     hipStream_t ingest_copy_stream = nullptr;   // ... the text of the next chunk on its way to the second device buffer while this one is parsed
-    hipEvent_t ingest_copy_ev = nullptr;
+    hipEvent_t ingest_copy_ev[2] = {nullptr, nullptr};
     void *workspace(int id, size_t bytes, std::string &err);
     void wait_streams();                    // every stream of this table (its own, the polishing lanes', the .jf writer's): before a buffer they may use is freed
     // grow-only PINNED host buffers kept with the table (the polisher's segment tables, candidate lists and records travel through
