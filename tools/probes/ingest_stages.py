@@ -2,9 +2,9 @@
 """GPU box: what bounds files -> table (src/jasper.sh:177 `zcat -f $READS | jellyfish count`)?  The stages of the chunk loop of
 jasper_count_reads_files timed one on top of the other on the same stream of text (JASPER_INGEST_STAGE in ingest_gpu.hip):
 
-    1  page cache -> pinned buffer (pread by READ_THREADS threads)           for 4 / 8 / 16 / 32 reader threads
+    1  page cache -> pinned buffer (READ_THREADS threads copy out of a mapping of the file; JASPER_INGEST_MMAP=0: pread)   for 4 / 8 / 16 / 32 reader threads
     2  + the copy to the device
-    3  + the parsing kernels (newline numbering, FASTQ check, base compaction)
+    3  + the parsing kernels (newline numbering, FASTQ check, base compaction; the next chunk's copy runs beside them: JASPER_INGEST_OVERLAP=0 = one after the other)
     0  + counting (everything)
 
 The stream: the configs[1] read file (2.9 GB of FASTQ) listed REPEAT times (default 8 = 23 GB, the size of one rank's share of
