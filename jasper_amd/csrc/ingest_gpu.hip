@@ -509,8 +509,8 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
         HIPCHK(hipHostMalloc((void **)&h_ingest, 3 * (2 * CHUNK + 64), hipHostMallocDefault));
         ingest_chunk = CHUNK;
     }
-    // Two text buffers: while the GPU parses one, a thread reads the next CHUNK of the stream into the other (file -> pinned memory
-    // is a copy out of the page cache at ~10 GB/s: as long as the whole GPU side of a chunk, and until round 3 the two took turns).
+    // Text buffers in pinned memory: while the GPU parses one, a thread reads the next CHUNK of the stream into another (and a third
+    // is on its way to the device: OVERLAP below).
     // A chunk's bytes go to offset CHUNK of its buffer; what the chunk before left over (an incomplete record, <= CHUNK) is put
     // right in front of them.
     // OVERLAP (late round 5): the GPU side of a chunk was its copy to the device (1.3 ms per 64 MiB at ~50 GB/s) and then the parsing
@@ -576,8 +576,8 @@ int Table::count_files_gpu(const char *const *paths, int n_paths, uint64_t *gpu_
 
     struct Report { uint64_t *g, *h; uint64_t &ng, &nh; ~Report() { if (g) *g = ng; if (h) *h = nh; } } report{gpu_bytes, host_bytes, n_gpu, n_host};
     uint64_t bases_len = 0;
-    if (dbg_t) fprintf(stderr, "[ingest] buffers ready %.1f ms after the call (pinned 2 x %zu MiB, device text + bases %.2f GB)\n", now_ms() - t_in, (2 * CHUNK) >> 20,
-                       (double)(BASES_CAP + 4 * CHUNK) / 1e9);
+    if (dbg_t) fprintf(stderr, "[ingest] buffers ready %.1f ms after the call (pinned 3 x %zu MiB, device text 2 x %zu MiB + bases %.2f GB)\n", now_ms() - t_in, (2 * CHUNK) >> 20,
+                       (2 * CHUNK) >> 20, (double)(BASES_CAP + 2 * CHUNK) / 1e9);
     auto flush_bases = [&]() -> int {
         if (!bases_len) return 0;
         if (two_buffers) {
