@@ -289,11 +289,26 @@ struct Reader {           // the concatenation of all input files as one byte st
     off_t off = 0, size = 0;   // thread copies out of the page cache at only ~7 GB/s
     // A plain file is MAPPED and the threads copy out of the mapping: the same bytes leave the page cache at 107-114 GB/s by memcpy
     // against 65-82 GB/s by pread (8 GB of distinct bytes into pinned memory, 8-32 threads: tools/probes/read_probe.hip) -- and this
-    // copy is what bounds files -> table.  JASPER_INGEST_MMAP=0: pread, as before (a file that is TRUNCATED while it
-    // is being read ends the process with SIGBUS through the mapping; pread would report a short read).
+    // copy is what bounds files -> table.  Only for a file that IS in the page cache (sampled with mincore: 32 windows of
+    // 64 pages over the part to be read, nine in ten resident): what has to come from a disk or over a network is better asked for by
+    // pread in pieces of megabytes than page fault by page fault.  JASPER_INGEST_MMAP=0: always pread, =1: always the mapping (a file
+    // that is TRUNCATED while it is being read ends the process with SIGBUS through the mapping; pread would report a short read).
     const char *map = nullptr;
     size_t map_len = 0;
-    const bool use_mmap = []() { const char *e = getenv("JASPER_INGEST_MMAP"); return !e || atoi(e) != 0; }();
+    const int mmap_mode = []() { const char *e = getenv("JASPER_INGEST_MMAP"); return !e ? 2 : atoi(e) != 0 ? 1 : 0; }();     // 2 = when cached
+    static bool mostly_cached(const char *m, size_t lo, size_t hi) {
+        const size_t page = (size_t)sysconf(_SC_PAGESIZE), win = 64 * page;
+        if (hi <= lo) return true;
+        size_t seen = 0, in = 0;
+        unsigned char vec[64];
+        const size_t span = hi - lo, step = std::max(win, (span / 32 + page - 1) / page * page);      // (whole pages: mincore wants its address on one)
+        for (size_t at = lo / page * page; at < hi; at += step) {
+            const size_t n = std::min(win, (hi - at + page - 1) / page * page);
+            if (mincore(const_cast<char *>(m) + at, n, vec) != 0) return false;
+            for (size_t i = 0; i < (n + page - 1) / page; ++i) { ++seen; in += vec[i] & 1u; }
+        }
+        return seen == 0 || in * 10 >= seen * 9;
+    }
     // (taking a mapping of GBs down costs tens of ms -- one page-table entry per 4 KB read: done by a thread of its own, off the reader's path)
     void unmap() {
         if (!map) return;
@@ -344,12 +359,17 @@ struct Reader {           // the concatenation of all input files as one byte st
                 } else {
                     off = (off_t)std::min<int64_t>(rb, (int64_t)st.st_size);
                     size = re >= 0 ? (off_t)std::min<int64_t>(re, (int64_t)st.st_size) : st.st_size;
-                    if (use_mmap && st.st_size > 0) {
+                    if (mmap_mode && st.st_size > 0 && size > off) {
                         void *m_ = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
                         if (m_ != MAP_FAILED) {
-                            map = static_cast<const char *>(m_);
-                            map_len = (size_t)st.st_size;
-                            (void)madvise(m_, map_len, MADV_SEQUENTIAL);
+                            const bool cached = mmap_mode != 2 || mostly_cached(static_cast<const char *>(m_), (size_t)off, (size_t)size);
+                            if (getenv("JASPER_COUNT_DEBUG")) fprintf(stderr, "[ingest] %s: %s\n", paths[cur], cached ? "copied out of a mapping" : "not in the page cache: pread");
+                            if (!cached) munmap(m_, (size_t)st.st_size);
+                            else {
+                                map = static_cast<const char *>(m_);
+                                map_len = (size_t)st.st_size;
+                                (void)madvise(m_, map_len, MADV_SEQUENTIAL);
+                            }
                         }
                     }
                 }
