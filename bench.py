@@ -311,7 +311,11 @@ def e2e_cli_big(fixture="fullsize_cfg3", need_gb=40):
         walls = []
         keys = ("threshold", "jfhisto_sha256", "polished_bases", "polished_fasta_sha256", "fixes_csv_lines", "fixes_csv_sha256")
         all_equal = True
-        for attempt in range(2):
+        for attempt in range(3):
+            # (a third run only when the first two are more than a quarter apart: the sign of allocations that waited for the driver --
+            #  on some boxes BOTH of two runs back to back do, 2.1 and 3.8 s against 0.8 s)
+            if attempt == 2 and max(walls) <= 1.25 * min(walls):
+                break
             for fn in set(os.listdir(d)) - inputs:
                 os.remove(os.path.join(d, fn))
             time.sleep(3.0 if attempt == 0 else 8.0)
@@ -330,7 +334,7 @@ def e2e_cli_big(fixture="fullsize_cfg3", need_gb=40):
         qm = re.search(r"^\[qv\] before (\d+) (\d+) after (\d+) (\d+)$", p.stderr, re.M)
         count_s = next((v for k, v in marks.items() if k.startswith("count reads")), None)
         split_s = marks.get("split", 0.0)
-        return {"seconds": round(wall, 3), "seconds_until_outputs_complete": _outputs_complete_s(p.stderr, t0_epoch), "seconds_of_both_runs": walls,
+        return {"seconds": round(wall, 3), "seconds_until_outputs_complete": _outputs_complete_s(p.stderr, t0_epoch), "seconds_of_both_runs": walls,      # (two, or three: see above)
                 "outputs_equal_reference": all_equal,
                 "qv_sums_equal_reference": bool(qm) and [int(qm.group(1)), int(qm.group(2))] == ref.get("qv_before") and [int(qm.group(3)), int(qm.group(4))] == ref.get("qv_after"),
                 "stage_seconds": marks, "ingest_text_GBps": round(fastq / 1e9 / (count_s + split_s), 2) if count_s else None,
